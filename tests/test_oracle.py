@@ -1,0 +1,157 @@
+"""The CPU oracle against the golden vectors -- no GPU."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def test_t1ha2_upstream_selfcheck(orc):
+    g = golden("kat_t1ha2.json")
+    pat = bytes(g["pattern"])
+    for c in g["cases"]:
+        assert orc.t1ha2_atonce(pat[: c["len"]], int(c["seed"])) == int(c["hash"], 16), c
+
+
+def test_wyrng_upstream_kat(orc):
+    g = golden("kat_wyrng.json")
+    assert orc.wyrng_stream(g["seed"], 1)[0] == int(g["first"], 16)
+    # seed_from_u64 is the identity on the state: successive states differ by the increment
+    a = orc.wyrng_stream(5, 3)
+    assert a[1:] == orc.wyrng_stream((5 + 0xA0761D6478BD642F) % 2**64, 2)
+
+
+def test_g1_reference_fixture(orc):
+    g = golden("g1_test_fna.json")
+    seq = orc.read_merge_seq(g["fasta"].encode())
+    assert bytes(seq) == b"NAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"
+    for key, k, scaled in (("k21_scaled1", 21, 1), ("k5_scaled1", 5, 1), ("k21_scaled1500", 21, 1500)):
+        got = orc.kmer_hash_sample(seq, k, scaled, g["seed"], g["canonical"])
+        assert ["%016x" % int(x) for x in got] == g[key], key
+    # config 1 end to end: empty set -> zero HV, norm 0, 6-bit payload of the constant 32
+    hv, n2, nh = orc.sketch_genome(seq)
+    assert nh == 0 and n2 == 0 and not hv.any()
+    q, packed = orc.pack_hv(hv)
+    assert q == 6 and packed.size == 6 * 4096 // 8
+    assert (orc.unpack_hv(packed, 4096, 6) == 0).all()
+    w = np.frombuffer(packed.tobytes(), "<u4")[:6]  # 32 x (32 at 6 bits) per lane
+    v = sum(32 << (6 * r) for r in range(32))
+    assert [int(x) for x in w[:1]] == [v & 0xFFFFFFFF]
+
+
+def test_read_merge_seq_layout(orc):
+    txt = b">a desc\nACGT\r\nAC\n>b\nGG\n\nTT"
+    assert bytes(orc.read_merge_seq(txt)) == b"NACGTACNGGTT"
+    assert orc.read_merge_seq(b"").size == 0
+
+
+def test_kmer_edge_cases(orc):
+    assert orc.kmer_hash_sample(b"", 21, 1).size == 0
+    assert orc.kmer_hash_sample(b"ACGT" * 5, 21, 1).size == 0  # 20 bases < k
+    one = orc.kmer_hash_sample(b"ACGTACGTACGTACGTACGTA", 21, 1)
+    assert one.size == 1
+    # strand symmetry: a sequence and its reverse complement sample the same set
+    rng = np.random.default_rng(1)
+    s = rng.choice(np.frombuffer(b"ACGT", np.uint8), 5000)
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    rc = comp[s[::-1]]
+    a, b = orc.kmer_hash_sample(s, 21, 50), orc.kmer_hash_sample(rc, 21, 50)
+    assert a.size > 50 and (a == b).all()
+    # non-canonical mode differs, lower case is folded, N breaks runs, U only in U2T mode
+    assert not np.array_equal(orc.kmer_hash_sample(s, 21, 50, canonical=False), a)
+    assert (orc.kmer_hash_sample(np.char.lower(s.view("S1")).view(np.uint8), 21, 50) == a).all()
+    t = s.copy()
+    t[100] = ord("N")
+    assert orc.kmer_hash_sample(t, 21, 1, unique=False).size == 5000 - 20 - 21
+    u = s.copy()
+    u[s == ord("T")] = ord("U")
+    assert (orc.kmer_hash_sample(u, 21, 50, norm=orc.NORM_U2T) == a).all()
+    assert orc.kmer_hash_sample(u, 21, 50, norm=orc.NORM_ACGT).size < a.size
+    # duplicates are reported by the walk and removed by the set
+    rep = np.tile(s[:300], 4)
+    d = orc.kmer_hash_sample(rep, 21, 10, unique=False)
+    assert np.unique(d).size < d.size
+
+
+def test_k_over_32(orc):
+    rng = np.random.default_rng(2)
+    s = rng.choice(np.frombuffer(b"ACGT", np.uint8), 400)
+    hs = orc.kmer_hash_sample(s, 41, 1, unique=False)
+    assert hs.size == 360
+    assert int(hs[0]) in (orc.t1ha2_atonce(s[:41], 123),
+                          orc.t1ha2_atonce(bytes(s[:41]).translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1], 123))
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 7, 50])
+@pytest.mark.parametrize("d", [256, 4096])
+def test_hv_layouts(orc, n, d):
+    rng = np.random.default_rng(n * 1000 + d)
+    hs = np.unique(rng.integers(0, 2**63, n, dtype=np.uint64))
+    sc = orc.encode_hv(hs, d, orc.LAYOUT_SCALAR)
+    av = orc.encode_hv(hs, d, orc.LAYOUT_AVX2)
+    # closed-form permutation == emulated intrinsic sequence of src/hd.rs:14-92
+    assert (av == orc.encode_hv_avx2_emulated(hs, d)).all()
+    j = np.arange(64)
+    perm = (np.arange(d) // 64 * 64)[:, None].reshape(-1, 64)[:, :1] + (4 * (j & 15) + (j >> 4))[None, :]
+    assert (av[perm.reshape(-1)] == sc).all()
+    # definition: hv = 2*count - n
+    cnt = np.zeros(d, np.int64)
+    for h in hs:
+        words = orc.wyrng_stream(int(h), d // 64)
+        bits = np.unpackbits(np.array(words, "<u8").view(np.uint8), bitorder="little")
+        cnt += bits
+    assert (sc == 2 * cnt - hs.size).all()
+    # src/lib.rs:224 intent: dot products are layout invariant
+    assert orc.hv_norm2(sc) == orc.hv_norm2(av) == int((sc.astype(np.int64) ** 2).sum())
+
+
+def test_pack_roundtrip_and_width(orc):
+    rng = np.random.default_rng(3)
+    for amp in (5, 31, 32, 33, 200, 600, 5000, 16000):
+        hv = rng.integers(-amp, amp + 1, 4096).astype(np.int16)
+        q, packed = orc.pack_hv(hv)
+        lo, hi = int(hv.min()), int(hv.max())
+        assert -(1 << (q - 1)) <= lo and hi <= (1 << (q - 1)) - 1
+        assert q == 6 or not (-(1 << (q - 2)) <= lo and hi <= (1 << (q - 2)) - 1)
+        assert packed.size == q * 4096 // 8
+        assert (orc.unpack_hv(packed, 4096, q) == hv).all()  # src/lib.rs:261 intent
+    # layout spot check: value r of lane l sits at bit r*q of that lane's stream
+    hv = np.zeros(256, np.int16)
+    hv[8 * 5 + 3] = 7  # row 5, lane 3
+    q, packed = orc.pack_hv(hv, 9)
+    words = np.frombuffer(packed.tobytes(), "<u4").reshape(9, 8)
+    stream = sum(int(words[w, 3]) << (32 * w) for w in range(9))
+    assert (stream >> (5 * 9)) & 0x1FF == 7 + 256
+
+
+def test_ani_golden(orc):
+    for c in golden("g4_ani.json"):
+        got = orc.ani_from_dot(c["dot"], c["nr"], c["nq"], c["k"])
+        assert abs(got - c["ani"]) <= 1e-4, c
+    assert orc.ani_from_dot(0, 10, 10) == 0.0 and orc.ani_from_dot(-3, 10, 10) == 0.0
+    assert orc.ani_from_dot(10, 10, 10) == 100.0
+
+
+def test_ani_matrix_matches_pairwise(orc):
+    rng = np.random.default_rng(4)
+    r = rng.integers(-200, 200, (5, 512)).astype(np.int16)
+    q = np.vstack([r[:2], rng.integers(-200, 200, (2, 512)).astype(np.int16)])
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+    m = orc.ani_matrix(r, rn, q, qn, 21)
+    assert m.shape == (5, 4) and m[0, 0] == 100.0 and m[1, 1] == 100.0
+    dot = int(r[3].astype(np.int64) @ q[2].astype(np.int64))
+    assert m[3, 2] == orc.ani_from_dot(dot, rn[3], qn[2])
+
+
+def test_synth_genomes(orc):
+    root = orc.synth_genome(0, 20000)
+    assert root[0] == ord("N") and set(root[1:].tolist()) <= set(b"ACGT")
+    assert (orc.synth_genome(0, 5000)[:5001] == root[:5001]).all()  # counter based
+    m50 = orc.synth_genome(50, 20000)
+    rate = float((m50[1:] != root[1:]).mean())
+    assert 0.04 < rate < 0.06
+    other = orc.synth_genome(100, 20000)
+    assert 0.70 < float((other[1:] != root[1:]).mean()) < 0.80
+    counts = np.bincount(root[1:], minlength=128)[list(b"ACGT")] / 20000
+    assert (abs(counts - 0.25) < 0.02).all()

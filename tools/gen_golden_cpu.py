@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Writes the CPU-side golden fixtures under tests/golden/.
+
+Sources of the numbers (none is produced by the code under test):
+  * kat_t1ha2.json  -- upstream t1ha self-check table for t1ha2_atonce (test pattern,
+    seed = 1 << (len-1)), lengths 0..18 and the 64-byte/seed-0 entry.  The values are
+    typed in here; the oracle merely has to reproduce them.
+  * kat_wyrng.json  -- wyhash crate README: WyRng::seed_from_u64(3).next_u64().
+  * g1_test_fna.json -- SURVEY.md 8c "G1": the reference's own kernel source
+    (src/cuda_kernel.cu) executed on the reference fixture test/test.fna.
+  * g4_ani.json     -- src/dist.rs:153-160 evaluated with numpy float32 scalars.
+"""
+import json
+import os
+
+import numpy as np
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+PATTERN = [0, 1, 2, 3, 4, 5, 6, 7, 0xFF, 0x7F, 0x3F, 0x1F, 0xF, 8, 16, 32, 64, 0x80, 0xFE,
+           0xFC, 0xF8, 0xF0, 0xE0, 0xC0, 0xFD, 0xFB, 0xF7, 0xEF, 0xDF, 0xBF, 0x55, 0xAA, 11,
+           17, 19, 23, 29, 37, 42, 43] + list(b"abcdefghijklmnopqrstuvwx")
+
+T1HA2 = [  # (len, seed, value)
+    (0, 0, 0x0),
+    (0, 2**64 - 1, 0x772C7311BE32FF42),
+    (64, 0, 0x444753D23F207E03),
+] + [(i + 1, 1 << i, v) for i, v in enumerate([
+    0x71F6DF5DA3B4F532, 0x555859635365F660, 0xE98808F1CD39C626, 0x2EB18FAF2163BB09,
+    0x7B9DD892C8019C87, 0xE2B1431C4DA4D15A, 0x1984E718A5477F70, 0x08DD17B266484F79,
+    0x4C83A05D766AD550, 0x92DCEBB131D1907D, 0xD67BC6FC881B8549, 0xF6A9886555FBF66B,
+    0x6E31616D7F33E25E, 0x36E31B7426E3049D, 0x4F8E4FAF46A13F5F, 0x03EB0CB3253F819F,
+    0x636A7769905770D2, 0x3ADF3781D16D1148])]
+
+G1_FASTA = ">test_seq\nAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"  # reference test/test.fna
+G1_K21_S1 = ["908794018d1f0246", "967bde3c7bcdbcba", "c0bd0cee44a5f3e0", "e003c78b7d4bace3"]
+G1_K5_S1 = """05154f11423d6f2d 1087f45976b8c17d 3736bdc2862be4cf 37490079ec20f055
+383d31b8dfc57fad 3f2c505a26d57370 3ffe1a360a93b3aa 440aab0326f64422 45816a9685dc411a
+4aafaa6d9d57e55a 4b1e0f3197bbc2f9 4f3dc66c3f45e403 57c55bdcac318125 654aaae8425fb2b4
+7a89512fda0db251 928883e5f36a9997 9347173f0ea6d47a 95eee8d29b40209c 998418d696683628
+a66dcaadba250048 e02a59e9b5121e75 ec4ebc51bcb9a28f edb41fdf139cc8f5 ff1b1c5541e296b1""".split()
+
+
+def ani_f32(dot, nr, nq, k):
+    f = np.float32
+    with np.errstate(all="ignore"):
+        den = np.int32(np.int64(nr) + np.int64(nq) - np.int64(dot))  # no wrap in these cases
+        j = f(dot) / f(den)
+        ani = f(1.0) + np.log(f(2.0) / (f(1.0) / j + f(1.0)), dtype=np.float32) / f(k)
+    if np.isnan(ani):
+        return 0.0
+    return float(np.maximum(np.minimum(ani, f(1.0)), f(0.0)) * f(100.0))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    json.dump({"pattern": PATTERN,
+               "cases": [{"len": l, "seed": str(s), "hash": "%016x" % v} for l, s, v in T1HA2]},
+              open(os.path.join(OUT, "kat_t1ha2.json"), "w"), indent=1)
+    json.dump({"seed": 3, "first": "%016x" % 0x3E99A772750DCBE},
+              open(os.path.join(OUT, "kat_wyrng.json"), "w"), indent=1)
+    json.dump({"fasta": G1_FASTA, "seed": 123, "canonical": True,
+               "k21_scaled1": G1_K21_S1, "k5_scaled1": G1_K5_S1, "k21_scaled1500": []},
+              open(os.path.join(OUT, "g1_test_fna.json"), "w"), indent=1)
+    cases = []
+    rng = np.random.default_rng(7)
+    tuples = [(13650000, 13650000, 13650000, 21), (0, 100, 100, 21), (-5, 100, 100, 21),
+              (50, 100, 100, 21), (1, 1, 1, 31), (9000000, 13000000, 14000000, 21),
+              (100, 0, 0, 21), (0, 0, 0, 21), (12000000, 13650000, 13700000, 16)]
+    for _ in range(40):
+        nr, nq = (int(x) for x in rng.integers(1_000_000, 30_000_000, 2))
+        dot = int(rng.integers(-200_000, min(nr, nq)))
+        tuples.append((dot, nr, nq, int(rng.choice([15, 21, 31]))))
+    for dot, nr, nq, k in tuples:
+        cases.append({"dot": dot, "nr": nr, "nq": nq, "k": k, "ani": ani_f32(dot, nr, nq, k)})
+    json.dump(cases, open(os.path.join(OUT, "g4_ani.json"), "w"), indent=1)
+    print("wrote fixtures to", os.path.abspath(OUT))
+
+
+if __name__ == "__main__":
+    main()
