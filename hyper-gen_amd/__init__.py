@@ -1,0 +1,350 @@
+"""hyper-gen_amd -- ctypes binding of libhypergen_hip.so (include/hypergen.h).
+
+This is a harness-side mirror of the C ABI: the product is the shared library (HIP kernels +
+C ABI) and the C++ `hyper-gen` CLI next to it.  There is no CPU fallback here: if the
+library is missing, or no HIP device is usable, calls raise.
+
+Import it as `hypergen_amd` (see the shim at the repo root; the directory name carries a
+hyphen because it is the reference's crate name).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhypergen_hip.so")
+CLI_PATH = os.path.join(_HERE, "hyper-gen")
+
+LAYOUT_SCALAR, LAYOUT_AVX2 = 0, 1
+NORM_ACGT, NORM_U2T = 0, 1
+(OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_IO,
+ ERR_INEXACT) = range(9)
+
+
+class HgError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("hypergen status %d: %s" % (status, msg))
+        self.status = status
+
+
+class SketchParams(C.Structure):
+    _fields_ = [("ksize", C.c_uint32), ("canonical", C.c_uint32), ("scaled", C.c_uint64),
+                ("seed", C.c_uint64), ("hv_d", C.c_uint32), ("hv_layout", C.c_uint32),
+                ("norm_mode", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class AniHit(C.Structure):
+    _fields_ = [("ref_idx", C.c_uint32), ("qry_idx", C.c_uint32), ("ani", C.c_float)]
+
+
+ANI_HIT_DTYPE = np.dtype([("ref_idx", "<u4"), ("qry_idx", "<u4"), ("ani", "<f4")])
+
+
+class FileSketch(C.Structure):
+    _fields_ = [("ksize", C.c_uint8), ("canonical", C.c_uint8), ("hv_quant_bits", C.c_uint8),
+                ("pad", C.c_uint8), ("hv_norm_2", C.c_int32), ("scaled", C.c_uint64),
+                ("seed", C.c_uint64), ("hv_d", C.c_uint64), ("file_str", C.c_char_p),
+                ("hv", C.POINTER(C.c_int16)), ("hv_len", C.c_uint64)]
+
+
+EXPORTS = [
+    "hg_status_str", "hg_last_error", "hg_version", "hg_ctx_create", "hg_ctx_destroy",
+    "hg_ctx_set_stream", "hg_ctx_sync", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
+    "hg_copy_h2d", "hg_copy_d2h", "hg_sketch_params_default", "hg_kmer_hash_sample",
+    "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
+    "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack",
+    "hg_hv_unpack", "hg_sketch_file_write", "hg_sketch_file_read", "hg_sketch_file_count",
+    "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_free",
+    "hg_synth_genomes_dev",
+]
+
+
+def build(force=False):
+    """Compile the library and CLI in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "all"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libhypergen_hip.so is not built: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    u8p, u64p, i16p, i32p, u32p, f32p = (C.POINTER(t) for t in (
+        C.c_uint8, C.c_uint64, C.c_int16, C.c_int32, C.c_uint32, C.c_float))
+    sig = {
+        "hg_status_str": (C.c_char_p, [C.c_int]),
+        "hg_last_error": (C.c_char_p, [vp]),
+        "hg_version": (C.c_char_p, []),
+        "hg_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "hg_ctx_destroy": (None, [vp]),
+        "hg_ctx_set_stream": (C.c_int, [vp, vp]),
+        "hg_ctx_sync": (C.c_int, [vp]),
+        "hg_device_count": (C.c_int, []),
+        "hg_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+        "hg_dev_free": (C.c_int, [vp, vp]),
+        "hg_copy_h2d": (C.c_int, [vp, vp, vp, sz]),
+        "hg_copy_d2h": (C.c_int, [vp, vp, vp, sz]),
+        "hg_sketch_params_default": (None, [C.POINTER(SketchParams)]),
+        "hg_kmer_hash_sample": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
+                                          C.c_uint32, vp, sz, C.POINTER(sz)]),
+        "hg_hv_encode": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_int32)]),
+        "hg_sketch_batch_dev": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(SketchParams), vp, vp, vp]),
+        "hg_sketch_batch": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(SketchParams),
+                                      vp, vp, vp]),
+        "hg_dist_full": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.c_uint32, C.c_uint32, vp]),
+        "hg_dist_full_dev": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.c_uint32, C.c_uint32, vp]),
+        "hg_dist": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
+                              vp, sz, C.POINTER(sz)]),
+        "hg_dist_dev": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.c_uint32, C.c_uint32, C.c_int,
+                                  C.c_float, vp, sz, C.POINTER(sz)]),
+        "hg_sort_ani_hits": (None, [vp, sz, sz, C.c_int]),
+        "hg_hv_quant_bits": (C.c_uint32, [vp, C.c_uint32]),
+        "hg_hv_pack": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "hg_hv_unpack": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "hg_sketch_file_write": (C.c_int, [C.c_char_p, C.POINTER(FileSketch), sz]),
+        "hg_sketch_file_read": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "hg_sketch_file_count": (sz, [vp]),
+        "hg_sketch_file_get": (C.POINTER(FileSketch), [vp, sz]),
+        "hg_sketch_file_free": (None, [vp]),
+        "hg_read_merge_seq": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz)]),
+        "hg_free": (None, [vp]),
+        "hg_synth_genomes_dev": (C.c_int, [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32,
+                                           C.c_uint64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here == the ABI lost a symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if isinstance(a, np.ndarray) else C.c_void_p(int(a))
+
+
+def default_params(**kw):
+    p = SketchParams()
+    lib().hg_sketch_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One device + stream + workspaces (hg_ctx).  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        st = lib().hg_ctx_create(device, C.byref(self._h))
+        if st != OK:
+            raise HgError(st, lib().hg_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            lib().hg_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, allow=()):
+        if st != OK and st not in allow:
+            raise HgError(st, lib().hg_last_error(self._h).decode())
+        return st
+
+    def set_stream(self, stream_handle):
+        self._ck(lib().hg_ctx_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def sync(self):
+        self._ck(lib().hg_ctx_sync(self._h))
+
+    # ---- host-buffer entry points -----------------------------------------------------------
+    def kmer_hash_sample(self, seq, ksize=21, scaled=1500, seed=123, canonical=True,
+                         norm=NORM_ACGT, threshold=None, cap=None):
+        a = np.ascontiguousarray(np.frombuffer(bytes(seq), np.uint8) if not isinstance(seq, np.ndarray) else seq,
+                                 dtype=np.uint8)
+        thr = (2**64 - 1) // scaled if threshold is None else threshold
+        cap = cap if cap is not None else max(1024, a.size // max(1, scaled) * 2 + 1024)
+        while True:
+            out = np.zeros(max(cap, 1), np.uint64)
+            n = C.c_size_t(0)
+            st = lib().hg_kmer_hash_sample(self._h, _ptr(a) if a.size else None, a.size, ksize,
+                                           C.c_uint64(thr), C.c_uint64(seed), int(canonical), norm,
+                                           _ptr(out), cap, C.byref(n))
+            if st == ERR_CAPACITY:
+                cap = n.value
+                continue
+            self._ck(st)
+            return out[: n.value].copy()
+
+    def hv_encode(self, hashes, hv_d=4096, layout=LAYOUT_AVX2):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        hv = np.zeros(hv_d, np.int16)
+        n2 = C.c_int32(0)
+        self._ck(lib().hg_hv_encode(self._h, _ptr(h) if h.size else None, h.size, hv_d, layout,
+                                    _ptr(hv), C.byref(n2)))
+        return hv, int(n2.value)
+
+    def sketch_batch(self, seqs, params=None):
+        p = params or default_params()
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) if isinstance(s, np.ndarray)
+                else np.frombuffer(bytes(s), np.uint8) for s in seqs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * max(n, 1))(*[a.size for a in arrs])
+        hv = np.zeros((n, p.hv_d), np.int16)
+        n2 = np.zeros(n, np.int32)
+        nh = np.zeros(n, np.uint32)
+        self._ck(lib().hg_sketch_batch(self._h, ptrs, lens, n, C.byref(p), _ptr(hv), _ptr(n2), _ptr(nh)))
+        return hv, n2, nh
+
+    def dist_full(self, ref_hv, ref_n2, qry_hv, qry_n2, ksize=21):
+        r = np.ascontiguousarray(ref_hv, np.int16)
+        q = np.ascontiguousarray(qry_hv, np.int16)
+        rn = np.ascontiguousarray(ref_n2, np.int32)
+        qn = np.ascontiguousarray(qry_n2, np.int32)
+        out = np.zeros((r.shape[0], q.shape[0]), np.float32)
+        self._ck(lib().hg_dist_full(self._h, _ptr(r), _ptr(rn), r.shape[0], _ptr(q), _ptr(qn),
+                                    q.shape[0], r.shape[1], ksize, _ptr(out)))
+        return out
+
+    def dist(self, ref_hv, ref_n2, qry_hv, qry_n2, ksize=21, symmetric=False, ani_th=85.0, cap=None):
+        r = np.ascontiguousarray(ref_hv, np.int16)
+        q = np.ascontiguousarray(qry_hv, np.int16)
+        rn = np.ascontiguousarray(ref_n2, np.int32)
+        qn = np.ascontiguousarray(qry_n2, np.int32)
+        cap = cap if cap is not None else max(1024, r.shape[0] * q.shape[0] // 8)
+        while True:
+            out = np.zeros(cap, ANI_HIT_DTYPE)
+            n = C.c_size_t(0)
+            st = lib().hg_dist(self._h, _ptr(r), _ptr(rn), r.shape[0], _ptr(q), _ptr(qn), q.shape[0],
+                               r.shape[1], ksize, int(symmetric), C.c_float(ani_th), _ptr(out), cap,
+                               C.byref(n))
+            if st == ERR_CAPACITY:
+                cap = n.value
+                continue
+            self._ck(st)
+            return out[: n.value].copy()
+
+    # ---- device-resident entry points (pointers are ints, e.g. torch.Tensor.data_ptr()) -------
+    def sketch_batch_dev(self, d_seq, offsets, lens, params, d_hv, d_norm2, d_nhash):
+        off = np.ascontiguousarray(offsets, np.uint64)
+        ln = np.ascontiguousarray(lens, np.uint64)
+        self._ck(lib().hg_sketch_batch_dev(self._h, _ptr(d_seq), _ptr(off), _ptr(ln), off.size,
+                                           C.byref(params), _ptr(d_hv), _ptr(d_norm2), _ptr(d_nhash)))
+
+    def synth_genomes_dev(self, first, n, L, stride, d_out, cluster_size=100, sub_ppm_per_member=1000):
+        done = 0
+        while done < n:  # grid.y limit
+            m = min(n - done, 32768)
+            self._ck(lib().hg_synth_genomes_dev(self._h, first + done, m, L, cluster_size, sub_ppm_per_member,
+                                                stride, C.c_void_p(int(d_out) + done * stride)))
+            done += m
+
+    def dist_full_dev(self, d_ref, d_rn, R, d_qry, d_qn, Q, hv_d, ksize, d_out):
+        self._ck(lib().hg_dist_full_dev(self._h, _ptr(d_ref), _ptr(d_rn), R, _ptr(d_qry), _ptr(d_qn), Q,
+                                        hv_d, ksize, _ptr(d_out)))
+
+    def dist_dev(self, d_ref, d_rn, R, d_qry, d_qn, Q, hv_d, ksize, symmetric, ani_th, d_out, cap):
+        n = C.c_size_t(0)
+        st = lib().hg_dist_dev(self._h, _ptr(d_ref), _ptr(d_rn), R, _ptr(d_qry), _ptr(d_qn), Q, hv_d,
+                               ksize, int(symmetric), C.c_float(ani_th), _ptr(d_out), cap, C.byref(n))
+        self._ck(st, allow=(ERR_CAPACITY,))
+        return n.value, st
+
+
+# ---- host-side formats (no device involved) ------------------------------------------------------
+def hv_quant_bits(hv):
+    hv = np.ascontiguousarray(hv, np.int16)
+    return int(lib().hg_hv_quant_bits(_ptr(hv), hv.size))
+
+
+def hv_pack(hv, q=None):
+    hv = np.ascontiguousarray(hv, np.int16)
+    q = hv_quant_bits(hv) if q is None else q
+    out = np.zeros(q * hv.size // 8, np.uint8)
+    st = lib().hg_hv_pack(_ptr(hv), hv.size, q, _ptr(out))
+    if st != OK:
+        raise HgError(st, "hg_hv_pack")
+    return q, out
+
+
+def hv_unpack(packed, hv_d, q):
+    packed = np.ascontiguousarray(packed, np.uint8)
+    hv = np.zeros(hv_d, np.int16)
+    st = lib().hg_hv_unpack(_ptr(packed), hv_d, q, _ptr(hv))
+    if st != OK:
+        raise HgError(st, "hg_hv_unpack")
+    return hv
+
+
+def sort_ani_hits(hits, Q, symmetric=False):
+    hits = np.ascontiguousarray(hits, ANI_HIT_DTYPE).copy()
+    lib().hg_sort_ani_hits(_ptr(hits), hits.size, Q, int(symmetric))
+    return hits
+
+
+def read_merge_seq(path):
+    p, n = C.c_void_p(), C.c_size_t(0)
+    st = lib().hg_read_merge_seq(os.fsencode(path), C.byref(p), C.byref(n))
+    if st != OK:
+        raise HgError(st, "hg_read_merge_seq(%s)" % path)
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy() if n.value \
+            else np.zeros(0, np.uint8)
+    finally:
+        lib().hg_free(p)
+
+
+def write_sketch_file(path, records):
+    """records: dicts with ksize, scaled, canonical, seed, hv_d, hv_quant_bits, hv_norm_2, file_str, hv."""
+    arr = (FileSketch * max(len(records), 1))()
+    keep = []
+    for i, r in enumerate(records):
+        hv = np.ascontiguousarray(r["hv"], np.int16)
+        name = r["file_str"].encode()
+        keep += [hv, name]
+        arr[i] = FileSketch(r["ksize"], int(bool(r["canonical"])), r["hv_quant_bits"], 0, r["hv_norm_2"],
+                            r["scaled"], r["seed"], r["hv_d"], name,
+                            hv.ctypes.data_as(C.POINTER(C.c_int16)), hv.size)
+    st = lib().hg_sketch_file_write(os.fsencode(path), arr, len(records))
+    if st != OK:
+        raise HgError(st, "hg_sketch_file_write(%s)" % path)
+
+
+def read_sketch_file(path):
+    h = C.c_void_p()
+    st = lib().hg_sketch_file_read(os.fsencode(path), C.byref(h))
+    if st != OK:
+        raise HgError(st, "hg_sketch_file_read(%s)" % path)
+    try:
+        out = []
+        for i in range(lib().hg_sketch_file_count(h)):
+            r = lib().hg_sketch_file_get(h, i).contents
+            hv = np.ctypeslib.as_array(r.hv, shape=(r.hv_len,)).copy() if r.hv_len else np.zeros(0, np.int16)
+            out.append(dict(ksize=r.ksize, scaled=r.scaled, canonical=bool(r.canonical), seed=r.seed,
+                            hv_d=r.hv_d, hv_quant_bits=r.hv_quant_bits, hv_norm_2=r.hv_norm_2,
+                            file_str=r.file_str.decode(), hv=hv))
+        return out
+    finally:
+        lib().hg_sketch_file_free(h)

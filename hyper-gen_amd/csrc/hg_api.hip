@@ -1,0 +1,551 @@
+// hg_api.hip -- the C ABI of include/hypergen.h: context, workspaces and the orchestration of
+// the sketch and dist kernels.  No CPU fallback lives here: every compute entry point runs
+// HIP kernels or fails.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hg_internal.h"
+
+static thread_local std::string g_create_err;
+
+hg_status hg_fail(hg_ctx *ctx, hg_status s, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  else g_create_err = msg;
+  return s;
+}
+
+extern "C" const char *hg_status_str(hg_status s) {
+  switch (s) {
+    case HG_OK: return "ok";
+    case HG_ERR_INVALID: return "invalid argument";
+    case HG_ERR_NO_DEVICE: return "no usable HIP device";
+    case HG_ERR_HIP: return "HIP runtime error";
+    case HG_ERR_OOM: return "out of memory";
+    case HG_ERR_CAPACITY: return "output capacity too small";
+    case HG_ERR_UNSUPPORTED: return "unsupported parameters";
+    case HG_ERR_IO: return "I/O error";
+    case HG_ERR_INEXACT: return "no exact device path";
+  }
+  return "unknown";
+}
+
+extern "C" const char *hg_last_error(const hg_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" const char *hg_version(void) { return "hypergen-hip 0.1.0 (gfx950)"; }
+
+extern "C" int hg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" hg_status hg_ctx_create(int device_id, hg_ctx **out) {
+  if (!out) return hg_fail(nullptr, HG_ERR_INVALID, "out == NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return hg_fail(nullptr, HG_ERR_NO_DEVICE,
+                   std::string("hipGetDeviceCount: ") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)));
+  if (device_id < 0 || device_id >= n)
+    return hg_fail(nullptr, HG_ERR_NO_DEVICE, "device id out of range");
+  hg_ctx *c = new (std::nothrow) hg_ctx();
+  if (!c) return hg_fail(nullptr, HG_ERR_OOM, "ctx allocation");
+  c->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete c;
+    return hg_fail(nullptr, HG_ERR_HIP, std::string("ctx setup: ") + hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  *out = c;
+  return HG_OK;
+}
+
+extern "C" void hg_ctx_destroy(hg_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv,
+                         &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
+                         &c->w_n2a, &c->w_n2b};
+  for (auto *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" hg_status hg_ctx_set_stream(hg_ctx *c, void *hip_stream) {
+  if (!c) return HG_ERR_INVALID;
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return HG_OK;
+}
+
+extern "C" hg_status hg_ctx_sync(hg_ctx *c) {
+  if (!c) return HG_ERR_INVALID;
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+hg_status hg_ensure(hg_ctx *c, hg_ctx::Buf &b, size_t bytes) {
+  if (bytes <= b.cap) return HG_OK;
+  HG_HIP(c, hipStreamSynchronize(c->stream));  // nothing in flight may still use the old block
+  if (b.p) {
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 4 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return hg_fail(c, HG_ERR_OOM, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+  }
+  b.cap = want;
+  return HG_OK;
+}
+
+hg_status hg_ensure_pinned(hg_ctx *c, size_t bytes) {
+  if (bytes <= c->h_pin_cap) return HG_OK;
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  c->h_pin = nullptr, c->h_pin_cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipHostMalloc(&c->h_pin, want, hipHostMallocDefault);
+  if (e != hipSuccess) return hg_fail(c, HG_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  c->h_pin_cap = want;
+  return HG_OK;
+}
+
+extern "C" hg_status hg_dev_alloc(hg_ctx *c, size_t bytes, void **dptr) {
+  if (!c || !dptr) return HG_ERR_INVALID;
+  HG_HIP(c, hipSetDevice(c->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+  if (e != hipSuccess) return hg_fail(c, HG_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return HG_OK;
+}
+extern "C" hg_status hg_dev_free(hg_ctx *c, void *dptr) {
+  if (!c) return HG_ERR_INVALID;
+  if (dptr) HG_HIP(c, hipFree(dptr));
+  return HG_OK;
+}
+extern "C" hg_status hg_copy_h2d(hg_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (!c) return HG_ERR_INVALID;
+  if (bytes) {
+    HG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return HG_OK;
+}
+extern "C" hg_status hg_copy_d2h(hg_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (!c) return HG_ERR_INVALID;
+  if (bytes) {
+    HG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return HG_OK;
+}
+
+extern "C" void hg_sketch_params_default(hg_sketch_params *p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof *p);
+  p->ksize = 21;  // src/types.rs:97-113
+  p->canonical = 1;
+  p->scaled = 1500;
+  p->seed = 123;
+  p->hv_d = 4096;
+  p->hv_layout = HG_LAYOUT_AVX2;
+  p->norm_mode = HG_NORM_ACGT;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sketch core: hash+sample -> sort/unique -> (optional) encode, all genomes of a batch
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct BatchPlan {
+  std::vector<hg_genome_meta> meta;
+  std::vector<uint32_t> item_genome;
+  uint64_t total_slots = 0;
+  uint32_t max_cap = 0;
+};
+
+uint32_t round_cap(uint64_t cap) {
+  if (cap > HG_SORT_LDS_MAX_KEYS) {  // in-place global sort needs a power of two
+    uint64_t p = 1;
+    while (p < cap) p <<= 1;
+    cap = p;
+  }
+  return cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cap;
+}
+
+// want_caps: optional per-genome minimum capacities (retry after overflow)
+hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize,
+                    uint64_t scaled, const std::vector<uint32_t> *want_caps, BatchPlan &pl) {
+  const uint64_t item_starts = hg_kmer_item_starts(ksize);
+  pl.meta.resize(n);
+  pl.item_genome.clear();
+  uint64_t slot = 0;
+  uint32_t max_cap = 0;
+  for (size_t g = 0; g < n; ++g) {
+    if (offsets[g] & 3) return hg_fail(c, HG_ERR_INVALID, "genome offsets must be multiples of 4");
+    hg_genome_meta &m = pl.meta[g];
+    m.seq_off = offsets[g];
+    m.n_bps = lens[g];
+    const uint64_t n_starts = lens[g] >= ksize ? lens[g] - ksize + 1 : 0;
+    uint64_t cap = n_starts / scaled * 2 + 1024;  // expected n_starts/scaled; sd ~ sqrt of that
+    if (cap > n_starts) cap = n_starts;             // can never exceed the number of k-mers
+    if (want_caps && (*want_caps)[g] > cap) cap = (*want_caps)[g];
+    if (cap == 0) cap = 1;
+    m.hit_cap = round_cap(cap);
+    m.hit_off = slot;
+    slot += m.hit_cap;
+    max_cap = std::max(max_cap, m.hit_cap);
+    const uint64_t n_items = (n_starts + item_starts - 1) / item_starts;
+    if (pl.item_genome.size() + n_items > 0x7FFFFFFFull)
+      return hg_fail(c, HG_ERR_UNSUPPORTED, "batch too large for one launch; split it");
+    m.item_first = (uint32_t)pl.item_genome.size();
+    pl.item_genome.insert(pl.item_genome.end(), (size_t)n_items, (uint32_t)g);
+  }
+  pl.total_slots = slot;
+  pl.max_cap = max_cap;
+  return HG_OK;
+}
+
+// Runs hash+sample and sort/unique.  On return (stream synchronised) the device hit buffer holds
+// each genome's ascending distinct hashes at meta[g].hit_off and h_nd[g] the distinct counts.
+hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
+                       size_t n, uint32_t ksize, uint64_t threshold, uint64_t scaled_for_cap, uint64_t seed,
+                       bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out) {
+  if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
+  std::vector<uint32_t> want;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    hg_status s = make_plan(c, offsets, lens, n, ksize, scaled_for_cap, attempt ? &want : nullptr, pl);
+    if (s != HG_OK) return s;
+    const size_t n_items = pl.item_genome.size();
+    if ((s = hg_ensure(c, c->w_gmeta, n * sizeof(hg_genome_meta) + 16)) != HG_OK) return s;
+    if ((s = hg_ensure(c, c->w_items, n_items * sizeof(uint32_t) + 16)) != HG_OK) return s;
+    if ((s = hg_ensure(c, c->w_hits, pl.total_slots * sizeof(uint64_t) + 16)) != HG_OK) return s;
+    if ((s = hg_ensure(c, c->w_cnt, 2 * n * sizeof(uint32_t) + 16)) != HG_OK) return s;
+    if ((s = hg_ensure_pinned(c, n * sizeof(uint32_t))) != HG_OK) return s;
+    auto *d_meta = static_cast<hg_genome_meta *>(c->w_gmeta.p);
+    auto *d_items = static_cast<uint32_t *>(c->w_items.p);
+    auto *d_hits = static_cast<uint64_t *>(c->w_hits.p);
+    auto *d_cnt = static_cast<uint32_t *>(c->w_cnt.p);
+    uint32_t *d_nd = d_cnt + n;
+    HG_HIP(c, hipMemcpyAsync(d_meta, pl.meta.data(), n * sizeof(hg_genome_meta), hipMemcpyHostToDevice, c->stream));
+    if (n_items)
+      HG_HIP(c, hipMemcpyAsync(d_items, pl.item_genome.data(), n_items * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HG_HIP(c, hipMemsetAsync(d_cnt, 0, 2 * n * sizeof(uint32_t), c->stream));
+    HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
+                                    seed, canonical, norm_mode, d_hits, d_cnt));
+    HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, pl.max_cap));
+    // overflow check on the raw counters (they keep counting past the capacity)
+    auto *h_cnt = static_cast<uint32_t *>(c->h_pin);
+    HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+    bool overflow = false;
+    want.assign(n, 0);
+    for (size_t g = 0; g < n; ++g)
+      if (h_cnt[g] > pl.meta[g].hit_cap) overflow = true, want[g] = h_cnt[g];
+    if (!overflow) {
+      *d_ndistinct_out = d_nd;
+      return HG_OK;
+    }
+  }
+  return hg_fail(c, HG_ERR_HIP, "hit buffer overflow persisted after resizing");
+}
+
+hg_status check_params(hg_ctx *c, const hg_sketch_params *p) {
+  if (!p) return hg_fail(c, HG_ERR_INVALID, "params == NULL");
+  if (p->ksize < 1) return hg_fail(c, HG_ERR_INVALID, "ksize must be >= 1");
+  if (p->ksize > 32)
+    return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize > 32 is not implemented on the device (like src/cuda_kernel.cu:196-246)");
+  if (p->scaled < 1) return hg_fail(c, HG_ERR_INVALID, "scaled must be >= 1");
+  if (p->hv_layout > HG_LAYOUT_AVX2 || p->norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad layout / norm mode");
+  if (p->hv_d == 0 || p->hv_d > 32768) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be in 1..32768");
+  return HG_OK;
+}
+
+}  // namespace
+
+extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
+                                         const uint64_t *lens, size_t n, const hg_sketch_params *p,
+                                         int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash) {
+  if (!c) return HG_ERR_INVALID;
+  hg_status s = check_params(c, p);
+  if (s != HG_OK) return s;
+  if (n == 0) return HG_OK;
+  if (!d_seq || !offsets || !lens || !d_hv || !d_norm2 || !d_nhash) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  HG_HIP(c, hipSetDevice(c->device));
+  BatchPlan pl;
+  uint32_t *d_nd = nullptr;
+  const uint64_t threshold = UINT64_MAX / p->scaled;  // src/sketch.rs:73
+  s = sample_batch(c, d_seq, offsets, lens, n, p->ksize, threshold, p->scaled, p->seed, p->canonical != 0,
+                   p->norm_mode, pl, &d_nd);
+  if (s != HG_OK) return s;
+  HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), (uint32_t)n,
+                             static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2));
+  HG_HIP(c, hipMemcpyAsync(d_nhash, d_nd, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  return HG_OK;
+}
+
+namespace {
+// packs host sequences into one staged device buffer, 16-byte aligned starts, 64 bytes of slack
+hg_status stage_sequences(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
+                          std::vector<uint64_t> &offs, std::vector<uint64_t> &l64) {
+  offs.resize(n), l64.resize(n);
+  uint64_t total = 0;
+  for (size_t g = 0; g < n; ++g) {
+    if (lens[g] && !seqs[g]) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
+    offs[g] = total, l64[g] = lens[g];
+    total += (lens[g] + 15) & ~(uint64_t)15;
+  }
+  hg_status s = hg_ensure(c, c->w_seq, total + 64);
+  if (s != HG_OK) return s;
+  auto *d = static_cast<uint8_t *>(c->w_seq.p);
+  for (size_t g = 0; g < n; ++g)
+    if (lens[g]) HG_HIP(c, hipMemcpyAsync(d + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, c->stream));
+  return HG_OK;
+}
+}  // namespace
+
+extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
+                                     const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
+                                     uint32_t *nhash_out) {
+  if (!c) return HG_ERR_INVALID;
+  hg_status s = check_params(c, p);
+  if (s != HG_OK) return s;
+  if (n == 0) return HG_OK;
+  if (!seqs || !lens || !hv_out || !norm2_out || !nhash_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  HG_HIP(c, hipSetDevice(c->device));
+  std::vector<uint64_t> offs, l64;
+  if ((s = stage_sequences(c, seqs, lens, n, offs, l64)) != HG_OK) return s;
+  const size_t hv_bytes = n * (size_t)p->hv_d * sizeof(int16_t);
+  if ((s = hg_ensure(c, c->w_hv, hv_bytes + n * 8 + 64)) != HG_OK) return s;
+  auto *d_hv = static_cast<int16_t *>(c->w_hv.p);
+  auto *d_n2 = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->w_hv.p) + ((hv_bytes + 15) & ~(size_t)15));
+  auto *d_nh = reinterpret_cast<uint32_t *>(d_n2 + n);
+  s = hg_sketch_batch_dev(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), n, p, d_hv, d_n2, d_nh);
+  if (s != HG_OK) return s;
+  HG_HIP(c, hipMemcpyAsync(hv_out, d_hv, hv_bytes, hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipMemcpyAsync(norm2_out, d_n2, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipMemcpyAsync(nhash_out, d_nh, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n_bps, uint32_t ksize,
+                                         uint64_t threshold, uint64_t seed, int canonical, uint32_t norm_mode,
+                                         uint64_t *out_hashes, size_t cap, size_t *n_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
+  *n_out = 0;
+  if (ksize < 1) return hg_fail(c, HG_ERR_INVALID, "ksize must be >= 1");
+  if (ksize > 32) return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize > 32 is not implemented on the device");
+  if (norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad norm mode");
+  if (n_bps && !seq) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
+  if (n_bps < ksize) return HG_OK;
+  HG_HIP(c, hipSetDevice(c->device));
+  std::vector<uint64_t> offs, l64;
+  const uint8_t *seqs[1] = {seq};
+  size_t lens[1] = {n_bps};
+  hg_status s = stage_sequences(c, seqs, lens, 1, offs, l64);
+  if (s != HG_OK) return s;
+  // capacity heuristic wants "scaled"; derive it from the threshold (threshold = MAX / scaled)
+  uint64_t scaled = threshold ? UINT64_MAX / threshold : UINT64_MAX;
+  if (scaled < 1) scaled = 1;
+  BatchPlan pl;
+  uint32_t *d_nd = nullptr;
+  s = sample_batch(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), 1, ksize, threshold, scaled,
+                   seed, canonical != 0, norm_mode, pl, &d_nd);
+  if (s != HG_OK) return s;
+  uint32_t nd = 0;
+  HG_HIP(c, hipMemcpyAsync(&nd, d_nd, sizeof nd, hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  *n_out = nd;
+  if (nd > cap) return hg_fail(c, HG_ERR_CAPACITY, "out_hashes too small");
+  if (nd) {
+    if (!out_hashes) return hg_fail(c, HG_ERR_INVALID, "out_hashes == NULL");
+    HG_HIP(c, hipMemcpyAsync(out_hashes, static_cast<uint64_t *>(c->w_hits.p) + pl.meta[0].hit_off,
+                             nd * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return HG_OK;
+}
+
+extern "C" hg_status hg_hv_encode(hg_ctx *c, const uint64_t *hashes, size_t n, uint32_t hv_d, uint32_t hv_layout,
+                                  int16_t *hv_out, int32_t *norm2_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (hv_d == 0 || hv_d > 32768) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be in 1..32768");
+  if (hv_layout > HG_LAYOUT_AVX2) return hg_fail(c, HG_ERR_INVALID, "bad layout");
+  if ((n && !hashes) || !hv_out || !norm2_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  if (n > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "too many hashes");
+  HG_HIP(c, hipSetDevice(c->device));
+  hg_status s;
+  if ((s = hg_ensure(c, c->w_gmeta, sizeof(hg_genome_meta))) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_hits, (n + 1) * sizeof(uint64_t))) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_cnt, 2 * sizeof(uint32_t))) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_hv, (size_t)hv_d * sizeof(int16_t) + 64)) != HG_OK) return s;
+  hg_genome_meta m{};
+  m.hit_off = 0, m.hit_cap = (uint32_t)n;
+  const uint32_t nd = (uint32_t)n;
+  auto *d_hv = static_cast<int16_t *>(c->w_hv.p);
+  auto *d_n2 = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->w_hv.p) + (((size_t)hv_d * 2 + 15) & ~(size_t)15));
+  HG_HIP(c, hipMemcpyAsync(c->w_gmeta.p, &m, sizeof m, hipMemcpyHostToDevice, c->stream));
+  HG_HIP(c, hipMemcpyAsync(c->w_cnt.p, &nd, sizeof nd, hipMemcpyHostToDevice, c->stream));
+  if (n) HG_HIP(c, hipMemcpyAsync(c->w_hits.p, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), 1,
+                             static_cast<uint64_t *>(c->w_hits.p), static_cast<uint32_t *>(c->w_cnt.p), hv_d,
+                             hv_layout, d_hv, d_n2));
+  HG_HIP(c, hipMemcpyAsync(hv_out, d_hv, (size_t)hv_d * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipMemcpyAsync(norm2_out, d_n2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dist
+// ---------------------------------------------------------------------------------------------
+namespace {
+hg_status check_dist(hg_ctx *c, size_t R, size_t Q, uint32_t hv_d, uint32_t ksize) {
+  if (R > 0x7FFFFFFFull || Q > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "R, Q must be < 2^31");
+  if (hv_d == 0 || hv_d > 65536) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be in 1..65536");
+  if (ksize == 0) return hg_fail(c, HG_ERR_INVALID, "ksize must be >= 1");
+  return HG_OK;
+}
+}  // namespace
+
+extern "C" hg_status hg_dist_full_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R,
+                                      const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, uint32_t hv_d,
+                                      uint32_t ksize, float *d_ani_out) {
+  if (!c) return HG_ERR_INVALID;
+  hg_status s = check_dist(c, R, Q, hv_d, ksize);
+  if (s != HG_OK) return s;
+  if (R == 0 || Q == 0) return HG_OK;
+  if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || !d_ani_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  HG_HIP(c, hipSetDevice(c->device));
+  hg_dist_args a{};
+  a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
+  a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
+  a.ani_out = d_ani_out;
+  return hg_run_dist(c, a);
+}
+
+extern "C" hg_status hg_dist_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R,
+                                 const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, uint32_t hv_d,
+                                 uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *d_out, size_t cap,
+                                 size_t *n_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
+  *n_out = 0;
+  hg_status s = check_dist(c, R, Q, hv_d, ksize);
+  if (s != HG_OK) return s;
+  if (R == 0 || Q == 0) return HG_OK;
+  if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  HG_HIP(c, hipSetDevice(c->device));
+  if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
+  auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
+  HG_HIP(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+  hg_dist_args a{};
+  a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
+  a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
+  a.hits = d_out, a.hit_count = d_count;
+  a.hit_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+  a.ani_th = ani_th, a.symmetric = symmetric;
+  if ((s = hg_run_dist(c, a)) != HG_OK) return s;
+  uint32_t found = 0;
+  HG_HIP(c, hipMemcpyAsync(&found, d_count, sizeof found, hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  *n_out = found;
+  if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
+  return HG_OK;
+}
+
+namespace {
+struct StagedDist {
+  const int16_t *d_ref, *d_qry;
+  const int32_t *d_rn, *d_qn;
+};
+hg_status stage_dist(hg_ctx *c, const int16_t *ref_hv, const int32_t *ref_n2, size_t R, const int16_t *qry_hv,
+                     const int32_t *qry_n2, size_t Q, uint32_t hv_d, StagedDist &o) {
+  hg_status s;
+  const size_t rb = R * (size_t)hv_d * 2, qb = Q * (size_t)hv_d * 2;
+  if ((s = hg_ensure(c, c->w_hv, rb + 64)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_hv2, qb + 64)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_n2a, R * 4 + 64)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_n2b, Q * 4 + 64)) != HG_OK) return s;
+  HG_HIP(c, hipMemcpyAsync(c->w_hv.p, ref_hv, rb, hipMemcpyHostToDevice, c->stream));
+  HG_HIP(c, hipMemcpyAsync(c->w_hv2.p, qry_hv, qb, hipMemcpyHostToDevice, c->stream));
+  HG_HIP(c, hipMemcpyAsync(c->w_n2a.p, ref_n2, R * 4, hipMemcpyHostToDevice, c->stream));
+  HG_HIP(c, hipMemcpyAsync(c->w_n2b.p, qry_n2, Q * 4, hipMemcpyHostToDevice, c->stream));
+  o.d_ref = static_cast<int16_t *>(c->w_hv.p), o.d_qry = static_cast<int16_t *>(c->w_hv2.p);
+  o.d_rn = static_cast<int32_t *>(c->w_n2a.p), o.d_qn = static_cast<int32_t *>(c->w_n2b.p);
+  return HG_OK;
+}
+}  // namespace
+
+extern "C" hg_status hg_dist_full(hg_ctx *c, const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
+                                  const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q, uint32_t hv_d,
+                                  uint32_t ksize, float *ani_out) {
+  if (!c) return HG_ERR_INVALID;
+  hg_status s = check_dist(c, R, Q, hv_d, ksize);
+  if (s != HG_OK) return s;
+  if (R == 0 || Q == 0) return HG_OK;
+  if (!ref_hv || !ref_norm2 || !qry_hv || !qry_norm2 || !ani_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  HG_HIP(c, hipSetDevice(c->device));
+  StagedDist sd;
+  if ((s = stage_dist(c, ref_hv, ref_norm2, R, qry_hv, qry_norm2, Q, hv_d, sd)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_ani, R * Q * sizeof(float) + 64)) != HG_OK) return s;
+  s = hg_dist_full_dev(c, sd.d_ref, sd.d_rn, R, sd.d_qry, sd.d_qn, Q, hv_d, ksize, static_cast<float *>(c->w_ani.p));
+  if (s != HG_OK) return s;
+  HG_HIP(c, hipMemcpyAsync(ani_out, c->w_ani.p, R * Q * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+extern "C" hg_status hg_dist(hg_ctx *c, const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
+                             const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q, uint32_t hv_d, uint32_t ksize,
+                             int symmetric, float ani_th, hg_ani_hit *out, size_t cap, size_t *n_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
+  *n_out = 0;
+  hg_status s = check_dist(c, R, Q, hv_d, ksize);
+  if (s != HG_OK) return s;
+  if (R == 0 || Q == 0) return HG_OK;
+  if (!ref_hv || !ref_norm2 || !qry_hv || !qry_norm2 || (cap && !out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  HG_HIP(c, hipSetDevice(c->device));
+  StagedDist sd;
+  if ((s = stage_dist(c, ref_hv, ref_norm2, R, qry_hv, qry_norm2, Q, hv_d, sd)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_ani, cap * sizeof(hg_ani_hit) + 64)) != HG_OK) return s;
+  size_t found = 0;
+  s = hg_dist_dev(c, sd.d_ref, sd.d_rn, R, sd.d_qry, sd.d_qn, Q, hv_d, ksize, symmetric, ani_th,
+                  static_cast<hg_ani_hit *>(c->w_ani.p), cap, &found);
+  *n_out = found;
+  if (s != HG_OK && s != HG_ERR_CAPACITY) return s;
+  const size_t ncopy = std::min(found, cap);
+  if (ncopy) {
+    HG_HIP(c, hipMemcpyAsync(out, c->w_ani.p, ncopy * sizeof(hg_ani_hit), hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return s;
+}
+
+extern "C" void hg_sort_ani_hits(hg_ani_hit *hits, size_t n, size_t Q, int symmetric) {
+  // dump_ani_file (src/utils.rs:262-269): stable ascending sort by ANI over the enumeration
+  // order (row-major, src/dist.rs:251-265), then reversed => descending ANI, ties in reverse
+  // enumeration order.
+  (void)symmetric;
+  auto key = [Q](const hg_ani_hit &h) { return (uint64_t)h.ref_idx * Q + h.qry_idx; };
+  std::sort(hits, hits + n, [&](const hg_ani_hit &a, const hg_ani_hit &b) {
+    if (a.ani != b.ani) return a.ani > b.ani;
+    return key(a) > key(b);
+  });
+}

@@ -1,0 +1,324 @@
+// hg_dist_kernels.hip -- all-pairs hypervector ANI on gfx950.
+//
+// Replaces dist::compute_hv_ani / compute_pairwise_ani (src/dist.rs:139-161,231-294): for every
+// (ref, query) pair   dot = sum_d r[d]*q[d]  (i32),  J = dot / (|r|^2 + |q|^2 - dot),
+// ANI = 1 + ln(2J/(1+J))/k, clamped, x100 -- float32 in the reference's operation order.
+//
+// The contraction is a dense R x Q x D GEMM and runs on the matrix cores.  The HV entries are
+// small integers (|x| ~ sqrt(n_hashes)), so they are converted once to f16 (exact for
+// |x| <= 2048) and multiplied with v_mfma_f32_16x16x32_f16; products are exact in f32, and the
+// f32 accumulator is exact as long as sum |r||q| over the accumulated K range stays below 2^24.
+// The prepass measures a guaranteed Cauchy-Schwarz bound for that sum per K-chunk; the kernel
+// moves the accumulator into i32 registers at chunk boundaries chosen from it.  If no chunk
+// size is safe (or |x| > 2048) the always-exact integer VALU kernel is used instead.  Either
+// way the dot product equals the reference's i32 value bit for bit; only logf differs from
+// glibc by <= 1 ulp.
+#include <vector>
+
+#include "hg_internal.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// ---- ANI epilogue (src/dist.rs:153-160) -----------------------------------------------------
+__device__ __forceinline__ float ani_from_dot(int32_t dot, int32_t nr, int32_t nq, float kf) {
+  const int32_t den = (int32_t)((uint32_t)nr + (uint32_t)nq - (uint32_t)dot);  // i32 wrapping
+  const float jaccard = (float)dot / (float)den;
+  const float inner = 1.0f / jaccard + 1.0f;
+  const float x = 2.0f / inner;
+  float ani = 1.0f + logf(x) / kf;
+  if (ani != ani) return 0.0f;  // is_nan -> 0
+  ani = fminf(ani, 1.0f);
+  ani = fmaxf(ani, 0.0f);
+  return ani * 100.0f;
+}
+
+// ---- prepass: i16 -> f16 (zero padded to Kp) + exactness statistics --------------------------
+// stats[0]            = max |x|
+// stats[1 + c]        = max over rows and aligned chunks of 64<<c dims of sum x^2   (c = 0..7)
+constexpr int N_CHUNK_CAND = 8;  // 64 .. 8192
+__global__ __launch_bounds__(256) void prep_kernel(const int16_t *__restrict__ hv, uint32_t rows,
+                                                   uint32_t hv_d, uint32_t kp, _Float16 *__restrict__ out,
+                                                   unsigned long long *__restrict__ stats) {
+  extern __shared__ unsigned long long s_blk[];  // kp/64 block sums
+  __shared__ uint32_t s_max;
+  const uint32_t row = blockIdx.x;
+  const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
+  _Float16 *__restrict__ dst = out + (size_t)row * kp;
+  const uint32_t nblk = kp / 64;
+  if (threadIdx.x == 0) s_max = 0;
+  for (uint32_t b = threadIdx.x; b < nblk; b += blockDim.x) s_blk[b] = 0;
+  __syncthreads();
+  uint32_t mx = 0;
+  // each wave handles whole 64-blocks so that the block sum is one wave reduction
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (uint32_t b = wave; b < nblk; b += nw) {
+    const uint32_t d = b * 64 + lane;
+    int32_t v = (d < hv_d) ? (int32_t)src[d] : 0;
+    dst[d] = (_Float16)v;
+    uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    mx = a > mx ? a : mx;
+    unsigned long long sq = (unsigned long long)a * a;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
+    if (lane == 0) s_blk[b] = sq;
+  }
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(&stats[0], (unsigned long long)s_max);
+  // chunk maxima for every candidate size
+  for (int c = 0; c < N_CHUNK_CAND; ++c) {
+    const uint32_t per = 1u << c;  // 64-blocks per chunk
+    unsigned long long best = 0;
+    for (uint32_t ch = threadIdx.x; ch * per < nblk; ch += blockDim.x) {
+      unsigned long long s = 0;
+      for (uint32_t b = ch * per; b < (ch + 1) * per && b < nblk; ++b) s += s_blk[b];
+      best = s > best ? s : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long t = __shfl_down(best, o);
+      best = t > best ? t : best;
+    }
+    if (lane == 0 && best) atomicMax(&stats[1 + c], best);
+  }
+}
+
+// ---- MFMA GEMM + ANI ------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_ROW = BK + 8;  // f16 elements per LDS row: 144 B => conflict-free ds_read_b128
+constexpr int GEMM_WG = 256;
+
+struct GemmArgs {
+  const _Float16 *A;  // Rp x Kp (ref)
+  const _Float16 *B;  // Qp x Kp (query)
+  const int32_t *nr, *nq;
+  uint32_t R, Q, Kp;
+  uint32_t chunk_steps;  // K-steps (of BK) per exact f32 accumulation window
+  float kf;
+  float *ani_out;
+  hg_ani_hit *hits;
+  uint32_t *hit_count;
+  uint32_t hit_cap;
+  float ani_th;
+  int symmetric;
+  uint32_t tiles_n;  // number of tile columns
+};
+
+template <bool CHUNKED>
+__global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) _Float16 sB[BN * LDS_ROW];
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
+  // contiguous run of tiles (bijective remap, MI355X guide T1)
+  const uint32_t nwg = gridDim.x;
+  uint32_t bid = blockIdx.x;
+  {
+    const uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const uint32_t tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const uint32_t row0 = tm * BM, col0 = tn * BN;
+  if (g.symmetric && row0 >= col0 + BN) return;  // tile entirely on/below the diagonal
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
+  const uint32_t fr = lane & 15, fq = lane >> 4;
+
+  float4v acc[4][4];
+  int32_t iacc[CHUNKED ? 4 : 1][CHUNKED ? 4 : 1][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
+      if (CHUNKED)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) iacc[m][n][r] = 0;
+    }
+
+  // staging: thread t moves 4 x 16 B of A and of B per K-step: row = t/8 + 32*i, 16-byte piece t%8
+  const uint32_t srow = tid >> 3, spc = tid & 7;
+  const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.Kp + spc * 8;
+  const _Float16 *gB = g.B + (size_t)(col0 + srow) * g.Kp + spc * 8;
+  const size_t rstep = (size_t)32 * g.Kp;
+  uint4 ra[4], rb[4];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const uint4 *>(gA + i * rstep + k0);
+      rb[i] = *reinterpret_cast<const uint4 *>(gB + i * rstep + k0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4 *>(&sA[(srow + 32 * i) * LDS_ROW + spc * 8]) = ra[i];
+      *reinterpret_cast<uint4 *>(&sB[(srow + 32 * i) * LDS_ROW + spc * 8]) = rb[i];
+    }
+  };
+
+  const uint32_t nsteps = g.Kp / BK;
+  gload(0);
+  uint32_t in_chunk = 0;
+  for (uint32_t ks = 0; ks < nsteps; ++ks) {
+    __syncthreads();  // previous step's fragment reads are done
+    lstore();
+    __syncthreads();
+    if (ks + 1 < nsteps) gload((ks + 1) * BK);  // in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      half8 af[4], bf[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        af[m] = *reinterpret_cast<const half8 *>(&sA[(wm * 64 + m * 16 + fr) * LDS_ROW + kk * 32 + fq * 8]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        bf[n] = *reinterpret_cast<const half8 *>(&sB[(wn * 64 + n * 16 + fr) * LDS_ROW + kk * 32 + fq * 8]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+    if (CHUNKED && ++in_chunk == g.chunk_steps) {  // move the exact f32 partial sums into i32
+      in_chunk = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) iacc[m][n][r] += (int32_t)acc[m][n][r];
+          acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
+
+  // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t i = row0 + wm * 64 + m * 16 + fq * 4 + r;
+      if (i >= g.R) continue;
+      const int32_t nri = g.nr[i];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const uint32_t j = col0 + wn * 64 + n * 16 + fr;
+        if (j >= g.Q) continue;
+        if (g.symmetric && i >= j) continue;
+        int32_t dot = (int32_t)acc[m][n][r];
+        if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[m][n][r]);
+        const float ani = ani_from_dot(dot, nri, g.nq[j], g.kf);
+        if (g.ani_out) g.ani_out[(size_t)i * g.Q + j] = ani;
+        if (g.hit_count && ani >= g.ani_th) {
+          const uint32_t idx = atomicAdd(g.hit_count, 1u);
+          if (idx < g.hit_cap) g.hits[idx] = hg_ani_hit{i, j, ani};
+        }
+      }
+    }
+  }
+}
+
+// ---- always-exact integer fallback -------------------------------------------------------------------
+// 16 x 16 outputs per workgroup, K staged through LDS in slices of 128 dims.
+constexpr int FB_T = 16, FB_K = 128;
+__global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__restrict__ ref,
+                                                               const int16_t *__restrict__ qry, hg_dist_args a,
+                                                               float kf) {
+  __shared__ int16_t sR[FB_T][FB_K + 2];
+  __shared__ int16_t sQ[FB_T][FB_K + 2];
+  const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const uint32_t i0 = blockIdx.y * FB_T, j0 = blockIdx.x * FB_T;
+  if (a.symmetric && i0 >= j0 + FB_T) return;
+  uint32_t acc = 0;
+  for (uint32_t k0 = 0; k0 < a.hv_d; k0 += FB_K) {
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < FB_T * FB_K; e += FB_T * FB_T) {
+      const uint32_t r = e / FB_K, k = e % FB_K;
+      const bool kin = k0 + k < a.hv_d;
+      sR[r][k] = (kin && i0 + r < a.R) ? ref[(size_t)(i0 + r) * a.hv_d + k0 + k] : (int16_t)0;
+      sQ[r][k] = (kin && j0 + r < a.Q) ? qry[(size_t)(j0 + r) * a.hv_d + k0 + k] : (int16_t)0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (uint32_t k = 0; k < FB_K; ++k) acc += (uint32_t)((int32_t)sR[ty][k] * (int32_t)sQ[tx][k]);
+  }
+  const uint32_t i = i0 + ty, j = j0 + tx;
+  if (i >= a.R || j >= a.Q) return;
+  if (a.symmetric && i >= j) return;
+  const float ani = ani_from_dot((int32_t)acc, a.ref_n2[i], a.qry_n2[j], kf);
+  if (a.ani_out) a.ani_out[(size_t)i * a.Q + j] = ani;
+  if (a.hit_count && ani >= a.ani_th) {
+    const uint32_t idx = atomicAdd(a.hit_count, 1u);
+    if (idx < a.hit_cap) a.hits[idx] = hg_ani_hit{i, j, ani};
+  }
+}
+
+}  // namespace
+
+hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
+  const uint32_t Kp = (a.hv_d + BK - 1) / BK * BK;
+  const uint32_t Rp = (a.R + BM - 1) / BM * BM, Qp = (a.Q + BN - 1) / BN * BN;
+  const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
+  hg_status s;
+  if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * Kp * 2)) != HG_OK) return s;
+  if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * Kp * 2)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_stats, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long))) != HG_OK) return s;
+  auto *fa = static_cast<_Float16 *>(c->w_f16a.p);
+  auto *fb = same ? fa : static_cast<_Float16 *>(c->w_f16b.p);
+  auto *st = static_cast<unsigned long long *>(c->w_stats.p);
+  HG_HIP(c, hipMemsetAsync(st, 0, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long), c->stream));
+  if (Rp > a.R) HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * Kp, 0, (size_t)(Rp - a.R) * Kp * 2, c->stream));
+  if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * Kp, 0, (size_t)(Qp - a.Q) * Kp * 2, c->stream));
+  const size_t plds = (size_t)(Kp / 64) * sizeof(unsigned long long);
+  hipLaunchKernelGGL(prep_kernel, dim3(a.R), dim3(256), plds, c->stream, a.ref_hv, a.R, a.hv_d, Kp, fa, st);
+  HG_HIP(c, hipGetLastError());
+  if (!same) {
+    hipLaunchKernelGGL(prep_kernel, dim3(a.Q), dim3(256), plds, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, fb,
+                       st + 1 + N_CHUNK_CAND);
+    HG_HIP(c, hipGetLastError());
+  }
+  unsigned long long h[2 * (1 + N_CHUNK_CAND)];
+  HG_HIP(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  const unsigned long long *hr = h, *hq = same ? h : h + 1 + N_CHUNK_CAND;
+
+  // largest accumulation window whose guaranteed bound sum|r||q| <= sqrt(SR*SQ) stays <= 2^24
+  int best_c = -1;
+  if (hr[0] <= 2048 && hq[0] <= 2048) {
+    for (int cnd = N_CHUNK_CAND - 1; cnd >= 0; --cnd) {
+      const unsigned __int128 prod = (unsigned __int128)hr[1 + cnd] * hq[1 + cnd];
+      if (prod <= ((unsigned __int128)1 << 48)) {
+        best_c = cnd;
+        break;
+      }
+    }
+  }
+  const float kf = (float)a.ksize;
+  if (best_c < 0) {  // values too large for the f16 path: exact integer kernel
+    dim3 grid((a.Q + FB_T - 1) / FB_T, (a.R + FB_T - 1) / FB_T);
+    hipLaunchKernelGGL(dist_int_kernel, grid, dim3(FB_T * FB_T), 0, c->stream, a.ref_hv, a.qry_hv, a, kf);
+    HG_HIP(c, hipGetLastError());
+    return HG_OK;
+  }
+  GemmArgs g{};
+  g.A = fa, g.B = fb, g.nr = a.ref_n2, g.nq = a.qry_n2;
+  g.R = a.R, g.Q = a.Q, g.Kp = Kp;
+  g.chunk_steps = (64u << best_c) / BK;
+  g.kf = kf;
+  g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
+  g.ani_th = a.ani_th, g.symmetric = a.symmetric;
+  g.tiles_n = Qp / BN;
+  const uint32_t n_tiles = (Rp / BM) * g.tiles_n;
+  const bool whole_k = (64u << best_c) >= Kp;  // one window covers K: no i32 side accumulators
+  if (whole_k)
+    hipLaunchKernelGGL((dist_mfma_kernel<false>), dim3(n_tiles), dim3(GEMM_WG), 0, c->stream, g);
+  else
+    hipLaunchKernelGGL((dist_mfma_kernel<true>), dim3(n_tiles), dim3(GEMM_WG), 0, c->stream, g);
+  HG_HIP(c, hipGetLastError());
+  return HG_OK;
+}

@@ -1,0 +1,233 @@
+// hg_formats.cpp -- host-side data formats either side of the device path:
+//   * lossless HV bit-packing   (hd::compress_hd_sketch / decompress_hd_sketch, src/hd.rs:114-232)
+//   * the .sketch container     (bincode 1.3 of Vec<FileSketch>, src/types.rs:224-235,
+//                                src/utils.rs:234-258)
+//   * FASTA -> merged sequence  (fastx_reader::read_merge_seq, src/fastx_reader.rs:6-29)
+// The BitPacker8x and bincode layouts are restated from the published crate algorithms; no
+// reference-produced .sketch file exists in this environment, so byte compatibility with the
+// Rust binary is UNPINNED ("parity status").
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hypergen.h"
+
+extern "C" uint32_t hg_hv_quant_bits(const int16_t *hv, uint32_t hv_d) {
+  if (!hv || hv_d == 0) return 6;
+  int16_t mn = hv[0], mx = hv[0];
+  for (uint32_t d = 1; d < hv_d; ++d) {
+    mn = hv[d] < mn ? hv[d] : mn;
+    mx = hv[d] > mx ? hv[d] : mx;
+  }
+  uint32_t q = 6;  // src/hd.rs:123-136: widen until [-2^(q-1), 2^(q-1)-1] covers [min, max]
+  while (q < 16) {
+    const int32_t lo = -(1 << (q - 1)), hi = (1 << (q - 1)) - 1;
+    if (lo <= mn && hi >= mx) break;
+    ++q;
+  }
+  return q;
+}
+
+namespace {
+// BitPacker8x block: 256 values = 32 rows x 8 lanes; lane l packs its 32 values LSB-first into
+// q u32 words, word w of lane l is output u32 number 8*w + l; values are OR-ed in unmasked.
+void pack_block(const uint32_t *in, uint32_t q, uint32_t *out) {
+  for (uint32_t l = 0; l < 8; ++l) {
+    uint32_t acc = 0, w = 0;
+    for (uint32_t r = 0; r < 32; ++r) {
+      const uint32_t v = in[8 * r + l], cur = (r * q) & 31;
+      acc = cur ? (acc | (v << cur)) : v;
+      const uint32_t remaining = 32 - cur;
+      if (remaining <= q) {
+        out[8 * w + l] = acc;
+        ++w;
+        acc = remaining < q ? (v >> remaining) : 0;
+      }
+    }
+  }
+}
+void unpack_block(const uint32_t *in, uint32_t q, uint32_t *out) {
+  const uint32_t mask = q >= 32 ? 0xffffffffu : ((1u << q) - 1);
+  for (uint32_t l = 0; l < 8; ++l)
+    for (uint32_t r = 0; r < 32; ++r) {
+      const uint32_t bit = r * q, w = bit >> 5, cur = bit & 31;
+      uint32_t v = in[8 * w + l] >> cur;
+      if (cur + q > 32) v |= in[8 * (w + 1) + l] << (32 - cur);
+      out[8 * r + l] = v & mask;
+    }
+}
+}  // namespace
+
+extern "C" hg_status hg_hv_pack(const int16_t *hv, uint32_t hv_d, uint32_t q, uint8_t *packed) {
+  if (!hv || !packed || q < 1 || q > 16 || hv_d % 256) return HG_ERR_INVALID;
+  const int16_t offset = (int16_t)(1 << (q - 1));  // i16 arithmetic, src/hd.rs:140-141
+  uint32_t blk[256], out[8 * 16];
+  for (uint32_t b = 0; b < hv_d / 256; ++b) {
+    for (uint32_t i = 0; i < 256; ++i) blk[i] = (uint32_t)(int32_t)(int16_t)(hv[b * 256 + i] + offset);
+    pack_block(blk, q, out);
+    std::memcpy(packed + (size_t)32 * q * b, out, (size_t)32 * q);
+  }
+  return HG_OK;
+}
+
+extern "C" hg_status hg_hv_unpack(const uint8_t *packed, uint32_t hv_d, uint32_t q, int16_t *hv) {
+  if (!hv || !packed || q < 1 || q > 16 || hv_d % 256) return HG_ERR_INVALID;
+  const int16_t offset = (int16_t)(1 << (q - 1));
+  uint32_t blk[256], in[8 * 16];
+  for (uint32_t b = 0; b < hv_d / 256; ++b) {
+    std::memcpy(in, packed + (size_t)32 * q * b, (size_t)32 * q);
+    unpack_block(in, q, blk);
+    for (uint32_t i = 0; i < 256; ++i) hv[b * 256 + i] = (int16_t)((int16_t)blk[i] - offset);  // :206-212
+  }
+  return HG_OK;
+}
+
+// ---- .sketch: bincode 1.x default config = little endian, fixed-width ints, u64 lengths --------------
+struct hg_sketch_file {
+  std::vector<hg_file_sketch> recs;
+  std::vector<std::string> names;
+  std::vector<std::vector<int16_t>> payloads;
+};
+
+namespace {
+template <class T>
+void put(std::vector<uint8_t> &o, T v) {
+  uint8_t b[sizeof(T)];
+  std::memcpy(b, &v, sizeof(T));
+  o.insert(o.end(), b, b + sizeof(T));
+}
+template <class T>
+bool get(const uint8_t *&p, const uint8_t *end, T &v) {
+  if ((size_t)(end - p) < sizeof(T)) return false;
+  std::memcpy(&v, p, sizeof(T));
+  p += sizeof(T);
+  return true;
+}
+}  // namespace
+
+extern "C" hg_status hg_sketch_file_write(const char *path, const hg_file_sketch *recs, size_t n) {
+  if (!path || (n && !recs)) return HG_ERR_INVALID;
+  std::vector<uint8_t> o;
+  put<uint64_t>(o, n);  // Vec length
+  for (size_t i = 0; i < n; ++i) {
+    const hg_file_sketch &r = recs[i];  // field order of src/types.rs:224-235
+    put<uint8_t>(o, r.ksize);
+    put<uint64_t>(o, r.scaled);
+    put<uint8_t>(o, r.canonical ? 1 : 0);
+    put<uint64_t>(o, r.seed);
+    put<uint64_t>(o, r.hv_d);  // usize
+    put<uint8_t>(o, r.hv_quant_bits);
+    put<int32_t>(o, r.hv_norm_2);
+    const size_t sl = r.file_str ? std::strlen(r.file_str) : 0;
+    put<uint64_t>(o, sl);
+    o.insert(o.end(), (const uint8_t *)r.file_str, (const uint8_t *)r.file_str + sl);
+    put<uint64_t>(o, r.hv_len);
+    const uint8_t *hb = reinterpret_cast<const uint8_t *>(r.hv);
+    o.insert(o.end(), hb, hb + r.hv_len * 2);
+  }
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return HG_ERR_IO;
+  const bool ok = o.empty() || std::fwrite(o.data(), 1, o.size(), f) == o.size();
+  return (std::fclose(f) == 0 && ok) ? HG_OK : HG_ERR_IO;
+}
+
+extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out) {
+  if (!path || !out) return HG_ERR_INVALID;
+  *out = nullptr;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return HG_ERR_IO;
+  std::vector<uint8_t> buf;
+  uint8_t tmp[1 << 16];
+  size_t got;
+  while ((got = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+  std::fclose(f);
+  const uint8_t *p = buf.data(), *end = p + buf.size();
+  uint64_t n = 0;
+  if (!get(p, end, n)) return HG_ERR_IO;
+  hg_sketch_file *sf = new (std::nothrow) hg_sketch_file();
+  if (!sf) return HG_ERR_OOM;
+  if (n > buf.size()) {  // each record is > 1 byte: cheap sanity bound
+    delete sf;
+    return HG_ERR_IO;
+  }
+  sf->recs.resize(n), sf->names.resize(n), sf->payloads.resize(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    hg_file_sketch &r = sf->recs[i];
+    std::memset(&r, 0, sizeof r);
+    uint64_t sl = 0, hl = 0;
+    bool ok = get(p, end, r.ksize) && get(p, end, r.scaled) && get(p, end, r.canonical) &&
+              get(p, end, r.seed) && get(p, end, r.hv_d) && get(p, end, r.hv_quant_bits) &&
+              get(p, end, r.hv_norm_2) && get(p, end, sl) && sl <= (uint64_t)(end - p);
+    if (ok) {
+      sf->names[i].assign(reinterpret_cast<const char *>(p), sl);
+      p += sl;
+      ok = get(p, end, hl) && hl <= (uint64_t)(end - p) / 2;
+    }
+    if (!ok) {
+      delete sf;
+      return HG_ERR_IO;
+    }
+    sf->payloads[i].resize(hl);
+    if (hl) std::memcpy(sf->payloads[i].data(), p, hl * 2);
+    p += hl * 2;
+    r.hv_len = hl;
+  }
+  for (uint64_t i = 0; i < n; ++i) {  // pointers only after the vectors stopped moving
+    sf->recs[i].file_str = sf->names[i].c_str();
+    sf->recs[i].hv = sf->payloads[i].data();
+  }
+  *out = sf;
+  return HG_OK;
+}
+
+extern "C" size_t hg_sketch_file_count(const hg_sketch_file *f) { return f ? f->recs.size() : 0; }
+extern "C" const hg_file_sketch *hg_sketch_file_get(const hg_sketch_file *f, size_t i) {
+  return (f && i < f->recs.size()) ? &f->recs[i] : nullptr;
+}
+extern "C" void hg_sketch_file_free(hg_sketch_file *f) { delete f; }
+
+// ---- FASTA -----------------------------------------------------------------------------------------------
+extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {
+  if (!path || !out || !n_bps) return HG_ERR_INVALID;
+  *out = nullptr, *n_bps = 0;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return HG_ERR_IO;
+  std::fseek(f, 0, SEEK_END);
+  const long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  if (sz < 0) {
+    std::fclose(f);
+    return HG_ERR_IO;
+  }
+  std::vector<uint8_t> text((size_t)sz);
+  if (sz && std::fread(text.data(), 1, (size_t)sz, f) != (size_t)sz) {
+    std::fclose(f);
+    return HG_ERR_IO;
+  }
+  std::fclose(f);
+  uint8_t *o = static_cast<uint8_t *>(std::malloc((size_t)sz + 64));  // merged text is never longer
+  if (!o) return HG_ERR_OOM;
+  size_t w = 0, i = 0;
+  const size_t n = (size_t)sz;
+  while (i < n) {  // line by line: header -> one 'N', else the line minus "\n" / "\r\n"
+    size_t j = i;
+    while (j < n && text[j] != '\n') ++j;
+    if (text[i] == '>') {
+      o[w++] = 'N';
+    } else {
+      size_t e = j;
+      if (e > i && text[e - 1] == '\r') --e;  // src/fastx_reader.rs:19-21 pops '\r' with or without '\n'
+      std::memcpy(o + w, text.data() + i, e - i);
+      w += e - i;
+    }
+    i = j < n ? j + 1 : j;
+  }
+  std::memset(o + w, 0, 64);
+  *out = o, *n_bps = w;
+  return HG_OK;
+}
+
+extern "C" void hg_free(void *p) { std::free(p); }

@@ -1,0 +1,103 @@
+// hg_internal.h -- shared declarations of the library's translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/hypergen.h"
+
+// ---- error plumbing ----------------------------------------------------------------
+struct hg_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // own_stream or a borrowed one
+  std::string err;
+  int n_cu = 256;
+
+  // growable device workspaces (never shrunk; freed in hg_ctx_destroy)
+  struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+  };
+  Buf w_items;    // uint32 work-item -> genome table
+  Buf w_gmeta;    // per-genome metadata (hg_genome_meta)
+  Buf w_hits;     // sampled hashes, per-genome regions
+  Buf w_cnt;      // per-genome raw hit counters + distinct counts
+  Buf w_seq;      // staged sequences (host entry points)
+  Buf w_hv;       // staged HV output (host entry points)
+  Buf w_misc;     // small scalars (hit counters of dist, flags)
+  Buf w_f16a;     // f16 copies of the HV matrices for the MFMA path
+  Buf w_f16b;
+  Buf w_stats;    // per-row |max| / block sums of squares
+  Buf w_ani;      // staged ANI output (host entry points)
+  Buf w_hv2;      // staged second HV matrix (host dist)
+  Buf w_n2a, w_n2b;
+  // pinned host scratch
+  void *h_pin = nullptr;
+  size_t h_pin_cap = 0;
+};
+
+hg_status hg_fail(hg_ctx *ctx, hg_status s, const std::string &msg);
+hg_status hg_ensure(hg_ctx *ctx, hg_ctx::Buf &b, size_t bytes);
+hg_status hg_ensure_pinned(hg_ctx *ctx, size_t bytes);
+
+#define HG_HIP(ctx, expr)                                                              \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return hg_fail((ctx), HG_ERR_HIP,                                                \
+                     std::string(#expr) + ": " + hipGetErrorString(e__));              \
+  } while (0)
+
+// ---- k-mer sampling kernel interface ---------------------------------------------------
+// One record per genome of a batch, in device memory.
+struct hg_genome_meta {
+  uint64_t seq_off;     // byte offset of the genome in d_seq (multiple of 4)
+  uint64_t n_bps;       // length in bytes
+  uint64_t hit_off;     // first slot of the genome's region in the hit buffer
+  uint32_t hit_cap;     // slots in that region
+  uint32_t item_first;  // index of the genome's first work item
+};
+
+// starts handled by one work item (one workgroup) of the fast kernel for a given k
+uint32_t hg_kmer_item_starts(uint32_t ksize);
+
+// Launch the hash + sample kernel over all work items.  d_cnt[g] is incremented once per
+// sampled k-mer (it may exceed hit_cap: only the first hit_cap hashes are stored).
+hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
+                                 const uint32_t *d_item_genome, uint32_t n_items, uint32_t ksize,
+                                 uint64_t threshold, uint64_t seed, bool canonical, uint32_t norm_mode,
+                                 uint64_t *d_hits, uint32_t *d_cnt);
+
+// keys one workgroup can sort in LDS; genomes with more sampled hashes are sorted in place in
+// global memory, which needs a power-of-two sized hit region (the host rounds hit_cap up).
+#define HG_SORT_LDS_MAX_KEYS 16384u
+
+// ---- sort/unique + encode kernels ---------------------------------------------------------
+// Sorts each genome's hits ascending, removes duplicates in place (region start),
+// d_ndistinct[g] = distinct count.  max_cnt_pow2 bounds the LDS sort size.
+hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
+                                 uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
+                                 uint32_t max_cap);
+
+hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
+                            const uint64_t *d_hits, const uint32_t *d_ndistinct, uint32_t hv_d,
+                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2);
+
+// ---- dist kernels ------------------------------------------------------------------------------
+struct hg_dist_args {
+  const int16_t *ref_hv;
+  const int32_t *ref_n2;
+  const int16_t *qry_hv;
+  const int32_t *qry_n2;
+  uint32_t R, Q, hv_d, ksize;
+  float *ani_out;        // full matrix or nullptr
+  hg_ani_hit *hits;      // thresholded output or nullptr
+  uint32_t *hit_count;   // device counter
+  uint32_t hit_cap;
+  float ani_th;
+  int symmetric;
+};
+hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a);

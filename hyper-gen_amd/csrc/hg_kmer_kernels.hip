@@ -1,0 +1,364 @@
+// hg_kmer_kernels.hip -- FracMinHash k-mer hash + threshold sample on gfx950.
+//
+// Computes what extract_kmer_hash (src/sketch.rs:71-98) / cuda_kmer_t1ha2
+// (src/cuda_kernel.cu:250-321) compute: for every k-window of ACGT bases the canonical
+// strand's ASCII bytes are hashed with t1ha2_atonce(seed) and hashes below the threshold
+// are kept.  The design is MI355X-first, not the reference's (1 thread x 512 k-mers with
+// two 544-byte scratch arrays):
+//
+//  * one lane owns a 32-base register window and the M = (33-k)&~3 k-mers that start in
+//    its first M bases; a 256-lane workgroup walks 8 consecutive tiles, so one 5 Mbp
+//    genome is ~200 workgroups and a 1000-genome batch fills the 256 CUs many times;
+//  * bases are classified 4 at a time (SWAR on dwords): 2-bit codes, upper-cased ASCII
+//    and complement ASCII come from v_perm_b32 lookups, validity from one XOR;
+//  * the canonical strand is chosen by ONE 64-bit compare of 2-bit packed k-mers
+//    (A<C<G<T holds both in ASCII and in the 2-bit code, so this equals the reference's
+//    byte-wise compare, src/cuda_kernel.cu:306-311);
+//  * the hash input words are cut out of the register window with v_alignbyte_b32 /
+//    v_perm_b32 (constant selectors), only the chosen strand is hashed, nothing touches
+//    scratch or LDS;
+//  * t1ha2 is specialised at compile time for k (17..24 => 3 mixups + final = 4 128-bit
+//    products + 2 64-bit products = 22 v_mad_u64_u32 / v_mul_lo_u32);
+//  * survivors (1/scaled of the k-mers) are appended through one aggregated atomic per
+//    wave into the genome's slice of the hit buffer (lossless: no 8-slot cap like
+//    src/cuda_kernel.cu:316, hash value 0 is kept).
+//
+// The kernel is integer-VALU bound (~170 lane-ops per input byte), not HBM bound.
+#include <utility>
+
+#include "hg_internal.h"
+
+namespace {
+
+// t1ha2 primes (src/cuda_kernel.cu:71-77)
+constexpr uint64_t P0 = 0xEC99BF0D8372CAABull;
+constexpr uint64_t P1 = 0x82434FE90EDCEF39ull;
+constexpr uint64_t P2 = 0xD4F06DB99D67BE4Bull;
+constexpr uint64_t P3 = 0xBD9CACC22C6E9571ull;
+constexpr uint64_t P4 = 0x9C06FAF4D023E3ABull;
+constexpr uint64_t P5 = 0xC060724A8424F345ull;
+constexpr uint64_t P6 = 0xCB5AF53AE3AAAC31ull;
+
+__device__ __forceinline__ uint64_t rot64(uint64_t v, unsigned s) {
+  return (v >> s) | (v << (64 - s));
+}
+// src/cuda_kernel.cu:136-141
+__device__ __forceinline__ void mixup64(uint64_t &a, uint64_t &b, uint64_t v, uint64_t prime) {
+  unsigned __int128 m = (unsigned __int128)(b + v) * prime;
+  a ^= (uint64_t)m;
+  b += (uint64_t)(m >> 64);
+}
+// src/cuda_kernel.cu:143-153
+__device__ __forceinline__ uint64_t final64(uint64_t a, uint64_t b) {
+  uint64_t x = (a + rot64(b, 41)) * P0;
+  uint64_t y = (rot64(a, 23) + b) * P6;
+  unsigned __int128 m = (unsigned __int128)(x ^ y) * P5;
+  return (uint64_t)m ^ (uint64_t)(m >> 64);
+}
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t c) {  // (a << SH) | c
+  uint32_t r;
+  asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
+  return r;
+}
+__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) {
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// t1ha2_atonce for a compile-time length K <= 32 whose bytes are given as little-endian
+// dwords d[0..ceil(K/4)) with the unused bytes of the last dword zero
+// (tail switch of src/cuda_kernel.cu:205-245).
+template <int K>
+__device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed) {
+  constexpr int ND = (K + 3) / 4;
+  auto word = [&](int i) -> uint64_t {  // i-th 8-byte word, zero padded
+    uint32_t lo = (2 * i < ND) ? d[2 * i] : 0u;
+    uint32_t hi = (2 * i + 1 < ND) ? d[2 * i + 1] : 0u;
+    return mk64(lo, hi);
+  };
+  uint64_t a = seed, b = (uint64_t)K;
+  int i = 0;
+  if (K > 24) mixup64(a, b, word(i++), P4);
+  if (K > 16) mixup64(b, a, word(i++), P3);
+  if (K > 8) mixup64(a, b, word(i++), P2);
+  if (K > 0) mixup64(b, a, word(i++), P1);
+  return final64(a, b);
+}
+
+// runtime-length variant for the generic kernel (len <= 32), bytes in w[0..3]
+__device__ __forceinline__ uint64_t t1ha2_le32(const uint64_t w[4], uint32_t len, uint64_t seed) {
+  uint64_t a = seed, b = (uint64_t)len;
+  int i = 0;
+  if (len > 24) mixup64(a, b, w[i++], P4);
+  if (len > 16) mixup64(b, a, w[i++], P3);
+  if (len > 8) mixup64(a, b, w[i++], P2);
+  if (len > 0) mixup64(b, a, w[i++], P1);
+  return final64(a, b);
+}
+
+template <int... Js, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F &&f) {
+  (f(std::integral_constant<int, Js>{}), ...);
+}
+
+// ---- geometry ---------------------------------------------------------------------------
+constexpr int WG = 256;        // lanes per workgroup
+constexpr int TILES_PER_ITEM = 8;
+template <int K>
+struct Geo {
+  static constexpr int M = (33 - K) & ~3;  // k-mer starts per lane, multiple of 4 (dword stride)
+  static constexpr int ND = (K + 3) / 4;   // dwords of one k-mer
+  static constexpr int NB = K - 4 * (ND - 1);  // bytes used in the last dword (1..4)
+  static constexpr int TILE = WG * M;
+  static constexpr int ITEM = TILE * TILES_PER_ITEM;
+};
+constexpr int GEN_STARTS = 32;                       // generic kernel: starts per lane
+constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
+constexpr bool fast_k(uint32_t k) { return k >= 9 && k <= 29; }
+
+__device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm, uint32_t g,
+                                           uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  uint32_t idx = atomicAdd(&cnt[g], 1u);  // hipcc folds this into one atomic per wave
+  if (idx < gm.hit_cap) hits[gm.hit_off + idx] = h;
+}
+
+// =========================================================================================
+// fast kernel: compile-time k in [9, 29]
+// =========================================================================================
+template <int K, bool CANON>
+__global__ __launch_bounds__(WG) void kmer_sample_fast(
+    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
+    const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
+    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  using G = Geo<K>;
+  constexpr int M = G::M, ND = G::ND, NB = G::NB;
+  constexpr uint64_t MASK2K = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
+  constexpr uint32_t MASKK = (1u << K) - 1;
+
+  const uint32_t item = blockIdx.x;
+  const uint32_t g = item_genome[item];
+  const hg_genome_meta gm = meta[g];
+  const uint64_t n_bps = gm.n_bps;
+  if (n_bps < (uint64_t)K) return;
+  const uint64_t n_starts = n_bps - K + 1;
+  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+
+#pragma unroll 1
+  for (int tile = 0; tile < TILES_PER_ITEM; ++tile) {
+    const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
+    if (tile_start >= n_starts) break;  // uniform
+    const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * M;
+
+    // ---- load the lane's 32-base window (8 dwords, 4-byte aligned, M-byte lane stride) ----
+    uint32_t x[8];
+    {
+      // lanes past the genome end produce nothing (inv = all ones below): point them at
+      // the genome start so that they never read beyond the 32-byte slack
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(gseq + (p0 < n_bps ? p0 : 0));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) x[t] = src[t];
+    }
+
+    // ---- classify 4 bases per dword -----------------------------------------------------
+    uint32_t FA[8], CA[8];      // upper-case ASCII, complement ASCII (same byte order)
+    uint32_t dacc = 0;          // != 0  <=> some byte of the window is not ACGTacgt
+    uint32_t Glo = 0, Ghi = 0;  // 2-bit codes, base b at bits [2b, 2b+1]
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      uint32_t xv = x[t];
+      if (u2t) {  // needletail normalize: u/U -> T  ('U' ^ 'T' == 1)
+        uint32_t e = (xv & 0xDFDFDFDFu) ^ 0x55555555u;
+        uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
+        xv ^= (~nz & 0x80808080u) >> 7;
+      }
+      uint32_t u = xv & 0xDFDFDFDFu;
+      uint32_t tt = xv ^ (xv >> 1);
+      uint32_t cd = (tt >> 1) & 0x03030303u;  // A,C,G,T -> 0,1,2,3 per byte
+      FA[t] = __builtin_amdgcn_perm(0u, 0x54474341u, cd);  // "ACGT"[code]
+      CA[t] = __builtin_amdgcn_perm(0u, 0x41434754u, cd);  // "TGCA"[code]
+      dacc |= u ^ FA[t];
+      // (cd << 6) | cd etc.; written as v_lshl_or_b32 because LLVM would otherwise turn the
+      // disjoint shift-or pairs into quarter-rate v_mul_lo_u32 by 65 / 4097
+      uint32_t t1 = lshl_or<6>(cd, cd);
+      uint32_t t2 = lshl_or<12>(t1, t1);
+      uint32_t p = (t2 >> 18) & 0xFFu;  // c0 | c1<<2 | c2<<4 | c3<<6
+      if (t < 4) Glo |= p << (8 * t);
+      else Ghi |= p << (8 * (t - 4));
+    }
+    // MSB-first copy of the codes (base 0 in the top two bits) for the forward k-mer value
+    auto pairrev = [](uint32_t v) {
+      uint32_t br = __builtin_bitreverse32(v);
+      return ((br >> 1) & 0x55555555u) | ((br & 0x55555555u) << 1);
+    };
+    const uint64_t Gl = mk64(Glo, Ghi);
+    const uint64_t Gm = mk64(pairrev(Ghi), pairrev(Glo));
+    const uint64_t Gc = ~Gl;  // complement codes; read LSB-first this IS the reverse strand
+
+    // ---- validity: rare path, taken only by waves that see a non-base or the genome end ----
+    const int64_t rem64 = (int64_t)n_bps - (int64_t)p0;
+    const uint32_t rem = rem64 >= 32 ? 32u : (rem64 <= 0 ? 0u : (uint32_t)rem64);
+    uint32_t inv = 0;  // bit b set <=> base b of the window cannot be part of a k-mer
+    if (__any((dacc != 0) | (rem < 32))) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        uint32_t xv = x[t];
+        if (u2t) {
+          uint32_t e = (xv & 0xDFDFDFDFu) ^ 0x55555555u;
+          uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;
+          xv ^= (~nz & 0x80808080u) >> 7;
+        }
+        uint32_t d = (xv & 0xDFDFDFDFu) ^ FA[t];
+        uint32_t z = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+        uint32_t nib = (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+        inv |= nib << (4 * t);
+      }
+      if (rem < 32) inv |= (rem == 0) ? ~0u : (~0u << rem);
+    }
+
+    // ---- the lane's M k-mers ------------------------------------------------------------------
+    static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int q = j >> 2, r = j & 3;
+      const bool valid = ((inv >> j) & MASKK) == 0;
+
+      bool use_rc = false;
+      if (CANON) {
+        const uint64_t fv = (Gm >> (2 * (32 - K - j))) & MASK2K;
+        const uint64_t rv = (Gc >> (2 * j)) & MASK2K;
+        use_rc = rv < fv;
+      }
+
+      uint32_t d[ND];
+#pragma unroll
+      for (int m = 0; m < ND; ++m) {
+        // forward strand: bytes j+4m .. j+4m+3 of FA
+        uint32_t f;
+        if (m < ND - 1) {
+          f = (r == 0) ? FA[q + m] : __builtin_amdgcn_alignbyte(FA[q + m + 1], FA[q + m], r);
+        } else if (r + NB <= 4) {
+          f = (NB == 4) ? FA[q + m] : ((FA[q + m] >> (8 * r)) & ((1u << (8 * (NB & 3))) - 1));
+        } else {
+          f = __builtin_amdgcn_alignbyte(FA[q + m + 1], FA[q + m], r);
+          if (NB < 4) f &= (1u << (8 * (NB & 3))) - 1;
+        }
+        uint32_t v = f;
+        if (CANON) {
+          // reverse strand: byte i of this dword is comp(base[e - i]), e = j+K-1-4m
+          const int e = j + K - 1 - 4 * m;
+          const int Q = e >> 2, s = e & 3;
+          uint32_t sel = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            uint32_t sb = (4 * m + i < K) ? (uint32_t)(s + 4 - i) : 0x0cu;  // 0x0c -> 0x00
+            sel |= sb << (8 * i);
+          }
+          uint32_t rcw = __builtin_amdgcn_perm(CA[Q], (Q >= 1) ? CA[Q - 1] : 0u, sel);
+          v = use_rc ? rcw : f;
+        }
+        d[m] = v;
+      }
+      const uint64_t h = t1ha2_fixed<K>(d, seed);
+      if (valid && h < threshold) append_hit(h, gm, g, hits, cnt);
+    });
+  }
+}
+
+// =========================================================================================
+// generic kernel: any k <= 32 at run time (slow path for unusual k)
+// =========================================================================================
+__device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
+  // 0..3 for ACGT (either case), 4 otherwise
+  uint8_t u = c & 0xDF;
+  if (u == 'A') return 0;
+  if (u == 'C') return 1;
+  if (u == 'G') return 2;
+  if (u == 'T') return 3;
+  if (u2t && u == 'U') return 3;
+  return 4;
+}
+
+__global__ __launch_bounds__(WG) void kmer_sample_generic(
+    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
+    const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
+    uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  const uint32_t item = blockIdx.x;
+  const uint32_t g = item_genome[item];
+  const hg_genome_meta gm = meta[g];
+  const uint64_t n_bps = gm.n_bps;
+  if (n_bps < ksize) return;
+  const uint64_t n_starts = n_bps - ksize + 1;
+  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint64_t s0 = (uint64_t)(item - gm.item_first) * GEN_ITEM + (uint64_t)threadIdx.x * GEN_STARTS;
+  if (s0 >= n_starts) return;
+  const uint64_t s1 = (s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts;  // starts [s0, s1)
+  const uint64_t mask = (ksize == 32) ? ~0ull : ((1ull << (2 * ksize)) - 1);
+  const char ACGT[4] = {'A', 'C', 'G', 'T'};
+
+  uint64_t fwd = 0, rev = 0;  // MSB-first forward value / reverse-complement value
+  uint32_t run = 0;
+  for (uint64_t i = s0; i < s1 + ksize - 1; ++i) {
+    uint32_t c = base_code(gseq[i], u2t);
+    if (c > 3) {
+      run = 0, fwd = rev = 0;
+      continue;
+    }
+    fwd = ((fwd << 2) | c) & mask;
+    rev = (rev >> 2) | ((uint64_t)(3 - c) << (2 * (ksize - 1)));
+    if (++run < ksize) continue;
+    const bool use_rc = canonical && (rev < fwd);
+    const uint64_t v = use_rc ? rev : fwd;  // first base of the chosen strand in the top bits
+    uint64_t w[4] = {0, 0, 0, 0};
+    for (uint32_t b = 0; b < ksize; ++b) {
+      uint32_t code = (uint32_t)(v >> (2 * (ksize - 1 - b))) & 3u;
+      w[b >> 3] |= (uint64_t)(uint8_t)ACGT[code] << (8 * (b & 7));
+    }
+    const uint64_t h = t1ha2_le32(w, ksize, seed);
+    if (h < threshold) append_hit(h, gm, g, hits, cnt);
+  }
+}
+
+template <int K>
+hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const uint8_t *d_seq,
+                       const hg_genome_meta *d_meta, const uint32_t *d_item_genome, uint64_t threshold,
+                       uint64_t seed, uint32_t u2t, uint64_t *d_hits, uint32_t *d_cnt) {
+  if (canonical)
+    hipLaunchKernelGGL((kmer_sample_fast<K, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
+                       d_item_genome, threshold, seed, u2t, d_hits, d_cnt);
+  else
+    hipLaunchKernelGGL((kmer_sample_fast<K, false>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
+                       d_item_genome, threshold, seed, u2t, d_hits, d_cnt);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+uint32_t hg_kmer_item_starts(uint32_t k) {
+  if (!fast_k(k)) return GEN_ITEM;
+  return (uint32_t)(WG * ((33 - k) & ~3u) * TILES_PER_ITEM);
+}
+
+hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
+                                 const uint32_t *d_item_genome, uint32_t n_items, uint32_t ksize,
+                                 uint64_t threshold, uint64_t seed, bool canonical, uint32_t norm_mode,
+                                 uint64_t *d_hits, uint32_t *d_cnt) {
+  if (n_items == 0) return hipSuccess;
+  const uint32_t u2t = (norm_mode == HG_NORM_U2T) ? 1u : 0u;
+#define HG_FAST_CASE(KK)                                                                       \
+  case KK:                                                                                     \
+    return launch_fast<KK>(st, canonical, n_items, d_seq, d_meta, d_item_genome, threshold,   \
+                           seed, u2t, d_hits, d_cnt);
+  switch (ksize) {
+    HG_FAST_CASE(9) HG_FAST_CASE(10) HG_FAST_CASE(11) HG_FAST_CASE(12) HG_FAST_CASE(13)
+    HG_FAST_CASE(14) HG_FAST_CASE(15) HG_FAST_CASE(16) HG_FAST_CASE(17) HG_FAST_CASE(18)
+    HG_FAST_CASE(19) HG_FAST_CASE(20) HG_FAST_CASE(21) HG_FAST_CASE(22) HG_FAST_CASE(23)
+    HG_FAST_CASE(24) HG_FAST_CASE(25) HG_FAST_CASE(26) HG_FAST_CASE(27) HG_FAST_CASE(28)
+    HG_FAST_CASE(29)
+    default:
+      break;
+  }
+#undef HG_FAST_CASE
+  hipLaunchKernelGGL(kmer_sample_generic, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
+                     d_item_genome, ksize, threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+  return hipGetLastError();
+}

@@ -1,0 +1,210 @@
+/*
+ * hypergen.h -- C ABI of libhypergen_hip.so, the MI355X (gfx950) implementation of
+ * the HyperGen sketch + ANI hot path.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface
+ * (wh-xu/Hyper-Gen, file:line) it replaces; INTEGRATION.md shows the Rust
+ * `extern "C"` block a maintainer would add in src/sketch_cuda.rs / src/dist.rs.
+ *
+ * Conventions
+ *   - plain C types only; every call returns an hg_status (the reference
+ *     .unwrap()s and aborts, src/sketch_cuda.rs:134-156 -- here the caller decides);
+ *   - `hg_ctx` owns one device, one stream and growable device workspaces; a ctx is
+ *     NOT thread-safe, create one per host thread (the reference binds one shared
+ *     CudaDevice per rayon worker, src/sketch_cuda.rs:82);
+ *   - "host" entry points take host pointers and stage through the ctx;
+ *     "_dev" entry points take device pointers (HBM resident, no PCIe traffic);
+ *   - outputs are caller allocated with explicit capacities;
+ *   - there is NO CPU fallback: without a usable HIP device hg_ctx_create fails.
+ */
+#ifndef HYPERGEN_H
+#define HYPERGEN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hg_ctx hg_ctx;
+
+typedef enum {
+  HG_OK = 0,
+  HG_ERR_INVALID = 1,     /* bad argument                                          */
+  HG_ERR_NO_DEVICE = 2,   /* no HIP device / device id out of range                */
+  HG_ERR_HIP = 3,         /* a HIP runtime call failed (see hg_last_error)         */
+  HG_ERR_OOM = 4,         /* device or host allocation failed                      */
+  HG_ERR_CAPACITY = 5,    /* caller's output buffer too small; *n_out = needed     */
+  HG_ERR_UNSUPPORTED = 6, /* parameter combination not implemented on the device   */
+  HG_ERR_IO = 7,          /* file could not be read / written / parsed             */
+  HG_ERR_INEXACT = 8      /* integer dot products cannot be evaluated exactly      */
+} hg_status;
+
+const char *hg_status_str(hg_status s);
+/* message of the last failing call on this ctx (or on ctx creation if ctx == NULL) */
+const char *hg_last_error(const hg_ctx *ctx);
+/* library version string */
+const char *hg_version(void);
+
+/* ---- context ------------------------------------------------------------------
+ * replaces CudaDevice::new(0) + load_ptx(..) + bind_to_thread()
+ * (src/sketch_cuda.rs:52-60,82).  Kernels are linked into the library, there is no
+ * PTX/code-object loading step. */
+hg_status hg_ctx_create(int device_id, hg_ctx **out);
+void hg_ctx_destroy(hg_ctx *ctx);
+/* run all subsequent work on an existing hipStream_t (e.g. torch's current stream);
+ * NULL restores the ctx's own stream. */
+hg_status hg_ctx_set_stream(hg_ctx *ctx, void *hip_stream);
+hg_status hg_ctx_sync(hg_ctx *ctx);
+int hg_device_count(void);
+
+/* minimal device-memory helpers for callers that have no HIP binding of their own
+ * (cudarc's htod_copy / alloc_zeros / sync_reclaim, src/sketch_cuda.rs:134,138,156) */
+hg_status hg_dev_alloc(hg_ctx *ctx, size_t bytes, void **dptr);
+hg_status hg_dev_free(hg_ctx *ctx, void *dptr);
+hg_status hg_copy_h2d(hg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+hg_status hg_copy_d2h(hg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- parameters --------------------------------------------------------------- */
+#define HG_LAYOUT_SCALAR 0u /* encode_hash_hd       src/hd.rs:94-112               */
+#define HG_LAYOUT_AVX2 1u   /* encode_hash_hd_avx2  src/hd.rs:14-92 (x86-64 output) */
+#define HG_NORM_ACGT 0u     /* only ACGTacgt are bases (src/cuda_kernel.cu:277-296) */
+#define HG_NORM_U2T 1u      /* additionally u/U -> T (needletail normalize)         */
+
+/* mirrors SketchParams (src/types.rs:83-113); defaults k=21 scaled=1500 seed=123
+ * canonical=1 hv_d=4096 */
+typedef struct {
+  uint32_t ksize;     /* 1..32 on the device                                        */
+  uint32_t canonical; /* 0/1 (honoured like src/cuda_kernel.cu:306-314)             */
+  uint64_t scaled;    /* threshold = UINT64_MAX / scaled (src/sketch.rs:73)          */
+  uint64_t seed;
+  uint32_t hv_d;      /* HV dimension; chunks of 64 are filled (src/hd.rs:34,102)    */
+  uint32_t hv_layout; /* HG_LAYOUT_*                                                 */
+  uint32_t norm_mode; /* HG_NORM_*                                                   */
+  uint32_t reserved;
+} hg_sketch_params;
+
+void hg_sketch_params_default(hg_sketch_params *p);
+
+/* ---- k-mer hash + FracMinHash sample --------------------------------------------
+ * replaces extract_kmer_t1ha2_cuda + kernel cuda_kmer_t1ha2
+ * (src/sketch_cuda.rs:120-166, src/cuda_kernel.cu:250-321; CPU twin
+ * extract_kmer_hash, src/sketch.rs:71-98).
+ * seq   : read_merge_seq layout (src/fastx_reader.rs:6-29), host memory.
+ * output: the DISTINCT sampled hashes, ascending (HashSet semantics, lossless: no
+ *         per-thread slot cap, hash value 0 is kept).
+ * If more than `cap` distinct hashes exist: HG_ERR_CAPACITY and *n_out = count. */
+hg_status hg_kmer_hash_sample(hg_ctx *ctx, const uint8_t *seq, size_t n_bps,
+                              uint32_t ksize, uint64_t threshold, uint64_t seed,
+                              int canonical, uint32_t norm_mode, uint64_t *out_hashes,
+                              size_t cap, size_t *n_out);
+
+/* ---- HV encode -------------------------------------------------------------------
+ * replaces hd::encode_hash_hd{,_avx2} + dist::compute_hv_l2_norm
+ * (src/hd.rs:14-112, src/dist.rs:132-137).  `hashes` must be distinct (host). */
+hg_status hg_hv_encode(hg_ctx *ctx, const uint64_t *hashes, size_t n, uint32_t hv_d,
+                       uint32_t hv_layout, int16_t *hv_out, int32_t *norm2_out);
+
+/* ---- whole-batch sketch ------------------------------------------------------------
+ * what the rayon loop body of src/sketch.rs:35-48 / src/sketch_cuda.rs:79-96 does per
+ * file (hash+sample -> set -> HV encode -> norm), for n genomes in one call.
+ *
+ * _dev: d_seq holds all genomes (device memory); genome i occupies
+ * [offsets[i], offsets[i] + lens[i]) (host arrays).  offsets must be multiples of 4
+ * and the allocation must be readable for 32 bytes past every genome's end.
+ * d_hv      : n * hv_d int16 (device), d_norm2 : n int32 (device),
+ * d_nhash   : n uint32 (device) = number of distinct sampled hashes. */
+hg_status hg_sketch_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t *offsets,
+                              const uint64_t *lens, size_t n, const hg_sketch_params *p,
+                              int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash);
+/* host buffers in, host results out (one H2D of the sequences, one D2H of the HVs) */
+hg_status hg_sketch_batch(hg_ctx *ctx, const uint8_t *const *seqs, const size_t *lens,
+                          size_t n, const hg_sketch_params *p, int16_t *hv_out,
+                          int32_t *norm2_out, uint32_t *nhash_out);
+
+/* ---- ANI ------------------------------------------------------------------------------
+ * replaces dist::compute_hv_ani / compute_pairwise_ani (src/dist.rs:139-161,231-294).
+ * ref_hv: R x hv_d int16 row-major (decompressed sketches), qry_hv: Q x hv_d.
+ * ani_out[r * Q + q] = ANI in percent (0..100), float32 arithmetic in the reference's
+ * operation order.  Dot products are exact integers (HG_ERR_INEXACT is never a silent
+ * rounding: it is returned only if no exact device path applies). */
+hg_status hg_dist_full(hg_ctx *ctx, const int16_t *ref_hv, const int32_t *ref_norm2,
+                       size_t R, const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q,
+                       uint32_t hv_d, uint32_t ksize, float *ani_out);
+hg_status hg_dist_full_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *d_ref_norm2,
+                           size_t R, const int16_t *d_qry_hv, const int32_t *d_qry_norm2,
+                           size_t Q, uint32_t hv_d, uint32_t ksize, float *d_ani_out);
+
+/* one reported pair: what dump_ani_file prints per line (src/utils.rs:275-285) */
+typedef struct {
+  uint32_t ref_idx;
+  uint32_t qry_idx;
+  float ani;
+} hg_ani_hit;
+
+/* thresholded form: pairs with ani >= ani_th.  symmetric != 0 enumerates only
+ * ref_idx < qry_idx (src/dist.rs:243-265).  Hits come back in no particular order
+ * (hg_sort_ani_hits gives the reference's file order).  *n_out = number of hits found;
+ * if it exceeds cap only cap are stored and HG_ERR_CAPACITY is returned.
+ * `out` is host memory for hg_dist and device memory for hg_dist_dev. */
+hg_status hg_dist(hg_ctx *ctx, const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
+                  const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q, uint32_t hv_d,
+                  uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *out, size_t cap,
+                  size_t *n_out);
+hg_status hg_dist_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *d_ref_norm2,
+                      size_t R, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
+                      uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
+                      hg_ani_hit *d_out, size_t cap, size_t *n_out);
+
+/* order of dump_ani_file (src/utils.rs:262-269): stable ascending sort by ANI over the
+ * reference's pair enumeration, then reversed.  Host side. */
+void hg_sort_ani_hits(hg_ani_hit *hits, size_t n, size_t Q, int symmetric);
+
+/* ---- sketch compression (host side; src/hd.rs:114-232) -------------------------------- */
+uint32_t hg_hv_quant_bits(const int16_t *hv, uint32_t hv_d);
+/* packed must hold quant_bits * hv_d / 8 bytes; hv_d must be a multiple of 256 */
+hg_status hg_hv_pack(const int16_t *hv, uint32_t hv_d, uint32_t quant_bits, uint8_t *packed);
+hg_status hg_hv_unpack(const uint8_t *packed, uint32_t hv_d, uint32_t quant_bits, int16_t *hv);
+
+/* ---- .sketch files (host side; src/types.rs:224-235, src/utils.rs:234-258) ------------ */
+typedef struct {
+  uint8_t ksize;
+  uint8_t canonical;
+  uint8_t hv_quant_bits;
+  uint8_t pad;
+  int32_t hv_norm_2;
+  uint64_t scaled;
+  uint64_t seed;
+  uint64_t hv_d;
+  const char *file_str; /* UTF-8, NUL terminated                                      */
+  const int16_t *hv;    /* payload exactly as stored (packed when hv_quant_bits < 16) */
+  uint64_t hv_len;      /* number of int16 in the payload                             */
+} hg_file_sketch;
+
+typedef struct hg_sketch_file hg_sketch_file; /* owns the records of a loaded file */
+
+hg_status hg_sketch_file_write(const char *path, const hg_file_sketch *recs, size_t n);
+hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out);
+size_t hg_sketch_file_count(const hg_sketch_file *f);
+const hg_file_sketch *hg_sketch_file_get(const hg_sketch_file *f, size_t i);
+void hg_sketch_file_free(hg_sketch_file *f);
+
+/* ---- FASTA ingest (host side; src/fastx_reader.rs:6-29) ------------------------------- */
+/* read_merge_seq: returns a malloc'ed buffer (free with hg_free) and its length */
+hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps);
+void hg_free(void *p);
+
+/* ---- synthetic genomes (benchmark / test utility, not part of the reference surface) -----
+ * Genome g = first_genome + i is written at d_out + i * stride as 'N' followed by L bases
+ * (the read_merge_seq layout of a one-record FASTA).  Cluster c = g / cluster_size is an iid
+ * uniform ACGT root; member m = g % cluster_size has iid substitutions at rate
+ * m * sub_ppm_per_member / 1e6.  stride >= L + 1; n <= 65535 per call. */
+hg_status hg_synth_genomes_dev(hg_ctx *ctx, uint64_t first_genome, size_t n, uint64_t L,
+                               uint32_t cluster_size, uint32_t sub_ppm_per_member, uint64_t stride,
+                               uint8_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERGEN_H */

@@ -203,7 +203,7 @@ size_t orc_read_merge_seq(const uint8_t *text, size_t n_text, uint8_t *out) {
       out[o++] = 'N';
     } else {
       size_t e = end;
-      if (j < n_text && e > i && text[e - 1] == '\r') e--; /* "\r\n" */
+      if (e > i && text[e - 1] == '\r') e--; /* :19-21, with or without '\n' */
       memcpy(out + o, text + i, e - i);
       o += e - i;
     }

@@ -1,0 +1,257 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bit-exact for hash sets, HV integers and norms; ANI within 1e-4 (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+@pytest.fixture(scope="module")
+def hg():
+    import hypergen_amd
+    return hypergen_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(hg):
+    c = hg.Context(0)
+    yield c
+    c.close()
+
+
+def rand_seq(rng, n):
+    return rng.choice(ACGT, n)
+
+
+# ---- k-mer hash + sample ---------------------------------------------------------------------
+def test_g1_reference_fixture(ctx, orc):
+    g = golden("g1_test_fna.json")
+    seq = orc.read_merge_seq(g["fasta"].encode())
+    for key, k, scaled in (("k21_scaled1", 21, 1), ("k5_scaled1", 5, 1), ("k21_scaled1500", 21, 1500)):
+        got = ctx.kmer_hash_sample(seq, k, scaled, g["seed"], g["canonical"])
+        assert ["%016x" % int(x) for x in got] == g[key], key
+
+
+@pytest.mark.parametrize("k", [1, 4, 8, 9, 12, 15, 16, 17, 20, 21, 22, 24, 25, 28, 29, 30, 31, 32])
+def test_hash_sets_all_k(ctx, orc, k):
+    rng = np.random.default_rng(100 + k)
+    s = rand_seq(rng, 20011)
+    s[[5, 777, 778, 5000, 12345, 20010]] = ord("N")
+    s[3000:3300] = np.char.lower(s[3000:3300].view("S1")).view(np.uint8)
+    for canonical in (True, False):
+        want = orc.kmer_hash_sample(s, k, 7, 123, canonical)
+        got = ctx.kmer_hash_sample(s, k, 7, 123, canonical)
+        assert got.size == want.size and (got == want).all(), (k, canonical)
+
+
+@pytest.mark.parametrize("n", [0, 1, 20, 21, 22, 31, 32, 33, 43, 44, 45, 3071, 3072, 3073, 3092, 3093,
+                               24575, 24576, 24577, 24596, 24597, 50000])
+def test_hash_sets_ragged_lengths(ctx, orc, n):
+    rng = np.random.default_rng(n)
+    s = rand_seq(rng, n)
+    want = orc.kmer_hash_sample(s, 21, 3)
+    got = ctx.kmer_hash_sample(s, 21, 3)
+    assert got.size == want.size and (got == want).all()
+
+
+def test_hash_set_scaled1_every_kmer(ctx, orc):
+    rng = np.random.default_rng(5)
+    s = rand_seq(rng, 30000)
+    want = orc.kmer_hash_sample(s, 21, 1)
+    got = ctx.kmer_hash_sample(s, 21, 1)
+    assert want.size > 29000 and (got == want).all()
+
+
+def test_non_bases_and_u2t(ctx, orc, hg):
+    rng = np.random.default_rng(6)
+    s = rand_seq(rng, 40000)
+    junk = np.frombuffer(b"NnRYKMSWBDHV-*. \t0\xff\x00Uu", np.uint8)
+    pos = rng.choice(40000, 600, replace=False)
+    s[pos] = rng.choice(junk, 600)
+    for norm in (hg.NORM_ACGT, hg.NORM_U2T):
+        want = orc.kmer_hash_sample(s, 21, 5, norm=norm)
+        got = ctx.kmer_hash_sample(s, 21, 5, norm=norm)
+        assert (got == want).all() and got.size == want.size, norm
+    rna = rand_seq(rng, 20000)
+    rna[rna == ord("T")] = ord("U")
+    a = ctx.kmer_hash_sample(rna, 21, 5, norm=hg.NORM_U2T)
+    assert a.size > 1000 and (a == orc.kmer_hash_sample(rna, 21, 5, norm=orc.NORM_U2T)).all()
+
+
+def test_duplicates_and_low_complexity(ctx, orc):
+    # poly-A: one k-mer repeated at every position, all consecutive lanes hit at once
+    s = np.full(10000, ord("A"), np.uint8)
+    thr = 2**64 - 1
+    got = ctx.kmer_hash_sample(s, 21, threshold=thr)
+    want = orc.kmer_hash_sample(s, 21, threshold=thr)
+    assert want.size == 1 and (got == want).all()
+    rng = np.random.default_rng(8)
+    rep = np.tile(rand_seq(rng, 997), 40)
+    got = ctx.kmer_hash_sample(rep, 21, 2)
+    want = orc.kmer_hash_sample(rep, 21, 2)
+    assert (got == want).all() and got.size == want.size
+
+
+def test_capacity_protocol(ctx, hg):
+    rng = np.random.default_rng(9)
+    s = rand_seq(rng, 5000)
+    full = ctx.kmer_hash_sample(s, 21, 1)
+    import ctypes as C
+    out = np.zeros(10, np.uint64)
+    n = C.c_size_t(0)
+    st = hg.lib().hg_kmer_hash_sample(ctx._h, s.ctypes.data, s.size, 21, C.c_uint64(2**64 - 1), C.c_uint64(123),
+                                      1, 0, out.ctypes.data, 10, C.byref(n))
+    assert st == hg.ERR_CAPACITY and n.value == full.size
+    st = hg.lib().hg_kmer_hash_sample(ctx._h, s.ctypes.data, s.size, 33, C.c_uint64(1), C.c_uint64(123),
+                                      1, 0, out.ctypes.data, 10, C.byref(n))
+    assert st == hg.ERR_UNSUPPORTED
+
+
+def test_synthetic_genome_hash_set(ctx, orc):
+    g = orc.synth_genome(3, 600_000)
+    want = orc.kmer_hash_sample(g, 21, 1500)
+    got = ctx.kmer_hash_sample(g, 21, 1500)
+    assert 300 < want.size < 500 and (got == want).all()
+
+
+# ---- HV encode -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 3, 15, 16, 17, 50, 129, 1000, 3333])
+@pytest.mark.parametrize("d", [256, 4096])
+def test_hv_encode(ctx, orc, hg, n, d):
+    rng = np.random.default_rng(n * 7 + d)
+    hs = np.unique(rng.integers(0, 2**63, n, dtype=np.uint64))
+    for layout, ol in ((hg.LAYOUT_SCALAR, orc.LAYOUT_SCALAR), (hg.LAYOUT_AVX2, orc.LAYOUT_AVX2)):
+        hv, n2 = ctx.hv_encode(hs, d, layout)
+        want = orc.encode_hv(hs, d, ol)
+        assert (hv == want).all(), (n, d, layout)
+        assert n2 == orc.hv_norm2(want)
+
+
+@pytest.mark.parametrize("d", [64, 100, 1000, 1024, 8192, 16384])
+def test_hv_encode_other_dims(ctx, orc, hg, d):
+    rng = np.random.default_rng(d)
+    hs = np.unique(rng.integers(0, 2**63, 300, dtype=np.uint64))
+    hv, n2 = ctx.hv_encode(hs, d, hg.LAYOUT_AVX2)
+    want = orc.encode_hv(hs, d, orc.LAYOUT_AVX2)
+    assert (hv == want).all() and n2 == orc.hv_norm2(want)
+
+
+def test_hv_encode_large_set_wraps_like_i16(ctx, orc, hg):
+    rng = np.random.default_rng(11)
+    hs = np.unique(rng.integers(0, 2**63, 40000, dtype=np.uint64))  # n > 32767: -(n as i16) wraps
+    hv, n2 = ctx.hv_encode(hs, 256, hg.LAYOUT_SCALAR)
+    want = orc.encode_hv(hs, 256, orc.LAYOUT_SCALAR)
+    assert (hv == want).all() and n2 == orc.hv_norm2(want)
+
+
+# ---- whole sketch --------------------------------------------------------------------------------
+def test_sketch_batch_matches_oracle(ctx, orc, hg):
+    rng = np.random.default_rng(12)
+    seqs = [orc.synth_genome(g, L) for g, L in ((0, 200_000), (1, 150_001), (57, 99_999), (100, 20), (101, 0), (102, 21))]
+    seqs.append(np.concatenate([rand_seq(rng, 5000), np.frombuffer(b"N", np.uint8), rand_seq(rng, 30)]))
+    seqs[4] = np.zeros(0, np.uint8)
+    p = hg.default_params(scaled=200)
+    hv, n2, nh = ctx.sketch_batch(seqs, p)
+    for i, s in enumerate(seqs):
+        w_hv, w_n2, w_nh = orc.sketch_genome(s, scaled=200)
+        assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), i
+    # scalar layout + different parameters
+    p2 = hg.default_params(scaled=50, ksize=15, hv_d=1024, hv_layout=hg.LAYOUT_SCALAR, seed=7, canonical=0)
+    hv, n2, nh = ctx.sketch_batch(seqs[:3], p2)
+    for i in range(3):
+        w = orc.sketch_genome(seqs[i], ksize=15, scaled=50, seed=7, canonical=False, hv_d=1024,
+                              layout=orc.LAYOUT_SCALAR)
+        assert nh[i] == w[2] and n2[i] == w[1] and (hv[i] == w[0]).all()
+
+
+def test_config1_test_fna(ctx, orc, hg):
+    g = golden("g1_test_fna.json")
+    seq = orc.read_merge_seq(g["fasta"].encode())
+    hv, n2, nh = ctx.sketch_batch([seq])
+    assert nh[0] == 0 and n2[0] == 0 and not hv.any()  # empty set at scaled=1500
+
+
+def test_sketch_5mbp_genome(ctx, orc, hg):
+    g = orc.synth_genome(7, 5_000_000)
+    hv, n2, nh = ctx.sketch_batch([g])
+    w_hv, w_n2, w_nh = orc.sketch_genome(g)
+    assert 3100 < w_nh < 3600 and nh[0] == w_nh and n2[0] == w_n2 and (hv[0] == w_hv).all()
+
+
+def test_large_hit_set_uses_global_sort(ctx, orc):
+    # > 16384 sampled hashes in one genome: exceeds the LDS sort, exercises the in-place variant
+    g = orc.synth_genome(9, 120_000)
+    want = orc.kmer_hash_sample(g, 21, 2)
+    got = ctx.kmer_hash_sample(g, 21, 2)
+    assert want.size > 40000 and (got == want).all()
+
+
+# ---- dist ------------------------------------------------------------------------------------------
+def _hvs(orc, n_rows, n_hash, d, seed, related=0.6):
+    """HVs of hash sets that share a common base set (so that ANIs are high and varied)."""
+    rng = np.random.default_rng(seed)
+    base = np.unique(rng.integers(0, 2**63, n_hash, dtype=np.uint64))
+    rows = []
+    for i in range(n_rows):
+        keep = base[rng.random(base.size) >= (1.0 - related) * (i % 5) / 4]
+        extra = np.unique(rng.integers(0, 2**63, 1 + int(n_hash * 0.05 * (i % 7)), dtype=np.uint64))
+        rows.append(orc.encode_hv(np.unique(np.concatenate([keep, extra])), d, orc.LAYOUT_AVX2))
+    hv = np.stack(rows)
+    n2 = np.array([orc.hv_norm2(r) for r in hv], np.int32)
+    return hv, n2
+
+
+@pytest.mark.parametrize("R,Q,d", [(1, 1, 4096), (5, 7, 4096), (130, 129, 1024), (257, 64, 256), (33, 300, 4096)])
+def test_dist_full_matches_oracle(ctx, orc, R, Q, d):
+    r, rn = _hvs(orc, R, 400, d, R * 31 + d, related=0.6)
+    q, qn = _hvs(orc, Q, 400, d, R * 31 + d, related=0.6)  # same base set => high ANIs
+    got = ctx.dist_full(r, rn, q, qn, 21)
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    assert np.abs(got - want).max() <= 1e-4
+    assert (want > 80).any() and (got[want == 0] == 0).all()
+
+
+def test_dist_exact_for_large_values(ctx, orc):
+    # |hv| beyond f16's exact range and norms beyond the f32-exact window: still bit-exact dots
+    rng = np.random.default_rng(21)
+    r = rng.integers(-3000, 3000, (40, 1024)).astype(np.int16)
+    q = np.vstack([r[:10], rng.integers(-3000, 3000, (20, 1024)).astype(np.int16)])
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+    assert np.abs(ctx.dist_full(r, rn, q, qn, 21) - orc.ani_matrix(r, rn, q, qn, 21)).max() <= 1e-4
+    # mid-size values: f16-exact but needing chunked accumulation
+    r = rng.integers(-1500, 1500, (40, 4096)).astype(np.int16)
+    q = np.vstack([r[:10] + rng.integers(-20, 20, (10, 4096)).astype(np.int16), r[10:25]])
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+    got, want = ctx.dist_full(r, rn, q, qn, 21), orc.ani_matrix(r, rn, q, qn, 21)
+    assert np.abs(got - want).max() <= 1e-4 and (want > 99).any()
+
+
+def test_dist_thresholded_and_symmetric(ctx, orc, hg):
+    r, rn = _hvs(orc, 150, 500, 4096, 77, related=0.5)
+    full = orc.ani_matrix(r, rn, r, rn, 21)
+    hits = ctx.dist(r, rn, r, rn, 21, symmetric=True, ani_th=85.0)
+    want = {(i, j) for i in range(150) for j in range(i + 1, 150) if full[i, j] >= 85.0}
+    assert {(int(h["ref_idx"]), int(h["qry_idx"])) for h in hits} == want and len(hits) == len(want)
+    for h in hits:
+        assert abs(h["ani"] - full[h["ref_idx"], h["qry_idx"]]) <= 1e-4
+    allp = ctx.dist(r, rn, r[:40], rn[:40], 21, symmetric=False, ani_th=90.0)
+    assert len(allp) == int((full[:, :40] >= 90.0).sum())
+    srt = hg.sort_ani_hits(allp, 40)
+    assert (np.diff(srt["ani"]) <= 0).all()
+
+
+def test_dist_of_sketched_synthetic_cluster(ctx, orc, hg):
+    seqs = [orc.synth_genome(g, 300_000) for g in (0, 10, 50, 99, 100)]
+    hv, n2, nh = ctx.sketch_batch(seqs, hg.default_params(scaled=100))
+    ani = ctx.dist_full(hv, n2, hv, n2, 21)
+    want = orc.ani_matrix(hv, n2, hv, n2, 21)
+    assert np.abs(ani - want).max() <= 1e-4
+    assert ani[0, 0] == 100.0 and 98.5 < ani[0, 1] < 99.5 and 94 < ani[0, 2] < 96 and ani[0, 4] < 85

@@ -1,0 +1,45 @@
+"""The reference's OWN kernel (src/cuda_kernel.cu built in place by hipcc into oracle/_ref/) run on
+the MI355X next to the oracle and the product: three-way agreement on the sampled hash sets."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(ROOT, "oracle", "_ref")
+HAVE_REF = os.path.exists(os.path.join(REF, "ref_kmer_runner")) and os.path.exists(os.path.join(REF, "ref_cuda_kernel.hsaco"))
+
+
+def run_ref(seq, k, scaled, seed=123, canonical=True, slots=0):
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "s.bin"), os.path.join(td, "o.bin")
+        np.ascontiguousarray(seq, np.uint8).tofile(fi)
+        subprocess.check_call([os.path.join(REF, "ref_kmer_runner"), os.path.join(REF, "ref_cuda_kernel.hsaco"),
+                               fi, str(k), str(scaled), str(seed), "1" if canonical else "0", str(slots), fo])
+        return np.fromfile(fo, np.uint64)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("g,L,k,scaled,canon,slots", [
+    (11, 150_000, 21, 1500, True, 0),     # the reference's own launch parameters (8 slots/thread)
+    (12, 150_000, 21, 1, True, 520),      # every k-mer
+    (13, 80_000, 21, 20, False, 128),     # non-canonical mode (src/cuda_kernel.cu:312-314)
+    (14, 80_000, 12, 20, True, 128),
+    (15, 80_000, 32, 20, True, 128),
+])
+def test_three_way_hash_sets(orc, g, L, k, scaled, canon, slots):
+    import hypergen_amd as hg
+    seq = orc.synth_genome(g, L).copy()
+    rng = np.random.default_rng(g)
+    seq[rng.choice(L, 30, replace=False) + 1] = ord("N")
+    seq[1000:1500] = np.char.lower(seq[1000:1500].view("S1")).view(np.uint8)
+    ref = run_ref(seq, k, scaled, canonical=canon, slots=slots)
+    want = orc.kmer_hash_sample(seq, k, scaled, 123, canon)
+    with hg.Context(0) as ctx:
+        got = ctx.kmer_hash_sample(seq, k, scaled, 123, canon)
+    assert ref.size == want.size and (ref == want).all(), "reference kernel vs oracle"
+    assert got.size == want.size and (got == want).all(), "product vs oracle"
