@@ -23,6 +23,10 @@ NORM_ACGT, NORM_U2T = 0, 1
  ERR_INEXACT) = range(9)
 
 
+T_NAMES = ("kmer", "sort", "encode", "dist_prep", "dist")
+T_COUNT = len(T_NAMES)
+
+
 class HgError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("hypergen status %d: %s" % (status, msg))
@@ -57,7 +61,7 @@ EXPORTS = [
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack",
     "hg_hv_unpack", "hg_sketch_file_write", "hg_sketch_file_read", "hg_sketch_file_count",
     "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_free",
-    "hg_synth_genomes_dev",
+    "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
 ]
 
 
@@ -119,6 +123,8 @@ def lib():
         "hg_sketch_file_free": (None, [vp]),
         "hg_read_merge_seq": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz)]),
         "hg_free": (None, [vp]),
+        "hg_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
+        "hg_ctx_timings": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
         "hg_synth_genomes_dev": (C.c_int, [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, vp]),
     }
@@ -177,6 +183,16 @@ class Context:
 
     def sync(self):
         self._ck(lib().hg_ctx_sync(self._h))
+
+    def enable_timing(self, on=True):
+        self._ck(lib().hg_ctx_enable_timing(self._h, int(on)))
+
+    def timings(self):
+        """{kernel class: (sum of launch durations in ms, launches)} since the last call."""
+        ms = (C.c_float * T_COUNT)()
+        n = (C.c_uint32 * T_COUNT)()
+        self._ck(lib().hg_ctx_timings(self._h, ms, n))
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(T_NAMES)}
 
     # ---- host-buffer entry points -----------------------------------------------------------
     def kmer_hash_sample(self, seq, ksize=21, scaled=1500, seed=123, canonical=True,

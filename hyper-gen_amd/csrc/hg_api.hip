@@ -77,6 +77,8 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
                          &c->w_n2a, &c->w_n2b};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (auto &t : c->t_pending) (void)hipEventDestroy(t.e0), (void)hipEventDestroy(t.e1);
+  for (auto e : c->t_pool) (void)hipEventDestroy(e);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -91,6 +93,48 @@ extern "C" hg_status hg_ctx_set_stream(hg_ctx *c, void *hip_stream) {
 extern "C" hg_status hg_ctx_sync(hg_ctx *c) {
   if (!c) return HG_ERR_INVALID;
   HG_HIP(c, hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+static hipEvent_t take_event(hg_ctx *c) {
+  if (!c->t_pool.empty()) {
+    hipEvent_t e = c->t_pool.back();
+    c->t_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+hg_timed::hg_timed(hg_ctx *ctx, int cls_) : c(ctx), cls(cls_) {
+  if (!c->timing) return;
+  e0 = take_event(c), e1 = take_event(c);
+  if (e0) (void)hipEventRecord(e0, c->stream);
+}
+hg_timed::~hg_timed() {
+  if (!e0 || !e1) return;
+  (void)hipEventRecord(e1, c->stream);
+  c->t_pending.push_back({e0, e1, cls});
+}
+
+extern "C" hg_status hg_ctx_enable_timing(hg_ctx *c, int on) {
+  if (!c) return HG_ERR_INVALID;
+  c->timing = on != 0;
+  return HG_OK;
+}
+
+extern "C" hg_status hg_ctx_timings(hg_ctx *c, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]) {
+  if (!c || !ms_sum || !launches) return HG_ERR_INVALID;
+  for (int i = 0; i < HG_T_COUNT; ++i) ms_sum[i] = 0.f, launches[i] = 0;
+  for (auto &t : c->t_pending) {
+    HG_HIP(c, hipEventSynchronize(t.e1));
+    float ms = 0.f;
+    HG_HIP(c, hipEventElapsedTime(&ms, t.e0, t.e1));
+    if (t.cls >= 0 && t.cls < HG_T_COUNT) ms_sum[t.cls] += ms, launches[t.cls] += 1;
+    c->t_pool.push_back(t.e0), c->t_pool.push_back(t.e1);
+  }
+  c->t_pending.clear();
   return HG_OK;
 }
 
@@ -244,9 +288,15 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     if (n_items)
       HG_HIP(c, hipMemcpyAsync(d_items, pl.item_genome.data(), n_items * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HG_HIP(c, hipMemsetAsync(d_cnt, 0, 2 * n * sizeof(uint32_t), c->stream));
-    HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
-                                    seed, canonical, norm_mode, d_hits, d_cnt));
-    HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, pl.max_cap));
+    {
+      hg_timed tm(c, HG_T_KMER);
+      HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
+                                      seed, canonical, norm_mode, d_hits, d_cnt));
+    }
+    {
+      hg_timed tm(c, HG_T_SORT);
+      HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, pl.max_cap));
+    }
     // overflow check on the raw counters (they keep counting past the capacity)
     auto *h_cnt = static_cast<uint32_t *>(c->h_pin);
     HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -291,8 +341,11 @@ extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const 
   s = sample_batch(c, d_seq, offsets, lens, n, p->ksize, threshold, p->scaled, p->seed, p->canonical != 0,
                    p->norm_mode, pl, &d_nd);
   if (s != HG_OK) return s;
-  HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), (uint32_t)n,
-                             static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2));
+  {
+    hg_timed tm(c, HG_T_ENCODE);
+    HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), (uint32_t)n,
+                               static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2));
+  }
   HG_HIP(c, hipMemcpyAsync(d_nhash, d_nd, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
   return HG_OK;
 }

@@ -1,0 +1,308 @@
+// hg_cli.cpp -- `hyper-gen` command line on top of libhypergen_hip.so.
+//
+// Mirrors the reference's CLI surface (src/utils.rs:42-162, src/main.rs:11-24): subcommands
+// sketch / dist / search with the same flags and defaults, the same .sketch container and the
+// same ANI TSV (src/utils.rs:260-308).  All arithmetic runs on the MI355X through the C ABI;
+// `-D cpu|gpu` only selects which of the reference's two base-normalisation behaviours is
+// reproduced (cpu: needletail, u/U -> T; gpu: src/cuda_kernel.cu, ACGTacgt only).
+#include <glob.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hypergen.h"
+
+namespace {
+
+void logline(const char *lvl, const std::string &msg) {
+  char ts[32];
+  std::time_t t = std::time(nullptr);
+  std::strftime(ts, sizeof ts, "%Y-%m-%d-%H:%M:%S", std::localtime(&t));  // src/utils.rs:17-29
+  std::printf("%s [%s] - %s\n", ts, lvl, msg.c_str());
+  std::fflush(stdout);
+}
+
+[[noreturn]] void die(const std::string &msg) {
+  std::fprintf(stderr, "error: %s\n", msg.c_str());
+  std::exit(2);
+}
+
+struct Cli {
+  std::string mode, path = "1", path_r = "1", path_q = "1", out, method = "t1ha2", device = "cpu";
+  unsigned threads = 16, ksize = 21;
+  bool canonical = true;
+  unsigned long long seed = 123, scaled = 1500, hv_d = 4096;
+  float quant_scale = 1.0f, ani_th = 85.0f;
+};
+
+Cli parse(int argc, char **argv) {
+  if (argc < 2) die("usage: hyper-gen <sketch|dist|search> [options]   (see --help)");
+  Cli c;
+  c.mode = argv[1];
+  if (c.mode == "--version" || c.mode == "-V") {
+    std::printf("hyper-gen 0.0.1 (%s)\n", hg_version());
+    std::exit(0);
+  }
+  if (c.mode == "--help" || c.mode == "-h") {
+    std::printf("HyperGen: Fast and memory-efficient genome sketching in hyperdimensional space (MI355X build)\n\n"
+                "  hyper-gen sketch -p {fna_path} -o {output_sketch_file}\n"
+                "  hyper-gen dist -r {ref_sketch} -q {query_sketch} -o {output_ANI_results}\n\n"
+                "options: -p --path, -r --path_r, -q --path_q, -o --out, -t --thread [16], -m --sketch_method,\n"
+                "         -C --canonical [true], -k --ksize [21], -S --seed [123], -s --scaled [1500], -d --hv_d [4096],\n"
+                "         -Q --quant_scale [1.0], -a --ani_th [85.0], -D --device [cpu]\n");
+    std::exit(0);
+  }
+  if (c.mode != "sketch" && c.mode != "dist" && c.mode != "search") die("unknown subcommand '" + c.mode + "'");
+  if (c.mode != "sketch") c.method = "fracminhash";
+  static const std::map<std::string, char> longs = {
+      {"path", 'p'}, {"path_r", 'r'}, {"path_q", 'q'}, {"out", 'o'}, {"thread", 't'}, {"sketch_method", 'm'},
+      {"canonical", 'C'}, {"ksize", 'k'}, {"seed", 'S'}, {"scaled", 's'}, {"hv_d", 'd'}, {"quant_scale", 'Q'},
+      {"ani_th", 'a'}, {"device", 'D'}};
+  for (int i = 2; i < argc; ++i) {
+    std::string a = argv[i], val;
+    char key = 0;
+    bool have_val = false;
+    if (a.rfind("--", 0) == 0) {
+      std::string name = a.substr(2);
+      size_t eq = name.find('=');
+      if (eq != std::string::npos) val = name.substr(eq + 1), name = name.substr(0, eq), have_val = true;
+      auto it = longs.find(name);
+      if (it == longs.end()) die("unexpected argument '" + a + "'");
+      key = it->second;
+    } else if (a.size() >= 2 && a[0] == '-') {
+      key = a[1];
+      if (a.size() > 2) val = a.substr(a[2] == '=' ? 3 : 2), have_val = true;
+    } else {
+      die("unexpected argument '" + a + "'");
+    }
+    if (!have_val) {
+      if (i + 1 >= argc) die("a value is required for '" + a + "'");
+      val = argv[++i];
+    }
+    auto u = [&](unsigned long long max) {
+      char *e = nullptr;
+      unsigned long long v = std::strtoull(val.c_str(), &e, 10);
+      if (val.empty() || *e || v > max) die("invalid value '" + val + "' for '" + a + "'");
+      return v;
+    };
+    switch (key) {
+      case 'p': c.path = val; break;
+      case 'r': c.path_r = val; break;
+      case 'q': c.path_q = val; break;
+      case 'o': c.out = val; break;
+      case 't': c.threads = (unsigned)u(255); break;  // u8
+      case 'm': c.method = val; break;
+      case 'C':
+        if (val == "true") c.canonical = true;
+        else if (val == "false") c.canonical = false;
+        else die("invalid value '" + val + "' for '--canonical'");
+        break;
+      case 'k': c.ksize = (unsigned)u(255); break;  // u8
+      case 'S': c.seed = u(~0ull); break;
+      case 's': c.scaled = u(~0ull); break;
+      case 'd': c.hv_d = u(~0ull); break;
+      case 'Q': c.quant_scale = std::strtof(val.c_str(), nullptr); break;
+      case 'a': c.ani_th = std::strtof(val.c_str(), nullptr); break;
+      case 'D': c.device = val; break;
+      default: die("unexpected argument '" + a + "'");
+    }
+  }
+  return c;
+}
+
+void ck(hg_ctx *ctx, hg_status s, const char *what) {
+  if (s != HG_OK) die(std::string(what) + ": " + hg_status_str(s) + " (" + hg_last_error(ctx) + ")");
+}
+
+// get_fasta_files (src/utils.rs:208-221): *.fna, *.fa, *.fasta, in that order
+std::vector<std::string> fasta_files(const std::string &dir) {
+  std::vector<std::string> out;
+  for (const char *pat : {"*.fna", "*.fa", "*.fasta"}) {
+    glob_t g;
+    std::string p = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + pat;
+    if (glob(p.c_str(), 0, nullptr, &g) == 0)
+      for (size_t i = 0; i < g.gl_pathc; ++i) out.push_back(g.gl_pathv[i]);
+    globfree(&g);
+  }
+  return out;
+}
+
+int run_sketch(const Cli &c) {
+  if (c.path == "1" && c.out.empty()) die("the following required arguments were not provided: --path --out");
+  if (c.out.empty()) die("the following required arguments were not provided: --out");
+  const auto files = fasta_files(c.path);
+  const size_t n = files.size();
+  logline("INFO", "Start sketching...");
+  const auto t0 = std::chrono::steady_clock::now();
+  if (c.scaled == 0) die("scaled must be >= 1");
+  if (c.hv_d % 256) die("hv_d must be a multiple of 256 (bit-packed sketch blocks, src/hd.rs:143-153)");
+  hg_ctx *ctx = nullptr;
+  if (hg_ctx_create(0, &ctx) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  hg_sketch_params p;
+  hg_sketch_params_default(&p);
+  p.ksize = c.ksize, p.canonical = c.canonical, p.scaled = c.scaled, p.seed = c.seed;
+  p.hv_d = (uint32_t)c.hv_d, p.hv_layout = HG_LAYOUT_AVX2;
+  p.norm_mode = c.device == "gpu" ? HG_NORM_ACGT : HG_NORM_U2T;
+
+  std::vector<std::vector<int16_t>> payload(n);
+  std::vector<hg_file_sketch> recs(n);
+  const size_t budget = (size_t)6 << 30;  // bytes of sequence per device batch
+  size_t i0 = 0;
+  while (i0 < n) {
+    // read a batch of files with -t host threads
+    std::vector<uint8_t *> seqs;
+    std::vector<size_t> lens;
+    size_t bytes = 0, i1 = i0;
+    while (i1 < n && (i1 == i0 || bytes < budget)) {
+      const size_t cnt = std::min<size_t>(std::max(1u, c.threads), n - i1);
+      seqs.resize(seqs.size() + cnt), lens.resize(lens.size() + cnt);
+      std::vector<std::thread> th;
+      for (size_t k = 0; k < cnt; ++k)
+        th.emplace_back([&, k] {
+          if (hg_read_merge_seq(files[i1 + k].c_str(), &seqs[i1 - i0 + k], &lens[i1 - i0 + k]) != HG_OK)
+            die("Opening .fna files failed: " + files[i1 + k]);
+        });
+      for (auto &t : th) t.join();
+      for (size_t k = 0; k < cnt; ++k) bytes += lens[i1 - i0 + k];
+      i1 += cnt;
+    }
+    const size_t nb = i1 - i0;
+    std::vector<int16_t> hv(nb * c.hv_d);
+    std::vector<int32_t> n2(nb);
+    std::vector<uint32_t> nh(nb);
+    ck(ctx, hg_sketch_batch(ctx, seqs.data(), lens.data(), nb, &p, hv.data(), n2.data(), nh.data()), "sketch");
+    for (size_t k = 0; k < nb; ++k) {
+      hg_free(seqs[k]);
+      const int16_t *v = hv.data() + k * c.hv_d;
+      const uint32_t q = hg_hv_quant_bits(v, (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
+      payload[i0 + k].resize((size_t)q * c.hv_d / 16);
+      if (hg_hv_pack(v, (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[i0 + k].data())) != HG_OK) die("pack");
+      hg_file_sketch &r = recs[i0 + k];
+      std::memset(&r, 0, sizeof r);
+      r.ksize = (uint8_t)c.ksize, r.canonical = c.canonical, r.hv_quant_bits = (uint8_t)q, r.hv_norm_2 = n2[k];
+      r.scaled = c.scaled, r.seed = c.seed, r.hv_d = c.hv_d;
+      r.file_str = files[i0 + k].c_str();
+      r.hv = payload[i0 + k].data(), r.hv_len = payload[i0 + k].size();
+    }
+    i0 = i1;
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "Sketching %zu files took %.2fs - Speed: %.1f files/s", n, secs, n / std::max(secs, 1e-9));
+  logline("INFO", buf);
+  if (hg_sketch_file_write(c.out.c_str(), recs.data(), n) != HG_OK) die("Dump sketch file failed!");
+  size_t total = 8;
+  for (auto &r : recs) total += 47 + std::strlen(r.file_str) + r.hv_len * 2;
+  std::snprintf(buf, sizeof buf, "Dump sketch file to %s with size %.2f MB", c.out.c_str(), total / 1024.0 / 1024.0);
+  logline("INFO", buf);
+  hg_ctx_destroy(ctx);
+  return 0;
+}
+
+struct Loaded {
+  hg_sketch_file *f = nullptr;
+  std::vector<int16_t> hv;
+  std::vector<int32_t> n2;
+  size_t n = 0;
+  uint64_t hv_d = 0;
+  uint8_t ksize = 0;
+};
+
+void load(const std::string &path, Loaded &L) {
+  logline("INFO", "Loading sketch from " + path);
+  if (hg_sketch_file_read(path.c_str(), &L.f) != HG_OK) die("Opening sketch file failed!");
+  L.n = hg_sketch_file_count(L.f);
+  if (L.n == 0) die("empty sketch file " + path);
+  const hg_file_sketch *r0 = hg_sketch_file_get(L.f, 0);
+  L.hv_d = r0->hv_d, L.ksize = r0->ksize;
+  char buf[96];
+  std::snprintf(buf, sizeof buf, "Decompressing sketch with HV dim=%llu", (unsigned long long)L.hv_d);
+  logline("INFO", buf);
+  L.hv.resize(L.n * L.hv_d), L.n2.resize(L.n);
+  for (size_t i = 0; i < L.n; ++i) {
+    const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
+    if (r->hv_d != L.hv_d) die("sketches of one file use different HV dimensions");
+    if (r->hv_len * 16 != (uint64_t)r->hv_quant_bits * L.hv_d) die("corrupt sketch payload in " + path);
+    if (hg_hv_unpack(reinterpret_cast<const uint8_t *>(r->hv), (uint32_t)L.hv_d, r->hv_quant_bits,
+                     L.hv.data() + i * L.hv_d) != HG_OK)
+      die("unpack failed");
+    L.n2[i] = r->hv_norm_2;
+  }
+}
+
+int run_dist(const Cli &c) {
+  if (c.path_r == "1" || c.path_q == "1" || c.out.empty())
+    die("the following required arguments were not provided: --path_r --path_q --out");
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool sym = c.path_r == c.path_q;  // src/dist.rs:13
+  Loaded R, Qs;
+  load(c.path_r, R);
+  if (!sym) load(c.path_q, Qs);
+  const Loaded &Q = sym ? R : Qs;
+  if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
+  if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
+  logline("INFO", "Computing ANI..");
+  hg_ctx *ctx = nullptr;
+  if (hg_ctx_create(0, &ctx) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  const size_t total = sym ? R.n * (Q.n - 1) / 2 : R.n * Q.n;
+  std::vector<hg_ani_hit> hits(std::max<size_t>(1024, total / 16));
+  size_t found = 0;
+  for (;;) {
+    hg_status s = hg_dist(ctx, R.hv.data(), R.n2.data(), R.n, Q.hv.data(), Q.n2.data(), Q.n, (uint32_t)R.hv_d, R.ksize,
+                          sym, c.ani_th, hits.data(), hits.size(), &found);
+    if (s == HG_ERR_CAPACITY) {
+      hits.resize(found);
+      continue;
+    }
+    ck(ctx, s, "dist");
+    break;
+  }
+  hits.resize(found);
+  hg_sort_ani_hits(hits.data(), hits.size(), Q.n, sym);
+  std::string tsv;
+  char line[64];
+  for (const auto &h : hits) {
+    tsv += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
+    tsv += '\t';
+    tsv += hg_sketch_file_get(Q.f, h.qry_idx)->file_str;
+    std::snprintf(line, sizeof line, "\t%.3f\n", (double)h.ani);  // "{}\t{}\t{:.3}\n", src/utils.rs:277-282
+    tsv += line;
+  }
+  FILE *f = std::fopen(c.out.c_str(), "wb");
+  if (!f || (tsv.size() && std::fwrite(tsv.data(), 1, tsv.size(), f) != tsv.size())) die("Dump ANI file failed!");
+  std::fclose(f);
+  char buf[512];
+  const double perc = total ? 100.0 * found / total : 0.0;
+  if (perc < 5.0) {
+    std::snprintf(buf, sizeof buf, "Output ANIs with threshold %.1f are too divergent: %zu of %zu (%.2f%%) ANIs are reported",
+                  c.ani_th, found, total, perc);
+    logline("WARN", buf);
+  } else {
+    std::snprintf(buf, sizeof buf, "Output %zu of %zu ANIs above threshold %.1f to file %s", found, total, c.ani_th, c.out.c_str());
+    logline("INFO", buf);
+  }
+  std::snprintf(buf, sizeof buf, "Computed ANIs for %zu ref files and %zu query files took %.3fs", R.n, Q.n,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  logline("INFO", buf);
+  hg_sketch_file_free(R.f);
+  if (!sym) hg_sketch_file_free(Qs.f);
+  hg_ctx_destroy(ctx);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const Cli c = parse(argc, argv);
+  if (c.mode == "sketch") return run_sketch(c);
+  if (c.mode == "dist") return run_dist(c);
+  return 0;  // search: parsed but a no-op in the reference too (src/main.rs:22-24)
+}

@@ -275,12 +275,15 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   if (Rp > a.R) HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * Kp, 0, (size_t)(Rp - a.R) * Kp * 2, c->stream));
   if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * Kp, 0, (size_t)(Qp - a.Q) * Kp * 2, c->stream));
   const size_t plds = (size_t)(Kp / 64) * sizeof(unsigned long long);
+  {
+  hg_timed tm(c, HG_T_DIST_PREP);
   hipLaunchKernelGGL(prep_kernel, dim3(a.R), dim3(256), plds, c->stream, a.ref_hv, a.R, a.hv_d, Kp, fa, st);
   HG_HIP(c, hipGetLastError());
   if (!same) {
     hipLaunchKernelGGL(prep_kernel, dim3(a.Q), dim3(256), plds, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, fb,
                        st + 1 + N_CHUNK_CAND);
     HG_HIP(c, hipGetLastError());
+  }
   }
   unsigned long long h[2 * (1 + N_CHUNK_CAND)];
   HG_HIP(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -299,6 +302,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
     }
   }
   const float kf = (float)a.ksize;
+  hg_timed tm(c, HG_T_DIST);
   if (best_c < 0) {  // values too large for the f16 path: exact integer kernel
     dim3 grid((a.Q + FB_T - 1) / FB_T, (a.R + FB_T - 1) / FB_T);
     hipLaunchKernelGGL(dist_int_kernel, grid, dim3(FB_T * FB_T), 0, c->stream, a.ref_hv, a.qry_hv, a, kf);

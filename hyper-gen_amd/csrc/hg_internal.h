@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/hypergen.h"
 
@@ -34,6 +35,14 @@ struct hg_ctx {
   Buf w_ani;      // staged ANI output (host entry points)
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
+  // optional per-kernel timing (hg_ctx_enable_timing)
+  bool timing = false;
+  struct TimedLaunch {
+    hipEvent_t e0, e1;
+    int cls;
+  };
+  std::vector<TimedLaunch> t_pending;   // recorded, not yet read
+  std::vector<hipEvent_t> t_pool;       // reusable events
   // pinned host scratch
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;
@@ -42,6 +51,16 @@ struct hg_ctx {
 hg_status hg_fail(hg_ctx *ctx, hg_status s, const std::string &msg);
 hg_status hg_ensure(hg_ctx *ctx, hg_ctx::Buf &b, size_t bytes);
 hg_status hg_ensure_pinned(hg_ctx *ctx, size_t bytes);
+
+// RAII bracket: records events around the launches issued while it is alive (no-op unless
+// timing is enabled).
+struct hg_timed {
+  hg_ctx *c;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int cls;
+  hg_timed(hg_ctx *ctx, int cls_);
+  ~hg_timed();
+};
 
 #define HG_HIP(ctx, expr)                                                              \
   do {                                                                                 \

@@ -59,6 +59,19 @@ hg_status hg_ctx_set_stream(hg_ctx *ctx, void *hip_stream);
 hg_status hg_ctx_sync(hg_ctx *ctx);
 int hg_device_count(void);
 
+/* per-kernel device timing: when enabled, every kernel launch of the sketch / dist entry
+ * points is bracketed by HIP events on the ctx's stream.  hg_ctx_timings waits for the last
+ * bracket and returns, per kernel class, the SUM of the launch durations (ms) and the number
+ * of launches since the previous hg_ctx_timings call. */
+#define HG_T_KMER 0      /* k-mer hash + sample            */
+#define HG_T_SORT 1      /* sort + unique                  */
+#define HG_T_ENCODE 2    /* HV encode + norm               */
+#define HG_T_DIST_PREP 3 /* i16 -> f16 + exactness bounds  */
+#define HG_T_DIST 4      /* ANI GEMM (MFMA or integer)     */
+#define HG_T_COUNT 5
+hg_status hg_ctx_enable_timing(hg_ctx *ctx, int on);
+hg_status hg_ctx_timings(hg_ctx *ctx, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]);
+
 /* minimal device-memory helpers for callers that have no HIP binding of their own
  * (cudarc's htod_copy / alloc_zeros / sync_reclaim, src/sketch_cuda.rs:134,138,156) */
 hg_status hg_dev_alloc(hg_ctx *ctx, size_t bytes, void **dptr);

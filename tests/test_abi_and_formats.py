@@ -1,0 +1,135 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, fails loudly without
+a device, and the host-side formats agree with the oracle.  No compute kernels run here."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+@pytest.fixture(scope="module")
+def hg():
+    import hypergen_amd
+    hypergen_amd.lib()
+    return hypergen_amd
+
+
+def test_every_declared_symbol_is_exported(hg):
+    hdr = open(os.path.join(ROOT, "include", "hypergen.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # declarations only, not prose
+    declared = set(re.findall(r"\b(hg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    L = hg.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(hg.EXPORTS)
+    nm = subprocess.run(["nm", "-D", "--defined-only", hg.LIB_PATH], capture_output=True, text=True).stdout
+    assert not re.search(r"\borc_", nm), "the product must not contain the oracle"
+
+
+def test_product_does_not_reference_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "hyper-gen_amd")):
+        for f in fs:
+            if f.endswith((".hip", ".cpp", ".h", ".py")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "hg_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_fails_loudly_without_device(hg):
+    with pytest.raises(hg.HgError) as e:
+        hg.Context(0)
+    assert e.value.status == hg.ERR_NO_DEVICE
+
+
+def test_status_strings_and_defaults(hg):
+    L = hg.lib()
+    assert L.hg_status_str(0) == b"ok" and b"capacity" in L.hg_status_str(hg.ERR_CAPACITY)
+    p = hg.default_params()
+    assert (p.ksize, p.scaled, p.seed, p.canonical, p.hv_d) == (21, 1500, 123, 1, 4096)  # src/types.rs:97-113
+
+
+def test_pack_matches_oracle(hg, orc):
+    rng = np.random.default_rng(0)
+    for amp, d in ((0, 256), (31, 4096), (32, 4096), (300, 4096), (1000, 1024), (20000, 512)):
+        hv = rng.integers(-amp, amp + 1, d).astype(np.int16)
+        q, packed = hg.hv_pack(hv)
+        oq, opacked = orc.pack_hv(hv)
+        assert q == oq == hg.hv_quant_bits(hv) and (packed == opacked).all()
+        if q < 16:  # q == 16 reproduces the reference's sign-extension bug (src/hd.rs:140-141) bit for bit
+            assert (hg.hv_unpack(packed, d, q) == hv).all()
+        else:
+            assert (hg.hv_unpack(packed, d, q) == orc.unpack_hv(opacked, d, q)).all()
+    with pytest.raises(hg.HgError):
+        hg.hv_pack(np.zeros(100, np.int16), 6)  # not a multiple of 256
+
+
+def test_sketch_file_layout_and_roundtrip(hg, tmp_path):
+    hv = (np.arange(1536) - 700).astype(np.int16)
+    recs = [dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=4096, hv_quant_bits=6, hv_norm_2=-5,
+                 file_str="dir/a.fna", hv=hv),
+            dict(ksize=31, scaled=7, canonical=False, seed=2**63 + 5, hv_d=256, hv_quant_bits=16, hv_norm_2=2**31 - 1,
+                 file_str="b.fa", hv=np.zeros(0, np.int16))]
+    path = str(tmp_path / "x.sketch")
+    hg.write_sketch_file(path, recs)
+    raw = open(path, "rb").read()
+    # bincode 1.x defaults (src/types.rs:224-235 field order): u64 count, then per record
+    # u8 ksize, u64 scaled, u8 canonical, u64 seed, u64 hv_d, u8 quant_bits, i32 norm, str, Vec<i16>
+    assert struct.unpack_from("<Q", raw, 0)[0] == 2
+    assert struct.unpack_from("<BQBQQBi", raw, 8) == (21, 1500, 1, 123, 4096, 6, -5)
+    off = 8 + 31
+    assert struct.unpack_from("<Q", raw, off)[0] == 9 and raw[off + 8:off + 17] == b"dir/a.fna"
+    off += 17
+    assert struct.unpack_from("<Q", raw, off)[0] == 1536
+    assert np.frombuffer(raw, "<i2", 1536, off + 8).tolist() == hv.tolist()
+    back = hg.read_sketch_file(path)
+    for a, b in zip(recs, back):
+        for k in a:
+            assert (np.array_equal(a[k], b[k]) if k == "hv" else a[k] == b[k]), k
+    open(path, "wb").write(raw[:50])
+    with pytest.raises(hg.HgError):
+        hg.read_sketch_file(path)
+
+
+def test_read_merge_seq(hg, orc, tmp_path):
+    txt = b">r1 x\nACGTNN\nacgu\r\n>r2\n\nTT\r"
+    p = tmp_path / "t.fna"
+    p.write_bytes(txt)
+    got = hg.read_merge_seq(str(p))
+    assert bytes(got) == b"NACGTNNacguNTT" and (got == orc.read_merge_seq(txt)).all()
+    ref_fixture = b">test_seq\nAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"
+    p.write_bytes(ref_fixture)
+    assert bytes(hg.read_merge_seq(str(p))) == b"NAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"
+
+
+def test_sort_ani_hits_matches_dump_ani_file_order(hg):
+    # model of src/utils.rs:262-269 on the row-major enumeration of src/dist.rs:251-265
+    rng = np.random.default_rng(3)
+    R, Q = 7, 9
+    ani = rng.choice([90.0, 95.5, 99.0, 100.0], (R, Q)).astype(np.float32)
+    pairs = [(i, j) for i in range(R) for j in range(Q)]
+    idx = sorted(range(len(pairs)), key=lambda t: ani[pairs[t]])  # stable ascending
+    idx.reverse()
+    want = [pairs[t] for t in idx]
+    hits = np.zeros(R * Q, hg.ANI_HIT_DTYPE)
+    perm = rng.permutation(R * Q)
+    for o, t in enumerate(perm):
+        hits[o] = (pairs[t][0], pairs[t][1], ani[pairs[t]])
+    got = hg.sort_ani_hits(hits, Q)
+    assert [(int(h["ref_idx"]), int(h["qry_idx"])) for h in got] == want
+
+
+def test_cli_surface(hg):
+    cli = hg.CLI_PATH
+    assert os.path.exists(cli)
+    out = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "sketch" in out.stdout and "--ani_th" in out.stdout
+    assert subprocess.run([cli, "search"], capture_output=True).returncode == 0  # no-op like src/main.rs:22-24
+    bad = subprocess.run([cli, "sketch", "-p", "/tmp", "-o", "/tmp/x", "-t", "300"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "invalid value" in bad.stderr  # -t is u8 (src/utils.rs:54-56)
+    assert subprocess.run([cli, "frobnicate"], capture_output=True).returncode != 0

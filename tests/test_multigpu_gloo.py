@@ -1,0 +1,67 @@
+"""world_size-2 CPU (gloo) test of the multi-GPU decomposition used by bench.py: genome sharding
+without a collective, one all-gather of the reference HVs for dist."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_genomes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hypergen_amd  # noqa: F401  (package import only; no device needed)
+    from hypergen_amd import shard
+    from oracle import oracle as orc
+    lo, hi = shard.shard_range(n_genomes, rank, world)
+    # "sketch" shard: every rank sketches only its genomes (CPU oracle stands in for the kernel here)
+    hv = np.stack([orc.sketch_genome(orc.synth_genome(g, 30_000), scaled=20, hv_d=512)[0] for g in range(lo, hi)])
+    n2 = np.array([orc.hv_norm2(r) for r in hv], np.int32)
+    # dist: all-gather the reference HV matrix, compute this rank's R x Q_local block
+    ref = shard.allgather_rows(torch.from_numpy(hv), world).numpy()
+    ref_n2 = shard.allgather_rows(torch.from_numpy(n2), world).numpy()
+    block = orc.ani_matrix(ref, ref_n2, hv, n2, 21)
+    np.save(os.path.join(out_dir, "block%d.npy" % rank), block)
+    np.save(os.path.join(out_dir, "hv%d.npy" % rank), hv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    sys.path.insert(0, ROOT)
+    import hypergen_amd  # noqa: F401
+    from hypergen_amd import shard
+    for n in (0, 1, 7, 8, 1000, 10001):
+        for w in (1, 2, 3, 8):
+            r = [shard.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sketch_and_dist_decomposition(tmp_path, orc):
+    n, world = 5, 2  # odd on purpose: ranks own 3 and 2 genomes
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    hv = np.concatenate([np.load(tmp_path / ("hv%d.npy" % r)) for r in range(world)])
+    want_hv = np.stack([orc.sketch_genome(orc.synth_genome(g, 30_000), scaled=20, hv_d=512)[0] for g in range(n)])
+    assert (hv == want_hv).all()  # sharded sketches == single-process sketches, in genome order
+    n2 = np.array([orc.hv_norm2(r) for r in hv], np.int32)
+    full = orc.ani_matrix(hv, n2, hv, n2, 21)
+    got = np.concatenate([np.load(tmp_path / ("block%d.npy" % r)) for r in range(world)], axis=1)
+    assert got.shape == full.shape and (got == full).all()

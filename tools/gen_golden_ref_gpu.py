@@ -40,9 +40,11 @@ def main():
         ("g2_5m_k21_s1500", 2, 5_000_000, 21, 1500, True, 0),
         ("g2_300k_k21_s100_noncanon", 3, 300_000, 21, 100, False, 32),
         ("g2_200k_k16_s50", 4, 200_000, 16, 50, True, 64),
-        ("g2_200k_k31_s50", 5, 200_000, 31, 50, True, 64),
-        ("g2_200k_k32_s50", 6, 200_000, 32, 50, True, 64),
+        ("g2_200k_k24_s50", 5, 200_000, 24, 50, True, 64),
         ("g2_50k_k9_s20", 7, 50_000, 9, 20, True, 128),
+        ("g2_50k_k12_s20", 8, 50_000, 12, 20, True, 128),
+        # k = 25 probes the reference kernel's `default:` branch (k=31/32 fault on gfx950)
+        ("g2_50k_k25_s20", 9, 50_000, 25, 20, True, 128),
     ]:
         seq = orc.synth_genome(g, L)
         if "100k" in name:  # sprinkle non-bases and lower case
@@ -50,7 +52,11 @@ def main():
             seq = seq.copy()
             seq[rng.choice(L, 50, replace=False) + 1] = ord("N")
             seq[5000:6000] = np.char.lower(seq[5000:6000].view("S1")).view(np.uint8)
-        ref = run_ref(seq, k, scaled, canonical=canon, slots=slots)
+        try:
+            ref = run_ref(seq, k, scaled, canonical=canon, slots=slots)
+        except subprocess.CalledProcessError as e:
+            print(name, "REFERENCE KERNEL FAILED:", e.returncode)
+            continue
         mine = orc.kmer_hash_sample(seq, k, scaled, 123, canon)
         ok = ref.size == mine.size and bool((ref == mine).all())
         print(name, "ref", ref.size, "oracle", mine.size, "equal", ok)
