@@ -141,18 +141,13 @@ static inline uint8_t comp_base(uint8_t c) {
   }
 }
 
-size_t orc_kmer_hash_sample(const uint8_t *seq, size_t n_bps, unsigned ksize,
-                            uint64_t threshold, uint64_t seed, int canonical,
-                            int norm_mode, uint64_t *out, size_t cap) {
-  if (ksize == 0 || n_bps < ksize) return 0;
+/* fwd / rc: scratch of n_bps bytes each */
+static size_t kmer_sample_core(const uint8_t *seq, size_t n_bps, unsigned ksize,
+                               uint64_t threshold, uint64_t seed, int canonical,
+                               int norm_mode, uint64_t *out, size_t cap,
+                               uint8_t *fwd, uint8_t *rc) {
   /* like needletail (src/sketch.rs:84-87): a normalised copy and its reverse
    * complement for the whole buffer, windows are slices of the two. */
-  uint8_t *fwd = (uint8_t *)malloc(n_bps);
-  uint8_t *rc = (uint8_t *)malloc(n_bps);
-  if (!fwd || !rc) {
-    free(fwd), free(rc);
-    return 0;
-  }
   for (size_t i = 0; i < n_bps; i++) {
     uint8_t b = norm_base(seq[i], norm_mode);
     fwd[i] = b ? b : 'N';
@@ -174,8 +169,22 @@ size_t orc_kmer_hash_sample(const uint8_t *seq, size_t n_bps, unsigned ksize,
       n_hit++;
     }
   }
-  free(fwd), free(rc);
   return n_hit;
+}
+
+size_t orc_kmer_hash_sample(const uint8_t *seq, size_t n_bps, unsigned ksize,
+                            uint64_t threshold, uint64_t seed, int canonical,
+                            int norm_mode, uint64_t *out, size_t cap) {
+  if (ksize == 0 || n_bps < ksize) return 0;
+  uint8_t *fwd = (uint8_t *)malloc(n_bps);
+  uint8_t *rc = (uint8_t *)malloc(n_bps);
+  if (!fwd || !rc) {
+    free(fwd), free(rc);
+    return 0;
+  }
+  size_t n = kmer_sample_core(seq, n_bps, ksize, threshold, seed, canonical, norm_mode, out, cap, fwd, rc);
+  free(fwd), free(rc);
+  return n;
 }
 
 static int cmp_u64(const void *a, const void *b) {
@@ -463,6 +472,59 @@ int orc_sketch_genome(const uint8_t *seq, size_t n_bps, unsigned ksize,
   *n_hash = (uint32_t)n;
   free(hs);
   return 0;
+}
+
+/* Task-parallel over genomes like the rayon loop of src/sketch.rs:35 (one genome per task,
+ * per-thread scratch reused across genomes).  hv: n x hv_d.  Returns 0 on success. */
+int orc_sketch_batch_mt(const uint8_t *const *seqs, const size_t *lens, size_t n,
+                        unsigned ksize, uint64_t scaled, uint64_t seed, int canonical,
+                        int norm_mode, size_t hv_d, int layout, int n_threads,
+                        int16_t *hv, int32_t *norm2, uint32_t *n_hash) {
+  size_t max_len = 0;
+  for (size_t g = 0; g < n; g++) max_len = lens[g] > max_len ? lens[g] : max_len;
+  const uint64_t threshold = UINT64_MAX / scaled;
+  int fail = 0;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    uint8_t *fwd = (uint8_t *)malloc(max_len + 1), *rc = (uint8_t *)malloc(max_len + 1);
+    size_t cap = max_len / (scaled ? scaled : 1) * 2 + 1024;
+    uint64_t *hs = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    if (!fwd || !rc || !hs) {
+#pragma omp atomic write
+      fail = 1;
+    } else {
+#pragma omp for schedule(dynamic, 1)
+      for (long g = 0; g < (long)n; g++) {
+        size_t m = 0;
+        if (lens[g] >= ksize)
+          m = kmer_sample_core(seqs[g], lens[g], ksize, threshold, seed, canonical, norm_mode, hs, cap, fwd, rc);
+        if (m > cap) { /* repeats-heavy input: grow and redo */
+          uint64_t *h2 = (uint64_t *)realloc(hs, m * sizeof(uint64_t));
+          if (!h2) {
+#pragma omp atomic write
+            fail = 1;
+            continue;
+          }
+          hs = h2, cap = m;
+          m = kmer_sample_core(seqs[g], lens[g], ksize, threshold, seed, canonical, norm_mode, hs, cap, fwd, rc);
+        }
+        m = orc_sort_unique_u64(hs, m);
+        orc_encode_hv(hs, m, hv_d, layout, hv + (size_t)g * hv_d);
+        norm2[g] = orc_hv_norm2(hv + (size_t)g * hv_d, hv_d);
+        n_hash[g] = (uint32_t)m;
+      }
+    }
+    free(fwd), free(rc), free(hs);
+  }
+  return fail ? -1 : 0;
+}
+
+/* fills n genomes (ids first .. first+n-1) in parallel; out: n x (L+1) bytes */
+void orc_synth_genomes_mt(uint64_t first, size_t n, size_t L, unsigned cluster_size,
+                          uint32_t sub_ppm_per_member, int n_threads, uint8_t *out) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+  for (long g = 0; g < (long)n; g++)
+    orc_synth_genome(first + (uint64_t)g, L, cluster_size, sub_ppm_per_member, out + (size_t)g * (L + 1));
 }
 
 /* ------------------------------------------------------------------------- */

@@ -106,6 +106,13 @@ int orc_sketch_genome(const uint8_t *seq, size_t n_bps, unsigned ksize,
                       int norm_mode, size_t hv_d, int layout, int16_t *hv,
                       int32_t *norm2, uint32_t *n_hash);
 
+/* the same for n genomes, task-parallel over genomes with OpenMP (the rayon loop of
+ * src/sketch.rs:35); hv is n x hv_d.  This is the timed CPU baseline of bench.py. */
+int orc_sketch_batch_mt(const uint8_t *const *seqs, const size_t *lens, size_t n,
+                        unsigned ksize, uint64_t scaled, uint64_t seed, int canonical,
+                        int norm_mode, size_t hv_d, int layout, int n_threads,
+                        int16_t *hv, int32_t *norm2, uint32_t *n_hash);
+
 /* ---- synthetic inputs (repo-defined) ----------------------------- */
 
 /* Genome g of a clustered set: cluster c = g / cluster_size is an iid-uniform
@@ -115,6 +122,9 @@ int orc_sketch_genome(const uint8_t *seq, size_t n_bps, unsigned ksize,
  * single-record FASTA): out must hold L + 1 bytes. */
 void orc_synth_genome(uint64_t g, size_t L, unsigned cluster_size,
                       uint32_t sub_ppm_per_member, uint8_t *out);
+
+void orc_synth_genomes_mt(uint64_t first, size_t n, size_t L, unsigned cluster_size,
+                          uint32_t sub_ppm_per_member, int n_threads, uint8_t *out);
 
 #ifdef __cplusplus
 }

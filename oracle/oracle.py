@@ -68,6 +68,12 @@ def lib():
         L.orc_sketch_genome.argtypes = [u8p, C.c_size_t, C.c_uint, C.c_uint64, C.c_uint64,
                                         C.c_int, C.c_int, C.c_size_t, C.c_int, i16p, i32p,
                                         C.POINTER(C.c_uint32)]
+        L.orc_sketch_batch_mt.restype = C.c_int
+        L.orc_sketch_batch_mt.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_uint,
+                                          C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                          i16p, i32p, C.POINTER(C.c_uint32)]
+        L.orc_synth_genomes_mt.restype = None
+        L.orc_synth_genomes_mt.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint32, C.c_int, u8p]
         L.orc_synth_genome.restype = None
         L.orc_synth_genome.argtypes = [C.c_uint64, C.c_size_t, C.c_uint, C.c_uint32, u8p]
         _lib = L
@@ -199,3 +205,28 @@ def synth_genome(g, L, cluster_size=100, sub_ppm_per_member=1000):
     lib().orc_synth_genome(C.c_uint64(g), L, cluster_size, sub_ppm_per_member,
                            _p(out, C.c_uint8))
     return out
+
+
+def synth_genomes_mt(first, n, L, threads, cluster_size=100, sub_ppm_per_member=1000):
+    out = np.zeros((n, L + 1), np.uint8)
+    lib().orc_synth_genomes_mt(C.c_uint64(first), n, L, cluster_size, sub_ppm_per_member, threads,
+                               _p(out, C.c_uint8))
+    return out
+
+
+def sketch_batch_mt(seqs, threads, ksize=21, scaled=1500, seed=123, canonical=True, norm=NORM_ACGT,
+                    hv_d=4096, layout=LAYOUT_AVX2):
+    """seqs: 2-D uint8 array (n x len) or list of 1-D arrays.  OpenMP over genomes."""
+    arrs = [np.ascontiguousarray(s, np.uint8) for s in seqs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * max(n, 1))(*[a.size for a in arrs])
+    hv = np.zeros((n, hv_d), np.int16)
+    n2 = np.zeros(n, np.int32)
+    nh = np.zeros(n, np.uint32)
+    rc = lib().orc_sketch_batch_mt(ptrs, lens, n, ksize, C.c_uint64(scaled), C.c_uint64(seed), int(canonical),
+                                   norm, hv_d, layout, threads, _p(hv, C.c_int16), _p(n2, C.c_int32),
+                                   _p(nh, C.c_uint32))
+    if rc != 0:
+        raise MemoryError("orc_sketch_batch_mt failed")
+    return hv, n2, nh

@@ -155,3 +155,39 @@ def test_synth_genomes(orc):
     assert 0.70 < float((other[1:] != root[1:]).mean()) < 0.80
     counts = np.bincount(root[1:], minlength=128)[list(b"ACGT")] / 20000
     assert (abs(counts - 0.25) < 0.02).all()
+
+
+def test_g2_reference_kernel_vectors(orc):
+    """Hash sets produced ON THE MI355X by the reference's own kernel (src/cuda_kernel.cu compiled in
+    place by hipcc, tools/gen_golden_ref_gpu.py) -- the oracle must reproduce them on the CPU."""
+    cases = golden("g2_ref_kernel.json")
+    assert len(cases) >= 8
+    for c in cases:
+        if c["L"] > 1_000_000:
+            continue  # the 5 Mbp case runs in test_g2_reference_kernel_5mbp
+        _check_g2(orc, c)
+
+
+def test_g2_reference_kernel_5mbp(orc):
+    big = [c for c in golden("g2_ref_kernel.json") if c["L"] > 1_000_000]
+    assert big
+    for c in big:
+        _check_g2(orc, c)
+
+
+def _check_g2(orc, c):
+    seq = orc.synth_genome(c["genome"], c["L"])
+    if c["mutated"]:
+        rng = np.random.default_rng(c["genome"])
+        seq = seq.copy()
+        seq[rng.choice(c["L"], 50, replace=False) + 1] = ord("N")
+        seq[5000:6000] = np.char.lower(seq[5000:6000].view("S1")).view(np.uint8)
+    got = orc.kmer_hash_sample(seq, c["k"], c["scaled"], 123, c["canonical"])
+    assert got.size == c["n"], c["name"]
+    assert "%016x" % int(np.bitwise_xor.reduce(got) if got.size else 0) == c["xor"], c["name"]
+    assert "%016x" % (int(got.astype(object).sum()) % 2**64 if got.size else 0) == c["sum"], c["name"]
+    want = np.array([int(h, 16) for h in c["hashes"]], np.uint64)
+    if c["subsampled"]:
+        assert np.isin(want, got).all(), c["name"]
+    else:
+        assert (want == got).all(), c["name"]

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun).  Kernel-trace stats of the bench command + separate PMC passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; --pmc runs carry only --kernel-trace).
+# Usage: tools/profile_gpu.sh <round-tag>      outputs under gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.json" 2> "$OUT/stats.log"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY"; do
+  name=$(echo "$pass" | cut -d' ' -f1)
+  timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.log" || echo "pass $name failed" >> "$OUT/errors.txt"
+done
+cd "$ROOT" && python3 tools/summarize_prof.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
