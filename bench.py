@@ -86,13 +86,36 @@ def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100):
     return out
 
 
+def effective_cores():
+    """Host cores this process may really use: min(cpu_count, affinity mask, cgroup CPU quota),
+    capped at 255 like the reference's `-t` (u8, src/utils.rs:54-56)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 255))
+
+
 def cpu_baseline_sketch(seconds, log):
     """Oracle (CPU port of src/sketch.rs:35-56: per-genome task parallelism, ASCII canonical k-mers,
     t1ha2, set, AVX2-layout encode, norm) on a bounded sample of the same workload, all host cores."""
     from oracle import oracle as orc
     orc.lib()
-    cores = min(os.cpu_count() or 1, 255)  # the reference's -t is u8 (src/utils.rs:54-56)
-    n = min(2 * cores, 512)                # bounded host memory: n x 5 MB
+    cores = effective_cores()
+    n = min(max(2 * cores, 16), 512)                # bounded host memory: n x 5 MB
     genomes = orc.synth_genomes_mt(0, n, L_GENOME, cores)
     t0 = time.perf_counter()
     orc.sketch_batch_mt(genomes[:cores], cores)  # calibration pass (also warms the threads)
@@ -111,7 +134,8 @@ def cpu_baseline_sketch(seconds, log):
 
 def cpu_baseline_dist(hv, n2, seconds, log):
     from oracle import oracle as orc
-    cores = min(os.cpu_count() or 1, 255)
+    cores = effective_cores()
+    orc.set_threads(cores)
     rows = min(hv.shape[0], 512)
     r, rn = hv[:rows].cpu().numpy(), n2[:rows].cpu().numpy()
     t0 = time.perf_counter()

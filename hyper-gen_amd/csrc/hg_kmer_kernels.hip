@@ -39,30 +39,63 @@ constexpr uint64_t P4 = 0x9C06FAF4D023E3ABull;
 constexpr uint64_t P5 = 0xC060724A8424F345ull;
 constexpr uint64_t P6 = 0xCB5AF53AE3AAAC31ull;
 
+__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) {
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
 __device__ __forceinline__ uint64_t rot64(uint64_t v, unsigned s) {
   return (v >> s) | (v << (64 - s));
 }
-// src/cuda_kernel.cu:136-141
-__device__ __forceinline__ void mixup64(uint64_t &a, uint64_t &b, uint64_t v, uint64_t prime) {
-  unsigned __int128 m = (unsigned __int128)(b + v) * prime;
-  a ^= (uint64_t)m;
-  b += (uint64_t)(m >> 64);
+// lo64(x * P) returned, hi64(x * P) + addend stored in hi_plus.
+// Schoolbook product on 32-bit halves with four v_mad_u64_u32.  Written by hand because the
+// compiler's expansion of a 128-bit multiply spends 5 v_mov + one 64-bit add on zero-extending
+// partial words; here the third product takes the second as its 64-bit addend and hands its carry
+// out in an SGPR pair, and that carry plus the caller's addend are folded into the addend of the
+// last product with three 32-bit ops.
+template <uint64_t P, bool ZERO_ADDEND = false>
+__device__ __forceinline__ uint64_t mul128_lo_hiadd(uint64_t x, uint64_t addend, uint64_t &hi_plus) {
+  constexpr uint32_t p0 = (uint32_t)P, p1 = (uint32_t)(P >> 32);
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+  const uint64_t A = (uint64_t)x0 * p0;
+  const uint64_t T = (uint64_t)x1 * p0 + (A >> 32);  // cannot overflow
+  uint64_t W, cm;                                     // W = x0*p1 + T (mod 2^64), cm = carry-out lanes
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(W), "=s"(cm) : "v"(x0), "s"(p1), "v"(T));
+  // S = addend + {hi32(W), carry}
+  uint32_t slo, shi;
+  if (ZERO_ADDEND) {
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(shi) : "s"(cm));
+    slo = (uint32_t)(W >> 32);
+  } else {
+    asm("v_cndmask_b32_e64 %1, 0, 1, %4\n\t"
+        "v_add_co_u32_e32 %0, vcc, %2, %3\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %5, %1, vcc"
+        : "=&v"(slo), "=&v"(shi)
+        : "v"((uint32_t)addend), "v"((uint32_t)(W >> 32)), "s"(cm), "v"((uint32_t)(addend >> 32))
+        : "vcc");
+  }
+  hi_plus = (uint64_t)x1 * p1 + mk64(slo, shi);
+  return mk64((uint32_t)A, (uint32_t)W);
+}
+
+// src/cuda_kernel.cu:136-141 with the prime as a template argument
+template <uint64_t P>
+__device__ __forceinline__ void mixup64(uint64_t &a, uint64_t &b, uint64_t v) {
+  uint64_t nb;
+  a ^= mul128_lo_hiadd<P>(b + v, b, nb);
+  b = nb;
 }
 // src/cuda_kernel.cu:143-153
 __device__ __forceinline__ uint64_t final64(uint64_t a, uint64_t b) {
   uint64_t x = (a + rot64(b, 41)) * P0;
   uint64_t y = (rot64(a, 23) + b) * P6;
-  unsigned __int128 m = (unsigned __int128)(x ^ y) * P5;
-  return (uint64_t)m ^ (uint64_t)(m >> 64);
+  uint64_t hi;
+  const uint64_t lo = mul128_lo_hiadd<P5, true>(x ^ y, 0, hi);
+  return lo ^ hi;
 }
 template <int SH>
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t c) {  // (a << SH) | c
   uint32_t r;
   asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
   return r;
-}
-__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) {
-  return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // t1ha2_atonce for a compile-time length K <= 32 whose bytes are given as little-endian
@@ -78,10 +111,10 @@ __device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed
   };
   uint64_t a = seed, b = (uint64_t)K;
   int i = 0;
-  if (K > 24) mixup64(a, b, word(i++), P4);
-  if (K > 16) mixup64(b, a, word(i++), P3);
-  if (K > 8) mixup64(a, b, word(i++), P2);
-  if (K > 0) mixup64(b, a, word(i++), P1);
+  if (K > 24) mixup64<P4>(a, b, word(i++));
+  if (K > 16) mixup64<P3>(b, a, word(i++));
+  if (K > 8) mixup64<P2>(a, b, word(i++));
+  if (K > 0) mixup64<P1>(b, a, word(i++));
   return final64(a, b);
 }
 
@@ -89,10 +122,10 @@ __device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed
 __device__ __forceinline__ uint64_t t1ha2_le32(const uint64_t w[4], uint32_t len, uint64_t seed) {
   uint64_t a = seed, b = (uint64_t)len;
   int i = 0;
-  if (len > 24) mixup64(a, b, w[i++], P4);
-  if (len > 16) mixup64(b, a, w[i++], P3);
-  if (len > 8) mixup64(a, b, w[i++], P2);
-  if (len > 0) mixup64(b, a, w[i++], P1);
+  if (len > 24) mixup64<P4>(a, b, w[i++]);
+  if (len > 16) mixup64<P3>(b, a, w[i++]);
+  if (len > 8) mixup64<P2>(a, b, w[i++]);
+  if (len > 0) mixup64<P1>(b, a, w[i++]);
   return final64(a, b);
 }
 

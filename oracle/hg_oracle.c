@@ -17,6 +17,9 @@
 #include "hg_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -427,6 +430,14 @@ float orc_ani_from_dot(int32_t dot, int32_t nr, int32_t nq, unsigned ksize) {
   ani = ani < 1.0f ? ani : 1.0f; /* .min(1.0) */
   ani = ani > 0.0f ? ani : 0.0f; /* .max(0.0) */
   return ani * 100.0f;
+}
+
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }
 
 void orc_ani_matrix(const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,

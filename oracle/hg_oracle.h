@@ -92,6 +92,9 @@ int32_t orc_hv_dot(const int16_t *r, const int16_t *q, size_t hv_d);
 float orc_ani_from_dot(int32_t dot, int32_t norm2_r, int32_t norm2_q,
                        unsigned ksize);
 
+/* OpenMP team size for orc_ani_matrix */
+void orc_set_threads(int n);
+
 /* full R x Q ANI matrix, row-major [r][q]; OpenMP over rows when available. */
 void orc_ani_matrix(const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
                     const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q,

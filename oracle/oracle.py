@@ -64,6 +64,8 @@ def lib():
         L.orc_ani_matrix.restype = None
         L.orc_ani_matrix.argtypes = [i16p, i32p, C.c_size_t, i16p, i32p, C.c_size_t,
                                      C.c_size_t, C.c_uint, f32p]
+        L.orc_set_threads.restype = None
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_sketch_genome.restype = C.c_int
         L.orc_sketch_genome.argtypes = [u8p, C.c_size_t, C.c_uint, C.c_uint64, C.c_uint64,
                                         C.c_int, C.c_int, C.c_size_t, C.c_int, i16p, i32p,
@@ -173,6 +175,10 @@ def unpack_hv(packed, hv_d, q):
 
 def ani_from_dot(dot, nr, nq, ksize=21):
     return float(lib().orc_ani_from_dot(int(dot), int(nr), int(nq), ksize))
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
 
 
 def ani_matrix(ref_hv, ref_n2, qry_hv, qry_n2, ksize=21):
