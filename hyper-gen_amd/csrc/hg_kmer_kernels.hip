@@ -24,6 +24,7 @@
 //    src/cuda_kernel.cu:316, hash value 0 is kept).
 //
 // The kernel is integer-VALU bound (~170 lane-ops per input byte), not HBM bound.
+#include <cstdlib>
 #include <utility>
 
 #include "hg_internal.h"
@@ -77,19 +78,30 @@ __device__ __forceinline__ uint64_t mul128_lo_hiadd(uint64_t x, uint64_t addend,
 }
 
 // src/cuda_kernel.cu:136-141 with the prime as a template argument
-template <uint64_t P>
+template <uint64_t P, bool HAND = true>
 __device__ __forceinline__ void mixup64(uint64_t &a, uint64_t &b, uint64_t v) {
-  uint64_t nb;
-  a ^= mul128_lo_hiadd<P>(b + v, b, nb);
-  b = nb;
+  if (HAND) {
+    uint64_t nb;
+    a ^= mul128_lo_hiadd<P>(b + v, b, nb);
+    b = nb;
+  } else {
+    unsigned __int128 m = (unsigned __int128)(b + v) * P;
+    a ^= (uint64_t)m;
+    b += (uint64_t)(m >> 64);
+  }
 }
 // src/cuda_kernel.cu:143-153
+template <bool HAND = true>
 __device__ __forceinline__ uint64_t final64(uint64_t a, uint64_t b) {
   uint64_t x = (a + rot64(b, 41)) * P0;
   uint64_t y = (rot64(a, 23) + b) * P6;
-  uint64_t hi;
-  const uint64_t lo = mul128_lo_hiadd<P5, true>(x ^ y, 0, hi);
-  return lo ^ hi;
+  if (HAND) {
+    uint64_t hi;
+    const uint64_t lo = mul128_lo_hiadd<P5, true>(x ^ y, 0, hi);
+    return lo ^ hi;
+  }
+  unsigned __int128 m = (unsigned __int128)(x ^ y) * P5;
+  return (uint64_t)m ^ (uint64_t)(m >> 64);
 }
 template <int SH>
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t c) {  // (a << SH) | c
@@ -101,7 +113,7 @@ __device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t c) {  // (a << 
 // t1ha2_atonce for a compile-time length K <= 32 whose bytes are given as little-endian
 // dwords d[0..ceil(K/4)) with the unused bytes of the last dword zero
 // (tail switch of src/cuda_kernel.cu:205-245).
-template <int K>
+template <int K, bool HAND = true>
 __device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed) {
   constexpr int ND = (K + 3) / 4;
   auto word = [&](int i) -> uint64_t {  // i-th 8-byte word, zero padded
@@ -111,11 +123,11 @@ __device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed
   };
   uint64_t a = seed, b = (uint64_t)K;
   int i = 0;
-  if (K > 24) mixup64<P4>(a, b, word(i++));
-  if (K > 16) mixup64<P3>(b, a, word(i++));
-  if (K > 8) mixup64<P2>(a, b, word(i++));
-  if (K > 0) mixup64<P1>(b, a, word(i++));
-  return final64(a, b);
+  if (K > 24) mixup64<P4, HAND>(a, b, word(i++));
+  if (K > 16) mixup64<P3, HAND>(b, a, word(i++));
+  if (K > 8) mixup64<P2, HAND>(a, b, word(i++));
+  if (K > 0) mixup64<P1, HAND>(b, a, word(i++));
+  return final64<HAND>(a, b);
 }
 
 // runtime-length variant for the generic kernel (len <= 32), bytes in w[0..3]
@@ -158,7 +170,7 @@ __device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm,
 // =========================================================================================
 // fast kernel: compile-time k in [9, 29]
 // =========================================================================================
-template <int K, bool CANON>
+template <int K, bool CANON, int VAR = 0>
 __global__ __launch_bounds__(WG) void kmer_sample_fast(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
@@ -177,21 +189,27 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
 
+  // the lane's 32-base window: 8 dwords, 4-byte aligned, M-byte lane stride.  Lanes past the
+  // genome end produce nothing (inv = all ones below): they are pointed at the genome start so
+  // that they never read beyond the 32-byte slack.
+  uint32_t xn[8];
+  auto load_window = [&](uint64_t tile_start_) {
+    const uint64_t p = tile_start_ + (uint64_t)threadIdx.x * M;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(gseq + (p < n_bps ? p : 0));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xn[t] = src[t];
+  };
+
 #pragma unroll 1
   for (int tile = 0; tile < TILES_PER_ITEM; ++tile) {
     const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
     if (tile_start >= n_starts) break;  // uniform
     const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * M;
 
-    // ---- load the lane's 32-base window (8 dwords, 4-byte aligned, M-byte lane stride) ----
     uint32_t x[8];
-    {
-      // lanes past the genome end produce nothing (inv = all ones below): point them at
-      // the genome start so that they never read beyond the 32-byte slack
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(gseq + (p0 < n_bps ? p0 : 0));
+    load_window(tile_start);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) x[t] = src[t];
-    }
+    for (int t = 0; t < 8; ++t) x[t] = xn[t];
 
     // ---- classify 4 bases per dword -----------------------------------------------------
     uint32_t FA[8], CA[8];      // upper-case ASCII, complement ASCII (same byte order)
@@ -255,11 +273,22 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
       constexpr int q = j >> 2, r = j & 3;
       const bool valid = ((inv >> j) & MASKK) == 0;
 
+      // strand choice as an all-ones / all-zeros VGPR mask.  The obvious `use_rc ? rcw : f` becomes
+      // v_cmp + 6 x v_cndmask_b32 ... vcc, and that VOP2/VCC form measures ~14-20 cycles per
+      // instruction on gfx950 (tools/gpu_microbench.hip); the compare result is therefore taken into
+      // an SGPR pair once, turned into a mask, and the six dwords are muxed with v_bitop3_b32.
+      uint32_t rc_mask = 0;
       bool use_rc = false;
       if (CANON) {
         const uint64_t fv = (Gm >> (2 * (32 - K - j))) & MASK2K;
         const uint64_t rv = (Gc >> (2 * j)) & MASK2K;
-        use_rc = rv < fv;
+        if (VAR & 2) {
+          use_rc = rv < fv;
+        } else {
+          uint64_t lt;
+          asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
+          asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(rc_mask) : "s"(lt));
+        }
       }
 
       uint32_t d[ND];
@@ -287,11 +316,12 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
             sel |= sb << (8 * i);
           }
           uint32_t rcw = __builtin_amdgcn_perm(CA[Q], (Q >= 1) ? CA[Q - 1] : 0u, sel);
-          v = use_rc ? rcw : f;
+          v = (VAR & 2) ? (use_rc ? rcw : f)
+                        : __builtin_amdgcn_bitop3_b32(rc_mask, rcw, f, 0xCA);  // rc_mask ? rcw : f
         }
         d[m] = v;
       }
-      const uint64_t h = t1ha2_fixed<K>(d, seed);
+      const uint64_t h = t1ha2_fixed<K, !(VAR & 1)>(d, seed);
       if (valid && h < threshold) append_hit(h, gm, g, hits, cnt);
     });
   }
@@ -355,6 +385,19 @@ template <int K>
 hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const uint8_t *d_seq,
                        const hg_genome_meta *d_meta, const uint32_t *d_item_genome, uint64_t threshold,
                        uint64_t seed, uint32_t u2t, uint64_t *d_hits, uint32_t *d_cnt) {
+#ifdef HG_KMER_EXPERIMENT
+  if (K == 21 && canonical) {  // development switch: HG_KMER_VARIANT=0..3
+    const char *e = getenv("HG_KMER_VARIANT");
+    const int v = e ? atoi(e) : 0;
+#define HG_V(VV)                                                                                         \
+  case VV:                                                                                               \
+    hipLaunchKernelGGL((kmer_sample_fast<21, true, VV>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
+                       d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                              \
+    return hipGetLastError();
+    switch (v) { HG_V(1) HG_V(2) HG_V(3) default: break; }
+#undef HG_V
+  }
+#endif
   if (canonical)
     hipLaunchKernelGGL((kmer_sample_fast<K, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);

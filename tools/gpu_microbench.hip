@@ -52,6 +52,56 @@ __global__ void k(uint32_t *out, uint32_t seed, unsigned long long *cycles) {
       } else if (OP == 10) {  // v_mul_u32_u24
         asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+      } else if (OP == 12) {  // v_add_co_u32 + v_addc_co_u32 pairs
+        asm volatile("v_add_co_u32_e32 %0, vcc, %0, %4\n v_addc_co_u32_e32 %1, vcc, %1, %4, vcc\n"
+                     "v_add_co_u32_e32 %2, vcc, %2, %4\n v_addc_co_u32_e32 %3, vcc, %3, %4, vcc"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");
+      } else if (OP == 13) {  // v_and_b32 with a 32-bit literal
+        asm volatile("v_and_b32 %0, 0xdfdfdfdf, %0\n v_and_b32 %1, 0xdfdfdfdf, %1\n v_and_b32 %2, 0xdfdfdfdf, %2\n v_and_b32 %3, 0xdfdfdfdf, %3"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      } else if (OP == 14) {  // v_bitop3_b32
+        asm volatile("v_bitop3_b32 %0, %0, %4, %1 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, %2 bitop3:0x96\n"
+                     "v_bitop3_b32 %2, %2, %4, %3 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %0 bitop3:0x96"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+      } else if (OP == 15) {  // v_lshrrev_b32
+        asm volatile("v_lshrrev_b32 %0, 1, %0\n v_lshrrev_b32 %1, 1, %1\n v_lshrrev_b32 %2, 1, %2\n v_lshrrev_b32 %3, 1, %3"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      } else if (OP == 16) {  // v_cndmask_b32 (VOP2, vcc)
+        asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");
+      } else if (OP == 17) {  // v_lshl_or_b32 (VOP3)
+        asm volatile("v_lshl_or_b32 %0, %0, 1, %4\n v_lshl_or_b32 %1, %1, 1, %4\n v_lshl_or_b32 %2, %2, 1, %4\n v_lshl_or_b32 %3, %3, 1, %4"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+      } else if (OP == 18) {  // v_add3_u32 (VOP3)
+        asm volatile("v_add3_u32 %0, %0, %4, %1\n v_add3_u32 %1, %1, %4, %2\n v_add3_u32 %2, %2, %4, %3\n v_add3_u32 %3, %3, %4, %0"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+      } else if (OP == 19) {  // mixed: mad, mov, mad, xor  (mul128-like, dependent chain per accumulator)
+        asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mov_b32 %2, %3\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_xor_b32 %3, %2, %3"
+                     : "+v"(b0), "+v"(b1), "+v"(a2), "+v"(a3) : "v"(a0), "v"(seed) : "vcc");
+      } else if (OP == 20) {  // mixed: add, perm, add, alignbyte (2-cycle / 4-cycle alternation)
+        asm volatile("v_add_u32 %0, %0, %4\n v_perm_b32 %1, %1, %4, %5\n v_add_u32 %2, %2, %4\n v_alignbyte_b32 %3, %3, %4, 1"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed), "v"(0x07020500u));
+      } else if (OP == 21) {  // v_xor_b32 x4 but a single dependent chain
+        asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1"
+                     : "+v"(a0) : "v"(seed));
+      } else if (OP == 22) {  // v_mad_u64_u32 single dependent chain
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+                     "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0"
+                     : "+v"(b0) : "v"(a0), "v"(seed) : "vcc");
+      } else if (OP == 23) {  // v_cndmask_b32_e64 with an SGPR-pair mask
+        asm volatile("v_cndmask_b32_e64 %0, 0, 1, s[10:11]\n v_cndmask_b32_e64 %1, 0, 1, s[10:11]\n"
+                     "v_cndmask_b32_e64 %2, 0, 1, s[10:11]\n v_cndmask_b32_e64 %3, 0, 1, s[10:11]"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s10", "s11");
+      } else if (OP == 24) {  // 1 compare + 3 v_cndmask on the same vcc (kernel's strand select pattern)
+        asm volatile("v_cmp_lt_u64 vcc, %4, %5\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %1, %1, %2, vcc"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1) : "vcc");
+      } else if (OP == 25) {  // v_bfi_b32 select with a VGPR mask
+        asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+      } else if (OP == 26) {  // v_cndmask vcc, vcc written once by a VALU compare before the loop body (4 per compare... 16 per loop trip)
+        if (r == 0) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(seed) : "vcc");
+        asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");
       } else if (OP == 11) {  // v_alignbyte_b32
         asm volatile("v_alignbyte_b32 %0, %0, %4, 1\n v_alignbyte_b32 %1, %1, %4, 2\n v_alignbyte_b32 %2, %2, %4, 3\n v_alignbyte_b32 %3, %3, %4, 1"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
@@ -109,5 +159,20 @@ int main() {
   run<1>("v_mul_lo_u32");
   run<7>("v_mul_hi_u32");
   run<2>("v_mad_u64_u32");
+  run<22>("mad_u64 1 chain");
+  run<21>("v_xor 1 chain");
+  run<12>("add_co+addc");
+  run<13>("v_and literal");
+  run<14>("v_bitop3_b32");
+  run<15>("v_lshrrev_b32");
+  run<16>("v_cndmask vcc");
+  run<23>("v_cndmask_e64 sgpr");
+  run<17>("v_lshl_or_b32");
+  run<18>("v_add3_u32");
+  run<24>("cmp64 + 3 cndmask");
+  run<26>("cmp32 + 16 cndmask");
+  run<25>("v_bfi_b32");
+  run<19>("mix mad/mov/mad/xor");
+  run<20>("mix add/perm/add/align");
   return 0;
 }
