@@ -43,13 +43,14 @@ constexpr int N_CHUNK_CAND = 8;  // 64 .. 8192
 // One workgroup per row; each lane converts 8 consecutive values per trip (16-byte loads and
 // stores), so a 64-dim block is 8 adjacent lanes and its sum of squares is 3 xor-shuffles.
 __global__ __launch_bounds__(256) void prep_kernel(const int16_t *__restrict__ hv, uint32_t rows,
-                                                   uint32_t hv_d, uint32_t kp, _Float16 *__restrict__ out,
+                                                   uint32_t hv_d, uint32_t kp, uint32_t ldk,
+                                                   _Float16 *__restrict__ out,
                                                    unsigned long long *__restrict__ stats) {
   extern __shared__ unsigned long long s_blk[];  // kp/64 block sums
   __shared__ uint32_t s_max;
   const uint32_t row = blockIdx.x;
   const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
-  _Float16 *__restrict__ dst = out + (size_t)row * kp;
+  _Float16 *__restrict__ dst = out + (size_t)row * ldk;
   const uint32_t nblk = kp / 64;
   if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
@@ -132,6 +133,7 @@ struct GemmArgs {
   const _Float16 *B;  // Qp x Kp (query)
   const int32_t *nr, *nq;
   uint32_t R, Q, Kp;
+  uint32_t ldk;          // row pitch of A and B in elements (Kp + pad, see hg_run_dist)
   uint32_t chunk_steps;  // K-steps (of BK) per exact f32 accumulation window
   float kf;
   float *ani_out;
@@ -149,8 +151,10 @@ struct GemmArgs {
 // index), the exact reference arithmetic decides the survivors.
 template <bool CHUNKED, bool FULL>
 __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDS_ROW];
-  __shared__ __attribute__((aligned(16))) _Float16 sB[BN * LDS_ROW];
+  // two LDS stages of (A tile + B tile): 2 x 2 x 128 x 72 f16 = 72 KiB -> two workgroups per CU
+  __shared__ __attribute__((aligned(16))) _Float16 sAB[2 * 2 * BM * LDS_ROW];
+  constexpr uint32_t TILE_ELEMS = BM * LDS_ROW;      // one operand tile
+  constexpr uint32_t STAGE_ELEMS = 2 * TILE_ELEMS;   // A + B
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
   // contiguous run of tiles (bijective remap, MI355X guide T1)
@@ -191,11 +195,12 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
 
   // staging: thread t moves 4 x 16 B of A and of B per K-step: row = t/8 + 32*i, 16-byte piece t%8
   const uint32_t srow = tid >> 3, spc = tid & 7;
-  const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.Kp + spc * 8;
-  const _Float16 *gB = g.B + (size_t)(col0 + srow) * g.Kp + spc * 8;
-  const size_t rstep = (size_t)32 * g.Kp;
-  _Float16 *lA = &sA[srow * LDS_ROW + spc * 8];
-  _Float16 *lB = &sB[srow * LDS_ROW + spc * 8];
+  const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.ldk + spc * 8;
+  const _Float16 *gB = g.B + (size_t)(col0 + srow) * g.ldk + spc * 8;
+  const size_t rstep = (size_t)32 * g.ldk;
+  const uint32_t st_off = srow * LDS_ROW + spc * 8;                 // this thread's slot in a tile
+  const uint32_t fa_off = (wm * 64 + fr) * LDS_ROW + fq * 8;        // fragment bases in a stage
+  const uint32_t fb_off = TILE_ELEMS + (wn * 64 + fr) * LDS_ROW + fq * 8;
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define HG_GLOAD(k0)                                                    \
   ra0 = *reinterpret_cast<const uint4 *>(gA + (k0));                    \
@@ -206,29 +211,43 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
   rb1 = *reinterpret_cast<const uint4 *>(gB + rstep + (k0));            \
   rb2 = *reinterpret_cast<const uint4 *>(gB + 2 * rstep + (k0));        \
   rb3 = *reinterpret_cast<const uint4 *>(gB + 3 * rstep + (k0));
-#define HG_LSTORE()                                                     \
-  *reinterpret_cast<uint4 *>(lA) = ra0;                                 \
-  *reinterpret_cast<uint4 *>(lA + 32 * LDS_ROW) = ra1;                  \
-  *reinterpret_cast<uint4 *>(lA + 64 * LDS_ROW) = ra2;                  \
-  *reinterpret_cast<uint4 *>(lA + 96 * LDS_ROW) = ra3;                  \
-  *reinterpret_cast<uint4 *>(lB) = rb0;                                 \
-  *reinterpret_cast<uint4 *>(lB + 32 * LDS_ROW) = rb1;                  \
-  *reinterpret_cast<uint4 *>(lB + 64 * LDS_ROW) = rb2;                  \
-  *reinterpret_cast<uint4 *>(lB + 96 * LDS_ROW) = rb3;
+#define HG_LSTORE(stage)                                                                   \
+  {                                                                                        \
+    _Float16 *lA = sAB + (stage) * STAGE_ELEMS + st_off, *lB = lA + TILE_ELEMS;            \
+    *reinterpret_cast<uint4 *>(lA) = ra0;                                                  \
+    *reinterpret_cast<uint4 *>(lA + 32 * LDS_ROW) = ra1;                                   \
+    *reinterpret_cast<uint4 *>(lA + 64 * LDS_ROW) = ra2;                                   \
+    *reinterpret_cast<uint4 *>(lA + 96 * LDS_ROW) = ra3;                                   \
+    *reinterpret_cast<uint4 *>(lB) = rb0;                                                  \
+    *reinterpret_cast<uint4 *>(lB + 32 * LDS_ROW) = rb1;                                   \
+    *reinterpret_cast<uint4 *>(lB + 64 * LDS_ROW) = rb2;                                   \
+    *reinterpret_cast<uint4 *>(lB + 96 * LDS_ROW) = rb3;                                   \
+  }
 
-  const _Float16 *fA = &sA[(wm * 64 + fr) * LDS_ROW + fq * 8];
-  const _Float16 *fB = &sB[(wn * 64 + fr) * LDS_ROW + fq * 8];
+  // Software pipeline with ONE barrier per K-step:
+  //   top of step k : registers hold tile k+1 (requested during step k-1) -> store into stage (k+1)&1,
+  //                   immediately re-issue the loads for tile k+2 (a whole step of latency cover),
+  //                   then 32 MFMAs on stage k&1, then the barrier that publishes stage (k+1)&1 and
+  //                   retires the reads of stage k&1.
   const uint32_t nsteps = g.Kp / BK;
   HG_GLOAD(0)
+  HG_LSTORE(0)
+  if (nsteps > 1) {
+    HG_GLOAD(BK)
+  }
+  __syncthreads();
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
-    __syncthreads();  // previous step's fragment reads are done
-    HG_LSTORE()
-    __syncthreads();
-    if (ks + 1 < nsteps) {  // in flight during the MFMAs below
-      const uint32_t k1 = (ks + 1) * BK;
-      HG_GLOAD(k1)
+    const uint32_t cur = ks & 1;
+    if (ks + 1 < nsteps) {
+      HG_LSTORE(cur ^ 1)
+      if (ks + 2 < nsteps) {
+        const uint32_t k2 = (ks + 2) * BK;
+        HG_GLOAD(k2)
+      }
     }
+    const _Float16 *fA = sAB + cur * STAGE_ELEMS + fa_off;
+    const _Float16 *fB = sAB + cur * STAGE_ELEMS + fb_off;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       half8 af[4], bf[4];
@@ -253,11 +272,28 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
           acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
         }
     }
+    __syncthreads();
   }
 #undef HG_GLOAD
 #undef HG_LSTORE
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
+  // Hits are staged per wave in LDS (idle after the K loop; the loop's last barrier retired all
+  // fragment reads) and flushed with ONE global atomic per flush: a per-hit atomic on the single
+  // global counter serialises at ~12 ns per wave-instruction and cost more than the whole GEMM
+  // (2.30 ms vs 1.10 ms at 1.3 M hits).
+  constexpr uint32_t STAGE_CAP = 1024;  // 12 KiB per wave
+  hg_ani_hit *stage = reinterpret_cast<hg_ani_hit *>(sAB) + wave * STAGE_CAP;
+  uint32_t staged = 0;  // wave-uniform
+#define HG_FLUSH()                                                                          \
+  if (staged) {                                                                             \
+    uint32_t base = 0;                                                                      \
+    if (lane == 0) base = atomicAdd(g.hit_count, staged);                                   \
+    base = __builtin_amdgcn_readfirstlane(base);                                            \
+    for (uint32_t e = lane; e < staged; e += 64)                                            \
+      if (base + e < g.hit_cap) g.hits[base + e] = stage[e];                                \
+    staged = 0;                                                                             \
+  }
   int32_t nqv[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
@@ -281,17 +317,30 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
           const int32_t den = (int32_t)((uint32_t)nri + (uint32_t)nqv[n] - (uint32_t)dot);
           live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
         }
-        if (live) {
-          const float ani = ani_from_dot(dot, nri, nqv[n], g.kf);
-          if (FULL && g.ani_out) g.ani_out[(size_t)i * g.Q + j] = ani;
-          if (g.hit_count && ani >= g.ani_th) {
-            const uint32_t idx = atomicAdd(g.hit_count, 1u);
-            if (idx < g.hit_cap) g.hits[idx] = hg_ani_hit{i, j, ani};
+        if (__any(live)) {
+          float ani = 0.f;
+          bool hit = false;
+          if (live) {
+            ani = ani_from_dot(dot, nri, nqv[n], g.kf);
+            if (FULL && g.ani_out) g.ani_out[(size_t)i * g.Q + j] = ani;
+            hit = g.hit_count && ani >= g.ani_th;
+          }
+          const unsigned long long bal = __ballot(hit);
+          if (bal) {
+            const uint32_t pos =
+                staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (hit) stage[pos] = hg_ani_hit{i, j, ani};
+            staged += (uint32_t)__popcll(bal);
+            if (staged > STAGE_CAP - 64) {
+              HG_FLUSH()
+            }
           }
         }
       }
     }
   }
+  HG_FLUSH()
+#undef HG_FLUSH
 }
 
 // ---- always-exact integer fallback -------------------------------------------------------------------
@@ -344,25 +393,29 @@ static float jaccard_lower_bound(float ani_th, uint32_t ksize) {
 
 hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   const uint32_t Kp = (a.hv_d + BK - 1) / BK * BK;
+  // Row pitch of the f16 copies: Kp + 64 elements (+128 B).  With a power-of-two pitch (8 KiB at
+  // D = 4096) every workgroup reads the same 128-byte column offset of 256 different rows at the same
+  // moment, i.e. one L2 / Infinity-Cache channel; the odd 128-byte skew spreads rows over channels.
+  const uint32_t ldk = Kp + 64;
   const uint32_t Rp = (a.R + BM - 1) / BM * BM, Qp = (a.Q + BN - 1) / BN * BN;
   const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
-  if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * Kp * 2)) != HG_OK) return s;
-  if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * Kp * 2)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
+  if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * ldk * 2)) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_stats, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long))) != HG_OK) return s;
   auto *fa = static_cast<_Float16 *>(c->w_f16a.p);
   auto *fb = same ? fa : static_cast<_Float16 *>(c->w_f16b.p);
   auto *st = static_cast<unsigned long long *>(c->w_stats.p);
   HG_HIP(c, hipMemsetAsync(st, 0, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long), c->stream));
-  if (Rp > a.R) HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * Kp, 0, (size_t)(Rp - a.R) * Kp * 2, c->stream));
-  if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * Kp, 0, (size_t)(Qp - a.Q) * Kp * 2, c->stream));
+  if (Rp > a.R) HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * ldk, 0, (size_t)(Rp - a.R) * ldk * 2, c->stream));
+  if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * ldk, 0, (size_t)(Qp - a.Q) * ldk * 2, c->stream));
   const size_t plds = (size_t)(Kp / 64) * sizeof(unsigned long long);
   {
   hg_timed tm(c, HG_T_DIST_PREP);
-  hipLaunchKernelGGL(prep_kernel, dim3(a.R), dim3(256), plds, c->stream, a.ref_hv, a.R, a.hv_d, Kp, fa, st);
+  hipLaunchKernelGGL(prep_kernel, dim3(a.R), dim3(256), plds, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, st);
   HG_HIP(c, hipGetLastError());
   if (!same) {
-    hipLaunchKernelGGL(prep_kernel, dim3(a.Q), dim3(256), plds, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, fb,
+    hipLaunchKernelGGL(prep_kernel, dim3(a.Q), dim3(256), plds, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, ldk, fb,
                        st + 1 + N_CHUNK_CAND);
     HG_HIP(c, hipGetLastError());
   }
@@ -393,7 +446,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   }
   GemmArgs g{};
   g.A = fa, g.B = fb, g.nr = a.ref_n2, g.nq = a.qry_n2;
-  g.R = a.R, g.Q = a.Q, g.Kp = Kp;
+  g.R = a.R, g.Q = a.Q, g.Kp = Kp, g.ldk = ldk;
   g.chunk_steps = (64u << best_c) / BK;
   g.kf = kf;
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
