@@ -264,29 +264,57 @@ hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, si
 }
 
 // Runs hash+sample and sort/unique.  On return (stream synchronised) the device hit buffer holds
-// each genome's ascending distinct hashes at meta[g].hit_off and h_nd[g] the distinct counts.
+// each genome's ascending distinct hashes at meta[g].hit_off and *d_ndistinct_out the counts.
 hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
                        size_t n, uint32_t ksize, uint64_t threshold, uint64_t scaled_for_cap, uint64_t seed,
                        bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out) {
   if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
   std::vector<uint32_t> want;
   for (int attempt = 0; attempt < 3; ++attempt) {
-    hg_status s = make_plan(c, offsets, lens, n, ksize, scaled_for_cap, attempt ? &want : nullptr, pl);
-    if (s != HG_OK) return s;
-    const size_t n_items = pl.item_genome.size();
+    hg_status s;
+    // same geometry as the previous call (typical for a stream of equally shaped batches): the
+    // work-item table and the per-genome records are still on the device
+    const bool reuse = attempt == 0 && c->plan_valid && c->plan_ksize == ksize && c->plan_scaled == scaled_for_cap &&
+                       c->plan_offs.size() == n && std::memcmp(c->plan_offs.data(), offsets, n * 8) == 0 &&
+                       std::memcmp(c->plan_lens.data(), lens, n * 8) == 0;
+    size_t n_items;
+    if (reuse) {
+      n_items = c->plan_items;
+      pl.total_slots = c->plan_slots, pl.max_cap = c->plan_max_cap;
+      pl.meta.resize(n);
+      uint64_t slot = 0;
+      for (size_t g = 0; g < n; ++g) {  // only what callers read back: capacities and hit offsets
+        pl.meta[g].hit_cap = c->plan_caps[g];
+        pl.meta[g].hit_off = slot;
+        slot += c->plan_caps[g];
+      }
+    } else {
+      c->plan_valid = false;
+      if ((s = make_plan(c, offsets, lens, n, ksize, scaled_for_cap, attempt ? &want : nullptr, pl)) != HG_OK) return s;
+      n_items = pl.item_genome.size();
+    }
     if ((s = hg_ensure(c, c->w_gmeta, n * sizeof(hg_genome_meta) + 16)) != HG_OK) return s;
     if ((s = hg_ensure(c, c->w_items, n_items * sizeof(uint32_t) + 16)) != HG_OK) return s;
     if ((s = hg_ensure(c, c->w_hits, pl.total_slots * sizeof(uint64_t) + 16)) != HG_OK) return s;
     if ((s = hg_ensure(c, c->w_cnt, 2 * n * sizeof(uint32_t) + 16)) != HG_OK) return s;
-    if ((s = hg_ensure_pinned(c, n * sizeof(uint32_t))) != HG_OK) return s;
+    const size_t pin_meta = (n * sizeof(hg_genome_meta) + 63) & ~(size_t)63;
+    const size_t pin_items = (n_items * sizeof(uint32_t) + 63) & ~(size_t)63;
+    if ((s = hg_ensure_pinned(c, n * sizeof(uint32_t) + 64 + (reuse ? 0 : pin_meta + pin_items))) != HG_OK) return s;
     auto *d_meta = static_cast<hg_genome_meta *>(c->w_gmeta.p);
     auto *d_items = static_cast<uint32_t *>(c->w_items.p);
     auto *d_hits = static_cast<uint64_t *>(c->w_hits.p);
     auto *d_cnt = static_cast<uint32_t *>(c->w_cnt.p);
     uint32_t *d_nd = d_cnt + n;
-    HG_HIP(c, hipMemcpyAsync(d_meta, pl.meta.data(), n * sizeof(hg_genome_meta), hipMemcpyHostToDevice, c->stream));
-    if (n_items)
-      HG_HIP(c, hipMemcpyAsync(d_items, pl.item_genome.data(), n_items * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    auto *h_cnt = static_cast<uint32_t *>(c->h_pin);
+    if (!reuse) {  // upload through pinned staging so that the copies are truly asynchronous
+      uint8_t *pin = static_cast<uint8_t *>(c->h_pin) + ((n * sizeof(uint32_t) + 63) & ~(size_t)63);
+      std::memcpy(pin, pl.meta.data(), n * sizeof(hg_genome_meta));
+      HG_HIP(c, hipMemcpyAsync(d_meta, pin, n * sizeof(hg_genome_meta), hipMemcpyHostToDevice, c->stream));
+      if (n_items) {
+        std::memcpy(pin + pin_meta, pl.item_genome.data(), n_items * sizeof(uint32_t));
+        HG_HIP(c, hipMemcpyAsync(d_items, pin + pin_meta, n_items * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      }
+    }
     HG_HIP(c, hipMemsetAsync(d_cnt, 0, 2 * n * sizeof(uint32_t), c->stream));
     {
       hg_timed tm(c, HG_T_KMER);
@@ -298,7 +326,6 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, pl.max_cap));
     }
     // overflow check on the raw counters (they keep counting past the capacity)
-    auto *h_cnt = static_cast<uint32_t *>(c->h_pin);
     HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HG_HIP(c, hipStreamSynchronize(c->stream));
     bool overflow = false;
@@ -306,9 +333,19 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     for (size_t g = 0; g < n; ++g)
       if (h_cnt[g] > pl.meta[g].hit_cap) overflow = true, want[g] = h_cnt[g];
     if (!overflow) {
+      if (!reuse) {  // remember this plan for the next call
+        c->plan_offs.assign(offsets, offsets + n);
+        c->plan_lens.assign(lens, lens + n);
+        c->plan_caps.resize(n);
+        for (size_t g = 0; g < n; ++g) c->plan_caps[g] = pl.meta[g].hit_cap;
+        c->plan_ksize = ksize, c->plan_scaled = scaled_for_cap;
+        c->plan_slots = pl.total_slots, c->plan_max_cap = pl.max_cap, c->plan_items = n_items;
+        c->plan_valid = true;
+      }
       *d_ndistinct_out = d_nd;
       return HG_OK;
     }
+    c->plan_valid = false;
   }
   return hg_fail(c, HG_ERR_HIP, "hit buffer overflow persisted after resizing");
 }
@@ -447,6 +484,7 @@ extern "C" hg_status hg_hv_encode(hg_ctx *c, const uint64_t *hashes, size_t n, u
   if ((s = hg_ensure(c, c->w_hits, (n + 1) * sizeof(uint64_t))) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_cnt, 2 * sizeof(uint32_t))) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_hv, (size_t)hv_d * sizeof(int16_t) + 64)) != HG_OK) return s;
+  c->plan_valid = false;  // w_gmeta is about to be overwritten
   hg_genome_meta m{};
   m.hit_off = 0, m.hit_cap = (uint32_t)n;
   const uint32_t nd = (uint32_t)n;

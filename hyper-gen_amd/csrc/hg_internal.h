@@ -43,6 +43,15 @@ struct hg_ctx {
   };
   std::vector<TimedLaunch> t_pending;   // recorded, not yet read
   std::vector<hipEvent_t> t_pool;       // reusable events
+  // cached batch plan of the last sketch call: when the next call has the same geometry the host
+  // neither rebuilds the work-item table nor uploads it again (see sample_batch)
+  std::vector<uint64_t> plan_offs, plan_lens;
+  std::vector<uint32_t> plan_caps;  // hit_cap per genome of the cached plan
+  uint32_t plan_ksize = 0;
+  uint64_t plan_scaled = 0, plan_slots = 0;
+  uint32_t plan_max_cap = 0;
+  size_t plan_items = 0;
+  bool plan_valid = false;
   // pinned host scratch
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;
