@@ -353,8 +353,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
 hg_status check_params(hg_ctx *c, const hg_sketch_params *p) {
   if (!p) return hg_fail(c, HG_ERR_INVALID, "params == NULL");
   if (p->ksize < 1) return hg_fail(c, HG_ERR_INVALID, "ksize must be >= 1");
-  if (p->ksize > 32)
-    return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize > 32 is not implemented on the device (like src/cuda_kernel.cu:196-246)");
+  if (p->ksize > 255) return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize must be <= 255 (the reference's -k is u8)");
   if (p->scaled < 1) return hg_fail(c, HG_ERR_INVALID, "scaled must be >= 1");
   if (p->hv_layout > HG_LAYOUT_AVX2 || p->norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad layout / norm mode");
   if (p->hv_d == 0 || p->hv_d > 32768) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be in 1..32768");
@@ -439,7 +438,7 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
   *n_out = 0;
   if (ksize < 1) return hg_fail(c, HG_ERR_INVALID, "ksize must be >= 1");
-  if (ksize > 32) return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize > 32 is not implemented on the device");
+  if (ksize > 255) return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize must be <= 255 (the reference's -k is u8)");
   if (norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad norm mode");
   if (n_bps && !seq) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
   if (n_bps < ksize) return HG_OK;

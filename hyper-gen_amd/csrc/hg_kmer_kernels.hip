@@ -381,6 +381,90 @@ __global__ __launch_bounds__(WG) void kmer_sample_generic(
   }
 }
 
+// =========================================================================================
+// long-k kernel: 33 <= k <= 255 (the CPU path's t1ha2 long-input loop; src/cuda_kernel.cu has none)
+// =========================================================================================
+// Slow, simple and exact: bytes of the chosen strand are fetched on demand.
+struct StrandBytes {
+  const uint8_t *base;  // first base of the window (forward coordinates)
+  uint32_t k;
+  bool rc;
+  uint32_t u2t;
+  __device__ __forceinline__ uint8_t at(uint32_t i) const {
+    const char ACGT[4] = {'A', 'C', 'G', 'T'};
+    const uint32_t c = rc ? 3u - base_code(base[k - 1 - i], u2t) : base_code(base[i], u2t);
+    return (uint8_t)ACGT[c & 3];
+  }
+  __device__ __forceinline__ uint64_t word(uint32_t byte_off, uint32_t nbytes) const {  // little endian
+    uint64_t w = 0;
+    for (uint32_t b = 0; b < nbytes; ++b) w |= (uint64_t)at(byte_off + b) << (8 * b);
+    return w;
+  }
+};
+
+__device__ __forceinline__ uint64_t t1ha2_long(const StrandBytes &sb, uint32_t len, uint64_t seed) {
+  uint64_t a = seed, b = (uint64_t)len;
+  uint32_t off = 0;
+  if (len > 32) {  // published t1ha2: lanes c,d, 32 bytes per round, squash
+    uint64_t c = rot64((uint64_t)len, 23) + ~seed;
+    uint64_t d = ~(uint64_t)len + rot64(seed, 19);
+    do {
+      const uint64_t w0 = sb.word(off, 8), w1 = sb.word(off + 8, 8), w2 = sb.word(off + 16, 8), w3 = sb.word(off + 24, 8);
+      off += 32;
+      const uint64_t d02 = w0 + rot64(w2 + d, 56);
+      const uint64_t c13 = w1 + rot64(w3 + c, 19);
+      d ^= b + rot64(w1, 38);
+      c ^= a + rot64(w0, 57);
+      b ^= P6 * (c13 + w2);
+      a ^= P5 * (d02 + w3);
+    } while (off + 31 < len);  // data < detent  <=>  off < len - 31
+    a ^= P6 * (c + rot64(d, 23));
+    b ^= P5 * (rot64(c, 19) + d);
+    len &= 31;
+  }
+  uint32_t rem = len;
+  if (rem > 24) { mixup64<P4>(a, b, sb.word(off, 8)); off += 8, rem -= 8; }
+  if (rem > 16) { mixup64<P3>(b, a, sb.word(off, 8)); off += 8, rem -= 8; }
+  if (rem > 8) { mixup64<P2>(a, b, sb.word(off, 8)); off += 8, rem -= 8; }
+  if (rem > 0) mixup64<P1>(b, a, sb.word(off, rem));
+  return final64(a, b);
+}
+
+__global__ __launch_bounds__(WG) void kmer_sample_long(
+    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
+    const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
+    uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  const uint32_t item = blockIdx.x;
+  const uint32_t g = item_genome[item];
+  const hg_genome_meta gm = meta[g];
+  const uint64_t n_bps = gm.n_bps;
+  if (n_bps < ksize) return;
+  const uint64_t n_starts = n_bps - ksize + 1;
+  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint64_t s0 = (uint64_t)(item - gm.item_first) * GEN_ITEM + (uint64_t)threadIdx.x * GEN_STARTS;
+  if (s0 >= n_starts) return;
+  const uint64_t s1 = (s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts;
+  uint32_t run = 0;  // valid bases ending at the current position
+  for (uint64_t i = s0; i < s1 + ksize - 1; ++i) {
+    run = (base_code(gseq[i], u2t) < 4) ? run + 1 : 0;
+    if (run < ksize) continue;
+    const uint8_t *w = gseq + (i + 1 - ksize);
+    bool use_rc = false;
+    if (canonical) {  // first differing position decides (expected ~1.3 iterations)
+      for (uint32_t t = 0; t < ksize; ++t) {
+        const uint32_t f = base_code(w[t], u2t), r = 3u - base_code(w[ksize - 1 - t], u2t);
+        if (f != r) {
+          use_rc = r < f;
+          break;
+        }
+      }
+    }
+    const StrandBytes sb{w, ksize, use_rc, u2t};
+    const uint64_t h = t1ha2_long(sb, ksize, seed);
+    if (h < threshold) append_hit(h, gm, g, hits, cnt);
+  }
+}
+
 template <int K>
 hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const uint8_t *d_seq,
                        const hg_genome_meta *d_meta, const uint32_t *d_item_genome, uint64_t threshold,
@@ -434,7 +518,11 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
       break;
   }
 #undef HG_FAST_CASE
-  hipLaunchKernelGGL(kmer_sample_generic, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
-                     d_item_genome, ksize, threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+  if (ksize > 32)
+    hipLaunchKernelGGL(kmer_sample_long, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
+                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+  else
+    hipLaunchKernelGGL(kmer_sample_generic, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
+                       d_item_genome, ksize, threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
   return hipGetLastError();
 }

@@ -50,6 +50,19 @@ def test_hash_sets_all_k(ctx, orc, k):
         assert got.size == want.size and (got == want).all(), (k, canonical)
 
 
+@pytest.mark.parametrize("k", [33, 40, 41, 51, 63, 64, 65, 96, 97, 128, 255])
+def test_hash_sets_long_k(ctx, orc, k):
+    """k > 32: t1ha2's long-input loop on the device (the CPU path supports it, src/cuda_kernel.cu does not)."""
+    rng = np.random.default_rng(1000 + k)
+    s = rand_seq(rng, 9000)
+    s[[17, 4000, 4001, 8999]] = ord("N")
+    s[2000:2100] = np.char.lower(s[2000:2100].view("S1")).view(np.uint8)
+    for canonical in (True, False):
+        want = orc.kmer_hash_sample(s, k, 5, 123, canonical)
+        got = ctx.kmer_hash_sample(s, k, 5, 123, canonical)
+        assert want.size > 100 and got.size == want.size and (got == want).all(), (k, canonical)
+
+
 @pytest.mark.parametrize("n", [0, 1, 20, 21, 22, 31, 32, 33, 43, 44, 45, 3071, 3072, 3073, 3092, 3093,
                                24575, 24576, 24577, 24596, 24597, 50000])
 def test_hash_sets_ragged_lengths(ctx, orc, n):
@@ -108,7 +121,7 @@ def test_capacity_protocol(ctx, hg):
     st = hg.lib().hg_kmer_hash_sample(ctx._h, s.ctypes.data, s.size, 21, C.c_uint64(2**64 - 1), C.c_uint64(123),
                                       1, 0, out.ctypes.data, 10, C.byref(n))
     assert st == hg.ERR_CAPACITY and n.value == full.size
-    st = hg.lib().hg_kmer_hash_sample(ctx._h, s.ctypes.data, s.size, 33, C.c_uint64(1), C.c_uint64(123),
+    st = hg.lib().hg_kmer_hash_sample(ctx._h, s.ctypes.data, s.size, 256, C.c_uint64(1), C.c_uint64(123),
                                       1, 0, out.ctypes.data, 10, C.byref(n))
     assert st == hg.ERR_UNSUPPORTED
 
