@@ -123,10 +123,20 @@ __global__ __launch_bounds__(256) void prep_kernel(const int16_t *__restrict__ h
 }
 
 // ---- MFMA GEMM + ANI ------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int LDS_ROW = BK + 8;  // f16 elements per LDS row: 144 B => conflict-free ds_read_b128
-constexpr int GEMM_WG = 256;
-constexpr uint32_t ST = 8;  // super-tile edge, in tiles
+constexpr uint32_t ST = 8;       // super-tile edge, in tiles
+// Two tile geometries (waves are 2 (M) x NWN (N), each wave owns WTM x 4 MFMA tiles of 16 x 16):
+//   small: 128 x 128, 4 waves, 72 KiB LDS, 2 workgroups / CU  -- small problems, little padding
+//   big  : 256 x 256, 8 waves, 144 KiB LDS, 1 workgroup / CU  -- half the LDS and L2 bytes per flop
+template <bool BIG>
+struct TileCfg {
+  static constexpr int WTM = BIG ? 8 : 4;   // 16-row MFMA tiles per wave in M
+  static constexpr int NWN = BIG ? 4 : 2;   // waves in N
+  static constexpr int BM = 2 * WTM * 16, BN = NWN * 64;
+  static constexpr int THREADS = 2 * NWN * 64;
+  static constexpr int LOADS = BM * BK * 2 / 16 / THREADS;  // 16-byte pieces per thread and operand
+};
 
 struct GemmArgs {
   const _Float16 *A;  // Rp x Kp (ref)
@@ -149,12 +159,17 @@ struct GemmArgs {
 // FULL: every ANI is evaluated and stored (parity / small problems).  Otherwise only pairs that can
 // reach ani_th are evaluated: one multiply-compare rejects the rest (ANI is monotone in the Jaccard
 // index), the exact reference arithmetic decides the survivors.
-template <bool CHUNKED, bool FULL>
-__global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
-  // two LDS stages of (A tile + B tile): 2 x 2 x 128 x 72 f16 = 72 KiB -> two workgroups per CU
-  __shared__ __attribute__((aligned(16))) _Float16 sAB[2 * 2 * BM * LDS_ROW];
-  constexpr uint32_t TILE_ELEMS = BM * LDS_ROW;      // one operand tile
-  constexpr uint32_t STAGE_ELEMS = 2 * TILE_ELEMS;   // A + B
+template <bool CHUNKED, bool FULL, bool BIG>
+__global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
+  using TC = TileCfg<BIG>;
+  constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
+  static_assert(LOADS == 4, "staging macros move 4 pieces per operand");
+  // two LDS stages of (A tile + B tile)
+  extern __shared__ __attribute__((aligned(16))) _Float16 sAB[];
+  constexpr uint32_t A_ELEMS = BM * LDS_ROW, B_ELEMS = BN * LDS_ROW;
+  constexpr uint32_t TILE_ELEMS = A_ELEMS;           // offset of the B tile inside a stage
+  constexpr uint32_t STAGE_ELEMS = A_ELEMS + B_ELEMS;
+  constexpr uint32_t SROWS = THREADS / 8;            // rows covered by one staging pass
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
   // contiguous run of tiles (bijective remap, MI355X guide T1)
@@ -175,31 +190,31 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
   if (g.symmetric && row0 >= col0 + BN) return;  // tile entirely on/below the diagonal
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
+  const uint32_t wm = wave / NWN, wn = wave % NWN;  // 2 x NWN waves, (WTM*16) x 64 each
   const uint32_t fr = lane & 15, fq = lane >> 4;
 
-  float4v acc[4][4];
-  int32_t iacc[CHUNKED ? 4 : 1][CHUNKED ? 4 : 1][4];
+  float4v acc[WTM][4];
+  int32_t iacc[CHUNKED ? WTM : 1][CHUNKED ? 4 : 1][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < WTM; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
   if (CHUNKED) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < WTM; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] = 0;
   }
 
-  // staging: thread t moves 4 x 16 B of A and of B per K-step: row = t/8 + 32*i, 16-byte piece t%8
+  // staging: thread t moves 4 x 16 B of A and of B per K-step: row = t/8 + SROWS*i, 16-byte piece t%8
   const uint32_t srow = tid >> 3, spc = tid & 7;
   const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.ldk + spc * 8;
   const _Float16 *gB = g.B + (size_t)(col0 + srow) * g.ldk + spc * 8;
-  const size_t rstep = (size_t)32 * g.ldk;
+  const size_t rstep = (size_t)SROWS * g.ldk;
   const uint32_t st_off = srow * LDS_ROW + spc * 8;                 // this thread's slot in a tile
-  const uint32_t fa_off = (wm * 64 + fr) * LDS_ROW + fq * 8;        // fragment bases in a stage
+  const uint32_t fa_off = (wm * WTM * 16 + fr) * LDS_ROW + fq * 8;  // fragment bases in a stage
   const uint32_t fb_off = TILE_ELEMS + (wn * 64 + fr) * LDS_ROW + fq * 8;
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define HG_GLOAD(k0)                                                    \
@@ -215,13 +230,13 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
   {                                                                                        \
     _Float16 *lA = sAB + (stage) * STAGE_ELEMS + st_off, *lB = lA + TILE_ELEMS;            \
     *reinterpret_cast<uint4 *>(lA) = ra0;                                                  \
-    *reinterpret_cast<uint4 *>(lA + 32 * LDS_ROW) = ra1;                                   \
-    *reinterpret_cast<uint4 *>(lA + 64 * LDS_ROW) = ra2;                                   \
-    *reinterpret_cast<uint4 *>(lA + 96 * LDS_ROW) = ra3;                                   \
+    *reinterpret_cast<uint4 *>(lA + SROWS * LDS_ROW) = ra1;                                \
+    *reinterpret_cast<uint4 *>(lA + 2 * SROWS * LDS_ROW) = ra2;                            \
+    *reinterpret_cast<uint4 *>(lA + 3 * SROWS * LDS_ROW) = ra3;                            \
     *reinterpret_cast<uint4 *>(lB) = rb0;                                                  \
-    *reinterpret_cast<uint4 *>(lB + 32 * LDS_ROW) = rb1;                                   \
-    *reinterpret_cast<uint4 *>(lB + 64 * LDS_ROW) = rb2;                                   \
-    *reinterpret_cast<uint4 *>(lB + 96 * LDS_ROW) = rb3;                                   \
+    *reinterpret_cast<uint4 *>(lB + SROWS * LDS_ROW) = rb1;                                \
+    *reinterpret_cast<uint4 *>(lB + 2 * SROWS * LDS_ROW) = rb2;                            \
+    *reinterpret_cast<uint4 *>(lB + 3 * SROWS * LDS_ROW) = rb3;                            \
   }
 
   // Software pipeline with ONE barrier per K-step:
@@ -250,21 +265,21 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
     const _Float16 *fB = sAB + cur * STAGE_ELEMS + fb_off;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
-      half8 af[4], bf[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const half8 *>(fA + m * 16 * LDS_ROW + kk * 32);
+      half8 bf[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) bf[n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LDS_ROW + kk * 32);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < WTM; ++m) {
+        const half8 af = *reinterpret_cast<const half8 *>(fA + m * 16 * LDS_ROW + kk * 32);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[n], acc[m][n], 0, 0, 0);
+      }
     }
     if (CHUNKED && ++in_chunk == g.chunk_steps) {  // move the exact f32 partial sums into i32
       in_chunk = 0;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < WTM; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
 #pragma unroll
@@ -278,21 +293,50 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
 #undef HG_LSTORE
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
-  // Hits are staged per wave in LDS (idle after the K loop; the loop's last barrier retired all
-  // fragment reads) and flushed with ONE global atomic per flush: a per-hit atomic on the single
-  // global counter serialises at ~12 ns per wave-instruction and cost more than the whole GEMM
-  // (2.30 ms vs 1.10 ms at 1.3 M hits).
-  constexpr uint32_t STAGE_CAP = 1024;  // 12 KiB per wave
-  hg_ani_hit *stage = reinterpret_cast<hg_ani_hit *>(sAB) + wave * STAGE_CAP;
+  // Phase 1 (unrolled over the accumulator registers, a handful of instructions per element): one
+  // multiply-compare against a conservative Jaccard bound keeps only the pairs that can reach the
+  // threshold (ANI is monotone in J) and pushes them as {local i, local j, dot} into a per-wave list in
+  // LDS -- idle after the K loop, whose last barrier retired all fragment reads.
+  // Phase 2 (dense: one candidate per lane): exact reference arithmetic, threshold, hits compacted in
+  // place, then ONE global atomic per flush.  (A per-hit atomic on the single global counter serialised
+  // at ~12 ns and cost more than the GEMM: 2.30 ms vs 1.10 ms at 1.3 M hits.)
+  constexpr uint32_t CAND_CAP = 2048;  // 16 KiB per wave
+  uint2 *cand = reinterpret_cast<uint2 *>(sAB) + wave * CAND_CAP;
   uint32_t staged = 0;  // wave-uniform
-#define HG_FLUSH()                                                                          \
-  if (staged) {                                                                             \
-    uint32_t base = 0;                                                                      \
-    if (lane == 0) base = atomicAdd(g.hit_count, staged);                                   \
-    base = __builtin_amdgcn_readfirstlane(base);                                            \
-    for (uint32_t e = lane; e < staged; e += 64)                                            \
-      if (base + e < g.hit_cap) g.hits[base + e] = stage[e];                                \
-    staged = 0;                                                                             \
+#define HG_PROCESS()                                                                                   \
+  {                                                                                                    \
+    uint32_t nh = 0;                                                                                   \
+    for (uint32_t b = 0; b < staged; b += 64) {                                                        \
+      const uint32_t e = b + lane;                                                                     \
+      bool hit = false;                                                                                \
+      uint2 c2 = make_uint2(0u, 0u);                                                                   \
+      float ani = 0.f;                                                                                 \
+      if (e < staged) {                                                                                \
+        c2 = cand[e];                                                                                  \
+        const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);                         \
+        ani = ani_from_dot((int32_t)c2.y, g.nr[gi], g.nq[gj], g.kf);                                   \
+        if (FULL && g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;                                 \
+        hit = g.hit_count && ani >= g.ani_th;                                                          \
+      }                                                                                                \
+      const unsigned long long bal = __ballot(hit);                                                    \
+      if (hit) {                                                                                       \
+        const uint32_t pos = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),                     \
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)); \
+        cand[pos] = make_uint2(c2.x, __float_as_uint(ani)); /* pos <= e: never ahead of an unread entry */ \
+      }                                                                                                \
+      nh += (uint32_t)__popcll(bal);                                                                   \
+    }                                                                                                  \
+    if (nh) {                                                                                          \
+      uint32_t base = 0;                                                                               \
+      if (lane == 0) base = atomicAdd(g.hit_count, nh);                                                \
+      base = __builtin_amdgcn_readfirstlane(base);                                                     \
+      for (uint32_t e = lane; e < nh; e += 64)                                                         \
+        if (base + e < g.hit_cap) {                                                                    \
+          const uint2 h2 = cand[e];                                                                    \
+          g.hits[base + e] = hg_ani_hit{row0 + (h2.x >> 16), col0 + (h2.x & 0xffffu), __uint_as_float(h2.y)}; \
+        }                                                                                              \
+    }                                                                                                  \
+    staged = 0;                                                                                        \
   }
   int32_t nqv[4];
 #pragma unroll
@@ -301,15 +345,15 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
     nqv[n] = j < g.Q ? g.nq[j] : 0;
   }
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < WTM; ++m) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const uint32_t i = row0 + wm * 64 + m * 16 + fq * 4 + r;
+      const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
       const bool iok = i < g.R;
       const int32_t nri = iok ? g.nr[i] : 0;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const uint32_t j = col0 + wn * 64 + n * 16 + fr;
+        const uint32_t lj = wn * 64 + n * 16 + fr, j = col0 + lj;
         int32_t dot = (int32_t)acc[m][n][r];
         if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
         bool live = iok && j < g.Q && !(g.symmetric && i >= j);
@@ -317,30 +361,20 @@ __global__ __launch_bounds__(GEMM_WG) void dist_mfma_kernel(GemmArgs g) {
           const int32_t den = (int32_t)((uint32_t)nri + (uint32_t)nqv[n] - (uint32_t)dot);
           live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
         }
-        if (__any(live)) {
-          float ani = 0.f;
-          bool hit = false;
-          if (live) {
-            ani = ani_from_dot(dot, nri, nqv[n], g.kf);
-            if (FULL && g.ani_out) g.ani_out[(size_t)i * g.Q + j] = ani;
-            hit = g.hit_count && ani >= g.ani_th;
-          }
-          const unsigned long long bal = __ballot(hit);
-          if (bal) {
-            const uint32_t pos =
-                staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (hit) stage[pos] = hg_ani_hit{i, j, ani};
-            staged += (uint32_t)__popcll(bal);
-            if (staged > STAGE_CAP - 64) {
-              HG_FLUSH()
-            }
-          }
+        const unsigned long long bal = __ballot(live);
+        if (live) {
+          const uint32_t pos =
+              staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          cand[pos] = make_uint2((li << 16) | lj, (uint32_t)dot);
         }
+        staged += (uint32_t)__popcll(bal);
       }
     }
+    // at most 16 x 64 = 1024 candidates per m: one overflow check per m is enough
+    if (staged > CAND_CAP - 1024) HG_PROCESS()
   }
-  HG_FLUSH()
-#undef HG_FLUSH
+  if (staged) HG_PROCESS()
+#undef HG_PROCESS
 }
 
 // ---- always-exact integer fallback -------------------------------------------------------------------
@@ -397,7 +431,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   // D = 4096) every workgroup reads the same 128-byte column offset of 256 different rows at the same
   // moment, i.e. one L2 / Infinity-Cache channel; the odd 128-byte skew spreads rows over channels.
   const uint32_t ldk = Kp + 64;
-  const uint32_t Rp = (a.R + BM - 1) / BM * BM, Qp = (a.Q + BN - 1) / BN * BN;
+  const uint32_t Rp = (a.R + 255) / 256 * 256, Qp = (a.Q + 255) / 256 * 256;  // covers both tile sizes
   const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
   if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
@@ -452,18 +486,27 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
   g.ani_th = a.ani_th, g.symmetric = a.symmetric;
   g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
-  g.tiles_m = Rp / BM, g.tiles_n = Qp / BN;
-  const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   const bool whole_k = (64u << best_c) >= Kp;  // one window covers K: no i32 side accumulators
   const bool full = a.ani_out != nullptr;
-  if (whole_k && full)
-    hipLaunchKernelGGL((dist_mfma_kernel<false, true>), dim3(n_tiles), dim3(GEMM_WG), 0, c->stream, g);
-  else if (whole_k)
-    hipLaunchKernelGGL((dist_mfma_kernel<false, false>), dim3(n_tiles), dim3(GEMM_WG), 0, c->stream, g);
-  else if (full)
-    hipLaunchKernelGGL((dist_mfma_kernel<true, true>), dim3(n_tiles), dim3(GEMM_WG), 0, c->stream, g);
-  else
-    hipLaunchKernelGGL((dist_mfma_kernel<true, false>), dim3(n_tiles), dim3(GEMM_WG), 0, c->stream, g);
-  HG_HIP(c, hipGetLastError());
+  // big tiles when the problem fills the chip with them (Rp, Qp are multiples of 128: the last big
+  // tile may hang over by 128 rows, which the zero padding of the operand copies must cover)
+  const bool big = !full && whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
+  const uint32_t bm = big ? 256 : 128, bn = big ? 256 : 128;
+  g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
+  const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+  auto launch = [&](auto kern, int threads, size_t lds) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(threads), lds, c->stream, g);
+    return hipGetLastError();
+  };
+  const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16), lds_big = 2 * (256 + 256) * LDS_ROW * sizeof(_Float16);
+  hipError_t le;
+  if (big) le = launch(&dist_mfma_kernel<false, false, true>, TileCfg<true>::THREADS, lds_big);
+  else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);
+  else if (whole_k) le = launch(&dist_mfma_kernel<false, false, false>, TileCfg<false>::THREADS, lds_small);
+  else if (full) le = launch(&dist_mfma_kernel<true, true, false>, TileCfg<false>::THREADS, lds_small);
+  else le = launch(&dist_mfma_kernel<true, false, false>, TileCfg<false>::THREADS, lds_small);
+  HG_HIP(c, le);
   return HG_OK;
 }
