@@ -251,7 +251,9 @@ def main():
         def dstep():
             nonlocal found
             if world > 1:  # the path's one exchange step: all-gather the reference HV matrix (RCCL/xGMI)
-                torch.distributed.all_gather_into_tensor(ref_all, mine)
+                # as raw bytes: RCCL has no int16 datatype and the payload is opaque to the collective
+                torch.distributed.all_gather_into_tensor(ref_all.view(torch.uint8).view(-1),
+                                                         mine.view(torch.uint8).view(-1))
                 torch.distributed.all_gather_into_tensor(ref_n2, mine_n2)
                 r, rn, nr = ref_all, ref_n2, ref_all.shape[0]
             else:

@@ -36,6 +36,12 @@ def _worker(rank, world, port, n_genomes, out_dir):
     # dist: all-gather the reference HV matrix, compute this rank's R x Q_local block
     ref = shard.allgather_rows(torch.from_numpy(hv), world).numpy()
     ref_n2 = shard.allgather_rows(torch.from_numpy(n2), world).numpy()
+    # the exact call pattern of bench.py's dist step for equal-sized shards: int16 rows gathered as raw
+    # bytes into a preallocated tensor (RCCL, like gloo, has no int16 datatype)
+    eq = torch.from_numpy(hv[:2].copy())
+    ref_eq = torch.empty((2 * world, eq.shape[1]), dtype=torch.int16)
+    dist.all_gather_into_tensor(ref_eq.view(torch.uint8).view(-1), eq.view(torch.uint8).view(-1))
+    assert (ref_eq[2 * rank:2 * rank + 2] == eq).all()
     block = orc.ani_matrix(ref, ref_n2, hv, n2, 21)
     np.save(os.path.join(out_dir, "block%d.npy" % rank), block)
     np.save(os.path.join(out_dir, "hv%d.npy" % rank), hv)
