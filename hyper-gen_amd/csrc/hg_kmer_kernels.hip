@@ -328,6 +328,169 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
 }
 
 // =========================================================================================
+// fast kernel, 64-base window: compile-time k in [30, 32]
+// =========================================================================================
+// Same scheme as kmer_sample_fast with a 64-base register window per lane (16 dwords, 32 k-mer starts,
+// 32-byte lane stride); the 2-bit streams are 128 bits wide, k-mer values are still <= 64 bits.
+constexpr int TILES_PER_ITEM64 = 4;
+template <int K>
+struct Geo64 {
+  static constexpr int M = 32;
+  static constexpr int ND = (K + 3) / 4;
+  static constexpr int NB = K - 4 * (ND - 1);
+  static constexpr int TILE = WG * M;
+  static constexpr int ITEM = TILE * TILES_PER_ITEM64;
+};
+constexpr bool fast64_k(uint32_t k) { return k >= 30 && k <= 32; }
+
+template <int K, bool CANON>
+__global__ __launch_bounds__(WG) void kmer_sample_fast64(
+    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
+    const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
+    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  using G = Geo64<K>;
+  constexpr int M = G::M, ND = G::ND, NB = G::NB;
+  constexpr uint64_t MASK2K = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
+  constexpr uint64_t MASKK = (1ull << K) - 1;
+
+  const uint32_t item = blockIdx.x;
+  const uint32_t g = item_genome[item];
+  const hg_genome_meta gm = meta[g];
+  const uint64_t n_bps = gm.n_bps;
+  if (n_bps < (uint64_t)K) return;
+  const uint64_t n_starts = n_bps - K + 1;
+  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+
+#pragma unroll 1
+  for (int tile = 0; tile < TILES_PER_ITEM64; ++tile) {
+    const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
+    if (tile_start >= n_starts) break;  // uniform
+    const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * M;
+    uint32_t x[16];
+    {
+      // reads 64 bytes; the last lanes of a genome may run past its end by up to 63 bytes, so the
+      // window start is clamped to stay inside [0, n_bps + 32 - 64] ... lanes whose window would
+      // cross the slack are redirected to the genome start and masked out below
+      const bool in = p0 + 64 <= n_bps + 32;
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(gseq + (in ? p0 : 0));
+#pragma unroll
+      for (int t = 0; t < 16; ++t) x[t] = src[t];
+      if (!in && p0 < n_bps) {  // rare tail lanes: byte-wise, bounded by the genome end
+#pragma unroll 1
+        for (int t = 0; t < 16; ++t) {
+          uint32_t w = 0;
+          for (int bb = 0; bb < 4; ++bb) {
+            const uint64_t pos = p0 + 4 * t + bb;
+            w |= (uint32_t)(pos < n_bps ? gseq[pos] : (uint8_t)'N') << (8 * bb);
+          }
+          x[t] = w;
+        }
+      }
+    }
+    uint32_t FA[16], CA[16];
+    uint32_t dacc = 0;
+    uint32_t Gw[4] = {0, 0, 0, 0};  // 2-bit codes, base b at bits [2b, 2b+1] of the 128-bit value
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      uint32_t xv = x[t];
+      if (u2t) {
+        uint32_t e = (xv & 0xDFDFDFDFu) ^ 0x55555555u;
+        uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;
+        xv ^= (~nz & 0x80808080u) >> 7;
+        x[t] = xv;
+      }
+      uint32_t u = xv & 0xDFDFDFDFu;
+      uint32_t tt = xv ^ (xv >> 1);
+      uint32_t cd = (tt >> 1) & 0x03030303u;
+      FA[t] = __builtin_amdgcn_perm(0u, 0x54474341u, cd);
+      CA[t] = __builtin_amdgcn_perm(0u, 0x41434754u, cd);
+      dacc |= u ^ FA[t];
+      uint32_t t1 = lshl_or<6>(cd, cd);
+      uint32_t t2 = lshl_or<12>(t1, t1);
+      uint32_t p = (t2 >> 18) & 0xFFu;
+      Gw[t >> 2] |= p << (8 * (t & 3));
+    }
+    auto pairrev = [](uint32_t v) {
+      uint32_t br = __builtin_bitreverse32(v);
+      return ((br >> 1) & 0x55555555u) | ((br & 0x55555555u) << 1);
+    };
+    // LSB-first 128-bit code stream [Gl1:Gl0], its complement, and the MSB-first copy [Gm1:Gm0]
+    const uint64_t Gl0 = mk64(Gw[0], Gw[1]), Gl1 = mk64(Gw[2], Gw[3]);
+    const uint64_t Gc0 = ~Gl0, Gc1 = ~Gl1;
+    const uint64_t Gm1 = mk64(pairrev(Gw[1]), pairrev(Gw[0]));  // bases 0..31, base 0 on top
+    const uint64_t Gm0 = mk64(pairrev(Gw[3]), pairrev(Gw[2]));  // bases 32..63
+
+    const int64_t rem64 = (int64_t)n_bps - (int64_t)p0;
+    const uint32_t rem = rem64 >= 64 ? 64u : (rem64 <= 0 ? 0u : (uint32_t)rem64);
+    uint64_t inv = 0;
+    if (__any((dacc != 0) | (rem < 64))) {
+      uint32_t iv[2] = {0, 0};
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        uint32_t d = (x[t] & 0xDFDFDFDFu) ^ FA[t];
+        uint32_t z = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+        uint32_t nib = (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+        iv[t >> 3] |= nib << (4 * (t & 7));
+      }
+      inv = mk64(iv[0], iv[1]);
+      if (rem < 64) inv |= (rem == 0) ? ~0ull : (~0ull << rem);
+    }
+
+    static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int q = j >> 2, r = j & 3;
+      const bool valid = ((inv >> j) & MASKK) == 0;
+      uint32_t rc_mask = 0;
+      if (CANON) {
+        constexpr int sf = 2 * (64 - K - j);  // forward value: bits [sf, sf+2K) of [Gm1:Gm0]
+        uint64_t fv;
+        if constexpr (sf >= 64) fv = Gm1 >> (sf - 64);
+        else if constexpr (sf == 0) fv = Gm0;
+        else fv = (Gm0 >> sf) | (Gm1 << (64 - sf));
+        constexpr int sr = 2 * j;  // reverse value: bits [sr, sr+2K) of [Gc1:Gc0]
+        uint64_t rv;
+        if constexpr (sr == 0) rv = Gc0;
+        else rv = (Gc0 >> sr) | (Gc1 << (64 - sr));
+        fv &= MASK2K, rv &= MASK2K;
+        uint64_t lt;
+        asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
+        asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(rc_mask) : "s"(lt));
+      }
+      uint32_t d[ND];
+#pragma unroll
+      for (int m = 0; m < ND; ++m) {
+        uint32_t f;
+        if (m < ND - 1) {
+          f = (r == 0) ? FA[q + m] : __builtin_amdgcn_alignbyte(FA[q + m + 1], FA[q + m], r);
+        } else if (r + NB <= 4) {
+          f = (NB == 4) ? FA[q + m] : ((FA[q + m] >> (8 * r)) & ((1u << (8 * (NB & 3))) - 1));
+        } else {
+          f = __builtin_amdgcn_alignbyte(FA[q + m + 1], FA[q + m], r);
+          if (NB < 4) f &= (1u << (8 * (NB & 3))) - 1;
+        }
+        uint32_t v = f;
+        if (CANON) {
+          const int e = j + K - 1 - 4 * m;
+          const int Q = e >> 2, sft = e & 3;
+          uint32_t sel = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            uint32_t sb = (4 * m + i < K) ? (uint32_t)(sft + 4 - i) : 0x0cu;
+            sel |= sb << (8 * i);
+          }
+          uint32_t rcw = __builtin_amdgcn_perm(CA[Q], (Q >= 1) ? CA[Q - 1] : 0u, sel);
+          v = __builtin_amdgcn_bitop3_b32(rc_mask, rcw, f, 0xCA);
+        }
+        d[m] = v;
+      }
+      const uint64_t h = t1ha2_fixed<K>(d, seed);
+      if (valid && h < threshold) append_hit(h, gm, g, hits, cnt);
+    });
+  }
+}
+
+// =========================================================================================
 // generic kernel: any k <= 32 at run time (slow path for unusual k)
 // =========================================================================================
 __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
@@ -494,6 +657,7 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 }  // namespace
 
 uint32_t hg_kmer_item_starts(uint32_t k) {
+  if (fast64_k(k)) return (uint32_t)(WG * 32 * TILES_PER_ITEM64);
   if (!fast_k(k)) return GEN_ITEM;
   return (uint32_t)(WG * ((33 - k) & ~3u) * TILES_PER_ITEM);
 }
@@ -518,6 +682,21 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
       break;
   }
 #undef HG_FAST_CASE
+#define HG_FAST64_CASE(KK)                                                                              \
+  case KK:                                                                                              \
+    if (canonical)                                                                                      \
+      hipLaunchKernelGGL((kmer_sample_fast64<KK, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
+                         d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                           \
+    else                                                                                                \
+      hipLaunchKernelGGL((kmer_sample_fast64<KK, false>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
+                         d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                           \
+    return hipGetLastError();
+  switch (ksize) {
+    HG_FAST64_CASE(30) HG_FAST64_CASE(31) HG_FAST64_CASE(32)
+    default:
+      break;
+  }
+#undef HG_FAST64_CASE
   if (ksize > 32)
     hipLaunchKernelGGL(kmer_sample_long, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
                        threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);

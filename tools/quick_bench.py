@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--L", type=int, default=5_000_000)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dist", type=int, default=4096, help="R=Q for the dist timing (0 = skip)")
+    ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--variants", default="", help="comma list of HG_KMER_VARIANT values to A/B (library built with -DHG_KMER_EXPERIMENT)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -29,7 +30,7 @@ def main():
     torch.cuda.synchronize()
     offs = np.arange(a.genomes, dtype=np.uint64) * stride
     lens = np.full(a.genomes, a.L + 1, np.uint64)
-    p = hg.default_params()
+    p = hg.default_params(ksize=a.k)
     hv = torch.empty((a.genomes, p.hv_d), dtype=torch.int16, device=dev)
     n2 = torch.empty(a.genomes, dtype=torch.int32, device=dev)
     nh = torch.empty(a.genomes, dtype=torch.int32, device=dev)
