@@ -6,6 +6,9 @@ library is missing, or no HIP device is usable, calls raise.
 
 Import it as `hypergen_amd` (see the shim at the repo root; the directory name carries a
 hyphen because it is the reference's crate name).
+
+Note for processes that also use PyTorch-ROCm: import torch BEFORE this module loads the library
+(torch bundles its own copy of the HIP runtime; loaded second it finds no devices).
 """
 import ctypes as C
 import os
@@ -44,6 +47,7 @@ class AniHit(C.Structure):
 
 
 ANI_HIT_DTYPE = np.dtype([("ref_idx", "<u4"), ("qry_idx", "<u4"), ("ani", "<f4")])
+HAM_HIT_DTYPE = np.dtype([("ref_idx", "<u4"), ("qry_idx", "<u4"), ("dist", "<u4")])
 
 
 class FileSketch(C.Structure):
@@ -62,6 +66,7 @@ EXPORTS = [
     "hg_hv_unpack", "hg_sketch_file_write", "hg_sketch_file_read", "hg_sketch_file_count",
     "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_free",
     "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
+    "hg_hv_binarize_dev", "hg_hamming_full_dev", "hg_hamming_search_dev",
 ]
 
 
@@ -123,6 +128,9 @@ def lib():
         "hg_sketch_file_free": (None, [vp]),
         "hg_read_merge_seq": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz)]),
         "hg_free": (None, [vp]),
+        "hg_hv_binarize_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
+        "hg_hamming_full_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, vp]),
+        "hg_hamming_search_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, sz, C.POINTER(sz)]),
         "hg_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
         "hg_ctx_timings": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
         "hg_synth_genomes_dev": (C.c_int, [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32,
@@ -276,6 +284,20 @@ class Context:
             self._ck(lib().hg_synth_genomes_dev(self._h, first + done, m, L, cluster_size, sub_ppm_per_member,
                                                 stride, C.c_void_p(int(d_out) + done * stride)))
             done += m
+
+    # ---- bit-packed extension (device pointers) ---------------------------------------------------
+    def hv_binarize_dev(self, d_hv, n, hv_d, d_bits):
+        self._ck(lib().hg_hv_binarize_dev(self._h, _ptr(d_hv), n, hv_d, _ptr(d_bits)))
+
+    def hamming_full_dev(self, d_ref, R, d_qry, Q, hv_d, d_out):
+        self._ck(lib().hg_hamming_full_dev(self._h, _ptr(d_ref), R, _ptr(d_qry), Q, hv_d, _ptr(d_out)))
+
+    def hamming_search_dev(self, d_ref, R, d_qry, Q, hv_d, max_dist, d_out, cap):
+        n = C.c_size_t(0)
+        st = lib().hg_hamming_search_dev(self._h, _ptr(d_ref), R, _ptr(d_qry), Q, hv_d, max_dist, _ptr(d_out), cap,
+                                         C.byref(n))
+        self._ck(st, allow=(ERR_CAPACITY,))
+        return n.value, st
 
     def dist_full_dev(self, d_ref, d_rn, R, d_qry, d_qn, Q, hv_d, ksize, d_out):
         self._ck(lib().hg_dist_full_dev(self._h, _ptr(d_ref), _ptr(d_rn), R, _ptr(d_qry), _ptr(d_qn), Q,

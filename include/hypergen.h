@@ -208,6 +208,24 @@ void hg_sketch_file_free(hg_sketch_file *f);
 hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps);
 void hg_free(void *p);
 
+/* ---- bit-packed hypervectors + Hamming search (extension: BASELINE.json configs[4]) ------------
+ * No reference counterpart exists (the reference's `search` is an empty stub, src/main.rs:22-24);
+ * the semantics are defined here and by oracle/hg_oracle.c: bit d = (hv[d] >= 0), uint32 word w holds
+ * dims 32w..32w+31 LSB first ((hv_d+31)/32 words per vector), distance = popcount(xor).
+ * All pointers are device pointers; hv_d must be a multiple of 128 for the search. */
+typedef struct {
+  uint32_t ref_idx;
+  uint32_t qry_idx;
+  uint32_t dist;
+} hg_ham_hit;
+hg_status hg_hv_binarize_dev(hg_ctx *ctx, const int16_t *d_hv, size_t n, uint32_t hv_d, uint32_t *d_bits);
+hg_status hg_hamming_full_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R, const uint32_t *d_qry_bits,
+                              size_t Q, uint32_t hv_d, uint32_t *d_dist_out);
+/* all pairs with distance <= max_dist, in no particular order; *n_out = found (HG_ERR_CAPACITY if > cap) */
+hg_status hg_hamming_search_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R, const uint32_t *d_qry_bits,
+                                size_t Q, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap,
+                                size_t *n_out);
+
 /* ---- synthetic genomes (benchmark / test utility, not part of the reference surface) -----
  * Genome g = first_genome + i is written at d_out + i * stride as 'N' followed by L bases
  * (the read_merge_seq layout of a one-record FASTA).  Cluster c = g / cluster_size is an iid

@@ -453,6 +453,33 @@ void orc_ani_matrix(const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
 }
 
 /* ------------------------------------------------------------------------- */
+/* bit-packed hypervectors (extension, BASELINE configs[4]; no reference code) */
+/* ------------------------------------------------------------------------- */
+
+void orc_binarize(const int16_t *hv, size_t n, size_t hv_d, uint32_t *bits) {
+  size_t words = (hv_d + 31) / 32;
+  for (size_t g = 0; g < n; g++)
+    for (size_t w = 0; w < words; w++) {
+      uint32_t v = 0;
+      for (unsigned j = 0; j < 32 && w * 32 + j < hv_d; j++)
+        if (hv[g * hv_d + w * 32 + j] >= 0) v |= 1u << j;
+      bits[g * words + w] = v;
+    }
+}
+
+void orc_hamming_matrix(const uint32_t *ref_bits, size_t R, const uint32_t *qry_bits, size_t Q,
+                        size_t words, uint32_t *dist_out) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)R; i++)
+    for (size_t j = 0; j < Q; j++) {
+      uint32_t d = 0;
+      for (size_t w = 0; w < words; w++)
+        d += (uint32_t)__builtin_popcount(ref_bits[(size_t)i * words + w] ^ qry_bits[j * words + w]);
+      dist_out[(size_t)i * Q + j] = d;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* per-genome sketch                                                          */
 /* ------------------------------------------------------------------------- */
 

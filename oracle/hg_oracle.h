@@ -100,6 +100,13 @@ void orc_ani_matrix(const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
                     const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q,
                     size_t hv_d, unsigned ksize, float *ani_out);
 
+/* ---- bit-packed hypervectors: extension of BASELINE configs[4], defined by this repository
+ * (the reference has no such path).  bit d = (hv[d] >= 0); uint32 word w holds dims 32w..32w+31,
+ * LSB first; distance = popcount(xor). */
+void orc_binarize(const int16_t *hv, size_t n, size_t hv_d, uint32_t *bits);
+void orc_hamming_matrix(const uint32_t *ref_bits, size_t R, const uint32_t *qry_bits, size_t Q,
+                        size_t words, uint32_t *dist_out);
+
 /* ---- whole-genome sketch (what src/sketch.rs:35-56 does per file) ---------- */
 
 /* seq = merged buffer.  Writes hv (layout as given), norm2, n distinct hashes.

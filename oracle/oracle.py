@@ -64,6 +64,11 @@ def lib():
         L.orc_ani_matrix.restype = None
         L.orc_ani_matrix.argtypes = [i16p, i32p, C.c_size_t, i16p, i32p, C.c_size_t,
                                      C.c_size_t, C.c_uint, f32p]
+        L.orc_binarize.restype = None
+        L.orc_binarize.argtypes = [i16p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.orc_hamming_matrix.restype = None
+        L.orc_hamming_matrix.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t,
+                                         C.c_size_t, C.POINTER(C.c_uint32)]
         L.orc_set_threads.restype = None
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_sketch_genome.restype = C.c_int
@@ -236,3 +241,20 @@ def sketch_batch_mt(seqs, threads, ksize=21, scaled=1500, seed=123, canonical=Tr
     if rc != 0:
         raise MemoryError("orc_sketch_batch_mt failed")
     return hv, n2, nh
+
+
+def binarize(hv):
+    hv = np.ascontiguousarray(hv, np.int16)
+    n, d = hv.shape
+    bits = np.zeros((n, (d + 31) // 32), np.uint32)
+    lib().orc_binarize(_p(hv, C.c_int16), n, d, _p(bits, C.c_uint32))
+    return bits
+
+
+def hamming_matrix(ref_bits, qry_bits):
+    r = np.ascontiguousarray(ref_bits, np.uint32)
+    q = np.ascontiguousarray(qry_bits, np.uint32)
+    out = np.zeros((r.shape[0], q.shape[0]), np.uint32)
+    lib().orc_hamming_matrix(_p(r, C.c_uint32), r.shape[0], _p(q, C.c_uint32), q.shape[0], r.shape[1],
+                             _p(out, C.c_uint32))
+    return out

@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:  # load torch's bundled ROCm runtime BEFORE libhypergen_hip.so pulls in /opt/rocm's: with the
+    import torch  # noqa: F401  opposite order torch later reports "No HIP GPUs are available"
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -268,3 +268,50 @@ def test_dist_of_sketched_synthetic_cluster(ctx, orc, hg):
     want = orc.ani_matrix(hv, n2, hv, n2, 21)
     assert np.abs(ani - want).max() <= 1e-4
     assert ani[0, 0] == 100.0 and 98.5 < ani[0, 1] < 99.5 and 94 < ani[0, 2] < 96 and ani[0, 4] < 85
+
+
+# ---- bit-packed extension (BASELINE configs[4]; the oracle's popcount definition is the reference) ----
+@pytest.mark.parametrize("R,Q,d", [(1, 1, 128), (37, 300, 16384), (200, 129, 4096), (130, 5, 256)])
+def test_binarize_and_hamming(ctx, orc, R, Q, d):
+    import torch
+    rng = np.random.default_rng(R * 1000 + Q)
+    r = rng.integers(-40, 40, (R, d)).astype(np.int16)
+    q = np.vstack([r[: min(R, Q) // 2], rng.integers(-40, 40, (Q - min(R, Q) // 2, d)).astype(np.int16)])
+    dev = torch.device("cuda:0")
+    tr, tq = torch.from_numpy(r).to(dev), torch.from_numpy(q).to(dev)
+    br = torch.empty((R, d // 32), dtype=torch.int32, device=dev)
+    bq = torch.empty((Q, d // 32), dtype=torch.int32, device=dev)
+    ctx.hv_binarize_dev(tr.data_ptr(), R, d, br.data_ptr())
+    ctx.hv_binarize_dev(tq.data_ptr(), Q, d, bq.data_ptr())
+    ctx.sync()
+    wr, wq = orc.binarize(r), orc.binarize(q)
+    assert (br.cpu().numpy().view(np.uint32) == wr).all() and (bq.cpu().numpy().view(np.uint32) == wq).all()
+    out = torch.empty((R, Q), dtype=torch.int32, device=dev)
+    ctx.hamming_full_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, out.data_ptr())
+    ctx.sync()
+    want = orc.hamming_matrix(wr, wq)
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+    # thresholded search: exactly the pairs at distance <= max_dist
+    max_dist = int(np.percentile(want, 30))
+    cap = R * Q
+    hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+    n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, max_dist, hits.data_ptr(), cap)
+    got = hits.cpu().numpy().view(np.uint32)[: 3 * n].reshape(-1, 3)
+    assert st == 0 and n == int((want <= max_dist).sum())
+    assert {(int(a), int(b), int(c)) for a, b, c in got} == {(i, j, int(want[i, j])) for i, j in zip(*np.nonzero(want <= max_dist))}
+
+
+def test_hamming_of_d16384_sketches(ctx, orc, hg):
+    import torch
+    seqs = [orc.synth_genome(g, 200_000) for g in (0, 20, 60, 100)]
+    hv, n2, nh = ctx.sketch_batch(seqs, hg.default_params(scaled=100, hv_d=16384))
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(hv).to(dev)
+    b = torch.empty((4, 512), dtype=torch.int32, device=dev)
+    ctx.hv_binarize_dev(t.data_ptr(), 4, 16384, b.data_ptr())
+    out = torch.empty((4, 4), dtype=torch.int32, device=dev)
+    ctx.hamming_full_dev(b.data_ptr(), 4, b.data_ptr(), 4, 16384, out.data_ptr())
+    ctx.sync()
+    d = out.cpu().numpy()
+    assert (d == orc.hamming_matrix(orc.binarize(hv), orc.binarize(hv))).all()
+    assert d[0, 0] == 0 and d[0, 1] < d[0, 2] < d[0, 3] and 7000 < d[0, 3] < 9400  # unrelated ~ D/2
