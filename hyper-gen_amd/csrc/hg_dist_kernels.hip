@@ -14,6 +14,8 @@
 // way the dot product equals the reference's i32 value bit for bit; only logf differs from
 // glibc by <= 1 ulp.
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "hg_internal.h"
@@ -490,7 +492,11 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   const bool full = a.ani_out != nullptr;
   // big tiles when the problem fills the chip with them (Rp, Qp are multiples of 128: the last big
   // tile may hang over by 128 rows, which the zero padding of the operand copies must cover)
-  const bool big = !full && whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
+  bool big = !full && whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
+  if (const char *e = std::getenv("HG_DIST_TILE")) {  // test hook: force a geometry ("big" needs !full && whole_k)
+    if (!std::strcmp(e, "big")) big = !full && whole_k;
+    else if (!std::strcmp(e, "small")) big = false;
+  }
   const uint32_t bm = big ? 256 : 128, bn = big ? 256 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;

@@ -315,3 +315,109 @@ def test_hamming_of_d16384_sketches(ctx, orc, hg):
     d = out.cpu().numpy()
     assert (d == orc.hamming_matrix(orc.binarize(hv), orc.binarize(hv))).all()
     assert d[0, 0] == 0 and d[0, 1] < d[0, 2] < d[0, 3] and 7000 < d[0, 3] < 9400  # unrelated ~ D/2
+
+
+# ---- robustness -------------------------------------------------------------------------------------
+def test_hit_buffer_overflow_retry(ctx, orc, hg):
+    """A sampled k-mer repeated thousands of times overflows the expected-size hit buffer: the raw counter
+    keeps counting, the batch is re-run with exact capacities, results stay exact (lossless, unlike the
+    reference's 8 slots per thread, src/cuda_kernel.cu:316)."""
+    rng = np.random.default_rng(77)
+    thr = (2**64 - 1) // 1500
+    kmer = None
+    for _ in range(20000):
+        cand = rand_seq(rng, 21)
+        if orc.kmer_hash_sample(cand, 21, threshold=thr).size == 1:
+            kmer = cand
+            break
+    assert kmer is not None
+    unit = np.concatenate([kmer, np.frombuffer(b"N", np.uint8)])
+    seq = np.concatenate([np.tile(unit, 4000), rand_seq(rng, 100_000)])  # 4000 raw hits, cap would be ~1.3 k
+    other = orc.synth_genome(5, 150_000)
+    hv, n2, nh = ctx.sketch_batch([other, seq, other])
+    for i, s in enumerate([other, seq, other]):
+        w = orc.sketch_genome(s)
+        assert nh[i] == w[2] and n2[i] == w[1] and (hv[i] == w[0]).all(), i
+    got = ctx.kmer_hash_sample(seq, 21, 1500)
+    assert (got == orc.kmer_hash_sample(seq, 21, 1500)).all()
+
+
+def test_dev_api_argument_checks(ctx, hg):
+    import torch
+    dev = torch.device("cuda:0")
+    seq = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    hv = torch.empty((2, 4096), dtype=torch.int16, device=dev)
+    n2 = torch.empty(2, dtype=torch.int32, device=dev)
+    nh = torch.empty(2, dtype=torch.int32, device=dev)
+    p = hg.default_params()
+    with pytest.raises(hg.HgError) as e:  # offsets must be multiples of 4
+        ctx.sketch_batch_dev(seq.data_ptr(), [0, 1001], [1000, 1000], p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+    assert e.value.status == hg.ERR_INVALID
+    for bad in (dict(ksize=0), dict(ksize=256), dict(scaled=0), dict(hv_d=0), dict(hv_layout=7)):
+        with pytest.raises(hg.HgError):
+            ctx.sketch_batch_dev(seq.data_ptr(), [0, 1000], [1000, 1000], hg.default_params(**bad), hv.data_ptr(),
+                                 n2.data_ptr(), nh.data_ptr())
+    ctx.sketch_batch_dev(seq.data_ptr(), [0, 1000], [1000, 1000], p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+    ctx.sync()
+    assert int(nh.sum()) == 0  # all-zero bytes are not bases
+
+
+def test_dist_big_tiles_and_chunked_paths(ctx, orc, hg):
+    """Large thresholded problems take the 256 x 256 geometry; rows whose norms exceed the f32-exact
+    window take the chunked (i32 side accumulator) variant -- both against the oracle."""
+    rng = np.random.default_rng(31)
+    R, Q, D = 700, 1300, 4096
+    base = rng.integers(-60, 60, (8, D))
+    r = (base[rng.integers(0, 8, R)] + rng.integers(-25, 25, (R, D))).astype(np.int16)
+    q = (base[rng.integers(0, 8, Q)] + rng.integers(-25, 25, (Q, D))).astype(np.int16)
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    th = float(np.percentile(want, 90))
+    import os
+    os.environ["HG_DIST_TILE"] = "big"
+    try:
+        hits_big = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+    finally:
+        os.environ["HG_DIST_TILE"] = "small"
+    hits = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+    del os.environ["HG_DIST_TILE"]
+    key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
+    assert (key(hits_big) == key(hits)).all()  # both tile geometries: identical hits, bit for bit
+    sel = want >= th
+    # pairs within 1e-4 of the threshold may legitimately fall on either side
+    near = np.abs(want - th) <= 1e-4
+    got = {(int(h["ref_idx"]), int(h["qry_idx"])) for h in hits}
+    must = {(i, j) for i, j in zip(*np.nonzero(sel & ~near))}
+    may = {(i, j) for i, j in zip(*np.nonzero(sel | near))}
+    assert must <= got <= may
+    for h in hits[:2000]:
+        assert abs(h["ani"] - want[h["ref_idx"], h["qry_idx"]]) <= 1e-4
+    # big values: |x| up to ~900 -> norms ~1e9: exact only through chunked accumulation
+    r2 = (r.astype(np.int32) * 12).astype(np.int16)
+    q2 = (q.astype(np.int32) * 12).astype(np.int16)
+    rn2 = np.array([orc.hv_norm2(x) for x in r2], np.int32)
+    qn2 = np.array([orc.hv_norm2(x) for x in q2], np.int32)
+    want2 = orc.ani_matrix(r2[:300], rn2[:300], q2[:400], qn2[:400], 21)
+    got2 = ctx.dist_full(r2[:300], rn2[:300], q2[:400], qn2[:400], 21)
+    assert np.abs(got2 - want2).max() <= 1e-4
+    hits2 = ctx.dist(r2, rn2, q2, qn2, 21, ani_th=float(np.percentile(want2, 50)))
+    full2 = orc.ani_matrix(r2, rn2, q2, qn2, 21)
+    for h in hits2[:3000]:
+        assert abs(h["ani"] - full2[h["ref_idx"], h["qry_idx"]]) <= 1e-4
+
+
+def test_symmetric_large(ctx, orc, hg):
+    rng = np.random.default_rng(41)
+    n, D = 900, 4096
+    base = rng.integers(-60, 60, (6, D))
+    r = (base[rng.integers(0, 6, n)] + rng.integers(-30, 30, (n, D))).astype(np.int16)
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    want = orc.ani_matrix(r, rn, r, rn, 21)
+    th = float(np.percentile(want, 80)) + 3e-4
+    hits = ctx.dist(r, rn, r, rn, 21, symmetric=True, ani_th=th)
+    near = np.abs(want - th) <= 1e-4
+    iu = np.triu(np.ones((n, n), bool), 1)
+    got = {(int(h["ref_idx"]), int(h["qry_idx"])) for h in hits}
+    assert {(i, j) for i, j in zip(*np.nonzero((want >= th) & iu & ~near))} <= got
+    assert got <= {(i, j) for i, j in zip(*np.nonzero(((want >= th) | near) & iu))}
