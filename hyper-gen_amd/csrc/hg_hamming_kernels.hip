@@ -2,8 +2,8 @@
 //
 // Extension named by BASELINE.json configs[4] (D = 16384 sign-binarised HVs, database search); the
 // reference has no such path, so the semantics are this repository's: bit d = (hv[d] >= 0), uint32
-// word w holds dims 32w..32w+31 LSB first, distance = popcount(xor).  oracle/hg_oracle.c
-// (orc_binarize / orc_hamming_matrix) is the CPU definition the tests compare with, bit for bit.
+// word w holds dims 32w..32w+31 LSB first, distance = popcount(xor).  The CPU definition the tests
+// compare with, bit for bit, lives with the test infrastructure.
 //
 // The search is HBM/L2 + VALU work (v_xor_b32 + v_bcnt_u32_b32 per 32 dims and pair), not a GEMM: a
 // 128 x 128 tile of pairs per workgroup, 8 x 8 pairs per lane in registers, operand slices of 32

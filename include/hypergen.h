@@ -210,7 +210,7 @@ void hg_free(void *p);
 
 /* ---- bit-packed hypervectors + Hamming search (extension: BASELINE.json configs[4]) ------------
  * No reference counterpart exists (the reference's `search` is an empty stub, src/main.rs:22-24);
- * the semantics are defined here and by oracle/hg_oracle.c: bit d = (hv[d] >= 0), uint32 word w holds
+ * the semantics are defined here (and restated on the CPU by the test oracle): bit d = (hv[d] >= 0), uint32 word w holds
  * dims 32w..32w+31 LSB first ((hv_d+31)/32 words per vector), distance = popcount(xor).
  * All pointers are device pointers; hv_d must be a multiple of 128 for the search. */
 typedef struct {
