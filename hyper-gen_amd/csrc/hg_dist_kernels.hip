@@ -161,14 +161,21 @@ struct GemmArgs {
 // FULL: every ANI is evaluated and stored (parity / small problems).  Otherwise only pairs that can
 // reach ani_th are evaluated: one multiply-compare rejects the rest (ANI is monotone in the Jaccard
 // index), the exact reference arithmetic decides the survivors.
-template <bool CHUNKED, bool FULL, bool BIG>
+// GLDS (big geometry only): operand tiles go HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no
+// VGPR staging and no ds_write pass).  The DMA writes each wave-instruction's 1 KiB linearly, so the
+// LDS image is unpadded [row][8 chunks of 16 B] and bank conflicts are removed by an XOR swizzle of the
+// chunk index with (row >> 1) & 7 -- applied to the per-lane SOURCE address when loading and to the
+// fragment address when reading (same involution on both sides).
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG>;
+  static_assert(!GLDS || BIG, "LDS-DMA variant exists for the 256 x 256 geometry only");
+  constexpr int LROW = GLDS ? BK : LDS_ROW;  // elements per LDS row
   constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
   static_assert(LOADS == 4, "staging macros move 4 pieces per operand");
   // two LDS stages of (A tile + B tile)
   extern __shared__ __attribute__((aligned(16))) _Float16 sAB[];
-  constexpr uint32_t A_ELEMS = BM * LDS_ROW, B_ELEMS = BN * LDS_ROW;
+  constexpr uint32_t A_ELEMS = BM * LROW, B_ELEMS = BN * LROW;
   constexpr uint32_t TILE_ELEMS = A_ELEMS;           // offset of the B tile inside a stage
   constexpr uint32_t STAGE_ELEMS = A_ELEMS + B_ELEMS;
   constexpr uint32_t SROWS = THREADS / 8;            // rows covered by one staging pass
@@ -215,9 +222,14 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.ldk + spc * 8;
   const _Float16 *gB = g.B + (size_t)(col0 + srow) * g.ldk + spc * 8;
   const size_t rstep = (size_t)SROWS * g.ldk;
-  const uint32_t st_off = srow * LDS_ROW + spc * 8;                 // this thread's slot in a tile
-  const uint32_t fa_off = (wm * WTM * 16 + fr) * LDS_ROW + fq * 8;  // fragment bases in a stage
-  const uint32_t fb_off = TILE_ELEMS + (wn * 64 + fr) * LDS_ROW + fq * 8;
+  const uint32_t st_off = srow * LROW + spc * 8;                    // this thread's slot in a tile
+  // fragment bases in a stage; with the swizzle the lane's 16-byte chunk is (kk*4 + fq) ^ ((row>>1)&7),
+  // and (row>>1)&7 == (fr>>1)&7 because all row bases are multiples of 16
+  const uint32_t swz = (fr >> 1) & 7;
+  const uint32_t fa_off = (wm * WTM * 16 + fr) * LROW + (GLDS ? (fq ^ swz) * 8 : fq * 8);
+  const uint32_t fb_off = TILE_ELEMS + (wn * 64 + fr) * LROW + (GLDS ? (fq ^ swz) * 8 : fq * 8);
+  // kk = 1 adds 4 chunks: (4 + fq) ^ swz = (fq ^ swz) ^ 4
+  const int32_t kk1_off = GLDS ? ((((fq ^ swz) ^ 4) - (int32_t)(fq ^ swz)) * 8) : 32;
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define HG_GLOAD(k0)                                                    \
   ra0 = *reinterpret_cast<const uint4 *>(gA + (k0));                    \
@@ -232,13 +244,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   {                                                                                        \
     _Float16 *lA = sAB + (stage) * STAGE_ELEMS + st_off, *lB = lA + TILE_ELEMS;            \
     *reinterpret_cast<uint4 *>(lA) = ra0;                                                  \
-    *reinterpret_cast<uint4 *>(lA + SROWS * LDS_ROW) = ra1;                                \
-    *reinterpret_cast<uint4 *>(lA + 2 * SROWS * LDS_ROW) = ra2;                            \
-    *reinterpret_cast<uint4 *>(lA + 3 * SROWS * LDS_ROW) = ra3;                            \
+    *reinterpret_cast<uint4 *>(lA + SROWS * LROW) = ra1;                                \
+    *reinterpret_cast<uint4 *>(lA + 2 * SROWS * LROW) = ra2;                            \
+    *reinterpret_cast<uint4 *>(lA + 3 * SROWS * LROW) = ra3;                            \
     *reinterpret_cast<uint4 *>(lB) = rb0;                                                  \
-    *reinterpret_cast<uint4 *>(lB + SROWS * LDS_ROW) = rb1;                                \
-    *reinterpret_cast<uint4 *>(lB + 2 * SROWS * LDS_ROW) = rb2;                            \
-    *reinterpret_cast<uint4 *>(lB + 3 * SROWS * LDS_ROW) = rb3;                            \
+    *reinterpret_cast<uint4 *>(lB + SROWS * LROW) = rb1;                                \
+    *reinterpret_cast<uint4 *>(lB + 2 * SROWS * LROW) = rb2;                            \
+    *reinterpret_cast<uint4 *>(lB + 3 * SROWS * LROW) = rb3;                            \
   }
 
   // Software pipeline with ONE barrier per K-step:
@@ -247,16 +259,45 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   //                   then 32 MFMAs on stage k&1, then the barrier that publishes stage (k+1)&1 and
   //                   retires the reads of stage k&1.
   const uint32_t nsteps = g.Kp / BK;
-  HG_GLOAD(0)
-  HG_LSTORE(0)
-  if (nsteps > 1) {
-    HG_GLOAD(BK)
+  // LDS-DMA staging: thread t fills slots s = i*THREADS + t (i < 4) of each operand tile; slot s is
+  // row s/8, LDS chunk s%8, and holds global chunk (s%8) ^ ((row>>1)&7) of that row.  The wave's 64 slots
+  // of one instruction are 1 KiB contiguous in LDS, as the DMA requires.
+  const _Float16 *dA[4], *dB[4];
+  if (GLDS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t sl = i * THREADS + tid, r = sl >> 3, ch = (sl & 7) ^ ((r >> 1) & 7);
+      dA[i] = g.A + (size_t)(row0 + r) * g.ldk + ch * 8;
+      dB[i] = g.B + (size_t)(col0 + r) * g.ldk + ch * 8;
+    }
   }
-  __syncthreads();
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+#define HG_DMA(stage, k0)                                                                                   \
+  {                                                                                                         \
+    _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dA[i] + (k0)), (lds_ptr_t)(wbase + i * THREADS * 8), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dB[i] + (k0)), (lds_ptr_t)(wbase + TILE_ELEMS + i * THREADS * 8), 16, 0, 0); \
+    }                                                                                                       \
+  }
+  if (GLDS) {
+    HG_DMA(0, 0)
+  } else {
+    HG_GLOAD(0)
+    HG_LSTORE(0)
+    if (nsteps > 1) {
+      HG_GLOAD(BK)
+    }
+  }
+  __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
     const uint32_t cur = ks & 1;
-    if (ks + 1 < nsteps) {
+    if (GLDS) {
+      // stage cur^1 was last read during step ks-1, retired by that step's closing barrier
+      if (ks + 1 < nsteps) HG_DMA(cur ^ 1, (ks + 1) * BK)
+    } else if (ks + 1 < nsteps) {
       HG_LSTORE(cur ^ 1)
       if (ks + 2 < nsteps) {
         const uint32_t k2 = (ks + 2) * BK;
@@ -268,11 +309,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       half8 bf[4];
+      const int32_t ko = kk ? kk1_off : 0;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bf[n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LDS_ROW + kk * 32);
+      for (int n = 0; n < 4; ++n) bf[n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LROW + ko);
 #pragma unroll
       for (int m = 0; m < WTM; ++m) {
-        const half8 af = *reinterpret_cast<const half8 *>(fA + m * 16 * LDS_ROW + kk * 32);
+        const half8 af = *reinterpret_cast<const half8 *>(fA + m * 16 * LROW + ko);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[n], acc[m][n], 0, 0, 0);
@@ -293,6 +335,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   }
 #undef HG_GLOAD
 #undef HG_LSTORE
+#undef HG_DMA
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
   // Phase 1 (unrolled over the accumulator registers, a handful of instructions per element): one
@@ -493,8 +536,10 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   // big tiles when the problem fills the chip with them (Rp, Qp are multiples of 128: the last big
   // tile may hang over by 128 rows, which the zero padding of the operand copies must cover)
   bool big = !full && whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
+  bool dma = true;
   if (const char *e = std::getenv("HG_DIST_TILE")) {  // test hook: force a geometry ("big" needs !full && whole_k)
     if (!std::strcmp(e, "big")) big = !full && whole_k;
+    else if (!std::strcmp(e, "big_reg")) big = !full && whole_k, dma = false;
     else if (!std::strcmp(e, "small")) big = false;
   }
   const uint32_t bm = big ? 256 : 128, bn = big ? 256 : 128;
@@ -508,7 +553,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   };
   const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16), lds_big = 2 * (256 + 256) * LDS_ROW * sizeof(_Float16);
   hipError_t le;
-  if (big) le = launch(&dist_mfma_kernel<false, false, true>, TileCfg<true>::THREADS, lds_big);
+  const size_t lds_dma = 2 * (256 + 256) * BK * sizeof(_Float16);
+  if (big && dma) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
+  else if (big) le = launch(&dist_mfma_kernel<false, false, true, false>, TileCfg<true>::THREADS, lds_big);
   else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);
   else if (whole_k) le = launch(&dist_mfma_kernel<false, false, false>, TileCfg<false>::THREADS, lds_small);
   else if (full) le = launch(&dist_mfma_kernel<true, true, false>, TileCfg<false>::THREADS, lds_small);

@@ -375,15 +375,18 @@ def test_dist_big_tiles_and_chunked_paths(ctx, orc, hg):
     want = orc.ani_matrix(r, rn, q, qn, 21)
     th = float(np.percentile(want, 90))
     import os
-    os.environ["HG_DIST_TILE"] = "big"
-    try:
-        hits_big = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
-    finally:
-        os.environ["HG_DIST_TILE"] = "small"
-    hits = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
-    del os.environ["HG_DIST_TILE"]
     key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
-    assert (key(hits_big) == key(hits)).all()  # both tile geometries: identical hits, bit for bit
+    try:
+        os.environ["HG_DIST_TILE"] = "big"       # 256 x 256, LDS-DMA staging (swizzled image)
+        hits_big = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+        os.environ["HG_DIST_TILE"] = "big_reg"   # 256 x 256, register staging
+        hits_big_reg = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+        os.environ["HG_DIST_TILE"] = "small"     # 128 x 128
+        hits = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+    finally:
+        del os.environ["HG_DIST_TILE"]
+    assert (key(hits_big) == key(hits)).all()      # all geometries: identical hits, bit for bit
+    assert (key(hits_big_reg) == key(hits)).all()
     sel = want >= th
     # pairs within 1e-4 of the threshold may legitimately fall on either side
     near = np.abs(want - th) <= 1e-4
