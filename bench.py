@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU and step")
     ap.add_argument("--dist-n", type=int, default=10000, help="R = Q of the ANI matrix (0 = skip)")
+    ap.add_argument("--hamming-refs", type=int, default=50000, help="refs of the bit-packed D=16384 search (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -289,6 +290,46 @@ def main():
         }
         log("dist: %.0f M pairs/s, gemm %.3f ms/launch = %.1f TFLOP/s, hits/rank %d" % (
             out["dist"]["value"], gemm_ms, ach, found))
+
+    # ---------------- bit-packed D=16384 Hamming search (BASELINE configs[4], extension) -------------------
+    if a.hamming_refs:
+        HD, HQ = 16384, 1000
+        refs = a.hamming_refs // world  # the reference database is sharded, the (small) query set replicated
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x48480000 + rank)
+        rb = torch.randint(-2**31, 2**31 - 1, (refs, HD // 32), dtype=torch.int32, device=dev, generator=gen)
+        qb = rb[:HQ].clone()
+        qb ^= (1 << torch.randint(0, 31, (HQ, HD // 32), device=dev, generator=gen)).int()  # 512 flipped bits
+        hcap = 1 << 20
+        hh = torch.empty(hcap * 3, dtype=torch.int32, device=dev)
+        nfound = 0
+
+        def hstep():
+            nonlocal nfound
+            nfound, _ = ctx.hamming_search_dev(rb.data_ptr(), refs, qb.data_ptr(), HQ, HD, 2000, hh.data_ptr(), hcap)
+
+        hstep()
+        ctx.enable_timing(True)
+        ctx.timings()
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            hstep()
+        barrier_sync(world)
+        hdt = max_over_ranks(time.perf_counter() - t0, world, dev)
+        htm = ctx.timings()
+        ctx.enable_timing(False)
+        hms = htm["dist"][0] / max(htm["dist"][1], 1)
+        out["hamming"] = {
+            "metric": "M Hamming-pairs/sec (D=16384 bit-packed)", "value": refs * world * HQ * a.steps / hdt / 1e6,
+            "unit": "M pairs/sec", "ms_per_step": hdt / a.steps * 1e3, "scaling": "strong",
+            "config": {"workload": "%d ref x %d query sign-binarised D=16384 HVs, popcount(xor) <= 2000 (BASELINE "
+                                   "configs[4]; extension, no reference counterpart)" % (refs * world, HQ),
+                       "hits_per_rank": int(nfound)},
+            "kernel_ms": hms, "word_ops_per_sec": refs * HQ * (HD / 32) / (hms * 1e-3),
+        }
+        log("hamming: %.0f M pairs/s, kernel %.3f ms, hits/rank %d" % (out["hamming"]["value"], hms, nfound))
+        del rb, qb, hh
 
     # ---------------- CPU baseline (rank 0, single-GPU runs only) ----------------------------------
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
