@@ -154,45 +154,61 @@ int run_sketch(const Cli &c) {
 
   std::vector<std::vector<int16_t>> payload(n);
   std::vector<hg_file_sketch> recs(n);
-  const size_t budget = (size_t)6 << 30;  // bytes of sequence per device batch
-  size_t i0 = 0;
-  while (i0 < n) {
-    // read a batch of files with -t host threads
+  const size_t budget = (size_t)1 << 30;  // bytes of sequence per device batch (read ahead of the device)
+
+  struct Batch {
+    size_t i0 = 0, i1 = 0;
     std::vector<uint8_t *> seqs;
     std::vector<size_t> lens;
-    size_t bytes = 0, i1 = i0;
-    while (i1 < n && (i1 == i0 || bytes < budget)) {
-      const size_t cnt = std::min<size_t>(std::max(1u, c.threads), n - i1);
-      seqs.resize(seqs.size() + cnt), lens.resize(lens.size() + cnt);
+  };
+  // reads files [i0, ...) until the byte budget is reached, -t files at a time
+  auto read_batch = [&](size_t i0) {
+    Batch b;
+    b.i0 = b.i1 = i0;
+    size_t bytes = 0;
+    while (b.i1 < n && (b.i1 == i0 || bytes < budget)) {
+      const size_t cnt = std::min<size_t>(std::max(1u, c.threads), n - b.i1);
+      const size_t base = b.seqs.size();
+      b.seqs.resize(base + cnt), b.lens.resize(base + cnt);
       std::vector<std::thread> th;
       for (size_t k = 0; k < cnt; ++k)
         th.emplace_back([&, k] {
-          if (hg_read_merge_seq(files[i1 + k].c_str(), &seqs[i1 - i0 + k], &lens[i1 - i0 + k]) != HG_OK)
-            die("Opening .fna files failed: " + files[i1 + k]);
+          if (hg_read_merge_seq(files[b.i1 + k].c_str(), &b.seqs[base + k], &b.lens[base + k]) != HG_OK)
+            die("Opening .fna files failed: " + files[b.i1 + k]);
         });
       for (auto &t : th) t.join();
-      for (size_t k = 0; k < cnt; ++k) bytes += lens[i1 - i0 + k];
-      i1 += cnt;
+      for (size_t k = 0; k < cnt; ++k) bytes += b.lens[base + k];
+      b.i1 += cnt;
     }
-    const size_t nb = i1 - i0;
+    return b;
+  };
+
+  // two-stage pipeline: the host reads (and inflates) batch i+1 while the device sketches batch i
+  Batch cur = n ? read_batch(0) : Batch{};
+  while (cur.i1 > cur.i0) {
+    Batch nxt;
+    std::thread reader;
+    if (cur.i1 < n) reader = std::thread([&] { nxt = read_batch(cur.i1); });
+    const size_t nb = cur.i1 - cur.i0;
     std::vector<int16_t> hv(nb * c.hv_d);
     std::vector<int32_t> n2(nb);
     std::vector<uint32_t> nh(nb);
-    ck(ctx, hg_sketch_batch(ctx, seqs.data(), lens.data(), nb, &p, hv.data(), n2.data(), nh.data()), "sketch");
+    ck(ctx, hg_sketch_batch(ctx, cur.seqs.data(), cur.lens.data(), nb, &p, hv.data(), n2.data(), nh.data()), "sketch");
     for (size_t k = 0; k < nb; ++k) {
-      hg_free(seqs[k]);
+      hg_free(cur.seqs[k]);
       const int16_t *v = hv.data() + k * c.hv_d;
       const uint32_t q = hg_hv_quant_bits(v, (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
-      payload[i0 + k].resize((size_t)q * c.hv_d / 16);
-      if (hg_hv_pack(v, (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[i0 + k].data())) != HG_OK) die("pack");
-      hg_file_sketch &r = recs[i0 + k];
+      payload[cur.i0 + k].resize((size_t)q * c.hv_d / 16);
+      if (hg_hv_pack(v, (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[cur.i0 + k].data())) != HG_OK) die("pack");
+      hg_file_sketch &r = recs[cur.i0 + k];
       std::memset(&r, 0, sizeof r);
       r.ksize = (uint8_t)c.ksize, r.canonical = c.canonical, r.hv_quant_bits = (uint8_t)q, r.hv_norm_2 = n2[k];
       r.scaled = c.scaled, r.seed = c.seed, r.hv_d = c.hv_d;
-      r.file_str = files[i0 + k].c_str();
-      r.hv = payload[i0 + k].data(), r.hv_len = payload[i0 + k].size();
+      r.file_str = files[cur.i0 + k].c_str();
+      r.hv = payload[cur.i0 + k].data(), r.hv_len = payload[cur.i0 + k].size();
     }
-    i0 = i1;
+    if (reader.joinable()) reader.join();
+    cur = std::move(nxt);
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   char buf[256];

@@ -6,6 +6,8 @@
 // The BitPacker8x and bincode layouts are restated from the published crate algorithms; no
 // reference-produced .sketch file exists in this environment, so byte compatibility with the
 // Rust binary is UNPINNED ("parity status").
+#include <zlib.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -193,28 +195,28 @@ extern "C" void hg_sketch_file_free(hg_sketch_file *f) { delete f; }
 extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {
   if (!path || !out || !n_bps) return HG_ERR_INVALID;
   *out = nullptr, *n_bps = 0;
-  FILE *f = std::fopen(path, "rb");
+  // gzread passes plain text through and inflates gzip transparently -- what needletail's reader does
+  // for the reference's CPU path (src/sketch.rs:76); the reference's GPU reader is plain text only
+  gzFile f = gzopen(path, "rb");
   if (!f) return HG_ERR_IO;
-  std::fseek(f, 0, SEEK_END);
-  const long sz = std::ftell(f);
-  std::fseek(f, 0, SEEK_SET);
-  if (sz < 0) {
-    std::fclose(f);
-    return HG_ERR_IO;
+  gzbuffer(f, 1 << 20);
+  std::vector<uint8_t> text;
+  {
+    std::vector<uint8_t> buf(4 << 20);
+    int got;
+    while ((got = gzread(f, buf.data(), (unsigned)buf.size())) > 0) text.insert(text.end(), buf.begin(), buf.begin() + got);
+    const bool bad = got < 0;
+    gzclose(f);
+    if (bad) return HG_ERR_IO;
   }
-  std::vector<uint8_t> text((size_t)sz);
-  if (sz && std::fread(text.data(), 1, (size_t)sz, f) != (size_t)sz) {
-    std::fclose(f);
-    return HG_ERR_IO;
-  }
-  std::fclose(f);
-  uint8_t *o = static_cast<uint8_t *>(std::malloc((size_t)sz + 64));  // merged text is never longer
+  const size_t n = text.size();
+  uint8_t *o = static_cast<uint8_t *>(std::malloc(n + 64));  // merged text is never longer
   if (!o) return HG_ERR_OOM;
   size_t w = 0, i = 0;
-  const size_t n = (size_t)sz;
   while (i < n) {  // line by line: header -> one 'N', else the line minus "\n" / "\r\n"
     size_t j = i;
-    while (j < n && text[j] != '\n') ++j;
+    const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(text.data() + i, '\n', n - i));
+    j = nl ? (size_t)(nl - text.data()) : n;
     if (text[i] == '>') {
       o[w++] = 'N';
     } else {

@@ -102,6 +102,14 @@ def test_read_merge_seq(hg, orc, tmp_path):
     p.write_bytes(txt)
     got = hg.read_merge_seq(str(p))
     assert bytes(got) == b"NACGTNNacguNTT" and (got == orc.read_merge_seq(txt)).all()
+    import gzip
+    gz = tmp_path / "t2.fna"  # gzip content behind a .fna name: sniffed like needletail does
+    gz.write_bytes(gzip.compress(txt))
+    assert bytes(hg.read_merge_seq(str(gz))) == b"NACGTNNacguNTT"
+    big = b">x\n" + b"ACGT" * 3_000_000 + b"\n>y\n" + b"TTGA" * 10
+    gz.write_bytes(gzip.compress(big))
+    got = hg.read_merge_seq(str(gz))
+    assert got.size == 2 + 12_000_000 + 40 and (got == orc.read_merge_seq(big)).all()
     ref_fixture = b">test_seq\nAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"
     p.write_bytes(ref_fixture)
     assert bytes(hg.read_merge_seq(str(p))) == b"NAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"
