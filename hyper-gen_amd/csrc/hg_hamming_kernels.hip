@@ -85,20 +85,21 @@ __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < HK; kk += 4) {
-      uint4 ra[8], rb[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const uint4 *>(&sA[(ty + 16 * i) * HROW + kk]);
+      uint4 rb[8];  // the B quads stay in registers, the A quads stream through (keeps the kernel
+                    // near 128 VGPRs instead of 240: 4 waves per SIMD instead of 2)
 #pragma unroll
       for (int j = 0; j < 8; ++j) rb[j] = *reinterpret_cast<const uint4 *>(&sB[(tx + 16 * j) * HROW + kk]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
+        const uint4 ra = *reinterpret_cast<const uint4 *>(&sA[(ty + 16 * i) * HROW + kk]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          acc[i][j] += __builtin_popcount(ra[i].x ^ rb[j].x);
-          acc[i][j] += __builtin_popcount(ra[i].y ^ rb[j].y);
-          acc[i][j] += __builtin_popcount(ra[i].z ^ rb[j].z);
-          acc[i][j] += __builtin_popcount(ra[i].w ^ rb[j].w);
+          acc[i][j] += __builtin_popcount(ra.x ^ rb[j].x);
+          acc[i][j] += __builtin_popcount(ra.y ^ rb[j].y);
+          acc[i][j] += __builtin_popcount(ra.z ^ rb[j].z);
+          acc[i][j] += __builtin_popcount(ra.w ^ rb[j].w);
         }
+      }
     }
   }
   __syncthreads();  // LDS is free now: per-wave hit staging (one global atomic per flush)
