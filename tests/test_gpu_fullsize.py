@@ -1,0 +1,92 @@
+"""BASELINE-size runs checked through size-independent properties (the oracle cannot redo 1 000 x 5 Mbp
+in seconds): determinism, sampled full parity, norm / dot identities, ANI symmetry, hit-set consistency."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, L, D = 1000, 5_000_000, 4096
+
+
+@pytest.fixture(scope="module")
+def sketched(orc):
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    ctx = hg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    stride = (L + 1 + 15) // 16 * 16
+    seq = torch.empty(N * stride + 64, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_dev(0, N, L, stride, seq.data_ptr())
+    offs = np.arange(N, dtype=np.uint64) * stride
+    lens = np.full(N, L + 1, np.uint64)
+    p = hg.default_params()
+    out = []
+    for _ in range(2):
+        hv = torch.empty((N, D), dtype=torch.int16, device=dev)
+        n2 = torch.empty(N, dtype=torch.int32, device=dev)
+        nh = torch.empty(N, dtype=torch.int32, device=dev)
+        ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+        torch.cuda.synchronize()
+        out.append((hv, n2, nh))
+    yield ctx, seq, stride, out
+    ctx.close()
+
+
+def test_sketch_1000x5mbp_properties(sketched, orc):
+    ctx, seq, stride, out = sketched
+    (hv, n2, nh), (hv_b, n2_b, nh_b) = out
+    # idempotence: two runs are bit-identical although hits are appended in nondeterministic order
+    assert torch.equal(hv, hv_b) and torch.equal(n2, n2_b) and torch.equal(nh, nh_b)
+    nhc = nh.cpu().numpy()
+    assert 3100 < nhc.min() and nhc.max() < 3600 and abs(nhc.mean() - (L - 20) / 1500) < 60  # 10 independent cluster roots
+    # norm identity (i32) and the bundling identity sum_d hv[d] == 2*ones - n*D with parity n (mod 2)
+    assert torch.equal((hv.int() ** 2).sum(1).int(), n2)
+    assert bool(((hv.int() - nh[:, None]) % 2 == 0).all())  # hv[d] = 2*count - n
+    # device generator == host generator, and full parity for a sample of genomes spread over the batch
+    for g in (0, 1, 137, 500, 999):
+        host = orc.synth_genome(g, L)
+        assert np.array_equal(seq[g * stride: g * stride + L + 1].cpu().numpy(), host)
+        w_hv, w_n2, w_nh = orc.sketch_genome(host)
+        assert nhc[g] == w_nh and int(n2[g]) == w_n2 and np.array_equal(hv[g].cpu().numpy(), w_hv), g
+
+
+def test_dist_of_the_1000_sketches_properties(sketched, orc):
+    ctx, seq, stride, out = sketched
+    hv, n2, nh = out[0]
+    dev = hv.device
+    full = torch.empty((N, N), dtype=torch.float32, device=dev)
+    ctx.dist_full_dev(hv.data_ptr(), n2.data_ptr(), N, hv.data_ptr(), n2.data_ptr(), N, D, 21, full.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(full, full.T)                       # exact integer dots -> exactly symmetric
+    assert bool((full.diagonal() == 100.0).all())
+    # exact dots: recompute a block with int64 matmul on the device and the reference's float32 formula
+    blk = slice(100, 228)
+    dots = (hv[blk].double() @ hv.double().T).round().long()  # exact: |dot| << 2^53
+    den = (n2[blk].long()[:, None] + n2.long()[None, :] - dots).float()
+    j = dots.float() / den
+    ani = (1.0 + torch.log(2.0 / (1.0 / j + 1.0)) / 21.0)
+    ani = torch.nan_to_num(ani, nan=0.0).clamp(0.0, 1.0) * 100.0
+    assert float((full[blk] - ani).abs().max()) <= 1e-4
+    # clustered workload: members of a cluster (100 consecutive genomes, <= 9.9 % substitutions) are
+    # close, different clusters are far
+    # (member m differs from its root by 0.1*m %, two members by up to ~20 %)
+    # unrelated genomes sit at the estimator's noise floor (chance dot > 0 => up to ~87 % at D=4096, n~3333)
+    assert float(full[0, :100].min()) > 89.0 and float(full[:100, 100:].max()) < 90.0
+    # thresholded path == thresholded full matrix (up to pairs within 1e-4 of the threshold)
+    cap = 1 << 20
+    hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+    n, st = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), N, hv.data_ptr(), n2.data_ptr(), N, D, 21, True, 95.0,
+                         hits.data_ptr(), cap)
+    assert st == 0
+    iu = torch.triu(torch.ones((N, N), dtype=torch.bool, device=dev), 1)
+    lo = int(((full >= 95.0 + 1e-4) & iu).sum())
+    hi = int(((full >= 95.0 - 1e-4) & iu).sum())
+    assert lo <= n <= hi and n > 1000
+    h = hits[: 3 * n].view(-1, 3)
+    vals = h[:, 2].view(torch.float32)
+    assert float((full[h[:, 0].long(), h[:, 1].long()] - vals).abs().max()) == 0.0  # same kernel arithmetic
+    # model check of the estimator itself: substitution rate p -> ANI ~ 100*(1-p)
+    est = full[0, 1:100].cpu().numpy()
+    true = 100.0 * (1.0 - 0.001 * np.arange(1, 100))
+    assert np.abs(est - true).max() < 1.0
