@@ -8,6 +8,7 @@
 // Rust binary is UNPINNED ("parity status").
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -192,43 +193,97 @@ extern "C" const hg_file_sketch *hg_sketch_file_get(const hg_sketch_file *f, siz
 extern "C" void hg_sketch_file_free(hg_sketch_file *f) { delete f; }
 
 // ---- FASTA -----------------------------------------------------------------------------------------------
-extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {
-  if (!path || !out || !n_bps) return HG_ERR_INVALID;
-  *out = nullptr, *n_bps = 0;
-  // gzread passes plain text through and inflates gzip transparently -- what needletail's reader does
-  // for the reference's CPU path (src/sketch.rs:76); the reference's GPU reader is plain text only
-  gzFile f = gzopen(path, "rb");
-  if (!f) return HG_ERR_IO;
-  gzbuffer(f, 1 << 20);
-  std::vector<uint8_t> text;
-  {
-    std::vector<uint8_t> buf(4 << 20);
-    int got;
-    while ((got = gzread(f, buf.data(), (unsigned)buf.size())) > 0) text.insert(text.end(), buf.begin(), buf.begin() + got);
-    const bool bad = got < 0;
-    gzclose(f);
-    if (bad) return HG_ERR_IO;
-  }
-  const size_t n = text.size();
-  uint8_t *o = static_cast<uint8_t *>(std::malloc(n + 64));  // merged text is never longer
-  if (!o) return HG_ERR_OOM;
+namespace {
+// in-place merge of FASTA text held in buf[0..n): header lines become one 'N', sequence lines lose their
+// line ends (src/fastx_reader.rs:14-26).  The write index never passes the read index.
+size_t merge_in_place(uint8_t *buf, size_t n) {
   size_t w = 0, i = 0;
-  while (i < n) {  // line by line: header -> one 'N', else the line minus "\n" / "\r\n"
-    size_t j = i;
-    const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(text.data() + i, '\n', n - i));
-    j = nl ? (size_t)(nl - text.data()) : n;
-    if (text[i] == '>') {
-      o[w++] = 'N';
+  while (i < n) {
+    const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + i, '\n', n - i));
+    const size_t j = nl ? (size_t)(nl - buf) : n;
+    if (buf[i] == '>') {
+      buf[w++] = 'N';
     } else {
       size_t e = j;
-      if (e > i && text[e - 1] == '\r') --e;  // src/fastx_reader.rs:19-21 pops '\r' with or without '\n'
-      std::memcpy(o + w, text.data() + i, e - i);
+      if (e > i && buf[e - 1] == '\r') --e;  // :19-21 pops '\r' with or without '\n'
+      std::memmove(buf + w, buf + i, e - i);
       w += e - i;
     }
     i = j < n ? j + 1 : j;
   }
-  std::memset(o + w, 0, 64);
-  *out = o, *n_bps = w;
+  return w;
+}
+}  // namespace
+
+extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {
+  if (!path || !out || !n_bps) return HG_ERR_INVALID;
+  *out = nullptr, *n_bps = 0;
+  FILE *fp = std::fopen(path, "rb");
+  if (!fp) return HG_ERR_IO;
+  unsigned char magic[2] = {0, 0};
+  const size_t got_magic = std::fread(magic, 1, 2, fp);
+  uint8_t *buf = nullptr;
+  size_t n = 0;
+  if (got_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+    // gzip: inflate transparently -- what needletail's reader does for the reference's CPU path
+    // (src/sketch.rs:76); the reference's GPU reader is plain text only
+    std::fclose(fp);
+    gzFile f = gzopen(path, "rb");
+    if (!f) return HG_ERR_IO;
+    gzbuffer(f, 1 << 20);
+    size_t cap = (size_t)16 << 20;
+    buf = static_cast<uint8_t *>(std::malloc(cap + 64));
+    if (!buf) {
+      gzclose(f);
+      return HG_ERR_OOM;
+    }
+    int got;
+    while ((got = gzread(f, buf + n, (unsigned)std::min<size_t>(cap - n, 1u << 30))) > 0) {
+      n += (size_t)got;
+      if (n == cap) {
+        cap *= 2;
+        uint8_t *nb = static_cast<uint8_t *>(std::realloc(buf, cap + 64));
+        if (!nb) {
+          std::free(buf);
+          gzclose(f);
+          return HG_ERR_OOM;
+        }
+        buf = nb;
+      }
+    }
+    const bool bad = got < 0;
+    gzclose(f);
+    if (bad) {
+      std::free(buf);
+      return HG_ERR_IO;
+    }
+  } else {
+    // plain text: one read of the whole file straight into the result buffer
+    if (std::fseek(fp, 0, SEEK_END) != 0) {
+      std::fclose(fp);
+      return HG_ERR_IO;
+    }
+    const long sz = std::ftell(fp);
+    if (sz < 0) {
+      std::fclose(fp);
+      return HG_ERR_IO;
+    }
+    std::rewind(fp);
+    buf = static_cast<uint8_t *>(std::malloc((size_t)sz + 64));
+    if (!buf) {
+      std::fclose(fp);
+      return HG_ERR_OOM;
+    }
+    n = sz ? std::fread(buf, 1, (size_t)sz, fp) : 0;
+    std::fclose(fp);
+    if (n != (size_t)sz) {
+      std::free(buf);
+      return HG_ERR_IO;
+    }
+  }
+  const size_t w = merge_in_place(buf, n);
+  std::memset(buf + w, 0, 64);
+  *out = buf, *n_bps = w;
   return HG_OK;
 }
 
