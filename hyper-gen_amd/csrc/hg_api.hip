@@ -4,6 +4,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "hg_internal.h"
@@ -80,6 +83,8 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   for (auto &t : c->t_pending) (void)hipEventDestroy(t.e0), (void)hipEventDestroy(t.e1);
   for (auto e : c->t_pool) (void)hipEventDestroy(e);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  for (auto e : c->copy_events) (void)hipEventDestroy(e);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -386,25 +391,11 @@ extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const 
   return HG_OK;
 }
 
-namespace {
-// packs host sequences into one staged device buffer, 16-byte aligned starts, 64 bytes of slack
-hg_status stage_sequences(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
-                          std::vector<uint64_t> &offs, std::vector<uint64_t> &l64) {
-  offs.resize(n), l64.resize(n);
-  uint64_t total = 0;
-  for (size_t g = 0; g < n; ++g) {
-    if (lens[g] && !seqs[g]) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
-    offs[g] = total, l64[g] = lens[g];
-    total += (lens[g] + 15) & ~(uint64_t)15;
-  }
-  hg_status s = hg_ensure(c, c->w_seq, total + 64);
-  if (s != HG_OK) return s;
-  auto *d = static_cast<uint8_t *>(c->w_seq.p);
-  for (size_t g = 0; g < n; ++g)
-    if (lens[g]) HG_HIP(c, hipMemcpyAsync(d + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, c->stream));
-  return HG_OK;
-}
-}  // namespace
+// Host-fed batch.  The batch is cut into sub-batches of about HG_STAGE_BYTES; a helper thread queues their
+// uploads on the context's copy stream (one event per sub-batch) while this thread runs hash/sort/encode
+// of the sub-batches already on the device, so PCIe transfer and kernels overlap for pinned and for
+// pageable caller memory alike (a pageable hipMemcpyAsync blocks the thread that issues it).
+constexpr uint64_t HG_STAGE_BYTES = 64ull << 20;
 
 extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
                                      const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
@@ -415,16 +406,82 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
   if (n == 0) return HG_OK;
   if (!seqs || !lens || !hv_out || !norm2_out || !nhash_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   HG_HIP(c, hipSetDevice(c->device));
-  std::vector<uint64_t> offs, l64;
-  if ((s = stage_sequences(c, seqs, lens, n, offs, l64)) != HG_OK) return s;
+  // device layout: 16-byte aligned starts, 64 bytes of slack; sub-batch boundaries by bytes
+  std::vector<uint64_t> offs(n), l64(n);
+  std::vector<size_t> cut{0};
+  uint64_t total = 0, in_chunk = 0;
+  for (size_t g = 0; g < n; ++g) {
+    if (lens[g] && !seqs[g]) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
+    if (in_chunk >= HG_STAGE_BYTES) cut.push_back(g), in_chunk = 0;
+    offs[g] = total, l64[g] = lens[g];
+    const uint64_t padded = (lens[g] + 15) & ~(uint64_t)15;
+    total += padded, in_chunk += padded;
+  }
+  cut.push_back(n);
+  const size_t n_chunks = cut.size() - 1;
+  if ((s = hg_ensure(c, c->w_seq, total + 64)) != HG_OK) return s;
   const size_t hv_bytes = n * (size_t)p->hv_d * sizeof(int16_t);
   if ((s = hg_ensure(c, c->w_hv, hv_bytes + n * 8 + 64)) != HG_OK) return s;
+  auto *d_seq = static_cast<uint8_t *>(c->w_seq.p);
   auto *d_hv = static_cast<int16_t *>(c->w_hv.p);
   auto *d_n2 = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->w_hv.p) + ((hv_bytes + 15) & ~(size_t)15));
   auto *d_nh = reinterpret_cast<uint32_t *>(d_n2 + n);
-  s = hg_sketch_batch_dev(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), n, p, d_hv, d_n2, d_nh);
-  if (s != HG_OK) return s;
-  HG_HIP(c, hipMemcpyAsync(hv_out, d_hv, hv_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (!c->copy_stream) HG_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  while (c->copy_events.size() < n_chunks) {
+    hipEvent_t e;
+    HG_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->copy_events.push_back(e);
+  }
+
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t queued = 0;  // sub-batches whose uploads and event are queued
+  hipError_t copy_err = hipSuccess;
+  auto upload = [&](size_t first_chunk) {
+    hipError_t e = hipSetDevice(c->device);
+    for (size_t k = first_chunk; k < n_chunks; ++k) {
+      for (size_t g = cut[k]; g < cut[k + 1] && e == hipSuccess; ++g)
+        if (lens[g]) e = hipMemcpyAsync(d_seq + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, c->copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(c->copy_events[k], c->copy_stream);
+      std::lock_guard<std::mutex> lk(mu);
+      if (e != hipSuccess) copy_err = e;
+      queued = e == hipSuccess ? k + 1 : n_chunks;  // on error release the consumer, which then reports it
+      cv.notify_all();
+      if (e != hipSuccess) return;
+    }
+  };
+  std::thread uploader;
+  if (n_chunks > 1) uploader = std::thread(upload, (size_t)0);
+  else upload(0);
+  s = HG_OK;
+  for (size_t k = 0; k < n_chunks && s == HG_OK; ++k) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return queued > k; });
+      if (copy_err != hipSuccess) {
+        s = hg_fail(c, HG_ERR_HIP, std::string("sequence upload: ") + hipGetErrorString(copy_err));
+        break;
+      }
+    }
+    const size_t g0 = cut[k], m = cut[k + 1] - g0;
+    hipError_t e = hipStreamWaitEvent(c->stream, c->copy_events[k], 0);
+    if (e != hipSuccess) {
+      s = hg_fail(c, HG_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+      break;
+    }
+    s = hg_sketch_batch_dev(c, d_seq, offs.data() + g0, l64.data() + g0, m, p, d_hv + g0 * (size_t)p->hv_d, d_n2 + g0,
+                            d_nh + g0);
+    if (s != HG_OK) break;
+    e = hipMemcpyAsync(hv_out + g0 * (size_t)p->hv_d, d_hv + g0 * (size_t)p->hv_d, m * (size_t)p->hv_d * sizeof(int16_t),
+                       hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) s = hg_fail(c, HG_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+  }
+  if (uploader.joinable()) uploader.join();
+  (void)hipStreamSynchronize(c->copy_stream);
+  if (s != HG_OK) {
+    (void)hipStreamSynchronize(c->stream);
+    return s;
+  }
   HG_HIP(c, hipMemcpyAsync(norm2_out, d_n2, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipMemcpyAsync(nhash_out, d_nh, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));
@@ -443,11 +500,10 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   if (n_bps && !seq) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
   if (n_bps < ksize) return HG_OK;
   HG_HIP(c, hipSetDevice(c->device));
-  std::vector<uint64_t> offs, l64;
-  const uint8_t *seqs[1] = {seq};
-  size_t lens[1] = {n_bps};
-  hg_status s = stage_sequences(c, seqs, lens, 1, offs, l64);
+  const std::vector<uint64_t> offs{0}, l64{n_bps};
+  hg_status s = hg_ensure(c, c->w_seq, n_bps + 64);
   if (s != HG_OK) return s;
+  HG_HIP(c, hipMemcpyAsync(c->w_seq.p, seq, n_bps, hipMemcpyHostToDevice, c->stream));
   // capacity heuristic wants "scaled"; derive it from the threshold (threshold = MAX / scaled)
   uint64_t scaled = threshold ? UINT64_MAX / threshold : UINT64_MAX;
   if (scaled < 1) scaled = 1;

@@ -52,6 +52,9 @@ struct hg_ctx {
   uint32_t plan_max_cap = 0;
   size_t plan_items = 0;
   bool plan_valid = false;
+  // host-fed batches: uploads run on their own stream, one event per sub-batch (hg_sketch_batch)
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> copy_events;
   // pinned host scratch
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;

@@ -90,3 +90,27 @@ def test_dist_of_the_1000_sketches_properties(sketched, orc):
     est = full[0, 1:100].cpu().numpy()
     true = 100.0 * (1.0 - 0.001 * np.arange(1, 100))
     assert np.abs(est - true).max() < 1.0
+
+
+def test_host_fed_batch_in_several_uploads_equals_resident(sketched, orc):
+    """hg_sketch_batch cuts a host batch into ~64 MiB sub-batches whose uploads overlap the kernels; the
+    result must equal the device-resident run of the same genomes, for pageable and for pinned sources and
+    for ragged lengths (the last genome of a sub-batch differs from the first of the next)."""
+    ctx, seq, stride, out = sketched
+    hv, n2, nh = out[0]
+    import hypergen_amd as hg
+    p = hg.default_params()
+    pick = list(range(0, 48))  # 48 x 5 Mbp = 240 MB: four sub-batches
+    host = seq.cpu().numpy()
+    rows = [np.ascontiguousarray(host[g * stride: g * stride + L + 1]) for g in pick]
+    for label in ("pageable", "pinned"):
+        src = rows if label == "pageable" else [torch.from_numpy(r).pin_memory().numpy() for r in rows]
+        h_hv, h_n2, h_nh = ctx.sketch_batch(src, p)
+        assert np.array_equal(h_hv, hv[pick].cpu().numpy()), label
+        assert np.array_equal(h_n2, n2[pick].cpu().numpy()) and np.array_equal(h_nh, nh[pick].cpu().numpy()), label
+    # ragged: truncated copies, checked against the oracle on a sample
+    ragged = [rows[i][: 1 + (i * 977_773) % L] for i in range(len(rows))]
+    r_hv, r_n2, r_nh = ctx.sketch_batch(ragged, p)
+    for i in (0, 1, 13, 14, 15, 47):
+        w_hv, w_n2, w_nh = orc.sketch_genome(ragged[i])
+        assert r_nh[i] == w_nh and r_n2[i] == w_n2 and np.array_equal(r_hv[i], w_hv), i
