@@ -262,23 +262,28 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // LDS-DMA staging: thread t fills slots s = i*THREADS + t (i < 4) of each operand tile; slot s is
   // row s/8, LDS chunk s%8, and holds global chunk (s%8) ^ ((row>>1)&7) of that row.  The wave's 64 slots
   // of one instruction are 1 KiB contiguous in LDS, as the DMA requires.
-  const _Float16 *dA[4], *dB[4];
+  // The DMA is issued as buffer_load_dwordx4 ... lds through a per-workgroup buffer descriptor (base = the
+  // tile's first row, 32-bit per-lane offset, K offset in an SGPR).  The global_load_lds form moves the same
+  // bytes, but being FLAT-encoded it makes the compiler flush lgkmcnt to 0 at every LDS dependency while
+  // one is in flight, which serialises the fragment reads below with the MFMAs.
+  uint32_t vA[4], vB[4];  // byte offsets of this thread's four 16-byte pieces inside the A / B row block
+  __amdgpu_buffer_rsrc_t rsA, rsB;
   if (GLDS) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t sl = i * THREADS + tid, r = sl >> 3, ch = (sl & 7) ^ ((r >> 1) & 7);
-      dA[i] = g.A + (size_t)(row0 + r) * g.ldk + ch * 8;
-      dB[i] = g.B + (size_t)(col0 + r) * g.ldk + ch * 8;
+      vA[i] = vB[i] = (r * g.ldk + ch * 8) * 2;
     }
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
   }
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 #define HG_DMA(stage, k0)                                                                                   \
   {                                                                                                         \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dA[i] + (k0)), (lds_ptr_t)(wbase + i * THREADS * 8), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dB[i] + (k0)), (lds_ptr_t)(wbase + TILE_ELEMS + i * THREADS * 8), 16, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * THREADS * 8), 16, vA[i], (k0) * 2, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * THREADS * 8), 16, vB[i], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
   if (GLDS) {
@@ -306,19 +311,36 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     }
     const _Float16 *fA = sAB + cur * STAGE_ELEMS + fa_off;
     const _Float16 *fB = sAB + cur * STAGE_ELEMS + fb_off;
+    // Fragment reads run one phase ahead of the MFMAs that use them (phase = one 32-wide K slice x two
+    // 16-row A fragments = 8 MFMAs): left to itself the compiler issues each ds_read right before its
+    // first use and waits lgkmcnt(0), exposing the LDS latency once per 8 MFMAs.
+    constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
+    half8 bfr[2][4], afr[2][2];
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      half8 bf[4];
-      const int32_t ko = kk ? kk1_off : 0;
+    for (int n = 0; n < 4; ++n) bfr[0][n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LROW);
+    afr[0][0] = *reinterpret_cast<const half8 *>(fA);
+    afr[0][1] = *reinterpret_cast<const half8 *>(fA + 16 * LROW);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bf[n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LROW + ko);
+    for (int t = 0; t < PHASES; ++t) {
+      const int kk = t / MP, mp = t % MP;
+      if (t + 1 < PHASES) {
+        const int kk2 = (t + 1) / MP, mp2 = (t + 1) % MP;
+        const int32_t ko2 = kk2 ? kk1_off : 0;
+        if (mp2 == 0) {
 #pragma unroll
-      for (int m = 0; m < WTM; ++m) {
-        const half8 af = *reinterpret_cast<const half8 *>(fA + m * 16 * LROW + ko);
+          for (int n = 0; n < 4; ++n) bfr[kk2 & 1][n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LROW + ko2);
+        }
+        afr[(t + 1) & 1][0] = *reinterpret_cast<const half8 *>(fA + (2 * mp2) * 16 * LROW + ko2);
+        afr[(t + 1) & 1][1] = *reinterpret_cast<const half8 *>(fA + (2 * mp2 + 1) * 16 * LROW + ko2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[n], acc[m][n], 0, 0, 0);
-      }
+          acc[2 * mp + i][n] =
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (CHUNKED && ++in_chunk == g.chunk_steps) {  // move the exact f32 partial sums into i32
       in_chunk = 0;
