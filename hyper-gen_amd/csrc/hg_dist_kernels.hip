@@ -154,9 +154,18 @@ struct GemmArgs {
   uint32_t hit_cap;
   float ani_th;
   float j_lo;  // conservative Jaccard bound: dot < j_lo * den  =>  ANI < ani_th for sure
+  float pre_c, pre_b;  // phase-0 form of the same bound: dot < pre_c * (nr + nq) + pre_b  =>  rejected
   int symmetric;
   uint32_t tiles_m, tiles_n;  // tile grid
+#ifdef HG_DIST_EXPERIMENT
+  uint32_t exp;  // timing experiments (results are wrong): 1 no in-loop DMA, 2 no reads/MFMA, 4 no epilogue
+#endif
 };
+#ifdef HG_DIST_EXPERIMENT
+#define HG_EXP(bit) (g.exp & (bit))
+#else
+#define HG_EXP(bit) false
+#endif
 
 // FULL: every ANI is evaluated and stored (parity / small problems).  Otherwise only pairs that can
 // reach ani_th are evaluated: one multiply-compare rejects the rest (ANI is monotone in the Jaccard
@@ -253,11 +262,16 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     *reinterpret_cast<uint4 *>(lB + 3 * SROWS * LROW) = rb3;                            \
   }
 
-  // Software pipeline with ONE barrier per K-step:
-  //   top of step k : registers hold tile k+1 (requested during step k-1) -> store into stage (k+1)&1,
-  //                   immediately re-issue the loads for tile k+2 (a whole step of latency cover),
-  //                   then 32 MFMAs on stage k&1, then the barrier that publishes stage (k+1)&1 and
-  //                   retires the reads of stage k&1.
+  // Software pipeline with ONE barrier per K-step.  A step is PHASES phases of 8 MFMAs; the fragments of
+  // phase t+1 are read from LDS while phase t multiplies.  The barrier sits BEFORE the last phase of a
+  // step, not after it: at that point every fragment of the current stage is already in registers, so
+  // once all waves have arrived (and, DMA variant, the next tile has landed: vmcnt(0)) the stage can be
+  // refilled and the first fragments of the next stage can be read -- both under the cover of the 8 MFMAs
+  // still to issue, instead of an idle matrix pipe right after every barrier.
+  //   register-staged: top of step k stores tile k+1 (requested during step k-1) into stage (k+1)&1 and
+  //                    requests tile k+2; the barrier in the last phase publishes it.
+  //   DMA            : right after the barrier of step k the DMA of tile k+2 starts into stage k&1 (a whole
+  //                    step of latency cover).
   const uint32_t nsteps = g.Kp / BK;
   // LDS-DMA staging: thread t fills slots s = i*THREADS + t (i < 4) of each operand tile; slot s is
   // row s/8, LDS chunk s%8, and holds global chunk (s%8) ^ ((row>>1)&7) of that row.  The wave's 64 slots
@@ -286,6 +300,19 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * THREADS * 8), 16, vB[i], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
+  constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
+  half8 bfr[2][4], afr[2][2];
+  // fragments of phase (kk, mp) of the stage whose fragment bases are pa / pb, into buffer set `buf`
+#define HG_FRAGS(buf, pa, pb, kk, mp)                                                                       \
+  {                                                                                                         \
+    const int32_t ko_ = (kk) ? kk1_off : 0;                                                                 \
+    if ((mp) == 0) {                                                                                        \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                         \
+          bfr[(kk) & 1][n] = *reinterpret_cast<const half8 *>((pb) + n * 16 * LROW + ko_);                  \
+    }                                                                                                       \
+    afr[buf][0] = *reinterpret_cast<const half8 *>((pa) + (2 * (mp)) * 16 * LROW + ko_);                    \
+    afr[buf][1] = *reinterpret_cast<const half8 *>((pa) + (2 * (mp) + 1) * 16 * LROW + ko_);                \
+  }
   if (GLDS) {
     HG_DMA(0, 0)
   } else {
@@ -296,50 +323,41 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     }
   }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
+  if (GLDS && nsteps > 1) HG_DMA(1, BK)
+  if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
     const uint32_t cur = ks & 1;
-    if (GLDS) {
-      // stage cur^1 was last read during step ks-1, retired by that step's closing barrier
-      if (ks + 1 < nsteps) HG_DMA(cur ^ 1, (ks + 1) * BK)
-    } else if (ks + 1 < nsteps) {
+    if (!GLDS && ks + 1 < nsteps) {
       HG_LSTORE(cur ^ 1)
       if (ks + 2 < nsteps) {
         const uint32_t k2 = (ks + 2) * BK;
         HG_GLOAD(k2)
       }
     }
-    const _Float16 *fA = sAB + cur * STAGE_ELEMS + fa_off;
-    const _Float16 *fB = sAB + cur * STAGE_ELEMS + fb_off;
-    // Fragment reads run one phase ahead of the MFMAs that use them (phase = one 32-wide K slice x two
-    // 16-row A fragments = 8 MFMAs): left to itself the compiler issues each ds_read right before its
-    // first use and waits lgkmcnt(0), exposing the LDS latency once per 8 MFMAs.
-    constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
-    half8 bfr[2][4], afr[2][2];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) bfr[0][n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LROW);
-    afr[0][0] = *reinterpret_cast<const half8 *>(fA);
-    afr[0][1] = *reinterpret_cast<const half8 *>(fA + 16 * LROW);
+    const _Float16 *fA = sAB + cur * STAGE_ELEMS + fa_off, *fB = sAB + cur * STAGE_ELEMS + fb_off;
+    const _Float16 *nA = sAB + (cur ^ 1) * STAGE_ELEMS + fa_off, *nB = sAB + (cur ^ 1) * STAGE_ELEMS + fb_off;
 #pragma unroll
     for (int t = 0; t < PHASES; ++t) {
       const int kk = t / MP, mp = t % MP;
       if (t + 1 < PHASES) {
-        const int kk2 = (t + 1) / MP, mp2 = (t + 1) % MP;
-        const int32_t ko2 = kk2 ? kk1_off : 0;
-        if (mp2 == 0) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) bfr[kk2 & 1][n] = *reinterpret_cast<const half8 *>(fB + n * 16 * LROW + ko2);
-        }
-        afr[(t + 1) & 1][0] = *reinterpret_cast<const half8 *>(fA + (2 * mp2) * 16 * LROW + ko2);
-        afr[(t + 1) & 1][1] = *reinterpret_cast<const half8 *>(fA + (2 * mp2 + 1) * 16 * LROW + ko2);
+        if (!HG_EXP(2)) HG_FRAGS((t + 1) & 1, fA, fB, (t + 1) / MP, (t + 1) % MP)
+      } else {
+        // every fragment read of this stage must have returned before another wave may refill it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (GLDS && ks + 2 < nsteps && !HG_EXP(1)) HG_DMA(cur, (ks + 2) * BK)
+        if (ks + 1 < nsteps && !HG_EXP(2)) HG_FRAGS(0, nA, nB, 0, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (!HG_EXP(2)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-          acc[2 * mp + i][n] =
-              __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n)
+            acc[2 * mp + i][n] =
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (CHUNKED && ++in_chunk == g.chunk_steps) {  // move the exact f32 partial sums into i32
@@ -353,11 +371,23 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
           acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
         }
     }
-    __syncthreads();
   }
+  // The epilogue reuses the operand stages (every fragment read was retired by the last in-loop barrier):
+  // per-wave candidate lists, then the tile's BM + BN norms -- phase 2 gathers them by candidate, and from
+  // global memory each 64-candidate batch paid a full dependent-load latency (0.12 ms per launch at 1.3 M hits).
+  constexpr uint32_t CAND_CAP = 2048;  // 16 KiB per wave
+  int32_t *s_nr = reinterpret_cast<int32_t *>(reinterpret_cast<uint2 *>(sAB) + (THREADS / 64) * CAND_CAP), *s_nq = s_nr + BM;
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_nq + BN);  // per-wave hit counts + the workgroup's base
+  for (uint32_t t = tid; t < (uint32_t)(BM + BN); t += THREADS) {
+    const bool is_r = t < (uint32_t)BM;
+    const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
+    s_nr[t] = idx < (is_r ? g.R : g.Q) ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
+  }
+  __syncthreads();
 #undef HG_GLOAD
 #undef HG_LSTORE
 #undef HG_DMA
+#undef HG_FRAGS
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
   // Phase 1 (unrolled over the accumulator registers, a handful of instructions per element): one
@@ -367,12 +397,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // Phase 2 (dense: one candidate per lane): exact reference arithmetic, threshold, hits compacted in
   // place, then ONE global atomic per flush.  (A per-hit atomic on the single global counter serialised
   // at ~12 ns and cost more than the GEMM: 2.30 ms vs 1.10 ms at 1.3 M hits.)
-  constexpr uint32_t CAND_CAP = 2048;  // 16 KiB per wave
+  if (HG_EXP(4)) return;
   uint2 *cand = reinterpret_cast<uint2 *>(sAB) + wave * CAND_CAP;
   uint32_t staged = 0;  // wave-uniform
-#define HG_PROCESS()                                                                                   \
+  // phase 2 on cand[0 .. staged): exact ANI, hits compacted to cand[0 .. nh)
+#define HG_PHASE2(nh)                                                                                  \
   {                                                                                                    \
-    uint32_t nh = 0;                                                                                   \
     for (uint32_t b = 0; b < staged; b += 64) {                                                        \
       const uint32_t e = b + lane;                                                                     \
       bool hit = false;                                                                                \
@@ -381,7 +411,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       if (e < staged) {                                                                                \
         c2 = cand[e];                                                                                  \
         const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);                         \
-        ani = ani_from_dot((int32_t)c2.y, g.nr[gi], g.nq[gj], g.kf);                                   \
+        ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);               \
         if (FULL && g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;                                 \
         hit = g.hit_count && ani >= g.ani_th;                                                          \
       }                                                                                                \
@@ -393,23 +423,39 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       }                                                                                                \
       nh += (uint32_t)__popcll(bal);                                                                   \
     }                                                                                                  \
+    staged = 0;                                                                                        \
+  }
+#define HG_WRITE_HITS(base, nh)                                                                        \
+  for (uint32_t e = lane; e < (nh); e += 64)                                                           \
+    if ((base) + e < g.hit_cap) {                                                                      \
+      const uint2 h2 = cand[e];                                                                        \
+      g.hits[(base) + e] = hg_ani_hit{row0 + (h2.x >> 16), col0 + (h2.x & 0xffffu), __uint_as_float(h2.y)}; \
+    }
+  // list nearly full in the middle of the tile (dense tiles only): this wave reserves its own range
+#define HG_PROCESS()                                                                                   \
+  {                                                                                                    \
+    uint32_t nh = 0;                                                                                   \
+    HG_PHASE2(nh)                                                                                      \
     if (nh) {                                                                                          \
       uint32_t base = 0;                                                                               \
       if (lane == 0) base = atomicAdd(g.hit_count, nh);                                                \
       base = __builtin_amdgcn_readfirstlane(base);                                                     \
-      for (uint32_t e = lane; e < nh; e += 64)                                                         \
-        if (base + e < g.hit_cap) {                                                                    \
-          const uint2 h2 = cand[e];                                                                    \
-          g.hits[base + e] = hg_ani_hit{row0 + (h2.x >> 16), col0 + (h2.x & 0xffffu), __uint_as_float(h2.y)}; \
-        }                                                                                              \
+      HG_WRITE_HITS(base, nh)                                                                          \
     }                                                                                                  \
-    staged = 0;                                                                                        \
   }
+  // Phase 0 (thresholded mode): dot >= j_lo * (nr + nq - dot) rewritten as dot >= c * (nr + nq) with
+  // c = j_lo / (1 + j_lo) shaved by 1e-5, evaluated in f32 straight from the accumulator: one add, one
+  // compare and one wave-uniform branch per element slot.  Only slots where some lane passes (a superset
+  // of what phase 1 keeps: invalid rows/columns carry +inf, norms outside [0, 2^29] -- where the i32
+  // denominator could wrap -- carry -inf) run phase 1.
+  constexpr int32_t NORM_SAFE = 1 << 29;
   int32_t nqv[4];
+  float tq[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     const uint32_t j = col0 + wn * 64 + n * 16 + fr;
-    nqv[n] = j < g.Q ? g.nq[j] : 0;
+    nqv[n] = s_nq[wn * 64 + n * 16 + fr];
+    tq[n] = j >= g.Q ? INFINITY : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY : g.pre_c * (float)nqv[n] + g.pre_b);
   }
 #pragma unroll
   for (int m = 0; m < WTM; ++m) {
@@ -417,13 +463,18 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     for (int r = 0; r < 4; ++r) {
       const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
       const bool iok = i < g.R;
-      const int32_t nri = iok ? g.nr[i] : 0;
+      const int32_t nri = s_nr[li];
+      const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : g.pre_c * (float)nri);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
+        float d = acc[m][n][r];
+        if (CHUNKED) d += (float)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
+        const bool pass = FULL || d >= ur + tq[n];
+        if (__ballot(pass) == 0) continue;  // wave-uniform: typically > 80 % of the element slots
         const uint32_t lj = wn * 64 + n * 16 + fr, j = col0 + lj;
         int32_t dot = (int32_t)acc[m][n][r];
         if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
-        bool live = iok && j < g.Q && !(g.symmetric && i >= j);
+        bool live = pass && iok && j < g.Q && !(g.symmetric && i >= j);
         if (!FULL) {
           const int32_t den = (int32_t)((uint32_t)nri + (uint32_t)nqv[n] - (uint32_t)dot);
           live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
@@ -440,8 +491,28 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     // at most 16 x 64 = 1024 candidates per m: one overflow check per m is enough
     if (staged > CAND_CAP - 1024) HG_PROCESS()
   }
-  if (staged) HG_PROCESS()
+  // end of the tile: ONE reservation per workgroup.  Same-address returning atomics serialise at ~12 ns;
+  // with noise hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round,
+  // and one atomic per wave kept every CU waiting ~25 us per round (0.09 ms of a 0.74 ms launch).
+  {
+    uint32_t nh = 0;
+    HG_PHASE2(nh)
+    if (lane == 0) s_cnt[wave] = nh;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t total = 0;
+#pragma unroll
+      for (int w = 0; w < THREADS / 64; ++w) total += s_cnt[w];
+      s_cnt[THREADS / 64] = total ? atomicAdd(g.hit_count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_cnt[THREADS / 64];
+    for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
+    HG_WRITE_HITS(base, nh)
+  }
 #undef HG_PROCESS
+#undef HG_PHASE2
+#undef HG_WRITE_HITS
 }
 
 // ---- always-exact integer fallback -------------------------------------------------------------------
@@ -553,6 +624,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
   g.ani_th = a.ani_th, g.symmetric = a.symmetric;
   g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
+  if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;       // everything goes on to phase 1
+  else if (g.j_lo == INFINITY) g.pre_c = 0.f, g.pre_b = INFINITY;    // ANI <= 100 < ani_th: nothing does
+  else g.pre_c = (float)((double)g.j_lo / (1.0 + (double)g.j_lo) * (1.0 - 1e-5)), g.pre_b = 0.f;
   const bool whole_k = (64u << best_c) >= Kp;  // one window covers K: no i32 side accumulators
   const bool full = a.ani_out != nullptr;
   // big tiles when the problem fills the chip with them (Rp, Qp are multiples of 128: the last big
@@ -565,6 +639,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
     else if (!std::strcmp(e, "small")) big = false;
   }
   const uint32_t bm = big ? 256 : 128, bn = big ? 256 : 128;
+#ifdef HG_DIST_EXPERIMENT
+  g.exp = std::getenv("HG_DIST_EXP") ? (uint32_t)std::atoi(std::getenv("HG_DIST_EXP")) : 0u;
+#endif
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   auto launch = [&](auto kern, int threads, size_t lds) -> hipError_t {
@@ -575,7 +652,8 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   };
   const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16), lds_big = 2 * (256 + 256) * LDS_ROW * sizeof(_Float16);
   hipError_t le;
-  const size_t lds_dma = 2 * (256 + 256) * BK * sizeof(_Float16);
+  // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
+  const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 4 + 64);
   if (big && dma) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
   else if (big) le = launch(&dist_mfma_kernel<false, false, true, false>, TileCfg<true>::THREADS, lds_big);
   else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);

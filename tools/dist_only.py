@@ -23,13 +23,22 @@ n2 = (hv.int() ** 2).sum(1).int()
 cap = max(1 << 20, a.n * a.n // 20)
 hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
 ctx.enable_timing(True)
+variants = [v for v in os.environ.get("HG_DIST_VARIANTS", "").split(",") if v] or [os.environ.get("HG_DIST_TILE", "")]
+res = {v: [] for v in variants}
 for r in range(a.reps + 1):
-    ctx.timings()
-    found, _ = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False,
-                            a.th, hits.data_ptr(), cap)
-    torch.cuda.synchronize()
-    t = ctx.timings()
-    if r:
-        ms = t["dist"][0]
-        print("dist %dx%d: gemm %.3f ms = %.1f TFLOP/s, prep %.3f ms, hits %d" % (
-            a.n, a.n, ms, a.n * a.n * 8192 / ms / 1e9, t["dist_prep"][0], found))
+    for v in variants:  # interleaved so that clock / thermal drift hits every variant alike
+        if v:
+            os.environ["HG_DIST_TILE"] = v
+        ctx.timings()
+        found, _ = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False,
+                                a.th, hits.data_ptr(), cap)
+        torch.cuda.synchronize()
+        t = ctx.timings()
+        if r:
+            res[v].append((t["dist"][0], t["dist_prep"][0], found))
+for v in variants:
+    ms = sorted(x[0] for x in res[v])
+    med, best = ms[len(ms) // 2], ms[0]
+    print("dist %dx%d [%s]: gemm median %.3f ms = %.1f TFLOP/s (best %.3f ms = %.1f), prep %.3f ms, hits %d" % (
+        a.n, a.n, v or "default", med, a.n * a.n * 8192 / med / 1e9, best, a.n * a.n * 8192 / best / 1e9,
+        sorted(x[1] for x in res[v])[len(ms) // 2], res[v][0][2]))
