@@ -13,6 +13,7 @@
 // size is safe (or |x| > 2048) the always-exact integer VALU kernel is used instead.  Either
 // way the dot product equals the reference's i32 value bit for bit; only logf differs from
 // glibc by <= 1 ulp.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -42,62 +43,80 @@ __device__ __forceinline__ float ani_from_dot(int32_t dot, int32_t nr, int32_t n
 // stats[0]            = max |x|
 // stats[1 + c]        = max over rows and aligned chunks of 64<<c dims of sum x^2   (c = 0..7)
 constexpr int N_CHUNK_CAND = 8;  // 64 .. 8192
-// One workgroup per row; each lane converts 8 consecutive values per trip (16-byte loads and
-// stores), so a 64-dim block is 8 adjacent lanes and its sum of squares is 3 xor-shuffles.
+// One workgroup per row; each lane converts 8 consecutive values per trip (16-byte loads and stores), so
+// a 64-dim block is 8 adjacent lanes.  Everything per element is packed 16-bit or dot2 work straight on
+// the loaded words: |x| by v_pk_sub/v_pk_max, sum x^2 by v_dot2_i32_i16, the 8-lane block sum by three
+// DPP adds.  Block sums are 32-bit: exact whenever |x| <= 2048 (64 * 2^22 = 2^28), and when some |x| is
+// larger the f16 path is abandoned anyway (stats[0] decides first).  The chunk maxima for all candidate
+// window sizes come from a pairwise-sum tree over the block sums in LDS with one LDS atomic max per
+// level -- no cross-lane shuffles (the first version spent most of its time in ~100 dependent
+// ds_bpermute reductions per row: 0.115 ms for 10 000 rows against 0.04 ms of memory time).
+typedef short short2v __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ int dpp_add(int v) {  // v + v[lane permuted by CTRL]
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
 __global__ __launch_bounds__(256) void prep_kernel(const int16_t *__restrict__ hv, uint32_t rows,
                                                    uint32_t hv_d, uint32_t kp, uint32_t ldk,
                                                    _Float16 *__restrict__ out,
                                                    unsigned long long *__restrict__ stats) {
-  extern __shared__ unsigned long long s_blk[];  // kp/64 block sums
+  extern __shared__ unsigned long long s_lv[];  // tree levels: nblk, ceil(nblk/2), ... 1 values, then N_CHUNK_CAND maxima
   __shared__ uint32_t s_max;
   const uint32_t row = blockIdx.x;
   const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
   _Float16 *__restrict__ dst = out + (size_t)row * ldk;
   const uint32_t nblk = kp / 64;
+  uint32_t tree = 0;  // total tree size
+  for (uint32_t n = nblk;; n = (n + 1) / 2) {
+    tree += n;
+    if (n == 1) break;
+  }
+  unsigned long long *s_lvmax = s_lv + tree;
   if (threadIdx.x == 0) s_max = 0;
+  if (threadIdx.x < N_CHUNK_CAND) s_lvmax[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t mx = 0;
+  uint32_t mxpk = 0;  // packed running max of |x| (two u16 lanes)
   const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
   for (uint32_t d0 = threadIdx.x * 8; d0 < kp; d0 += blockDim.x * 8) {
-    int32_t v[8];
+    uint32_t w[4];
     if (vec_ok && d0 + 8 <= hv_d) {
       const uint4 raw = *reinterpret_cast<const uint4 *>(src + d0);
-      const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[2 * i] = (int32_t)(int16_t)(w[i] & 0xffff);
-        v[2 * i + 1] = (int32_t)(int16_t)(w[i] >> 16);
-      }
+      w[0] = raw.x, w[1] = raw.y, w[2] = raw.z, w[3] = raw.w;
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (d0 + i < hv_d) ? (int32_t)src[d0 + i] : 0;
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = (d0 + 2 * i < hv_d) ? (uint16_t)src[d0 + 2 * i] : 0u;
+        const uint32_t hi = (d0 + 2 * i + 1 < hv_d) ? (uint16_t)src[d0 + 2 * i + 1] : 0u;
+        w[i] = lo | (hi << 16);
+      }
     }
     half8 h;
-    uint32_t sq = 0;
+    int sq = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      h[i] = (_Float16)v[i];
-      const uint32_t a = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
-      mx = a > mx ? a : mx;
-      sq += a * a;  // 8 * 32768^2 < 2^33: keep 64-bit below
+    for (int i = 0; i < 4; ++i) {
+      short2v x2;
+      __builtin_memcpy(&x2, &w[i], 4);
+      sq = __builtin_amdgcn_sdot2(x2, x2, sq, false);
+      const short2v ab = __builtin_elementwise_max(x2, (short2v)(-x2));  // |x| (-32768 stays 0x8000: larger than any u16 <= 2048)
+      uint32_t abw;
+      __builtin_memcpy(&abw, &ab, 4);
+      typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+      ushort2v m0, m1;
+      __builtin_memcpy(&m0, &mxpk, 4);
+      __builtin_memcpy(&m1, &abw, 4);
+      m0 = __builtin_elementwise_max(m0, m1);
+      __builtin_memcpy(&mxpk, &m0, 4);
+      h[2 * i] = (_Float16)x2.x;
+      h[2 * i + 1] = (_Float16)x2.y;
     }
     *reinterpret_cast<half8 *>(dst + d0) = h;
-    unsigned long long s64 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s64 += (unsigned long long)((int64_t)v[i] * v[i]);
-    (void)sq;
-    s64 += __shfl_xor(s64, 1);
-    s64 += __shfl_xor(s64, 2);
-    s64 += __shfl_xor(s64, 4);
-    if ((threadIdx.x & 7) == 0) s_blk[d0 / 64] = s64;
+    sq = dpp_add<0xB1>(sq);   // quad_perm [1,0,3,2]
+    sq = dpp_add<0x4E>(sq);   // quad_perm [2,3,0,1]
+    sq = dpp_add<0x141>(sq);  // row_half_mirror: the other quad of the 8-lane group
+    if ((threadIdx.x & 7) == 0) s_lv[d0 / 64] = (unsigned long long)(uint32_t)sq;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = __shfl_down(mx, o);
-    mx = t > mx ? t : mx;
-  }
-  const uint32_t lane = threadIdx.x & 63;
-  if (lane == 0) atomicMax(&s_max, mx);
+  const uint32_t mx = (mxpk & 0xffffu) > (mxpk >> 16) ? (mxpk & 0xffffu) : (mxpk >> 16);
+  if (mx) atomicMax(&s_max, mx);
   __syncthreads();
   // same-address device atomics serialise at ~12 ns each: only the few rows that raise a maximum
   // issue one (a relaxed agent-scope load may be stale, which at worst costs a redundant atomic)
@@ -105,22 +124,128 @@ __global__ __launch_bounds__(256) void prep_kernel(const int16_t *__restrict__ h
     if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
   };
   if (threadIdx.x == 0) raise(&stats[0], (unsigned long long)s_max);
-  // chunk maxima for every candidate size (kp/64 <= 1024 block sums: a few trips per thread)
+  // level c holds the sums of aligned chunks of 2^c blocks (the last one may be partial)
+  unsigned long long *lv = s_lv;
+  uint32_t n = nblk;
   for (int c = 0; c < N_CHUNK_CAND; ++c) {
-    const uint32_t per = 1u << c;  // 64-blocks per chunk
     unsigned long long best = 0;
-    for (uint32_t ch = threadIdx.x; ch * per < nblk; ch += blockDim.x) {
-      unsigned long long sum = 0;
-      for (uint32_t b = ch * per; b < (ch + 1) * per && b < nblk; ++b) sum += s_blk[b];
-      best = sum > best ? sum : best;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) best = lv[i] > best ? lv[i] : best;
+    if (best) atomicMax(&s_lvmax[c], best);
+    if (n > 1) {  // build the next level
+      unsigned long long *nx = lv + n;
+      const uint32_t n2 = (n + 1) / 2;
+      for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) nx[i] = lv[2 * i] + (2 * i + 1 < n ? lv[2 * i + 1] : 0ull);
+      lv = nx, n = n2;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < N_CHUNK_CAND && s_lvmax[threadIdx.x]) raise(&stats[1 + threadIdx.x], s_lvmax[threadIdx.x]);
+}
+
+// Fast prepass for the common case: conversion plus only max |x| and the maximum whole-row sum of squares
+// (the statistic that decides whether ONE f32 accumulation window covers K).  One wave per row, four rows
+// per workgroup, no LDS and no barrier: all of a row's 16-byte loads are in flight together, the two row
+// statistics are reduced with DPP.  If the whole-row bound turns out unsafe, hg_run_dist runs prep_kernel
+// (all candidate windows) as a second pass.
+constexpr uint32_t PREP_SLOTS = 1024;
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_get(uint32_t v) {  // v[lane permuted by CTRL], 0 where nothing arrives
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned long long dpp_get64(unsigned long long v) {
+  return (unsigned long long)dpp_get<CTRL, ROW_MASK>((uint32_t)v) |
+         ((unsigned long long)dpp_get<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32);
+}
+__global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restrict__ hv, uint32_t rows,
+                                                        uint32_t hv_d, uint32_t kp, uint32_t ldk,
+                                                        _Float16 *__restrict__ out,
+                                                        unsigned long long *__restrict__ slots) {
+  const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // whole wave
+  const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
+  _Float16 *__restrict__ dst = out + (size_t)row * ldk;
+  const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  uint32_t mxpk = 0, sq = 0;  // per lane <= 512 squares <= 2^22 each when |x| <= 2048
+  auto fetch = [&](uint32_t d0, uint32_t w[4]) {
+    if (d0 >= kp) {
+      w[0] = w[1] = w[2] = w[3] = 0u;
+    } else if (vec_ok && d0 + 8 <= hv_d) {
+      const uint4 raw = *reinterpret_cast<const uint4 *>(src + d0);
+      w[0] = raw.x, w[1] = raw.y, w[2] = raw.z, w[3] = raw.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = (d0 + 2 * i < hv_d) ? (uint16_t)src[d0 + 2 * i] : 0u;
+        const uint32_t hi = (d0 + 2 * i + 1 < hv_d) ? (uint16_t)src[d0 + 2 * i + 1] : 0u;
+        w[i] = lo | (hi << 16);
+      }
+    }
+  };
+  // Four 16-byte loads in flight per lane.  The 512-dim chunks of a row are visited in an order rotated by
+  // the row index: with the natural order every resident wave would be at the same column offset of its
+  // row at the same time, and with a power-of-two row pitch (8 KiB at D = 4096) those addresses all fall
+  // on the same few memory channels (measured: 94 us instead of 30 us for 10 000 rows).
+  const uint32_t nchunks = (kp + 511) / 512;
+  for (uint32_t q = 0; q < nchunks; q += 4) {
+    uint32_t w[4][4], d0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d0[t] = q + t < nchunks ? ((q + t + row) % nchunks) * 512 + lane * 8 : kp;
+      fetch(d0[t], w[t]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long t = __shfl_down(best, o);
-      best = t > best ? t : best;
+    for (int t = 0; t < 4; ++t) {
+      half8 h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        short2v x2;
+        __builtin_memcpy(&x2, &w[t][i], 4);
+        sq = (uint32_t)__builtin_amdgcn_sdot2(x2, x2, (int)sq, false);
+        const short2v ab = __builtin_elementwise_max(x2, (short2v)(-x2));
+        typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+        ushort2v m0, m1;
+        __builtin_memcpy(&m0, &mxpk, 4);
+        __builtin_memcpy(&m1, &ab, 4);
+        m0 = __builtin_elementwise_max(m0, m1);
+        __builtin_memcpy(&mxpk, &m0, 4);
+        h[2 * i] = (_Float16)x2.x;
+        h[2 * i + 1] = (_Float16)x2.y;
+      }
+      if (d0[t] < kp) *reinterpret_cast<half8 *>(dst + d0[t]) = h;
     }
-    // only wave 0 can hold the block-wide maximum when nblk/per <= 64 chunks; otherwise every wave reports
-    if (lane == 0 && best) raise(&stats[1 + c], best);
+  }
+  uint32_t mx = (mxpk & 0xffffu) > (mxpk >> 16) ? (mxpk & 0xffffu) : (mxpk >> 16);
+  unsigned long long sum = sq;
+  // butterfly inside each row of 16 lanes, then row 0 -> 1, 2 -> 3 (row_bcast15), rows 0..1 -> 2..3 (row_bcast31)
+#define HG_STEP(CTRL)                                  \
+  {                                                    \
+    const uint32_t om = dpp_get<CTRL>(mx);             \
+    mx = om > mx ? om : mx;                            \
+    sum += dpp_get64<CTRL>(sum);                       \
+  }
+  HG_STEP(0xB1) HG_STEP(0x4E) HG_STEP(0x141) HG_STEP(0x140)
+#undef HG_STEP
+  {
+    const uint32_t om = dpp_get<0x142, 0xa>(mx);
+    mx = om > mx ? om : mx;
+    sum += dpp_get64<0x142, 0xa>(sum);
+  }
+  {
+    const uint32_t om = dpp_get<0x143, 0xc>(mx);
+    mx = om > mx ? om : mx;
+    sum += dpp_get64<0x143, 0xc>(sum);
+  }
+  if (lane == 63) {
+    auto raise = [](unsigned long long *p, unsigned long long v) {
+      if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+    };
+    // {max |x|, max row sum} per slot; the host takes the maximum over the slots.  (One shared pair of
+    // counters cost ~55 us per launch: the ~8 000 waves resident at the start all see the initial zero and
+    // all issue their atomics to the same address, ~12 ns each.)
+    unsigned long long *sl = slots + 2 * (blockIdx.x % PREP_SLOTS);
+    raise(&sl[0], (unsigned long long)mx);
+    raise(&sl[1], sum);
   }
 }
 
@@ -157,12 +282,11 @@ struct GemmArgs {
   float pre_c, pre_b;  // phase-0 form of the same bound: dot < pre_c * (nr + nq) + pre_b  =>  rejected
   int symmetric;
   uint32_t tiles_m, tiles_n;  // tile grid
-#ifdef HG_DIST_EXPERIMENT
-  uint32_t exp;  // timing experiments (results are wrong): 1 no in-loop DMA, 2 no reads/MFMA, 4 no epilogue
-#endif
 };
+// development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
+// compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs
 #ifdef HG_DIST_EXPERIMENT
-#define HG_EXP(bit) (g.exp & (bit))
+#define HG_EXP(bit) ((HG_DIST_EXPERIMENT & (bit)) != 0)
 #else
 #define HG_EXP(bit) false
 #endif
@@ -350,7 +474,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         if (ks + 1 < nsteps && !HG_EXP(2)) HG_FRAGS(0, nA, nB, 0, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!HG_EXP(2)) {
+      if (HG_EXP(8)) {  // fragment reads without the MFMAs
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(afr[t & 1][i]));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(bfr[kk & 1][n]));
+      } else if (!HG_EXP(2)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -397,7 +526,17 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // Phase 2 (dense: one candidate per lane): exact reference arithmetic, threshold, hits compacted in
   // place, then ONE global atomic per flush.  (A per-hit atomic on the single global counter serialised
   // at ~12 ns and cost more than the GEMM: 2.30 ms vs 1.10 ms at 1.3 M hits.)
-  if (HG_EXP(4)) return;
+  if (HG_EXP(4)) {  // keep the accumulators alive without running the epilogue
+    if (g.hit_cap == 0xFFFFFFFFu) {
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < WTM; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sum += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+      reinterpret_cast<float *>(g.hits)[tid] = sum;
+    }
+    return;
+  }
   uint2 *cand = reinterpret_cast<uint2 *>(sAB) + wave * CAND_CAP;
   uint32_t staged = 0;  // wave-uniform
   // phase 2 on cand[0 .. staged): exact ANI, hits compacted to cand[0 .. nh)
@@ -574,37 +713,80 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   hg_status s;
   if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
   if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * ldk * 2)) != HG_OK) return s;
-  if ((s = hg_ensure(c, c->w_stats, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long))) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_stats, 256 + 4 * PREP_SLOTS * sizeof(unsigned long long))) != HG_OK) return s;
   auto *fa = static_cast<_Float16 *>(c->w_f16a.p);
   auto *fb = same ? fa : static_cast<_Float16 *>(c->w_f16b.p);
   auto *st = static_cast<unsigned long long *>(c->w_stats.p);
   HG_HIP(c, hipMemsetAsync(st, 0, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long), c->stream));
   if (Rp > a.R) HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * ldk, 0, (size_t)(Rp - a.R) * ldk * 2, c->stream));
   if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * ldk, 0, (size_t)(Qp - a.Q) * ldk * 2, c->stream));
-  const size_t plds = (size_t)(Kp / 64) * sizeof(unsigned long long);
-  {
-  hg_timed tm(c, HG_T_DIST_PREP);
-  hipLaunchKernelGGL(prep_kernel, dim3(a.R), dim3(256), plds, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, st);
-  HG_HIP(c, hipGetLastError());
-  if (!same) {
-    hipLaunchKernelGGL(prep_kernel, dim3(a.Q), dim3(256), plds, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, ldk, fb,
-                       st + 1 + N_CHUNK_CAND);
-    HG_HIP(c, hipGetLastError());
-  }
-  }
+  const size_t plds = (size_t)(2 * (Kp / 64) + 16 + N_CHUNK_CAND) * sizeof(unsigned long long);  // tree + maxima
+  // first candidate window that covers all of K (windows are 64 << c dims; beyond the table: none does)
+  int c_whole = -1;
+  for (int cnd = 0; cnd < N_CHUNK_CAND; ++cnd)
+    if ((64u << cnd) >= Kp) {
+      c_whole = cnd;
+      break;
+    }
   unsigned long long h[2 * (1 + N_CHUNK_CAND)];
-  HG_HIP(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
-  HG_HIP(c, hipStreamSynchronize(c->stream));
   const unsigned long long *hr = h, *hq = same ? h : h + 1 + N_CHUNK_CAND;
-
-  // largest accumulation window whose guaranteed bound sum|r||q| <= sqrt(SR*SQ) stays <= 2^24
   int best_c = -1;
-  if (hr[0] <= 2048 && hq[0] <= 2048) {
-    for (int cnd = N_CHUNK_CAND - 1; cnd >= 0; --cnd) {
-      const unsigned __int128 prod = (unsigned __int128)hr[1 + cnd] * hq[1 + cnd];
-      if (prod <= ((unsigned __int128)1 << 48)) {
-        best_c = cnd;
-        break;
+  bool fast_done = false;
+  if (c_whole >= 0) {  // fast prepass: max |x| and the whole-row bound only
+    const size_t slot_bytes = 2 * PREP_SLOTS * sizeof(unsigned long long);
+    auto *sl = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(st) + 256);
+    HG_HIP(c, hipMemsetAsync(sl, 0, 2 * slot_bytes, c->stream));
+    {
+      hg_timed tm(c, HG_T_DIST_PREP);
+      hipLaunchKernelGGL(prep_fast_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, sl);
+      HG_HIP(c, hipGetLastError());
+      if (!same) {
+        hipLaunchKernelGGL(prep_fast_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, ldk,
+                           fb, sl + 2 * PREP_SLOTS);
+        HG_HIP(c, hipGetLastError());
+      }
+    }
+    hg_status ps = hg_ensure_pinned(c, 2 * slot_bytes);
+    if (ps != HG_OK) return ps;
+    auto *hs = static_cast<unsigned long long *>(c->h_pin);
+    HG_HIP(c, hipMemcpyAsync(hs, sl, (same ? 1 : 2) * slot_bytes, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+    std::memset(h, 0, sizeof h);
+    for (int m = 0; m < (same ? 1 : 2); ++m) {
+      unsigned long long *dstp = h + m * (1 + N_CHUNK_CAND);
+      for (uint32_t i = 0; i < PREP_SLOTS; ++i) {
+        dstp[0] = std::max(dstp[0], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i]);
+        dstp[1 + c_whole] = std::max(dstp[1 + c_whole], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i + 1]);
+      }
+    }
+    if (hr[0] <= 2048 && hq[0] <= 2048 &&
+        (unsigned __int128)hr[1 + c_whole] * hq[1 + c_whole] <= ((unsigned __int128)1 << 48))
+      best_c = c_whole, fast_done = true;
+    else if (hr[0] > 2048 || hq[0] > 2048)
+      fast_done = true;  // no f16 path at all: integer kernel below
+  }
+  if (!fast_done) {  // every candidate window (also rewrites the f16 copies: same values)
+    HG_HIP(c, hipMemsetAsync(st, 0, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long), c->stream));
+    {
+      hg_timed tm(c, HG_T_DIST_PREP);
+      hipLaunchKernelGGL(prep_kernel, dim3(a.R), dim3(256), plds, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, st);
+      HG_HIP(c, hipGetLastError());
+      if (!same) {
+        hipLaunchKernelGGL(prep_kernel, dim3(a.Q), dim3(256), plds, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, ldk, fb,
+                           st + 1 + N_CHUNK_CAND);
+        HG_HIP(c, hipGetLastError());
+      }
+    }
+    HG_HIP(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+    // largest accumulation window whose guaranteed bound sum|r||q| <= sqrt(SR*SQ) stays <= 2^24
+    if (hr[0] <= 2048 && hq[0] <= 2048) {
+      for (int cnd = N_CHUNK_CAND - 1; cnd >= 0; --cnd) {
+        const unsigned __int128 prod = (unsigned __int128)hr[1 + cnd] * hq[1 + cnd];
+        if (prod <= ((unsigned __int128)1 << 48)) {
+          best_c = cnd;
+          break;
+        }
       }
     }
   }
@@ -639,14 +821,15 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
     else if (!std::strcmp(e, "small")) big = false;
   }
   const uint32_t bm = big ? 256 : 128, bn = big ? 256 : 128;
-#ifdef HG_DIST_EXPERIMENT
-  g.exp = std::getenv("HG_DIST_EXP") ? (uint32_t)std::atoi(std::getenv("HG_DIST_EXP")) : 0u;
-#endif
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   auto launch = [&](auto kern, int threads, size_t lds) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    const void *fp = reinterpret_cast<const void *>(kern);
+    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+      hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      c->lds_attr_done.push_back(fp);
+    }
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(threads), lds, c->stream, g);
     return hipGetLastError();
   };

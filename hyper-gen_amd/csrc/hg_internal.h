@@ -55,6 +55,7 @@ struct hg_ctx {
   // host-fed batches: uploads run on their own stream, one event per sub-batch (hg_sketch_batch)
   hipStream_t copy_stream = nullptr;
   std::vector<hipEvent_t> copy_events;
+  std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // pinned host scratch
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;
