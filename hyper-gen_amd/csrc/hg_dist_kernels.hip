@@ -249,6 +249,34 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restric
   }
 }
 
+// Exactness verdict of the fast prepass, on the device: 0 when |x| <= 2048 everywhere and the whole-row
+// Cauchy-Schwarz bound keeps every dot product exact in one f32 accumulation window, else 1.
+__global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *__restrict__ slots_r,
+                                                     const unsigned long long *__restrict__ slots_q,
+                                                     uint32_t *__restrict__ verdict) {
+  __shared__ unsigned long long s_red[4][256];
+  unsigned long long v[4] = {0, 0, 0, 0};
+  for (uint32_t i = threadIdx.x; i < PREP_SLOTS; i += 256) {
+    v[0] = max(v[0], slots_r[2 * i]), v[1] = max(v[1], slots_r[2 * i + 1]);
+    v[2] = max(v[2], slots_q[2 * i]), v[3] = max(v[3], slots_q[2 * i + 1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = v[k];
+  __syncthreads();
+  for (uint32_t o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = max(s_red[k][threadIdx.x], s_red[k][threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const bool safe = s_red[0][0] <= 2048 && s_red[2][0] <= 2048 &&
+                      (unsigned __int128)s_red[1][0] * s_red[3][0] <= ((unsigned __int128)1 << 48);
+    verdict[0] = safe ? 0u : 1u;
+  }
+}
+
 // ---- MFMA GEMM + ANI ------------------------------------------------------------------------------
 constexpr int BK = 64;
 constexpr int LDS_ROW = BK + 8;  // f16 elements per LDS row: 144 B => conflict-free ds_read_b128
@@ -282,6 +310,7 @@ struct GemmArgs {
   float pre_c, pre_b;  // phase-0 form of the same bound: dot < pre_c * (nr + nq) + pre_b  =>  rejected
   int symmetric;
   uint32_t tiles_m, tiles_n;  // tile grid
+  const uint32_t *verdict;    // speculative launch: non-zero => this launch must do nothing (see decide_kernel)
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs
@@ -302,6 +331,7 @@ struct GemmArgs {
 template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG>;
+  if (g.verdict && *g.verdict) return;  // uniform
   static_assert(!GLDS || BIG, "LDS-DMA variant exists for the 256 x 256 geometry only");
   constexpr int LROW = GLDS ? BK : LDS_ROW;  // elements per LDS row
   constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
@@ -702,7 +732,8 @@ static float jaccard_lower_bound(float ani_th, uint32_t ksize) {
   return (float)(j * (1.0 - 1e-4));
 }
 
-hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
+hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, bool *speculated) {
+  if (speculated) *speculated = false;
   const uint32_t Kp = (a.hv_d + BK - 1) / BK * BK;
   // Row pitch of the f16 copies: Kp + 64 elements (+128 B).  With a power-of-two pitch (8 KiB at
   // D = 4096) every workgroup reads the same 128-byte column offset of 256 different rows at the same
@@ -717,9 +748,16 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   auto *fa = static_cast<_Float16 *>(c->w_f16a.p);
   auto *fb = same ? fa : static_cast<_Float16 *>(c->w_f16b.p);
   auto *st = static_cast<unsigned long long *>(c->w_stats.p);
-  HG_HIP(c, hipMemsetAsync(st, 0, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long), c->stream));
-  if (Rp > a.R) HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * ldk, 0, (size_t)(Rp - a.R) * ldk * 2, c->stream));
-  if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * ldk, 0, (size_t)(Qp - a.Q) * ldk * 2, c->stream));
+  // zero rows behind the last real one (tiles hang over); the prepass never writes them, so a repeat call
+  // on the same buffer and shape finds them still zero
+  if (Rp > a.R && !(c->pad_a_ptr == fa && c->pad_a_rows == a.R && c->pad_a_ldk == ldk)) {
+    HG_HIP(c, hipMemsetAsync(fa + (size_t)a.R * ldk, 0, (size_t)(Rp - a.R) * ldk * 2, c->stream));
+    c->pad_a_ptr = fa, c->pad_a_rows = a.R, c->pad_a_ldk = ldk;
+  }
+  if (!same && Qp > a.Q && !(c->pad_b_ptr == fb && c->pad_b_rows == a.Q && c->pad_b_ldk == ldk)) {
+    HG_HIP(c, hipMemsetAsync(fb + (size_t)a.Q * ldk, 0, (size_t)(Qp - a.Q) * ldk * 2, c->stream));
+    c->pad_b_ptr = fb, c->pad_b_rows = a.Q, c->pad_b_ldk = ldk;
+  }
   const size_t plds = (size_t)(2 * (Kp / 64) + 16 + N_CHUNK_CAND) * sizeof(unsigned long long);  // tree + maxima
   // first candidate window that covers all of K (windows are 64 << c dims; beyond the table: none does)
   int c_whole = -1;
@@ -731,7 +769,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   unsigned long long h[2 * (1 + N_CHUNK_CAND)];
   const unsigned long long *hr = h, *hq = same ? h : h + 1 + N_CHUNK_CAND;
   int best_c = -1;
-  bool fast_done = false;
+  bool fast_done = false, spec = false;
   if (c_whole >= 0) {  // fast prepass: max |x| and the whole-row bound only
     const size_t slot_bytes = 2 * PREP_SLOTS * sizeof(unsigned long long);
     auto *sl = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(st) + 256);
@@ -746,24 +784,33 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
         HG_HIP(c, hipGetLastError());
       }
     }
-    hg_status ps = hg_ensure_pinned(c, 2 * slot_bytes);
-    if (ps != HG_OK) return ps;
-    auto *hs = static_cast<unsigned long long *>(c->h_pin);
-    HG_HIP(c, hipMemcpyAsync(hs, sl, (same ? 1 : 2) * slot_bytes, hipMemcpyDeviceToHost, c->stream));
-    HG_HIP(c, hipStreamSynchronize(c->stream));
-    std::memset(h, 0, sizeof h);
-    for (int m = 0; m < (same ? 1 : 2); ++m) {
-      unsigned long long *dstp = h + m * (1 + N_CHUNK_CAND);
-      for (uint32_t i = 0; i < PREP_SLOTS; ++i) {
-        dstp[0] = std::max(dstp[0], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i]);
-        dstp[1 + c_whole] = std::max(dstp[1 + c_whole], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i + 1]);
+    if (d_verdict && !a.ani_out) {
+      // speculative schedule: the verdict is formed on the device and guards the GEMM queued right behind
+      // it; the caller reads it back together with its hit count (no host round trip in between)
+      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, sl, same ? sl : sl + 2 * PREP_SLOTS, d_verdict);
+      HG_HIP(c, hipGetLastError());
+      best_c = c_whole, fast_done = true, spec = true;
+      if (speculated) *speculated = true;
+    } else {
+      hg_status ps = hg_ensure_pinned(c, 2 * slot_bytes);
+      if (ps != HG_OK) return ps;
+      auto *hs = static_cast<unsigned long long *>(c->h_pin);
+      HG_HIP(c, hipMemcpyAsync(hs, sl, (same ? 1 : 2) * slot_bytes, hipMemcpyDeviceToHost, c->stream));
+      HG_HIP(c, hipStreamSynchronize(c->stream));
+      std::memset(h, 0, sizeof h);
+      for (int m = 0; m < (same ? 1 : 2); ++m) {
+        unsigned long long *dstp = h + m * (1 + N_CHUNK_CAND);
+        for (uint32_t i = 0; i < PREP_SLOTS; ++i) {
+          dstp[0] = std::max(dstp[0], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i]);
+          dstp[1 + c_whole] = std::max(dstp[1 + c_whole], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i + 1]);
+        }
       }
+      if (hr[0] <= 2048 && hq[0] <= 2048 &&
+          (unsigned __int128)hr[1 + c_whole] * hq[1 + c_whole] <= ((unsigned __int128)1 << 48))
+        best_c = c_whole, fast_done = true;
+      else if (hr[0] > 2048 || hq[0] > 2048)
+        fast_done = true;  // no f16 path at all: integer kernel below
     }
-    if (hr[0] <= 2048 && hq[0] <= 2048 &&
-        (unsigned __int128)hr[1 + c_whole] * hq[1 + c_whole] <= ((unsigned __int128)1 << 48))
-      best_c = c_whole, fast_done = true;
-    else if (hr[0] > 2048 || hq[0] > 2048)
-      fast_done = true;  // no f16 path at all: integer kernel below
   }
   if (!fast_done) {  // every candidate window (also rewrites the f16 copies: same values)
     HG_HIP(c, hipMemsetAsync(st, 0, 2 * (1 + N_CHUNK_CAND) * sizeof(unsigned long long), c->stream));
@@ -805,6 +852,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a) {
   g.kf = kf;
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
   g.ani_th = a.ani_th, g.symmetric = a.symmetric;
+  g.verdict = spec ? d_verdict : nullptr;
   g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
   if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;       // everything goes on to phase 1
   else if (g.j_lo == INFINITY) g.pre_c = 0.f, g.pre_b = INFINITY;    // ANI <= 100 < ani_th: nothing does

@@ -55,6 +55,9 @@ struct hg_ctx {
   // host-fed batches: uploads run on their own stream, one event per sub-batch (hg_sketch_batch)
   hipStream_t copy_stream = nullptr;
   std::vector<hipEvent_t> copy_events;
+  // rows [pad_rows, padded rows) of the f16 operand copies are known to be zero (dist tiles hang over)
+  const void *pad_a_ptr = nullptr, *pad_b_ptr = nullptr;
+  uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // pinned host scratch
   void *h_pin = nullptr;
@@ -132,4 +135,7 @@ struct hg_dist_args {
   float ani_th;
   int symmetric;
 };
-hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a);
+// d_verdict != nullptr allows the speculative schedule: prepass, on-device exactness verdict (0 = the whole-K
+// f16 path is exact) and the GEMM guarded by it are queued without a host round trip; *speculated tells the
+// caller to read the verdict back with its own results and to call again without d_verdict if it is non-zero.
+hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a, uint32_t *d_verdict = nullptr, bool *speculated = nullptr);

@@ -237,7 +237,12 @@ def test_dist_exact_for_large_values(ctx, orc):
     q = np.vstack([r[:10], rng.integers(-3000, 3000, (20, 1024)).astype(np.int16)])
     rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
     qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
-    assert np.abs(ctx.dist_full(r, rn, q, qn, 21) - orc.ani_matrix(r, rn, q, qn, 21)).max() <= 1e-4
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    assert np.abs(ctx.dist_full(r, rn, q, qn, 21) - want).max() <= 1e-4
+    # thresholded entry point: the speculative whole-K launch must veto itself and the integer kernel decide
+    hits = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=50.0)
+    assert {(int(h["ref_idx"]), int(h["qry_idx"])) for h in hits} == {(i, j) for i, j in zip(*np.nonzero(want >= 50.0))}
+    assert len(hits) >= 10 and all(abs(h["ani"] - want[h["ref_idx"], h["qry_idx"]]) <= 1e-4 for h in hits)
     # mid-size values: f16-exact but needing chunked accumulation
     r = rng.integers(-1500, 1500, (40, 4096)).astype(np.int16)
     q = np.vstack([r[:10] + rng.integers(-20, 20, (10, 4096)).astype(np.int16), r[10:25]])
