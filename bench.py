@@ -278,13 +278,20 @@ def main():
         gemm_ms = dtm["dist"][0] / max(dtm["dist"][1], 1)
         flops_per_launch = 2.0 * HV_D * (rows * world) * rows  # 2*D ops per pair
         ach = flops_per_launch / (gemm_ms * 1e-3) / 1e12
+        dist_traffic = None  # bytes leaving the XCD L2s per launch (PMC, profiles/): 10 000 x 10 000 only
+        dpath = os.path.join(ROOT, "profiles", "r01_dist_traffic.json")
+        if os.path.exists(dpath) and rows * world == 10000 and world == 1:
+            try:
+                dist_traffic = json.load(open(dpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                dist_traffic = None
         out["dist"] = {
             "metric": "M ANI-pairs/sec (D=4096, ani_th=85)", "value": pairs * a.steps / ddt / 1e6,
             "unit": "M ANI-pairs/sec", "ms_per_step": ddt / a.steps * 1e3, "scaling": "strong",
             "config": {"workload": "%d ref x %d query clustered synthetic HVs (BASELINE configs[3]), thresholded "
                                    "output" % (rows * world, rows * world), "hits_per_rank": int(found)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None, "kernel": "dist_mfma_kernel (f16)",
+                         "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": dist_traffic, "kernel": "dist_mfma_kernel (f16)",
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": flops_per_launch},
             "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in dtm.items() if v[1]},
         }

@@ -167,6 +167,35 @@ __device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm,
   if (idx < gm.hit_cap) hits[gm.hit_off + idx] = h;
 }
 
+// Workgroup-level staging of the sampled hashes (fast kernels).  A hit is 1 k-mer in `scaled`, but every
+// one used to cost its wave a returning global atomic -- a full memory round trip in the middle of ~1 400
+// VALU instructions, about once per two tiles per wave.  Hits go to an LDS list instead (LDS atomic) and the
+// workgroup reserves its range of the genome's hit buffer once, at the end of its work item.  A list that
+// overflows (low-complexity sequence: every position of a repeat samples the same hash) spills straight to
+// the global path; the raw counter semantics (it keeps counting past the capacity) are unchanged.
+constexpr uint32_t HIT_STAGE = 256;
+struct HitStage {
+  uint64_t h[HIT_STAGE];
+  uint32_t n, base;
+};
+__device__ __forceinline__ void stage_hit(HitStage &st, uint64_t h, const hg_genome_meta &gm, uint32_t g,
+                                          uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  const uint32_t idx = atomicAdd(&st.n, 1u);
+  if (idx < HIT_STAGE) st.h[idx] = h;
+  else append_hit(h, gm, g, hits, cnt);
+}
+__device__ __forceinline__ void flush_hits(HitStage &st, const hg_genome_meta &gm, uint32_t g,
+                                           uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  __syncthreads();
+  const uint32_t n = st.n < HIT_STAGE ? st.n : HIT_STAGE;
+  if (threadIdx.x == 0 && n) st.base = atomicAdd(&cnt[g], n);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t idx = st.base + i;
+    if (idx < gm.hit_cap) hits[gm.hit_off + idx] = st.h[i];
+  }
+}
+
 // =========================================================================================
 // fast kernel: compile-time k in [9, 29]
 // =========================================================================================
@@ -188,6 +217,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
   const uint64_t n_starts = n_bps - K + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+  __shared__ HitStage stage;
+  if (threadIdx.x == 0) stage.n = 0;
+  __syncthreads();
 
   // the lane's 32-base window: 8 dwords, 4-byte aligned, M-byte lane stride.  Lanes past the
   // genome end produce nothing (inv = all ones below): they are pointed at the genome start so
@@ -322,9 +354,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
         d[m] = v;
       }
       const uint64_t h = t1ha2_fixed<K, !(VAR & 1)>(d, seed);
-      if (valid && h < threshold) append_hit(h, gm, g, hits, cnt);
+      if (valid && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
     });
   }
+  flush_hits(stage, gm, g, hits, cnt);
 }
 
 // =========================================================================================
@@ -361,6 +394,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast64(
   const uint64_t n_starts = n_bps - K + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+  __shared__ HitStage stage;
+  if (threadIdx.x == 0) stage.n = 0;
+  __syncthreads();
 
 #pragma unroll 1
   for (int tile = 0; tile < TILES_PER_ITEM64; ++tile) {
@@ -485,9 +521,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast64(
         d[m] = v;
       }
       const uint64_t h = t1ha2_fixed<K>(d, seed);
-      if (valid && h < threshold) append_hit(h, gm, g, hits, cnt);
+      if (valid && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
     });
   }
+  flush_hits(stage, gm, g, hits, cnt);
 }
 
 // =========================================================================================

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.json" 2> "$OUT/stats.log"
@@ -15,4 +15,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE
   timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.log" || echo "pass $name failed" >> "$OUT/errors.txt"
 done
 cd "$ROOT" && python3 tools/summarize_prof.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1
+cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_rocprofv3_kernel_stats_full.csv"
+rm -rf "$OUT"/pmc_*/ "$OUT/stats"   # raw traces stay on the box; the summaries travel back
 cat "$OUT/summary.txt"

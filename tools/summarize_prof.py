@@ -10,7 +10,8 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("kmer_sample", "sort_unique", "encode_kernel", "dist_mfma", "dist_int", "prep_kernel", "synth_kernel")
+OURS = ("kmer_sample", "sort_unique", "encode_kernel", "dist_mfma", "dist_int", "prep_fast_kernel", "prep_kernel",
+        "decide_kernel", "synth_kernel", "hamming_kernel", "binarize_kernel")
 
 
 def short(name):
