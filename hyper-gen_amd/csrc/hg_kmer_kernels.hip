@@ -553,14 +553,18 @@ __global__ __launch_bounds__(WG) void kmer_sample_generic(
   const uint64_t n_starts = n_bps - ksize + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
   const uint64_t s0 = (uint64_t)(item - gm.item_first) * GEN_ITEM + (uint64_t)threadIdx.x * GEN_STARTS;
-  if (s0 >= n_starts) return;
-  const uint64_t s1 = (s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts;  // starts [s0, s1)
+  __shared__ HitStage stage;
+  if (threadIdx.x == 0) stage.n = 0;
+  __syncthreads();
+  // lanes past the last k-mer start run an empty range (no early return: the flush below has barriers)
+  const uint64_t s1 = s0 >= n_starts ? s0 : ((s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts);  // starts [s0, s1)
+  const uint64_t i_end = s0 >= n_starts ? s0 : s1 + ksize - 1;
   const uint64_t mask = (ksize == 32) ? ~0ull : ((1ull << (2 * ksize)) - 1);
   const char ACGT[4] = {'A', 'C', 'G', 'T'};
 
   uint64_t fwd = 0, rev = 0;  // MSB-first forward value / reverse-complement value
   uint32_t run = 0;
-  for (uint64_t i = s0; i < s1 + ksize - 1; ++i) {
+  for (uint64_t i = s0; i < i_end; ++i) {
     uint32_t c = base_code(gseq[i], u2t);
     if (c > 3) {
       run = 0, fwd = rev = 0;
@@ -577,8 +581,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_generic(
       w[b >> 3] |= (uint64_t)(uint8_t)ACGT[code] << (8 * (b & 7));
     }
     const uint64_t h = t1ha2_le32(w, ksize, seed);
-    if (h < threshold) append_hit(h, gm, g, hits, cnt);
+    if (h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
   }
+  flush_hits(stage, gm, g, hits, cnt);
 }
 
 // =========================================================================================
@@ -642,10 +647,13 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
   const uint64_t n_starts = n_bps - ksize + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
   const uint64_t s0 = (uint64_t)(item - gm.item_first) * GEN_ITEM + (uint64_t)threadIdx.x * GEN_STARTS;
-  if (s0 >= n_starts) return;
-  const uint64_t s1 = (s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts;
+  __shared__ HitStage stage;
+  if (threadIdx.x == 0) stage.n = 0;
+  __syncthreads();
+  const uint64_t s1 = s0 >= n_starts ? s0 : ((s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts);
+  const uint64_t i_end = s0 >= n_starts ? s0 : s1 + ksize - 1;
   uint32_t run = 0;  // valid bases ending at the current position
-  for (uint64_t i = s0; i < s1 + ksize - 1; ++i) {
+  for (uint64_t i = s0; i < i_end; ++i) {
     run = (base_code(gseq[i], u2t) < 4) ? run + 1 : 0;
     if (run < ksize) continue;
     const uint8_t *w = gseq + (i + 1 - ksize);
@@ -661,8 +669,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
     }
     const StrandBytes sb{w, ksize, use_rc, u2t};
     const uint64_t h = t1ha2_long(sb, ksize, seed);
-    if (h < threshold) append_hit(h, gm, g, hits, cnt);
+    if (h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
   }
+  flush_hits(stage, gm, g, hits, cnt);
 }
 
 template <int K>
