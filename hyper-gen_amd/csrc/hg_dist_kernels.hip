@@ -281,16 +281,19 @@ __global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *_
 constexpr int BK = 64;
 constexpr int LDS_ROW = BK + 8;  // f16 elements per LDS row: 144 B => conflict-free ds_read_b128
 constexpr uint32_t ST = 8;       // super-tile edge, in tiles
-// Two tile geometries (waves are 2 (M) x NWN (N), each wave owns WTM x 4 MFMA tiles of 16 x 16):
+// Tile geometries (waves are 2 (M) x NWN (N), each wave owns WTM x NT MFMA tiles of 16 x 16):
 //   small: 128 x 128, 4 waves, 72 KiB LDS, 2 workgroups / CU  -- small problems, little padding
 //   big  : 256 x 256, 8 waves, 144 KiB LDS, 1 workgroup / CU  -- half the LDS and L2 bytes per flop
-template <bool BIG>
+//   wide : 256 x 320 (NT = 5, LDS-DMA only): chosen when it divides the tile grid into fewer rounds over the
+//          CUs (10 000 x 10 000: 1 280 tiles = 5.0 rounds of 256 instead of 1 600 = 6.25 -> 7)
+template <bool BIG, int NT = 4>
 struct TileCfg {
   static constexpr int WTM = BIG ? 8 : 4;   // 16-row MFMA tiles per wave in M
   static constexpr int NWN = BIG ? 4 : 2;   // waves in N
-  static constexpr int BM = 2 * WTM * 16, BN = NWN * 64;
+  static constexpr int BM = 2 * WTM * 16, BN = NWN * NT * 16;  // NT = 16-column MFMA tiles per wave in N
   static constexpr int THREADS = 2 * NWN * 64;
-  static constexpr int LOADS = BM * BK * 2 / 16 / THREADS;  // 16-byte pieces per thread and operand
+  static constexpr int LOADS = BM * BK * 2 / 16 / THREADS;    // 16-byte pieces per thread, A operand
+  static constexpr int LOADS_B = BN * BK * 2 / 16 / THREADS;  // ... B operand
 };
 
 struct GemmArgs {
@@ -328,14 +331,15 @@ struct GemmArgs {
 // LDS image is unpadded [row][8 chunks of 16 B] and bank conflicts are removed by an XOR swizzle of the
 // chunk index with (row >> 1) & 7 -- applied to the per-lane SOURCE address when loading and to the
 // fragment address when reading (same involution on both sides).
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false>
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
-  using TC = TileCfg<BIG>;
+  using TC = TileCfg<BIG, NT>;
   if (g.verdict && *g.verdict) return;  // uniform
   static_assert(!GLDS || BIG, "LDS-DMA variant exists for the 256 x 256 geometry only");
   constexpr int LROW = GLDS ? BK : LDS_ROW;  // elements per LDS row
   constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
-  static_assert(LOADS == 4, "staging macros move 4 pieces per operand");
+  static_assert(LOADS == 4 && (GLDS || TC::LOADS_B == 4), "staging macros move 4 pieces per operand");
+  static_assert(NT == 4 || (GLDS && TC::LOADS_B == NT), "wide tiles exist for the LDS-DMA variant only");
   // two LDS stages of (A tile + B tile)
   extern __shared__ __attribute__((aligned(16))) _Float16 sAB[];
   constexpr uint32_t A_ELEMS = BM * LROW, B_ELEMS = BN * LROW;
@@ -365,17 +369,17 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   const uint32_t wm = wave / NWN, wn = wave % NWN;  // 2 x NWN waves, (WTM*16) x 64 each
   const uint32_t fr = lane & 15, fq = lane >> 4;
 
-  float4v acc[WTM][4];
-  int32_t iacc[CHUNKED ? WTM : 1][CHUNKED ? 4 : 1][4];
+  float4v acc[WTM][NT];
+  int32_t iacc[CHUNKED ? WTM : 1][CHUNKED ? NT : 1][4];
 #pragma unroll
   for (int m = 0; m < WTM; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n) acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
   if (CHUNKED) {
 #pragma unroll
     for (int m = 0; m < WTM; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] = 0;
   }
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // and (row>>1)&7 == (fr>>1)&7 because all row bases are multiples of 16
   const uint32_t swz = (fr >> 1) & 7;
   const uint32_t fa_off = (wm * WTM * 16 + fr) * LROW + (GLDS ? (fq ^ swz) * 8 : fq * 8);
-  const uint32_t fb_off = TILE_ELEMS + (wn * 64 + fr) * LROW + (GLDS ? (fq ^ swz) * 8 : fq * 8);
+  const uint32_t fb_off = TILE_ELEMS + (wn * (NT * 16) + fr) * LROW + (GLDS ? (fq ^ swz) * 8 : fq * 8);
   // kk = 1 adds 4 chunks: (4 + fq) ^ swz = (fq ^ swz) ^ 4
   const int32_t kk1_off = GLDS ? ((((fq ^ swz) ^ 4) - (int32_t)(fq ^ swz)) * 8) : 32;
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
@@ -434,13 +438,17 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // tile's first row, 32-bit per-lane offset, K offset in an SGPR).  The global_load_lds form moves the same
   // bytes, but being FLAT-encoded it makes the compiler flush lgkmcnt to 0 at every LDS dependency while
   // one is in flight, which serialises the fragment reads below with the MFMAs.
-  uint32_t vA[4], vB[4];  // byte offsets of this thread's four 16-byte pieces inside the A / B row block
+  // byte offsets of this thread's 16-byte pieces inside the A / B row block (NT of vB are used; a
+  // template-sized array here makes hipcc drop the kernel's host stub without a diagnostic)
+  uint32_t vA[4], vB[5];
+  static_assert(NT <= 5, "vB holds five pieces");
   __amdgpu_buffer_rsrc_t rsA, rsB;
   if (GLDS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NT; ++i) {
       const uint32_t sl = i * THREADS + tid, r = sl >> 3, ch = (sl & 7) ^ ((r >> 1) & 7);
-      vA[i] = vB[i] = (r * g.ldk + ch * 8) * 2;
+      vB[i] = (r * g.ldk + ch * 8) * 2;
+      if (i < 4) vA[i] = vB[i];
     }
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
@@ -449,19 +457,20 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #define HG_DMA(stage, k0)                                                                                   \
   {                                                                                                         \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * THREADS * 8), 16, vA[i], (k0) * 2, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                                        \
+      if (i < 4)                                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * THREADS * 8), 16, vA[i < 4 ? i : 0], (k0) * 2, 0, 0); \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * THREADS * 8), 16, vB[i], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
   constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
-  half8 bfr[2][4], afr[2][2];
+  half8 bfr[2][NT], afr[2][2];
   // fragments of phase (kk, mp) of the stage whose fragment bases are pa / pb, into buffer set `buf`
 #define HG_FRAGS(buf, pa, pb, kk, mp)                                                                       \
   {                                                                                                         \
     const int32_t ko_ = (kk) ? kk1_off : 0;                                                                 \
     if ((mp) == 0) {                                                                                        \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                         \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                         \
           bfr[(kk) & 1][n] = *reinterpret_cast<const half8 *>((pb) + n * 16 * LROW + ko_);                  \
     }                                                                                                       \
     afr[buf][0] = *reinterpret_cast<const half8 *>((pa) + (2 * (mp)) * 16 * LROW + ko_);                    \
@@ -508,12 +517,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(afr[t & 1][i]));
 #pragma unroll
-        for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(bfr[kk & 1][n]));
+        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(bfr[kk & 1][n]));
       } else if (!HG_EXP(2)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int n = 0; n < NT; ++n)
             acc[2 * mp + i][n] =
                 __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
       }
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #pragma unroll
       for (int m = 0; m < WTM; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NT; ++n) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] += (int32_t)acc[m][n][r];
           acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #pragma unroll
       for (int m = 0; m < WTM; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) sum += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+        for (int n = 0; n < NT; ++n) sum += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
       reinterpret_cast<float *>(g.hits)[tid] = sum;
     }
     return;
@@ -618,12 +627,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // of what phase 1 keeps: invalid rows/columns carry +inf, norms outside [0, 2^29] -- where the i32
   // denominator could wrap -- carry -inf) run phase 1.
   constexpr int32_t NORM_SAFE = 1 << 29;
-  int32_t nqv[4];
-  float tq[4];
+  int32_t nqv[NT];
+  float tq[NT];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const uint32_t j = col0 + wn * 64 + n * 16 + fr;
-    nqv[n] = s_nq[wn * 64 + n * 16 + fr];
+  for (int n = 0; n < NT; ++n) {
+    const uint32_t j = col0 + wn * (NT * 16) + n * 16 + fr;
+    nqv[n] = s_nq[wn * (NT * 16) + n * 16 + fr];
     tq[n] = j >= g.Q ? INFINITY : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY : g.pre_c * (float)nqv[n] + g.pre_b);
   }
 #pragma unroll
@@ -635,12 +644,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       const int32_t nri = s_nr[li];
       const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : g.pre_c * (float)nri);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NT; ++n) {
         float d = acc[m][n][r];
         if (CHUNKED) d += (float)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
         const bool pass = FULL || d >= ur + tq[n];
         if (__ballot(pass) == 0) continue;  // wave-uniform: typically > 80 % of the element slots
-        const uint32_t lj = wn * 64 + n * 16 + fr, j = col0 + lj;
+        const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
         int32_t dot = (int32_t)acc[m][n][r];
         if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
         bool live = pass && iok && j < g.Q && !(g.symmetric && i >= j);
@@ -657,8 +666,8 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         staged += (uint32_t)__popcll(bal);
       }
     }
-    // at most 16 x 64 = 1024 candidates per m: one overflow check per m is enough
-    if (staged > CAND_CAP - 1024) HG_PROCESS()
+    // at most 4 * NT * 64 candidates per m: one overflow check per m is enough
+    if (staged > CAND_CAP - 4 * NT * 64) HG_PROCESS()
   }
   // end of the tile: ONE reservation per workgroup.  Same-address returning atomics serialise at ~12 ns;
   // with noise hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round,
@@ -739,7 +748,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   // D = 4096) every workgroup reads the same 128-byte column offset of 256 different rows at the same
   // moment, i.e. one L2 / Infinity-Cache channel; the odd 128-byte skew spreads rows over channels.
   const uint32_t ldk = Kp + 64;
-  const uint32_t Rp = (a.R + 255) / 256 * 256, Qp = (a.Q + 255) / 256 * 256;  // covers both tile sizes
+  // padded row counts cover every tile geometry (128, 256 and 320 rows)
+  auto padded = [](uint32_t n) { return std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320); };
+  const uint32_t Rp = padded(a.R), Qp = padded(a.Q);
   const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
   if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
@@ -863,12 +874,20 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   // tile may hang over by 128 rows, which the zero padding of the operand copies must cover)
   bool big = !full && whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
   bool dma = true;
-  if (const char *e = std::getenv("HG_DIST_TILE")) {  // test hook: force a geometry ("big" needs !full && whole_k)
-    if (!std::strcmp(e, "big")) big = !full && whole_k;
-    else if (!std::strcmp(e, "big_reg")) big = !full && whole_k, dma = false;
+  int nt = 4;  // 16-column MFMA tiles per wave: 4 -> 256-wide tiles, 5 -> 320-wide
+  if (big) {   // the width that needs fewer rounds over the CUs (a round of 320-wide tiles costs 5/4)
+    const uint64_t tm = (a.R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
+    const uint64_t r4 = (tm * ((a.Q + 255) / 256) + ncu - 1) / ncu, r5 = (tm * ((a.Q + 319) / 320) + ncu - 1) / ncu;
+    if (r5 * 5 < r4 * 4) nt = 5;
+  }
+  if (const char *e = std::getenv("HG_DIST_TILE")) {  // test hook: force a geometry ("big"/"wide" need !full && whole_k)
+    if (!std::strcmp(e, "big")) big = !full && whole_k, nt = 4;
+    else if (!std::strcmp(e, "wide")) big = !full && whole_k, nt = 5;
+    else if (!std::strcmp(e, "big_reg")) big = !full && whole_k, dma = false, nt = 4;
     else if (!std::strcmp(e, "small")) big = false;
   }
-  const uint32_t bm = big ? 256 : 128, bn = big ? 256 : 128;
+  if (!big || !dma) nt = 4;
+  const uint32_t bm = big ? 256 : 128, bn = big ? (uint32_t)nt * 64 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   auto launch = [&](auto kern, int threads, size_t lds) -> hipError_t {
@@ -885,7 +904,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   hipError_t le;
   // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
   const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 4 + 64);
-  if (big && dma) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
+  const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 4 + 64);
+  if (big && dma && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
+  else if (big && dma) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
   else if (big) le = launch(&dist_mfma_kernel<false, false, true, false>, TileCfg<true>::THREADS, lds_big);
   else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);
   else if (whole_k) le = launch(&dist_mfma_kernel<false, false, false>, TileCfg<false>::THREADS, lds_small);

@@ -386,12 +386,15 @@ def test_dist_big_tiles_and_chunked_paths(ctx, orc, hg):
         hits_big = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
         os.environ["HG_DIST_TILE"] = "big_reg"   # 256 x 256, register staging
         hits_big_reg = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+        os.environ["HG_DIST_TILE"] = "wide"      # 256 x 320, LDS-DMA staging
+        hits_wide = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
         os.environ["HG_DIST_TILE"] = "small"     # 128 x 128
         hits = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
     finally:
         del os.environ["HG_DIST_TILE"]
     assert (key(hits_big) == key(hits)).all()      # all geometries: identical hits, bit for bit
     assert (key(hits_big_reg) == key(hits)).all()
+    assert (key(hits_wide) == key(hits)).all()
     sel = want >= th
     # pairs within 1e-4 of the threshold may legitimately fall on either side
     near = np.abs(want - th) <= 1e-4
