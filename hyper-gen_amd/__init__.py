@@ -64,7 +64,7 @@ EXPORTS = [
     "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack",
     "hg_hv_unpack", "hg_sketch_file_write", "hg_sketch_file_read", "hg_sketch_file_count",
-    "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_free",
+    "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_read_merge_seq_into", "hg_free",
     "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
     "hg_hv_binarize_dev", "hg_hamming_full_dev", "hg_hamming_search_dev",
 ]
@@ -127,6 +127,7 @@ def lib():
         "hg_sketch_file_get": (C.POINTER(FileSketch), [vp, sz]),
         "hg_sketch_file_free": (None, [vp]),
         "hg_read_merge_seq": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz)]),
+        "hg_read_merge_seq_into": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "hg_free": (None, [vp]),
         "hg_hv_binarize_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
         "hg_hamming_full_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, vp]),

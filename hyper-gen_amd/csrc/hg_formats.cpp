@@ -215,15 +215,27 @@ size_t merge_in_place(uint8_t *buf, size_t n) {
 }
 }  // namespace
 
-extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {
-  if (!path || !out || !n_bps) return HG_ERR_INVALID;
-  *out = nullptr, *n_bps = 0;
+namespace {
+bool grow(uint8_t *&buf, size_t &cap, size_t need) {
+  if (need <= cap) return true;
+  uint8_t *nb = static_cast<uint8_t *>(std::realloc(buf, need));
+  if (!nb) return false;
+  buf = nb, cap = need;
+  return true;
+}
+}  // namespace
+
+extern "C" hg_status hg_read_merge_seq_into(const char *path, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {
+  if (!path || !pbuf || !pcap || !n_bps) return HG_ERR_INVALID;
+  *n_bps = 0;
+  uint8_t *buf = *pbuf;
+  size_t cap = buf ? *pcap : 0;
   FILE *fp = std::fopen(path, "rb");
   if (!fp) return HG_ERR_IO;
   unsigned char magic[2] = {0, 0};
   const size_t got_magic = std::fread(magic, 1, 2, fp);
-  uint8_t *buf = nullptr;
   size_t n = 0;
+  hg_status st = HG_OK;
   if (got_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
     // gzip: inflate transparently -- what needletail's reader does for the reference's CPU path
     // (src/sketch.rs:76); the reference's GPU reader is plain text only
@@ -231,59 +243,46 @@ extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *
     gzFile f = gzopen(path, "rb");
     if (!f) return HG_ERR_IO;
     gzbuffer(f, 1 << 20);
-    size_t cap = (size_t)16 << 20;
-    buf = static_cast<uint8_t *>(std::malloc(cap + 64));
-    if (!buf) {
-      gzclose(f);
-      return HG_ERR_OOM;
-    }
-    int got;
-    while ((got = gzread(f, buf + n, (unsigned)std::min<size_t>(cap - n, 1u << 30))) > 0) {
+    if (!grow(buf, cap, ((size_t)16 << 20) + 64)) st = HG_ERR_OOM;
+    int got = 0;
+    while (st == HG_OK && (got = gzread(f, buf + n, (unsigned)std::min<size_t>(cap - 64 - n, 1u << 30))) > 0) {
       n += (size_t)got;
-      if (n == cap) {
-        cap *= 2;
-        uint8_t *nb = static_cast<uint8_t *>(std::realloc(buf, cap + 64));
-        if (!nb) {
-          std::free(buf);
-          gzclose(f);
-          return HG_ERR_OOM;
-        }
-        buf = nb;
-      }
+      if (n == cap - 64 && !grow(buf, cap, 2 * cap)) st = HG_ERR_OOM;
     }
-    const bool bad = got < 0;
+    if (st == HG_OK && got < 0) st = HG_ERR_IO;
     gzclose(f);
-    if (bad) {
-      std::free(buf);
-      return HG_ERR_IO;
-    }
   } else {
     // plain text: one read of the whole file straight into the result buffer
-    if (std::fseek(fp, 0, SEEK_END) != 0) {
-      std::fclose(fp);
-      return HG_ERR_IO;
+    long sz = -1;
+    if (std::fseek(fp, 0, SEEK_END) == 0) sz = std::ftell(fp);
+    if (sz < 0) st = HG_ERR_IO;
+    else if (!grow(buf, cap, (size_t)sz + 64)) st = HG_ERR_OOM;
+    if (st == HG_OK) {
+      std::rewind(fp);
+      n = sz ? std::fread(buf, 1, (size_t)sz, fp) : 0;
+      if (n != (size_t)sz) st = HG_ERR_IO;
     }
-    const long sz = std::ftell(fp);
-    if (sz < 0) {
-      std::fclose(fp);
-      return HG_ERR_IO;
-    }
-    std::rewind(fp);
-    buf = static_cast<uint8_t *>(std::malloc((size_t)sz + 64));
-    if (!buf) {
-      std::fclose(fp);
-      return HG_ERR_OOM;
-    }
-    n = sz ? std::fread(buf, 1, (size_t)sz, fp) : 0;
     std::fclose(fp);
-    if (n != (size_t)sz) {
-      std::free(buf);
-      return HG_ERR_IO;
-    }
   }
+  *pbuf = buf, *pcap = cap;  // the (possibly moved) buffer stays the caller's, also on error
+  if (st != HG_OK) return st;
   const size_t w = merge_in_place(buf, n);
   std::memset(buf + w, 0, 64);
-  *out = buf, *n_bps = w;
+  *n_bps = w;
+  return HG_OK;
+}
+
+extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {
+  if (!path || !out || !n_bps) return HG_ERR_INVALID;
+  *out = nullptr, *n_bps = 0;
+  uint8_t *buf = nullptr;
+  size_t cap = 0;
+  const hg_status st = hg_read_merge_seq_into(path, &buf, &cap, n_bps);
+  if (st != HG_OK) {
+    std::free(buf);
+    return st;
+  }
+  *out = buf;
   return HG_OK;
 }
 

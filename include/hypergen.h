@@ -206,6 +206,10 @@ void hg_sketch_file_free(hg_sketch_file *f);
 /* ---- FASTA ingest (host side; src/fastx_reader.rs:6-29) ------------------------------- */
 /* read_merge_seq: returns a malloc'ed buffer (free with hg_free) and its length */
 hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps);
+/* same, into a caller-owned growable buffer: *buf (NULL or from malloc/realloc) of *cap bytes is reused when
+ * large enough and realloc'ed otherwise -- a reader thread that recycles its buffers avoids one 5 MB
+ * mmap / page-fault / munmap cycle per file */
+hg_status hg_read_merge_seq_into(const char *path, uint8_t **buf, size_t *cap, size_t *n_bps);
 void hg_free(void *p);
 
 /* ---- bit-packed hypervectors + Hamming search (extension: BASELINE.json configs[4]) ------------
