@@ -316,7 +316,7 @@ struct GemmArgs {
   const uint32_t *verdict;    // speculative launch: non-zero => this launch must do nothing (see decide_kernel)
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
-// compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs
+// compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only
 #ifdef HG_DIST_EXPERIMENT
 #define HG_EXP(bit) ((HG_DIST_EXPERIMENT & (bit)) != 0)
 #else
@@ -504,13 +504,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     for (int t = 0; t < PHASES; ++t) {
       const int kk = t / MP, mp = t % MP;
       if (t + 1 < PHASES) {
-        if (!HG_EXP(2)) HG_FRAGS((t + 1) & 1, fA, fB, (t + 1) / MP, (t + 1) % MP)
+        if (!HG_EXP(2) && !(HG_EXP(32) && ks)) HG_FRAGS((t + 1) & 1, fA, fB, (t + 1) / MP, (t + 1) % MP)
       } else {
         // every fragment read of this stage must have returned before another wave may refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!HG_EXP(16)) __syncthreads();
         if (GLDS && ks + 2 < nsteps && !HG_EXP(1)) HG_DMA(cur, (ks + 2) * BK)
-        if (ks + 1 < nsteps && !HG_EXP(2)) HG_FRAGS(0, nA, nB, 0, 0)
+        if (ks + 1 < nsteps && !HG_EXP(2) && !HG_EXP(32)) HG_FRAGS(0, nA, nB, 0, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
       if (HG_EXP(8)) {  // fragment reads without the MFMAs
