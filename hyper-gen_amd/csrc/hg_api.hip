@@ -75,7 +75,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv,
+  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort,
                          &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
                          &c->w_n2a, &c->w_n2b};
   for (auto *b : bufs)
@@ -268,6 +268,74 @@ hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, si
   return HG_OK;
 }
 
+// Sorts + de-duplicates the genomes whose sampled hash count exceeds what one workgroup sorts in LDS.
+// h_cnt: raw per-genome counters (host copy).  Synchronises the stream when it had work to do.
+hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt, size_t n, uint64_t threshold,
+                          uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_nd) {
+  constexpr uint32_t TARGET = 2048, MAX_BUCKETS = 8192;  // keys per bucket aimed at / buckets per genome
+  std::vector<hg_bucket_job> jobs;
+  std::vector<uint32_t> chunk_job, bucket_job, inplace;
+  for (size_t g = 0; g < n; ++g) {
+    const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
+    if (cnt <= HG_SORT_LDS_MAX_KEYS) continue;
+    uint32_t P = 2;
+    while (P < MAX_BUCKETS && (uint64_t)P * TARGET < cnt) P <<= 1;
+    if (const char *e = std::getenv("HG_SORT_TEST_BUCKETS")) {  // test hook: force overflowing buckets / the fallback
+      P = (uint32_t)std::max(2, std::atoi(e));
+    } else if ((uint64_t)P * (HG_SORT_LDS_MAX_KEYS / 2) < cnt) {  // more than ~8 k keys per bucket expected: too many for LDS
+      inplace.push_back((uint32_t)g);
+      continue;
+    }
+    hg_bucket_job j{};
+    j.hit_off = pl.meta[g].hit_off, j.n = cnt, j.P = P, j.genome = (uint32_t)g;
+    // bucket(h) = floor(h * P / threshold) for h < threshold, as a multiply-high by ceil(P * 2^64 / threshold)
+    const unsigned __int128 num = ((unsigned __int128)P << 64) + threshold - 1;
+    const unsigned __int128 q = num / (threshold ? threshold : 1);
+    j.mul = q > (unsigned __int128)UINT64_MAX ? UINT64_MAX : (uint64_t)q;
+    j.bucket_first = (uint32_t)bucket_job.size(), j.chunk_first = (uint32_t)chunk_job.size();
+    bucket_job.insert(bucket_job.end(), P, (uint32_t)jobs.size());
+    chunk_job.insert(chunk_job.end(), (cnt + HG_BUCKET_CHUNK - 1) / HG_BUCKET_CHUNK, (uint32_t)jobs.size());
+    jobs.push_back(j);
+  }
+  if (jobs.empty() && inplace.empty()) return HG_OK;
+  hg_status s;
+  const size_t jb = (jobs.size() * sizeof(hg_bucket_job) + 63) & ~(size_t)63;
+  const size_t cb = (chunk_job.size() * 4 + 63) & ~(size_t)63, bb = (bucket_job.size() * 4 + 63) & ~(size_t)63;
+  const size_t kb = ((5 * bucket_job.size() + jobs.size()) * 4 + 63) & ~(size_t)63;
+  const size_t tb = ((std::max(inplace.size(), jobs.size())) * 4 + 63) & ~(size_t)63;
+  if ((s = hg_ensure(c, c->w_lsort, jb + cb + bb + kb + tb + 64)) != HG_OK) return s;
+  auto *base = static_cast<uint8_t *>(c->w_lsort.p);
+  auto *d_jobs = reinterpret_cast<hg_bucket_job *>(base);
+  auto *d_chunk = reinterpret_cast<uint32_t *>(base + jb), *d_bucket = reinterpret_cast<uint32_t *>(base + jb + cb);
+  auto *d_bk = reinterpret_cast<uint32_t *>(base + jb + cb + bb), *d_todo = reinterpret_cast<uint32_t *>(base + jb + cb + bb + kb);
+  if (!jobs.empty()) {
+    if ((s = hg_ensure(c, c->w_hits2, pl.total_slots * sizeof(uint64_t) + 16)) != HG_OK) return s;
+    HG_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(hg_bucket_job), hipMemcpyHostToDevice, c->stream));
+    HG_HIP(c, hipMemcpyAsync(d_chunk, chunk_job.data(), chunk_job.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HG_HIP(c, hipMemcpyAsync(d_bucket, bucket_job.data(), bucket_job.size() * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> fail(jobs.size());
+    {
+      hg_timed tm(c, HG_T_SORT);
+      HG_HIP(c, hg_launch_sort_large(c->stream, d_jobs, (uint32_t)jobs.size(), d_chunk, (uint32_t)chunk_job.size(), d_bucket,
+                                     (uint32_t)bucket_job.size(), d_bk, d_hits, static_cast<uint64_t *>(c->w_hits2.p), d_nd));
+    }
+    HG_HIP(c, hipMemcpyAsync(fail.data(), d_bk + 5 * bucket_job.size(), jobs.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipStreamSynchronize(c->stream));  // also keeps the host vectors alive until the uploads are done
+    for (size_t k = 0; k < jobs.size(); ++k)
+      if (fail[k]) inplace.push_back(jobs[k].genome);
+  }
+  if (!inplace.empty()) {
+    HG_HIP(c, hipMemcpyAsync(d_todo, inplace.data(), inplace.size() * 4, hipMemcpyHostToDevice, c->stream));
+    {
+      hg_timed tm(c, HG_T_SORT);
+      HG_HIP(c, hg_launch_sort_inplace(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), d_todo, (uint32_t)inplace.size(),
+                                       d_hits, d_cnt, d_nd));
+    }
+    HG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return HG_OK;
+}
+
 // Runs hash+sample and sort/unique.  On return (stream synchronised) the device hit buffer holds
 // each genome's ascending distinct hashes at meta[g].hit_off and *d_ndistinct_out the counts.
 hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
@@ -338,6 +406,8 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     for (size_t g = 0; g < n; ++g)
       if (h_cnt[g] > pl.meta[g].hit_cap) overflow = true, want[g] = h_cnt[g];
     if (!overflow) {
+      // hash sets beyond the LDS sort: bucketed multi-workgroup sort (or, where that cannot work, in place)
+      if ((s = sort_large_sets(c, pl, h_cnt, n, threshold, d_hits, d_cnt, d_nd)) != HG_OK) return s;
       if (!reuse) {  // remember this plan for the next call
         c->plan_offs.assign(offsets, offsets + n);
         c->plan_lens.assign(lens, lens + n);

@@ -80,17 +80,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratc
 template <bool USE_LDS>
 __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
     const hg_genome_meta *__restrict__ meta, uint64_t *__restrict__ hits,
-    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ ndistinct, uint32_t lds_keys) {
+    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ ndistinct, uint32_t lds_keys,
+    const uint32_t *__restrict__ todo) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
   __shared__ uint32_t s_scan[SORT_WG / 64 + 1];
-  const uint32_t g = blockIdx.x;
+  const uint32_t g = todo ? todo[blockIdx.x] : blockIdx.x;
   const hg_genome_meta gm = meta[g];
   uint32_t n = cnt[g];
   if (n > gm.hit_cap) n = gm.hit_cap;  // overflow is reported by the host from cnt[]
   uint64_t *region = hits + gm.hit_off;
   const uint32_t n2 = next_pow2(n);
   const bool in_lds = n2 <= lds_keys;
-  if (USE_LDS != in_lds) return;  // the other instantiation handles this genome
+  if (USE_LDS != in_lds) return;  // larger sets: bucketed sort (hg_launch_sort_large) or the in-place variant
   const uint32_t tid = threadIdx.x;
 
   if (n <= 1) {
@@ -127,6 +128,152 @@ __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
     __syncthreads();
   }
   if (tid == 0) ndistinct[g] = base;
+}
+
+// ---- large hash sets: bucket by value, sort + unique each bucket in LDS -----------------------------------
+constexpr uint32_t BK_WG = 256;
+__device__ __forceinline__ uint32_t bucket_of(uint64_t h, const hg_bucket_job &job) {
+  const uint32_t b = (uint32_t)__umul64hi(h, job.mul);  // monotone in h
+  return b < job.P ? b : job.P - 1;
+}
+
+// grid: key chunks.  bcount[bucket] += 1 per key (no value returned: the waves do not wait)
+__global__ __launch_bounds__(BK_WG) void bucket_count_kernel(const hg_bucket_job *__restrict__ jobs,
+                                                             const uint32_t *__restrict__ chunk_job,
+                                                             const uint64_t *__restrict__ hits,
+                                                             uint32_t *__restrict__ bcount) {
+  const hg_bucket_job job = jobs[chunk_job[blockIdx.x]];
+  const uint32_t k0 = (blockIdx.x - job.chunk_first) * HG_BUCKET_CHUNK;
+  const uint32_t k1 = k0 + HG_BUCKET_CHUNK < job.n ? k0 + HG_BUCKET_CHUNK : job.n;
+  for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG)
+    atomicAdd(&bcount[job.bucket_first + bucket_of(hits[job.hit_off + i], job)], 1u);
+}
+
+// grid: jobs.  out[b] = exclusive prefix of in[b] over the job's buckets; optionally the total per genome
+__global__ __launch_bounds__(SORT_WG) void bucket_scan_kernel(const hg_bucket_job *__restrict__ jobs,
+                                                              const uint32_t *__restrict__ in,
+                                                              uint32_t *__restrict__ out,
+                                                              uint32_t *__restrict__ total_per_genome) {
+  __shared__ uint32_t s_scan[SORT_WG / 64 + 1];
+  const hg_bucket_job job = jobs[blockIdx.x];
+  uint32_t run = 0;
+  for (uint32_t b0 = 0; b0 < job.P; b0 += SORT_WG) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t v = b < job.P ? in[job.bucket_first + b] : 0u;
+    uint32_t total;
+    const uint32_t pre = block_excl_scan(v, s_scan, &total);
+    if (b < job.P) out[job.bucket_first + b] = run + pre;
+    run += total;
+  }
+  if (total_per_genome && threadIdx.x == 0) total_per_genome[job.genome] = run;
+}
+
+// grid: key chunks.  Every key moves to its bucket's range of the scratch buffer.
+__global__ __launch_bounds__(BK_WG) void bucket_scatter_kernel(const hg_bucket_job *__restrict__ jobs,
+                                                               const uint32_t *__restrict__ chunk_job,
+                                                               const uint64_t *__restrict__ hits,
+                                                               const uint32_t *__restrict__ bstart,
+                                                               uint32_t *__restrict__ bcursor,
+                                                               uint64_t *__restrict__ tmp) {
+  const hg_bucket_job job = jobs[chunk_job[blockIdx.x]];
+  const uint32_t k0 = (blockIdx.x - job.chunk_first) * HG_BUCKET_CHUNK;
+  const uint32_t k1 = k0 + HG_BUCKET_CHUNK < job.n ? k0 + HG_BUCKET_CHUNK : job.n;
+  for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG) {
+    const uint64_t h = hits[job.hit_off + i];
+    const uint32_t gb = job.bucket_first + bucket_of(h, job);
+    const uint32_t pos = atomicAdd(&bcursor[gb], 1u);
+    tmp[job.hit_off + bstart[gb] + pos] = h;
+  }
+}
+
+// grid: buckets.  Sort + unique in LDS; the distinct keys go back to the start of the bucket's scratch range.
+// A bucket with more keys than LDS holds (only possible when duplicates pile up: the map is balanced for
+// distinct hashes) is first de-duplicated through an LDS hash set; if even its distinct keys do not fit the
+// job is flagged and the caller sorts that genome in place instead.
+constexpr uint32_t HSET_SLOTS = SORT_LDS_MAX_KEYS, HSET_MAX = HSET_SLOTS / 4 * 3;
+__global__ __launch_bounds__(SORT_WG) void bucket_sort_kernel(const hg_bucket_job *__restrict__ jobs,
+                                                              const uint32_t *__restrict__ bucket_job,
+                                                              const uint32_t *__restrict__ bcount,
+                                                              const uint32_t *__restrict__ bstart,
+                                                              uint64_t *__restrict__ tmp,
+                                                              uint32_t *__restrict__ bdist,
+                                                              uint32_t *__restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+  __shared__ uint32_t s_scan[SORT_WG / 64 + 1];
+  __shared__ uint32_t s_distinct;
+  const uint32_t gb = blockIdx.x, j = bucket_job[gb], tid = threadIdx.x;
+  const hg_bucket_job job = jobs[j];
+  const uint32_t n = bcount[gb];
+  uint64_t *base = tmp + job.hit_off + bstart[gb];
+  if (n == 0) {
+    if (tid == 0) bdist[gb] = 0;
+    return;
+  }
+  if (n > SORT_LDS_MAX_KEYS) {
+    for (uint32_t i = tid; i < HSET_SLOTS; i += SORT_WG) s_keys[i] = ~0ull;  // no hash equals ~0 (h < threshold)
+    if (tid == 0) s_distinct = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += SORT_WG) {
+      const uint64_t h = base[i];
+      uint32_t slot = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 50) & (HSET_SLOTS - 1);
+      for (;;) {
+        if (s_distinct > HSET_MAX) break;  // hopeless: flagged below
+        const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_keys[slot]), ~0ull, (unsigned long long)h);
+        if (old == ~0ull) {
+          atomicAdd(&s_distinct, 1u);
+          break;
+        }
+        if (old == h) break;
+        slot = (slot + 1) & (HSET_SLOTS - 1);
+      }
+    }
+    __syncthreads();
+    if (s_distinct > HSET_MAX) {
+      if (tid == 0) fail[j] = 1u, bdist[gb] = 0;
+      return;
+    }
+    bitonic_sort(s_keys, HSET_SLOTS, tid, SORT_WG);  // empty slots (~0) sort to the end
+    const uint32_t d = s_distinct;
+    for (uint32_t i = tid; i < d; i += SORT_WG) base[i] = s_keys[i];
+    if (tid == 0) bdist[gb] = d;
+    return;
+  }
+  const uint32_t n2 = next_pow2(n);
+  for (uint32_t i = tid; i < n2; i += SORT_WG) s_keys[i] = (i < n) ? base[i] : ~0ull;
+  __syncthreads();
+  bitonic_sort(s_keys, n2, tid, SORT_WG);
+  uint32_t run = 0;
+  for (uint32_t c0 = 0; c0 < n; c0 += SORT_WG) {
+    const uint32_t i = c0 + tid;
+    uint64_t v = 0;
+    uint32_t keep = 0;
+    if (i < n) {
+      v = s_keys[i];
+      keep = (i == 0 || v != s_keys[i - 1]) ? 1u : 0u;
+    }
+    uint32_t total;
+    const uint32_t pos = block_excl_scan(keep, s_scan, &total);
+    if (keep) base[run + pos] = v;
+    run += total;
+  }
+  if (tid == 0) bdist[gb] = run;
+}
+
+// grid: buckets.  Distinct keys of the bucket -> their final place in the genome's hit region.
+__global__ __launch_bounds__(BK_WG) void bucket_copy_kernel(const hg_bucket_job *__restrict__ jobs,
+                                                            const uint32_t *__restrict__ bucket_job,
+                                                            const uint32_t *__restrict__ bstart,
+                                                            const uint32_t *__restrict__ bdist,
+                                                            const uint32_t *__restrict__ bout,
+                                                            const uint32_t *__restrict__ fail,
+                                                            const uint64_t *__restrict__ tmp,
+                                                            uint64_t *__restrict__ hits) {
+  const uint32_t gb = blockIdx.x;
+  if (fail[bucket_job[gb]]) return;  // the genome's raw keys must survive for the in-place sort
+  const hg_bucket_job job = jobs[bucket_job[gb]];
+  const uint64_t *src = tmp + job.hit_off + bstart[gb];
+  uint64_t *dst = hits + job.hit_off + bout[gb];
+  for (uint32_t i = threadIdx.x; i < bdist[gb]; i += BK_WG) dst[i] = src[i];
 }
 
 // ---- encode -------------------------------------------------------------------------------
@@ -270,6 +417,18 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
 
 }  // namespace
 
+static hipError_t sort_lds_attr() {
+  static bool attr_set = false;
+  if (attr_set) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_unique_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_KEYS * sizeof(uint64_t));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bucket_sort_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_KEYS * sizeof(uint64_t));
+  attr_set = e == hipSuccess;
+  return e;
+}
+
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
                                  uint32_t max_cap) {
@@ -278,24 +437,43 @@ hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, u
   while (keys < max_cap) keys <<= 1;
   if (keys > SORT_LDS_MAX_KEYS) keys = SORT_LDS_MAX_KEYS;
   const size_t lds = (size_t)keys * sizeof(uint64_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_unique_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SORT_LDS_MAX_KEYS * sizeof(uint64_t));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_genomes), dim3(SORT_WG), lds, st, d_meta,
-                     d_hits, d_cnt, d_ndistinct, keys);
-  hipError_t e = hipGetLastError();
+  hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
-  if (max_cap > SORT_LDS_MAX_KEYS) {  // some genome may need the in-place global sort
-    hipLaunchKernelGGL((sort_unique_kernel<false>), dim3(n_genomes), dim3(SORT_WG), 0, st, d_meta,
-                       d_hits, d_cnt, d_ndistinct, keys);
-    e = hipGetLastError();
-  }
-  return e;
+  // genomes whose hit count exceeds the LDS budget are skipped here: the caller learns the counts and
+  // runs hg_launch_sort_large / hg_launch_sort_inplace for them
+  hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_genomes), dim3(SORT_WG), lds, st, d_meta,
+                     d_hits, d_cnt, d_ndistinct, keys, (const uint32_t *)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo,
+                                  uint32_t n_todo, uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct) {
+  if (n_todo == 0) return hipSuccess;
+  hipLaunchKernelGGL((sort_unique_kernel<false>), dim3(n_todo), dim3(SORT_WG), 0, st, d_meta, d_hits, d_cnt,
+                     d_ndistinct, SORT_LDS_MAX_KEYS, d_todo);
+  return hipGetLastError();
+}
+
+hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uint32_t n_jobs,
+                                const uint32_t *d_chunk_job, uint32_t n_chunks, const uint32_t *d_bucket_job,
+                                uint32_t n_buckets, uint32_t *d_bk, uint64_t *d_hits, uint64_t *d_tmp,
+                                uint32_t *d_ndistinct) {
+  if (n_jobs == 0) return hipSuccess;
+  hipError_t e = sort_lds_attr();
+  if (e != hipSuccess) return e;
+  uint32_t *bcount = d_bk, *bstart = d_bk + n_buckets, *bcursor = d_bk + 2 * (size_t)n_buckets;
+  uint32_t *bdist = d_bk + 3 * (size_t)n_buckets, *bout = d_bk + 4 * (size_t)n_buckets, *fail = d_bk + 5 * (size_t)n_buckets;
+  if ((e = hipMemsetAsync(d_bk, 0, (5 * (size_t)n_buckets + n_jobs) * sizeof(uint32_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(bucket_count_kernel, dim3(n_chunks), dim3(BK_WG), 0, st, d_jobs, d_chunk_job, d_hits, bcount);
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(n_jobs), dim3(SORT_WG), 0, st, d_jobs, bcount, bstart, (uint32_t *)nullptr);
+  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_chunks), dim3(BK_WG), 0, st, d_jobs, d_chunk_job, d_hits, bstart,
+                     bcursor, d_tmp);
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(SORT_WG), SORT_LDS_MAX_KEYS * sizeof(uint64_t), st, d_jobs,
+                     d_bucket_job, bcount, bstart, d_tmp, bdist, fail);
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(n_jobs), dim3(SORT_WG), 0, st, d_jobs, bdist, bout, d_ndistinct);
+  hipLaunchKernelGGL(bucket_copy_kernel, dim3(n_buckets), dim3(BK_WG), 0, st, d_jobs, d_bucket_job, bstart, bdist, bout,
+                     fail, d_tmp, d_hits);
+  return hipGetLastError();
 }
 
 hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,

@@ -26,6 +26,8 @@ struct hg_ctx {
   Buf w_gmeta;    // per-genome metadata (hg_genome_meta)
   Buf w_hits;     // sampled hashes, per-genome regions
   Buf w_cnt;      // per-genome raw hit counters + distinct counts
+  Buf w_hits2;    // scratch copy of the hit buffer (bucketed sort of large hash sets)
+  Buf w_lsort;    // job / chunk / bucket tables of the bucketed sort
   Buf w_seq;      // staged sequences (host entry points)
   Buf w_hv;       // staged HV output (host entry points)
   Buf w_misc;     // small scalars (hit counters of dist, flags)
@@ -116,6 +118,28 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
                                  uint32_t max_cap);
+
+// Genomes with more than HG_SORT_LDS_MAX_KEYS sampled hashes: keys are bucketed by value (monotone map, so
+// the concatenation of sorted buckets is sorted), every bucket is sorted + de-duplicated in LDS by its own
+// workgroup, and the distinct lists are packed back into the genome's hit region.
+struct hg_bucket_job {
+  uint64_t hit_off;  // the genome's region in the hit buffer (and in the scratch copy)
+  uint64_t mul;      // bucket(h) = min(P - 1, mulhi64(h, mul))
+  uint32_t n;        // keys (raw hits, duplicates included)
+  uint32_t P;        // buckets
+  uint32_t bucket_first, chunk_first;  // first bucket / first key chunk of this job in the global lists
+  uint32_t genome, pad;
+};
+#define HG_BUCKET_CHUNK 4096u  // keys per counting / scattering workgroup
+// d_bk: 5 * n_buckets + n_jobs uint32 of scratch (zeroed by the launcher); d_fail = d_bk + 5 * n_buckets gets
+// 1 for every job whose buckets could not be de-duplicated in LDS (the caller then runs the in-place sort).
+hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uint32_t n_jobs,
+                                const uint32_t *d_chunk_job, uint32_t n_chunks, const uint32_t *d_bucket_job,
+                                uint32_t n_buckets, uint32_t *d_bk, uint64_t *d_hits, uint64_t *d_tmp,
+                                uint32_t *d_ndistinct);
+// in-place global-memory sort + unique of the listed genomes (power-of-two sized hit regions)
+hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo,
+                                  uint32_t n_todo, uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct);
 
 hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                             const uint64_t *d_hits, const uint32_t *d_ndistinct, uint32_t hv_d,

@@ -197,12 +197,70 @@ def test_sketch_5mbp_genome(ctx, orc, hg):
     assert 3100 < w_nh < 3600 and nh[0] == w_nh and n2[0] == w_n2 and (hv[0] == w_hv).all()
 
 
-def test_large_hit_set_uses_global_sort(ctx, orc):
-    # > 16384 sampled hashes in one genome: exceeds the LDS sort, exercises the in-place variant
+def test_large_hit_set_uses_bucketed_sort(ctx, orc):
+    # > 16384 sampled hashes in one genome: exceeds the one-workgroup LDS sort -> bucketed multi-workgroup sort
     g = orc.synth_genome(9, 120_000)
     want = orc.kmer_hash_sample(g, 21, 2)
     got = ctx.kmer_hash_sample(g, 21, 2)
     assert want.size > 40000 and (got == want).all()
+    # a million distinct hashes (256+ buckets), scaled = 1 (threshold = u64::MAX) and a non-power-of-two count
+    g = orc.synth_genome(10, 3_000_000)
+    for scaled in (3, 1):
+        want = orc.kmer_hash_sample(g[: 1_200_000 if scaled == 1 else g.size], 21, scaled)
+        got = ctx.kmer_hash_sample(g[: 1_200_000 if scaled == 1 else g.size], 21, scaled)
+        assert want.size > 900_000 and got.size == want.size and (got == want).all(), scaled
+
+
+def test_large_hit_set_with_heavy_duplicates(ctx, orc):
+    """Repeats make raw hit counts far larger than the distinct set: buckets overflow LDS and go through the
+    LDS hash-set path; a genome that is one repeated k-mer collapses to a single hash."""
+    unit = orc.synth_genome(11, 30_000)[1:]            # 30 kbp unit repeated 40 times: 1.2 M raw hits, ~30 k distinct
+    g = np.concatenate([np.frombuffer(b"N", np.uint8)] + [unit] * 40)
+    want = orc.kmer_hash_sample(g, 21, 1)
+    got = ctx.kmer_hash_sample(g, 21, 1)
+    assert 29_000 < want.size < 61_000 and got.size == want.size and (got == want).all()
+    poly = np.frombuffer(b"N" + b"A" * 400_000, np.uint8)
+    want = orc.kmer_hash_sample(poly, 21, 1)
+    got = ctx.kmer_hash_sample(poly, 21, 1)
+    assert want.size == 1 and (got == want).all()
+    # every distinct key of a 70 k-key genome in ONE hot bucket is impossible for real hashes, but many distinct
+    # keys per bucket are not: 50 copies of a 300 kbp unit -> buckets of ~37 k raw / ~750 distinct keys
+    unit = orc.synth_genome(12, 300_000)[1:]
+    g = np.concatenate([np.frombuffer(b"N", np.uint8)] + [unit] * 12)
+    want = orc.kmer_hash_sample(g, 21, 1)
+    got = ctx.kmer_hash_sample(g, 21, 1)
+    assert got.size == want.size and (got == want).all()
+
+
+def test_large_hit_set_hash_set_and_inplace_fallback(ctx, orc):
+    import os
+    # hot hashes (a 40-base unit repeated 50 000 times) on top of a random megabase: their buckets overflow LDS
+    # with more than one distinct key -> LDS hash-set de-duplication
+    rnd = orc.synth_genome(13, 1_000_000)
+    g = np.concatenate([rnd, np.frombuffer(b"N", np.uint8), np.tile(orc.synth_genome(14, 40)[1:], 50_000)])
+    want = orc.kmer_hash_sample(g, 21, 1)
+    got = ctx.kmer_hash_sample(g, 21, 1)
+    assert got.size == want.size and (got == want).all()
+    # two buckets for ~100 k distinct keys: the hash set gives up, the genome is sorted in place instead
+    g = orc.synth_genome(15, 200_000)
+    want = orc.kmer_hash_sample(g, 21, 2)
+    try:
+        os.environ["HG_SORT_TEST_BUCKETS"] = "2"
+        got = ctx.kmer_hash_sample(g, 21, 2)
+    finally:
+        del os.environ["HG_SORT_TEST_BUCKETS"]
+    assert want.size > 90_000 and got.size == want.size and (got == want).all()
+
+
+def test_sketch_batch_mixing_small_and_large_sets(ctx, orc, hg):
+    # one batch: ordinary genomes (LDS sort) next to one whose set needs the bucketed sort
+    p = hg.default_params(scaled=40)
+    gs = [orc.synth_genome(20, 200_000), orc.synth_genome(21, 3_000_000), orc.synth_genome(22, 50_000)]
+    hv, n2, nh = ctx.sketch_batch(gs, p)
+    for i, g in enumerate(gs):
+        w_hv, w_n2, w_nh = orc.sketch_genome(g, scaled=40)
+        assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), i
+    assert nh[1] > 60_000 and nh[0] < 16_384
 
 
 # ---- dist ------------------------------------------------------------------------------------------
