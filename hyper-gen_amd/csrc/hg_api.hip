@@ -220,6 +220,7 @@ extern "C" void hg_sketch_params_default(hg_sketch_params *p) {
 namespace {
 
 struct BatchPlan {
+  std::vector<std::pair<uint32_t, uint32_t>> big;  // (genome, stored raw hits) with more than HG_ENC_SLAB hits
   std::vector<hg_genome_meta> meta;
   std::vector<uint32_t> item_genome;
   uint64_t total_slots = 0;
@@ -408,6 +409,12 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     if (!overflow) {
       // hash sets beyond the LDS sort: bucketed multi-workgroup sort (or, where that cannot work, in place)
       if ((s = sort_large_sets(c, pl, h_cnt, n, threshold, d_hits, d_cnt, d_nd)) != HG_OK) return s;
+      h_cnt = static_cast<uint32_t *>(c->h_pin);  // (unchanged unless the pinned scratch grew)
+      pl.big.clear();
+      for (size_t g = 0; g < n; ++g) {
+        const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
+        if (cnt > HG_ENC_SLAB) pl.big.emplace_back((uint32_t)g, cnt);
+      }
       if (!reuse) {  // remember this plan for the next call
         c->plan_offs.assign(offsets, offsets + n);
         c->plan_lens.assign(lens, lens + n);
@@ -452,11 +459,32 @@ extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const 
   s = sample_batch(c, d_seq, offsets, lens, n, p->ksize, threshold, p->scaled, p->seed, p->canonical != 0,
                    p->norm_mode, pl, &d_nd);
   if (s != HG_OK) return s;
+  // genomes with very large hash sets are encoded by several workgroups each (plan from the raw hit counts)
+  hg_encode_split split{};
+  std::vector<uint32_t> items, genomes;
+  if (!pl.big.empty() && pl.big.size() < 65536) {
+    for (size_t k = 0; k < pl.big.size(); ++k) {
+      const uint32_t slabs = std::min<uint32_t>((pl.big[k].second + HG_ENC_SLAB - 1) / HG_ENC_SLAB, 65535u);
+      for (uint32_t sl = 0; sl < slabs; ++sl) items.push_back(pl.big[k].first), items.push_back(sl | ((uint32_t)k << 16));
+      genomes.push_back(pl.big[k].first);
+    }
+    const size_t ib = (items.size() * 4 + 63) & ~(size_t)63, gb = (genomes.size() * 4 + 63) & ~(size_t)63;
+    if ((s = hg_ensure(c, c->w_lsort, ib + gb + 64)) != HG_OK) return s;
+    if ((s = hg_ensure(c, c->w_hits2, genomes.size() * (size_t)p->hv_d * 4 + 64)) != HG_OK) return s;
+    auto *d_items = static_cast<uint32_t *>(c->w_lsort.p);
+    auto *d_genomes = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->w_lsort.p) + ib);
+    HG_HIP(c, hipMemcpyAsync(d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HG_HIP(c, hipMemcpyAsync(d_genomes, genomes.data(), genomes.size() * 4, hipMemcpyHostToDevice, c->stream));
+    split.d_items = d_items, split.d_genomes = d_genomes, split.d_accum = static_cast<uint32_t *>(c->w_hits2.p);
+    split.n_items = (uint32_t)(items.size() / 2), split.n_genomes = (uint32_t)genomes.size();
+  }
   {
     hg_timed tm(c, HG_T_ENCODE);
     HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), (uint32_t)n,
-                               static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2));
+                               static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2,
+                               split.n_items ? &split : nullptr));
   }
+  if (split.n_items) HG_HIP(c, hipStreamSynchronize(c->stream));  // the pageable item tables must outlive their upload
   HG_HIP(c, hipMemcpyAsync(d_nhash, d_nd, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
   return HG_OK;
 }

@@ -300,16 +300,28 @@ constexpr int HI_PLANES = 10;  // counts up to 15 + 16*1023 per flush window
 
 // One workgroup per genome.  hv_d/64 words are spread over lanes; when hv_d/64 < 64*ENC_WAVES
 // several waves share a word and split the hashes.
+// SPLIT = false: one workgroup per genome, writes the hypervector.  Genomes with more than `split_over`
+// hashes are left to the split launch (split_over = ~0u: none are).
+// SPLIT = true : one workgroup per (genome, slab of HG_ENC_SLAB hashes) item; the per-dimension counts are
+// added into accum[slot][word * 64 + bit] and encode_finalize_kernel turns them into the hypervector --
+// a 3 Gbp genome (2 M hashes) otherwise keeps one workgroup busy for 30 ms while hashing it takes 8.
+template <bool SPLIT>
 __global__ __launch_bounds__(ENC_WG) void encode_kernel(
     const hg_genome_meta *__restrict__ meta, const uint64_t *__restrict__ hits,
     const uint32_t *__restrict__ ndistinct, uint32_t hv_d, uint32_t layout,
-    int16_t *__restrict__ hv_out, int32_t *__restrict__ norm2_out) {
+    int16_t *__restrict__ hv_out, int32_t *__restrict__ norm2_out, uint32_t split_over,
+    const uint2 *__restrict__ items, uint32_t *__restrict__ accum) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];  // [64][n_words + 1]
   __shared__ int32_t s_red[ENC_WAVES];
-  const uint32_t g = blockIdx.x;
+  const uint32_t g = SPLIT ? items[blockIdx.x].x : blockIdx.x;
   const hg_genome_meta gm = meta[g];
-  const uint32_t n = ndistinct[g];
-  const uint64_t *__restrict__ hs = hits + gm.hit_off;
+  const uint32_t n_all = ndistinct[g];
+  if (!SPLIT && n_all > split_over) return;
+  const uint32_t slab = SPLIT ? (items[blockIdx.x].y & 0xffffu) : 0u, slot = SPLIT ? (items[blockIdx.x].y >> 16) : 0u;
+  const uint32_t h0 = SPLIT ? slab * HG_ENC_SLAB : 0u;
+  if (SPLIT && h0 >= n_all) return;  // the plan was made from the raw (pre-unique) count
+  const uint32_t n = SPLIT ? (n_all - h0 < HG_ENC_SLAB ? n_all - h0 : HG_ENC_SLAB) : n_all;  // hashes of this workgroup
+  const uint64_t *__restrict__ hs = hits + gm.hit_off + h0;
   const uint32_t n_words = hv_d / 64;
   const uint32_t stride = n_words + 1;  // +1: conflict-free column writes and row reads
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -388,6 +400,14 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
   }
   __syncthreads();
 
+  if (SPLIT) {
+    uint32_t *__restrict__ a = accum + (size_t)slot * hv_d;
+    for (uint32_t i = tid; i < n_words * 64; i += ENC_WG) {
+      const uint32_t w = i >> 6, j = i & 63, c = s_cnt[j * stride + w];
+      if (c) atomicAdd(&a[i], c);  // no value returned: nothing waits for it
+    }
+    return;
+  }
   // hv[d] = 2*count - n (i16 wrapping), laid out per `layout`; norm2 = sum hv^2 (i32 wrapping)
   uint32_t acc = 0;
   int16_t *__restrict__ out = hv_out + (size_t)g * hv_d;
@@ -412,6 +432,40 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
     uint32_t s = 0;
     for (int w = 0; w < ENC_WAVES; ++w) s += (uint32_t)s_red[w];
     norm2_out[g] = (int32_t)s;
+  }
+}
+
+// grid: split genomes.  accum[slot][word * 64 + bit] -> hv (layout, i16 wrapping) + norm
+__global__ __launch_bounds__(ENC_WG) void encode_finalize_kernel(const uint32_t *__restrict__ genomes,
+                                                                 const uint32_t *__restrict__ ndistinct,
+                                                                 const uint32_t *__restrict__ accum, uint32_t hv_d,
+                                                                 uint32_t layout, int16_t *__restrict__ hv_out,
+                                                                 int32_t *__restrict__ norm2_out) {
+  __shared__ int32_t s_red[ENC_WAVES];
+  const uint32_t g = genomes[blockIdx.x], n = ndistinct[g], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t *__restrict__ a = accum + (size_t)blockIdx.x * hv_d;
+  int16_t *__restrict__ out = hv_out + (size_t)g * hv_d;
+  const uint32_t d_full = (hv_d / 64) * 64;
+  uint32_t acc = 0;
+  for (uint32_t d = tid; d < hv_d; d += ENC_WG) {
+    uint32_t c = 0;
+    if (d < d_full) {
+      const uint32_t w = d >> 6, pos = d & 63;
+      const uint32_t j = (layout == HG_LAYOUT_AVX2) ? (16 * (pos & 3) + (pos >> 2)) : pos;
+      c = a[w * 64 + j];
+    }
+    const int16_t v = (int16_t)(uint16_t)(2u * c - n);
+    out[d] = v;
+    acc += (uint32_t)((int32_t)v * (int32_t)v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) s_red[wave] = (int32_t)acc;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t sum = 0;
+    for (int w = 0; w < ENC_WAVES; ++w) sum += (uint32_t)s_red[w];
+    norm2_out[g] = (int32_t)sum;
   }
 }
 
@@ -476,20 +530,34 @@ hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uin
   return hipGetLastError();
 }
 
+static hipError_t encode_attr() {
+  static bool attr_set = false;
+  if (attr_set) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  attr_set = e == hipSuccess;
+  return e;
+}
+
 hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                             const uint64_t *d_hits, const uint32_t *d_ndistinct, uint32_t hv_d,
-                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2) {
+                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2, const hg_encode_split *split) {
   if (n_genomes == 0) return hipSuccess;
   const size_t lds = (size_t)64 * (hv_d / 64 + 1) * sizeof(uint32_t);
   if (lds > 150 * 1024) return hipErrorInvalidValue;  // hv_d up to ~38k
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(encode_kernel, dim3(n_genomes), dim3(ENC_WG), lds, st, d_meta, d_hits,
-                     d_ndistinct, hv_d, layout, d_hv, d_norm2);
+  hipError_t e = encode_attr();
+  if (e != hipSuccess) return e;
+  const bool sp = split && split->n_items;
+  hipLaunchKernelGGL(encode_kernel<false>, dim3(n_genomes), dim3(ENC_WG), lds, st, d_meta, d_hits, d_ndistinct, hv_d,
+                     layout, d_hv, d_norm2, sp ? (uint32_t)HG_ENC_SLAB : ~0u, (const uint2 *)nullptr, (uint32_t *)nullptr);
+  if ((e = hipGetLastError()) != hipSuccess || !sp) return e;
+  if ((e = hipMemsetAsync(split->d_accum, 0, (size_t)split->n_genomes * hv_d * sizeof(uint32_t), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(encode_kernel<true>, dim3(split->n_items), dim3(ENC_WG), lds, st, d_meta, d_hits, d_ndistinct, hv_d,
+                     layout, d_hv, d_norm2, ~0u, reinterpret_cast<const uint2 *>(split->d_items), split->d_accum);
+  hipLaunchKernelGGL(encode_finalize_kernel, dim3(split->n_genomes), dim3(ENC_WG), 0, st, split->d_genomes, d_ndistinct,
+                     split->d_accum, hv_d, layout, d_hv, d_norm2);
   return hipGetLastError();
 }

@@ -141,9 +141,19 @@ hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uin
 hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo,
                                   uint32_t n_todo, uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct);
 
+// Genomes with more than HG_ENC_SLAB distinct hashes can be encoded by several workgroups: d_items[i] =
+// {genome, slab | slot << 16} for every slab of HG_ENC_SLAB hashes (planned from an upper bound of the distinct
+// count), d_genomes[slot] = genome, d_accum = n_genomes * hv_d uint32 of scratch.  Slabs and slots are < 65536.
+#define HG_ENC_SLAB 32768u
+struct hg_encode_split {
+  const uint32_t *d_items;    // uint2 pairs
+  const uint32_t *d_genomes;
+  uint32_t *d_accum;
+  uint32_t n_items, n_genomes;
+};
 hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                             const uint64_t *d_hits, const uint32_t *d_ndistinct, uint32_t hv_d,
-                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2);
+                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2, const hg_encode_split *split = nullptr);
 
 // ---- dist kernels ------------------------------------------------------------------------------
 struct hg_dist_args {
