@@ -339,7 +339,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   constexpr int LROW = GLDS ? BK : LDS_ROW;  // elements per LDS row
   constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
   static_assert(LOADS == 4 && (GLDS || TC::LOADS_B == 4), "staging macros move 4 pieces per operand");
-  static_assert(NT == 4 || (GLDS && TC::LOADS_B == NT), "wide tiles exist for the LDS-DMA variant only");
+  static_assert(NT == 4 || GLDS, "wide tiles exist for the LDS-DMA variant only");
   // two LDS stages of (A tile + B tile)
   extern __shared__ __attribute__((aligned(16))) _Float16 sAB[];
   constexpr uint32_t A_ELEMS = BM * LROW, B_ELEMS = BN * LROW;
@@ -438,29 +438,38 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // tile's first row, 32-bit per-lane offset, K offset in an SGPR).  The global_load_lds form moves the same
   // bytes, but being FLAT-encoded it makes the compiler flush lgkmcnt to 0 at every LDS dependency while
   // one is in flight, which serialises the fragment reads below with the MFMAs.
-  // byte offsets of this thread's 16-byte pieces inside the A / B row block (NT of vB are used; a
-  // template-sized array here makes hipcc drop the kernel's host stub without a diagnostic)
-  uint32_t vA[4], vB[5];
-  static_assert(NT <= 5, "vB holds five pieces");
+  // DMA issue is left to LW of the 8 waves -- one per SIMD when LW = 4: a wave whose VMEM instructions queue
+  // up behind the workgroup's burst cannot issue MFMAs meanwhile, and with every wave loading right after the
+  // barrier both waves of a SIMD sit in that queue together while the matrix pipe idles.  With one loader
+  // per SIMD its partner keeps the pipe busy and the loader catches up while the partner waits at the barrier.
+#ifndef HG_DMA_LOADER_WAVES
+#define HG_DMA_LOADER_WAVES 4
+#endif
+  constexpr int LW = HG_DMA_LOADER_WAVES, LT = LW * 64;  // loader waves / threads
+  constexpr int PA = BM * 8 / LT, PB = BN * 8 / LT;      // 16-byte pieces per loader thread, A / B tile
+  // byte offsets of this thread's pieces inside the A / B row block (fixed-size arrays: a template-sized
+  // array here makes hipcc drop the kernel's host stub without a diagnostic)
+  uint32_t vA[8], vB[10];
+  static_assert(!GLDS || (PA <= 8 && PB <= 10), "piece tables too small");
   __amdgpu_buffer_rsrc_t rsA, rsB;
   if (GLDS) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const uint32_t sl = i * THREADS + tid, r = sl >> 3, ch = (sl & 7) ^ ((r >> 1) & 7);
+    for (int i = 0; i < PB; ++i) {
+      const uint32_t sl = i * LT + (tid & (LT - 1)), r = sl >> 3, ch = (sl & 7) ^ ((r >> 1) & 7);
       vB[i] = (r * g.ldk + ch * 8) * 2;
-      if (i < 4) vA[i] = vB[i];
+      if (i < PA) vA[i] = vB[i];
     }
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
   }
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
 #define HG_DMA(stage, k0)                                                                                   \
-  {                                                                                                         \
+  if (wave < (uint32_t)LW) {                                                                                \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
-    _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                                        \
-      if (i < 4)                                                                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * THREADS * 8), 16, vA[i < 4 ? i : 0], (k0) * 2, 0, 0); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * THREADS * 8), 16, vB[i], (k0) * 2, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                        \
+      if (i < PA)                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
   constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
