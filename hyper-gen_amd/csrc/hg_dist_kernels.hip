@@ -8,8 +8,10 @@
 // small integers (|x| ~ sqrt(n_hashes)), so they are converted once to f16 (exact for
 // |x| <= 2048) and multiplied with v_mfma_f32_16x16x32_f16; products are exact in f32, and the
 // f32 accumulator is exact as long as sum |r||q| over the accumulated K range stays below 2^24.
-// The prepass measures a guaranteed Cauchy-Schwarz bound for that sum per K-chunk; the kernel
-// moves the accumulator into i32 registers at chunk boundaries chosen from it.  If no chunk
+// The prepass measures a guaranteed Cauchy-Schwarz bound for that sum: normally the whole-row bound
+// shows that ONE accumulation window covers K (verdict formed on the device, the GEMM queued
+// behind it speculatively); otherwise a second prepass measures the bound per K-chunk and the
+// kernel moves the accumulator into i32 registers at chunk boundaries chosen from it.  If no chunk
 // size is safe (or |x| > 2048) the always-exact integer VALU kernel is used instead.  Either
 // way the dot product equals the reference's i32 value bit for bit; only logf differs from
 // glibc by <= 1 ulp.

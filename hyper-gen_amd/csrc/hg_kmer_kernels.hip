@@ -7,8 +7,9 @@
 // two 544-byte scratch arrays):
 //
 //  * one lane owns a 32-base register window and the M = (33-k)&~3 k-mers that start in
-//    its first M bases; a 256-lane workgroup walks 8 consecutive tiles, so one 5 Mbp
-//    genome is ~200 workgroups and a 1000-genome batch fills the 256 CUs many times;
+//    its first M bases (k <= 21; k = 22..32: a 64-base window and 32 starts); a 256-lane
+//    workgroup walks 8 consecutive tiles, so one 5 Mbp genome is ~200 workgroups and a
+//    1000-genome batch fills the 256 CUs many times;
 //  * bases are classified 4 at a time (SWAR on dwords): 2-bit codes, upper-cased ASCII
 //    and complement ASCII come from v_perm_b32 lookups, validity from one XOR;
 //  * the canonical strand is chosen by ONE 64-bit compare of 2-bit packed k-mers
@@ -16,14 +17,15 @@
 //    byte-wise compare, src/cuda_kernel.cu:306-311);
 //  * the hash input words are cut out of the register window with v_alignbyte_b32 /
 //    v_perm_b32 (constant selectors), only the chosen strand is hashed, nothing touches
-//    scratch or LDS;
+//    scratch;
 //  * t1ha2 is specialised at compile time for k (17..24 => 3 mixups + final = 4 128-bit
 //    products + 2 64-bit products = 22 v_mad_u64_u32 / v_mul_lo_u32);
-//  * survivors (1/scaled of the k-mers) are appended through one aggregated atomic per
-//    wave into the genome's slice of the hit buffer (lossless: no 8-slot cap like
-//    src/cuda_kernel.cu:316, hash value 0 is kept).
+//  * survivors (1/scaled of the k-mers) are staged in a small LDS list and the workgroup
+//    reserves its range of the genome's hit slice with ONE global atomic at the end of its
+//    work item (a returning global atomic per hit parked the wave for a memory round trip);
+//    lossless: no 8-slot cap like src/cuda_kernel.cu:316, hash value 0 is kept.
 //
-// The kernel is integer-VALU bound (~170 lane-ops per input byte), not HBM bound.
+// The kernel is integer-VALU bound (~100 lane-instructions per k-mer), not HBM bound.
 #include <cstdlib>
 #include <utility>
 
