@@ -13,6 +13,8 @@
 //               hashes, ~6 logic ops per word instead of 128 per-bit adds), expanded once
 //               per genome into LDS counters, and written out in the scalar or the AVX2
 //               dimension order.
+#include <atomic>
+
 #include "hg_internal.h"
 
 namespace {
@@ -471,15 +473,23 @@ __global__ __launch_bounds__(ENC_WG) void encode_finalize_kernel(const uint32_t 
 
 }  // namespace
 
+// hipFuncSetAttribute is per device: remember per device (one context per GPU may live in one process)
+static bool attr_done_on_this_device(std::atomic<uint64_t> &mask, bool set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+  if (set) mask.fetch_or(1ull << dev);
+  return (mask.load() >> dev) & 1;
+}
+
 static hipError_t sort_lds_attr() {
-  static bool attr_set = false;
-  if (attr_set) return hipSuccess;
+  static std::atomic<uint64_t> done{0};
+  if (attr_done_on_this_device(done, false)) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_unique_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_KEYS * sizeof(uint64_t));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bucket_sort_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_KEYS * sizeof(uint64_t));
-  attr_set = e == hipSuccess;
+  if (e == hipSuccess) attr_done_on_this_device(done, true);
   return e;
 }
 
@@ -531,14 +541,14 @@ hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uin
 }
 
 static hipError_t encode_attr() {
-  static bool attr_set = false;
-  if (attr_set) return hipSuccess;
+  static std::atomic<uint64_t> done{0};
+  if (attr_done_on_this_device(done, false)) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  attr_set = e == hipSuccess;
+  if (e == hipSuccess) attr_done_on_this_device(done, true);
   return e;
 }
 
