@@ -267,11 +267,8 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
       FA[t] = __builtin_amdgcn_perm(0u, 0x54474341u, cd);  // "ACGT"[code]
       CA[t] = __builtin_amdgcn_perm(0u, 0x41434754u, cd);  // "TGCA"[code]
       dacc |= u ^ FA[t];
-      // (cd << 6) | cd etc.; written as v_lshl_or_b32 because LLVM would otherwise turn the
-      // disjoint shift-or pairs into quarter-rate v_mul_lo_u32 by 65 / 4097
-      uint32_t t1 = lshl_or<6>(cd, cd);
-      uint32_t t2 = lshl_or<12>(t1, t1);
-      uint32_t p = (t2 >> 18) & 0xFFu;  // c0 | c1<<2 | c2<<4 | c3<<6
+      // c0 | c1<<2 | c2<<4 | c3<<6 as ONE byte dot product with (1, 4, 16, 64)
+      const uint32_t p = __builtin_amdgcn_udot4(cd, 0x40100401u, 0u, false);
       if (t < 4) Glo |= p << (8 * t);
       else Ghi |= p << (8 * (t - 4));
     }
@@ -448,9 +445,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast64(
       FA[t] = __builtin_amdgcn_perm(0u, 0x54474341u, cd);
       CA[t] = __builtin_amdgcn_perm(0u, 0x41434754u, cd);
       dacc |= u ^ FA[t];
-      uint32_t t1 = lshl_or<6>(cd, cd);
-      uint32_t t2 = lshl_or<12>(t1, t1);
-      uint32_t p = (t2 >> 18) & 0xFFu;
+      const uint32_t p = __builtin_amdgcn_udot4(cd, 0x40100401u, 0u, false);
       Gw[t >> 2] |= p << (8 * (t & 3));
     }
     auto pairrev = [](uint32_t v) {
