@@ -42,3 +42,15 @@ for v in variants:
     print("dist %dx%d [%s]: gemm median %.3f ms = %.1f TFLOP/s (best %.3f ms = %.1f), prep %.3f ms, hits %d" % (
         a.n, a.n, v or "default", med, a.n * a.n * 8192 / med / 1e9, best, a.n * a.n * 8192 / best / 1e9,
         sorted(x[1] for x in res[v])[len(ms) // 2], res[v][0][2]))
+if os.environ.get("HG_DIST_WALL"):
+    import time
+    for _ in range(3):
+        ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False, a.th,
+                     hits.data_ptr(), cap)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False, a.th,
+                     hits.data_ptr(), cap)
+    torch.cuda.synchronize()
+    print("wall per call: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
