@@ -59,7 +59,7 @@ class FileSketch(C.Structure):
 
 EXPORTS = [
     "hg_status_str", "hg_last_error", "hg_version", "hg_ctx_create", "hg_ctx_destroy",
-    "hg_ctx_set_stream", "hg_ctx_sync", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
+    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
     "hg_copy_h2d", "hg_copy_d2h", "hg_sketch_params_default", "hg_kmer_hash_sample",
     "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack",
@@ -98,6 +98,7 @@ def lib():
         "hg_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "hg_ctx_destroy": (None, [vp]),
         "hg_ctx_set_stream": (C.c_int, [vp, vp]),
+        "hg_ctx_reset_stream": (C.c_int, [vp]),
         "hg_ctx_sync": (C.c_int, [vp]),
         "hg_device_count": (C.c_int, []),
         "hg_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
@@ -188,7 +189,11 @@ class Context:
         return st
 
     def set_stream(self, stream_handle):
+        """Run on the given hipStream_t handle; 0 / None is HIP's default stream (torch's default current stream)."""
         self._ck(lib().hg_ctx_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def reset_stream(self):
+        self._ck(lib().hg_ctx_reset_stream(self._h))
 
     def sync(self):
         self._ck(lib().hg_ctx_sync(self._h))

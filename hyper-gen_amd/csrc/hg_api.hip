@@ -91,7 +91,13 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
 
 extern "C" hg_status hg_ctx_set_stream(hg_ctx *c, void *hip_stream) {
   if (!c) return HG_ERR_INVALID;
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's default stream, on purpose
+  return HG_OK;
+}
+
+extern "C" hg_status hg_ctx_reset_stream(hg_ctx *c) {
+  if (!c) return HG_ERR_INVALID;
+  c->stream = c->own_stream;
   return HG_OK;
 }
 

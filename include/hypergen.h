@@ -53,9 +53,12 @@ const char *hg_version(void);
  * PTX/code-object loading step. */
 hg_status hg_ctx_create(int device_id, hg_ctx **out);
 void hg_ctx_destroy(hg_ctx *ctx);
-/* run all subsequent work on an existing hipStream_t (e.g. torch's current stream);
- * NULL restores the ctx's own stream. */
+/* run all subsequent work on an existing hipStream_t (e.g. torch's current stream).  The handle is used as
+ * given: NULL is HIP's default (null) stream -- which IS torch's current stream unless the caller changed
+ * it -- so that the ctx's kernels are ordered with the caller's own work on that stream.
+ * hg_ctx_reset_stream goes back to the ctx's private non-blocking stream (the state after hg_ctx_create). */
 hg_status hg_ctx_set_stream(hg_ctx *ctx, void *hip_stream);
+hg_status hg_ctx_reset_stream(hg_ctx *ctx);
 hg_status hg_ctx_sync(hg_ctx *ctx);
 int hg_device_count(void);
 

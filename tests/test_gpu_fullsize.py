@@ -114,3 +114,46 @@ def test_host_fed_batch_in_several_uploads_equals_resident(sketched, orc):
     for i in (0, 1, 13, 14, 15, 47):
         w_hv, w_n2, w_nh = orc.sketch_genome(ragged[i])
         assert r_nh[i] == w_nh and r_n2[i] == w_n2 and np.array_equal(r_hv[i], w_hv), i
+
+
+@pytest.mark.parametrize("tile", ["", "big", "wide", "small"])
+def test_dist_10k_thresholded_equals_full_matrix(tile):
+    """BASELINE configs[3] size: the thresholded entry point (speculative schedule, 256-wide / 320-wide / 128
+    tiles, LDS-DMA with loader waves, phase-0 filter, one reservation per workgroup) must report exactly the
+    pairs whose ANI in the full-matrix mode (a different kernel variant) reaches the threshold, with the same
+    float, for an asymmetric and a symmetric call."""
+    import os
+    import bench
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    ctx = hg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 10000
+    hv = bench.clustered_hvs(n, 0, dev)
+    n2 = (hv.int() ** 2).sum(1).int()
+    full = torch.empty((n, n), dtype=torch.float32, device=dev)
+    ctx.dist_full_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, full.data_ptr())
+    torch.cuda.synchronize()
+    cap = 4_000_000
+    hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+    try:
+        if tile:
+            os.environ["HG_DIST_TILE"] = tile
+        for sym, th in ((False, 85.0), (True, 86.5)):
+            found, st = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, sym, th,
+                                     hits.data_ptr(), cap)
+            torch.cuda.synchronize()
+            assert st == 0 and 0 < found < cap
+            h = hits[: found * 3].view(found, 3)
+            ri, qi, ani = h[:, 0].long(), h[:, 1].long(), h[:, 2].view(torch.float32)
+            want = full >= th
+            if sym:
+                want = torch.triu(want, diagonal=1)
+            assert found == int(want.sum())
+            got = torch.zeros_like(want)
+            got[ri, qi] = True
+            assert bool((got == want).all())
+            assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+    finally:
+        os.environ.pop("HG_DIST_TILE", None)
+        ctx.close()
