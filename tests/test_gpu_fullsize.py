@@ -157,3 +157,37 @@ def test_dist_10k_thresholded_equals_full_matrix(tile):
     finally:
         os.environ.pop("HG_DIST_TILE", None)
         ctx.close()
+
+
+def test_work_is_ordered_with_the_callers_stream():
+    """Inputs produced by the caller's kernels on a stream (default and non-default) and consumed by the ctx
+    right away, no synchronisation in between: results must equal the synchronised run."""
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    n = 6000
+    ctx = hg.Context(0)
+    try:
+        want = None
+        for use_side_stream in (False, True, False):
+            side = torch.cuda.Stream() if use_side_stream else torch.cuda.current_stream()
+            with torch.cuda.stream(side):
+                ctx.set_stream(side.cuda_stream)
+                g = torch.Generator(device=dev)
+                g.manual_seed(11)
+                base = torch.randint(-60, 60, (60, D), generator=g, device=dev, dtype=torch.int32)
+                hv = (base[torch.arange(n, device=dev) % 60] + torch.randint(-25, 25, (n, D), generator=g, device=dev,
+                                                                            dtype=torch.int32)).to(torch.int16)
+                n2 = (hv.int() ** 2).sum(1).int()
+                hits = torch.empty(3 * 2_000_000, dtype=torch.int32, device=dev)
+                found, st = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, True, 90.0,
+                                         hits.data_ptr(), 2_000_000)
+                side.synchronize()
+            assert st == 0 and found > 1000
+            if want is None:
+                torch.cuda.synchronize()
+                found2, _ = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, True, 90.0,
+                                         hits.data_ptr(), 2_000_000)
+                want = found2
+            assert found == want, (use_side_stream, found, want)
+    finally:
+        ctx.close()
