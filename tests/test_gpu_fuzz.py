@@ -7,7 +7,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 ALPHA = np.frombuffer(b"ACGTacgtNnRYKMUu-.*\n\r>", np.uint8)
+SOAK = int(os.environ.get("HG_FUZZ_SEEDS", "0"))  # extra seeds for a one-off soak run
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +41,7 @@ def random_genome(rng, n):
     return s
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + SOAK))
 def test_random_hash_sets(ctx, orc, hg, seed):
     rng = np.random.default_rng(7000 + seed)
     for _ in range(6):
@@ -56,7 +59,7 @@ def test_random_hash_sets(ctx, orc, hg, seed):
         assert got.size == want.size and (got == want).all(), (seed, k, n, scaled, canonical, norm, sd)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + SOAK // 4))
 def test_random_ragged_batches(ctx, orc, hg, seed):
     rng = np.random.default_rng(8000 + seed)
     k = int(rng.choice([15, 21, 27, 31]))
@@ -73,7 +76,7 @@ def test_random_ragged_batches(ctx, orc, hg, seed):
         assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (seed, i, lens[i])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + SOAK // 4))
 def test_random_thresholded_dist(ctx, orc, seed):
     rng = np.random.default_rng(9000 + seed)
     R, Q = int(rng.integers(1, 700)), int(rng.integers(1, 700))
