@@ -87,6 +87,25 @@ def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100):
     return out
 
 
+def valu_issue(kmer_ms, n_genomes):
+    """Secondary, informative roofline of the k-mer kernel: its VALU instruction rate against the issue rate
+    the same instruction mix reaches in tools/gpu_microbench.hip.  Instruction count and kernel cycles come
+    from the committed PMC passes (profiles/r01_pmc.json: SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this command)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        k = [v for name, v in d.items() if name.startswith("kmer_sample_fast")][0]
+        insts, cycles = k["SQ_INSTS_VALU"], k["GRBM_GUI_ACTIVE"] / 8.0
+    except Exception:
+        return None
+    rate = insts / (1024 * cycles)  # wave-instructions per SIMD per cycle, as profiled
+    # mix of the kernel: ~42 slow-class (3.9 cycles) + ~55 plain (2.3 cycles) instructions per k-mer
+    # (profiles/r01_instruction_rates.txt) -> 97 instructions in ~290 cycles
+    bound = 97.0 / (42 * 3.9 + 55 * 2.3)
+    return {"valu_instr_per_simd_cycle": rate, "mix_issue_bound": bound, "frac": rate / bound,
+            "valu_instr_per_kmer": insts * 64.0 / (n_genomes * (L_GENOME + 1 - KSIZE + 1)) if n_genomes == 1000 else None,
+            "source": "profiles/r01_pmc.json (rocprofv3 --pmc of this command), profiles/r01_instruction_rates.txt"}
+
+
 def effective_cores():
     """Host cores this process may really use: min(cpu_count, affinity mask, cgroup CPU quota),
     capped at 255 like the reference's `-t` (u8, src/utils.rs:54-56)."""
@@ -231,7 +250,8 @@ def main():
                      "kernel": "kmer_sample_fast<21,true>", "launch_ms": kmer_avg_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "nominally a scan, so priced against HBM; the true binder is integer VALU issue "
-                             "(t1ha2: 22 half-rate multiplies + ~100 other VALU ops per input byte)",
+                             "(~97 VALU instructions per k-mer, ~60 of them the t1ha2 hash; see valu_issue)",
+                     "valu_issue": valu_issue(kmer_avg_ms, N),
                      "kmer_hashes_per_sec": N * (L_GENOME + 1 - KSIZE + 1) / (kmer_avg_ms * 1e-3)},
         "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in tm.items() if v[1]},
     }
