@@ -66,6 +66,12 @@ __global__ void k(uint32_t *out, uint32_t seed, unsigned long long *cycles) {
       } else if (OP == 15) {  // v_lshrrev_b32
         asm volatile("v_lshrrev_b32 %0, 1, %0\n v_lshrrev_b32 %1, 1, %1\n v_lshrrev_b32 %2, 1, %2\n v_lshrrev_b32 %3, 1, %3"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      } else if (OP == 27) {  // v_bcnt_u32_b32 (popcount + add: the Hamming kernel's second instruction)
+        asm volatile("v_bcnt_u32_b32 %0, %4, %0\n v_bcnt_u32_b32 %1, %4, %1\n v_bcnt_u32_b32 %2, %4, %2\n v_bcnt_u32_b32 %3, %4, %3"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+      } else if (OP == 28) {  // v_dot4_u32_u8 and v_dot2_i32_i16 style packed dot (k-mer classification / dist prepass)
+        asm volatile("v_dot4_u32_u8 %0, %4, %5, %0\n v_dot4_u32_u8 %1, %4, %5, %1\n v_dot4_u32_u8 %2, %4, %5, %2\n v_dot4_u32_u8 %3, %4, %5, %3"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed), "v"(0x40100401u));
       } else if (OP == 16) {  // v_cndmask_b32 (VOP2, vcc)
         asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");
@@ -172,6 +178,8 @@ int main() {
   run<24>("cmp64 + 3 cndmask");
   run<26>("cmp32 + 16 cndmask");
   run<25>("v_bfi_b32");
+  run<27>("v_bcnt_u32_b32");
+  run<28>("v_dot4_u32_u8");
   run<19>("mix mad/mov/mad/xor");
   run<20>("mix add/perm/add/align");
   return 0;
