@@ -1,0 +1,20 @@
+"""Host-side C++ of the product (bit packing, bincode .sketch container, FASTA / gzip readers) under
+AddressSanitizer + UBSan on the CPU build: round trips, truncated files, CRLF / empty / header-only inputs."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_formats_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "driver"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", os.path.join(ROOT, "tests", "native", "formats_sanitizer_driver.cpp"),
+                           os.path.join(ROOT, "hyper-gen_amd", "csrc", "hg_formats.cpp"), "-I", os.path.join(ROOT, "include"),
+                           "-lz", "-o", str(exe)])
+    out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "asan driver ok" in out.stdout, out.stdout + out.stderr
