@@ -51,6 +51,25 @@ int main(int argc, char **argv) {
     hg_status st = hg_sketch_file_read((T + "/c.sketch").c_str(), &g);
     if (st == HG_OK) hg_sketch_file_free(g);
   }
+  // random corruption of length fields / payload: must fail or succeed, never read out of bounds
+  {
+    FILE *in = fopen((T + "/t.sketch").c_str(), "rb"); std::vector<unsigned char> all(1 << 16); size_t n = fread(all.data(), 1, all.size(), in); fclose(in);
+    for (int rep = 0; rep < 300; ++rep) {
+      std::vector<unsigned char> bad(all.begin(), all.begin() + n);
+      for (int k = 0; k < 1 + (int)(rng() % 4); ++k) bad[rng() % n] = (unsigned char)rng();
+      FILE *out = fopen((T + "/c.sketch").c_str(), "wb"); fwrite(bad.data(), 1, n, out); fclose(out);
+      hg_sketch_file *g = nullptr;
+      if (hg_sketch_file_read((T + "/c.sketch").c_str(), &g) == HG_OK) {
+        for (size_t i = 0; i < hg_sketch_file_count(g); ++i) {
+          const hg_file_sketch *r = hg_sketch_file_get(g, i);
+          volatile unsigned acc = 0;
+          for (uint64_t j = 0; j < r->hv_len; ++j) acc += (unsigned)r->hv[j];
+          acc += (unsigned)strlen(r->file_str);
+        }
+        hg_sketch_file_free(g);
+      }
+    }
+  }
   // FASTA readers: plain, CRLF, no trailing newline, empty, gz, reuse buffer
   const char *cases[] = {">a\nACGT\nAC\n>b\nGG\n", ">a\r\nACGT\r\nAC\r\n", ">x\nACGT", "", "\n\n", ">only header\n"};
   uint8_t *buf = nullptr; size_t cap = 0;
