@@ -105,12 +105,6 @@ __device__ __forceinline__ uint64_t final64(uint64_t a, uint64_t b) {
   unsigned __int128 m = (unsigned __int128)(x ^ y) * P5;
   return (uint64_t)m ^ (uint64_t)(m >> 64);
 }
-template <int SH>
-__device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t c) {  // (a << SH) | c
-  uint32_t r;
-  asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
-  return r;
-}
 
 // t1ha2_atonce for a compile-time length K <= 32 whose bytes are given as little-endian
 // dwords d[0..ceil(K/4)) with the unused bytes of the last dword zero
