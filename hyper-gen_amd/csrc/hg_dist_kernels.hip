@@ -455,11 +455,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   static_assert(!GLDS || (PA <= 8 && PB <= 10), "piece tables too small");
   __amdgpu_buffer_rsrc_t rsA, rsB;
   if (GLDS) {
+    constexpr int PMAX = PA > PB ? PA : PB;
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
+    for (int i = 0; i < PMAX; ++i) {
       const uint32_t sl = i * LT + (tid & (LT - 1)), r = sl >> 3, ch = (sl & 7) ^ ((r >> 1) & 7);
-      vB[i] = (r * g.ldk + ch * 8) * 2;
-      if (i < PA) vA[i] = vB[i];
+      const uint32_t off = (r * g.ldk + ch * 8) * 2;
+      if (i < PB) vB[i] = off;
+      if (i < PA) vA[i] = off;
     }
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
@@ -468,10 +470,11 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #define HG_DMA(stage, k0)                                                                                   \
   if (wave < (uint32_t)LW) {                                                                                \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
-    _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                        \
+    _Pragma("unroll") for (int i = 0; i < (PA > PB ? PA : PB); ++i) {                                       \
       if (i < PA)                                                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i], (k0) * 2, 0, 0); \
+      if (i < PB)                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
   constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
@@ -894,10 +897,20 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   if (const char *e = std::getenv("HG_DIST_TILE")) {  // test hook: force a geometry ("big"/"wide" need !full && whole_k)
     if (!std::strcmp(e, "big")) big = !full && whole_k, nt = 4;
     else if (!std::strcmp(e, "wide")) big = !full && whole_k, nt = 5;
+    else if (!std::strcmp(e, "nt3")) big = !full && whole_k, nt = 3;
     else if (!std::strcmp(e, "big_reg")) big = !full && whole_k, dma = false, nt = 4;
     else if (!std::strcmp(e, "small")) big = false;
   }
   if (!big || !dma) nt = 4;
+  // several exact f32 windows per row (sketches of more than ~4 000 hashes at D = 4096): the i32 side
+  // accumulators double the accumulator registers, so the 256-row geometry narrows to 64 * NT_CHUNKED columns
+  constexpr int NT_CHUNKED = 3;
+  bool big_chunked = !full && !whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
+  if (const char *e = std::getenv("HG_DIST_TILE")) {
+    if (!std::strcmp(e, "small")) big_chunked = false;
+    else if (!std::strcmp(e, "big") || !std::strcmp(e, "wide")) big_chunked = !full && !whole_k;
+  }
+  if (big_chunked) big = true, nt = NT_CHUNKED;
   const uint32_t bm = big ? 256 : 128, bn = big ? (uint32_t)nt * 64 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
@@ -916,7 +929,11 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
   const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 4 + 64);
   const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 4 + 64);
-  if (big && dma && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
+  const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
+                                              8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 4 + 64);
+  if (big_chunked) le = launch(&dist_mfma_kernel<true, false, true, true, NT_CHUNKED>, TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
+  else if (big && dma && nt == 3) le = launch(&dist_mfma_kernel<false, false, true, true, 3>, TileCfg<true, 3>::THREADS, lds_chunked);
+  else if (big && dma && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
   else if (big && dma) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
   else if (big) le = launch(&dist_mfma_kernel<false, false, true, false>, TileCfg<true>::THREADS, lds_big);
   else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);

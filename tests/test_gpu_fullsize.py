@@ -116,12 +116,14 @@ def test_host_fed_batch_in_several_uploads_equals_resident(sketched, orc):
         assert r_nh[i] == w_nh and r_n2[i] == w_n2 and np.array_equal(r_hv[i], w_hv), i
 
 
-@pytest.mark.parametrize("tile", ["", "big", "wide", "small"])
-def test_dist_10k_thresholded_equals_full_matrix(tile):
-    """BASELINE configs[3] size: the thresholded entry point (speculative schedule, 256-wide / 320-wide / 128
-    tiles, LDS-DMA with loader waves, phase-0 filter, one reservation per workgroup) must report exactly the
+@pytest.mark.parametrize("tile,nhash", [("", 3333), ("big", 3333), ("wide", 3333), ("nt3", 3333), ("small", 3333),
+                                        ("", 6666), ("small", 6666), ("", 20000)])
+def test_dist_10k_thresholded_equals_full_matrix(tile, nhash):
+    """BASELINE configs[3] size: the thresholded entry point (speculative schedule, 256-wide / 320-wide / 192-wide
+    / 128 tiles, LDS-DMA with loader waves, phase-0 filter, one reservation per workgroup) must report exactly the
     pairs whose ANI in the full-matrix mode (a different kernel variant) reaches the threshold, with the same
-    float, for an asymmetric and a symmetric call."""
+    float, for an asymmetric and a symmetric call.  nhash > 4096: sketches whose dot products need several exact
+    f32 accumulation windows (speculation vetoed, windowed statistics, i32 side accumulators, 256 x 192 tiles)."""
     import os
     import bench
     import hypergen_amd as hg
@@ -129,7 +131,7 @@ def test_dist_10k_thresholded_equals_full_matrix(tile):
     ctx = hg.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     n = 10000
-    hv = bench.clustered_hvs(n, 0, dev)
+    hv = bench.clustered_hvs(n, 0, dev, n=nhash)
     n2 = (hv.int() ** 2).sum(1).int()
     full = torch.empty((n, n), dtype=torch.float32, device=dev)
     ctx.dist_full_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, full.data_ptr())

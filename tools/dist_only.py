@@ -14,11 +14,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10000)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--th", type=float, default=85.0)
+ap.add_argument("--nhash", type=int, default=3333, help="hashes per sketch (3333 = 5 Mbp at scaled 1500); > 4096 needs two exact f32 windows at D = 4096")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-hv = bench.clustered_hvs(a.n, 0, dev)
+hv = bench.clustered_hvs(a.n, 0, dev, n=a.nhash)
 n2 = (hv.int() ** 2).sum(1).int()
 cap = max(1 << 20, a.n * a.n // 20)
 hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
