@@ -702,25 +702,25 @@ extern "C" hg_status hg_dist_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32
   if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   HG_HIP(c, hipSetDevice(c->device));
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
-  auto *d_count = static_cast<uint32_t *>(c->w_misc.p);  // [0] hit counter, [1] exactness verdict
-  HG_HIP(c, hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), c->stream));
+  auto *d_count = static_cast<uint32_t *>(c->w_misc.p);  // [0] hit counter, [1] exactness verdict, [2] its window length
+  HG_HIP(c, hipMemsetAsync(d_count, 0, 4 * sizeof(uint32_t), c->stream));
   hg_dist_args a{};
   a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
   a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
   a.hits = d_out, a.hit_count = d_count;
   a.hit_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
   a.ani_th = ani_th, a.symmetric = symmetric;
-  bool speculated = false;
-  if ((s = hg_run_dist(c, a, d_count + 1, &speculated)) != HG_OK) return s;
+  int spec_cover = -1;
+  if ((s = hg_run_dist(c, a, d_count + 1, &spec_cover)) != HG_OK) return s;
   if ((s = hg_ensure_pinned(c, 64)) != HG_OK) return s;
   auto *h_res = static_cast<uint32_t *>(c->h_pin);
-  HG_HIP(c, hipMemcpyAsync(h_res, d_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipMemcpyAsync(h_res, d_count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));
-  if (speculated && h_res[1]) {  // the guarded launch did nothing: run the statistics-driven schedule
-    HG_HIP(c, hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), c->stream));
+  if (spec_cover >= 0 && (int)h_res[1] > spec_cover) {  // no guarded launch applied: statistics-driven schedule
+    HG_HIP(c, hipMemsetAsync(d_count, 0, 4 * sizeof(uint32_t), c->stream));
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
     h_res = static_cast<uint32_t *>(c->h_pin);  // the pinned scratch may have grown meanwhile
-    HG_HIP(c, hipMemcpyAsync(h_res, d_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HG_HIP(c, hipMemcpyAsync(h_res, d_count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HG_HIP(c, hipStreamSynchronize(c->stream));
   }
   const uint32_t found = h_res[0];

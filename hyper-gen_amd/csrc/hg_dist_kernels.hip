@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const int16_t *__restrict__ h
 // per workgroup, no LDS and no barrier: all of a row's 16-byte loads are in flight together, the two row
 // statistics are reduced with DPP.  If the whole-row bound turns out unsafe, hg_run_dist runs prep_kernel
 // (all candidate windows) as a second pass.
-constexpr uint32_t PREP_SLOTS = 1024;
+constexpr uint32_t PREP_SLOTS = 1024, PREP_SLOT_VALS = 4, PREP_MAX_WIN = 32;
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ uint32_t dpp_get(uint32_t v) {  // v[lane permuted by CTRL], 0 where nothing arrives
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
@@ -162,9 +162,14 @@ __device__ __forceinline__ unsigned long long dpp_get64(unsigned long long v) {
 __global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restrict__ hv, uint32_t rows,
                                                         uint32_t hv_d, uint32_t kp, uint32_t ldk,
                                                         _Float16 *__restrict__ out,
-                                                        unsigned long long *__restrict__ slots) {
-  const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                        unsigned long long *__restrict__ slots, uint32_t win) {
+  // win != 0 (kp a multiple of 1024, at most PREP_MAX_WIN windows): the row's sum of squares per aligned
+  // 1024-dim window is collected too (per-wave LDS accumulators), for the 2 048- and 1 024-dim bounds
+  __shared__ unsigned long long s_win[4][PREP_MAX_WIN];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
   if (row >= rows) return;  // whole wave
+  volatile unsigned long long *mywin = s_win[wv];
+  if (win && lane < PREP_MAX_WIN) mywin[lane] = 0;
   const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
   _Float16 *__restrict__ dst = out + (size_t)row * ldk;
   const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -199,11 +204,12 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restric
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       half8 h;
+      uint32_t sqc = 0;  // this lane's share of the chunk
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         short2v x2;
         __builtin_memcpy(&x2, &w[t][i], 4);
-        sq = (uint32_t)__builtin_amdgcn_sdot2(x2, x2, (int)sq, false);
+        sqc = (uint32_t)__builtin_amdgcn_sdot2(x2, x2, (int)sqc, false);
         const short2v ab = __builtin_elementwise_max(x2, (short2v)(-x2));
         typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
         ushort2v m0, m1;
@@ -215,6 +221,13 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restric
         h[2 * i + 1] = (_Float16)x2.y;
       }
       if (d0[t] < kp) *reinterpret_cast<half8 *>(dst + d0[t]) = h;
+      sq += sqc;
+      if (win) {  // row-of-16 sums by DPP, then four LDS adds per chunk instead of 64 on one address
+        uint32_t rs = sqc;
+        rs += dpp_get<0xB1>(rs), rs += dpp_get<0x4E>(rs), rs += dpp_get<0x141>(rs), rs += dpp_get<0x140>(rs);
+        if ((lane & 15) == 0 && d0[t] < kp)
+          atomicAdd(const_cast<unsigned long long *>(&mywin[d0[t] >> 10]), (unsigned long long)rs);
+      }
     }
   }
   uint32_t mx = (mxpk & 0xffffu) > (mxpk >> 16) ? (mxpk & 0xffffu) : (mxpk >> 16);
@@ -238,44 +251,67 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restric
     mx = om > mx ? om : mx;
     sum += dpp_get64<0x143, 0xc>(sum);
   }
+  // window maxima of this row: lane w holds window w (LDS is in order per wave: the adds above are done)
+  unsigned long long w1 = (win && lane < kp / 1024) ? mywin[lane] : 0ull;
+  unsigned long long w2 = w1 + dpp_get64<0xB1>(w1);  // aligned pairs of 1 024-windows = 2 048-windows
+#define HG_MAXSTEP(CTRL, MASK)                                   \
+  {                                                              \
+    const unsigned long long o1 = dpp_get64<CTRL, MASK>(w1), o2 = dpp_get64<CTRL, MASK>(w2); \
+    w1 = o1 > w1 ? o1 : w1, w2 = o2 > w2 ? o2 : w2;              \
+  }
+  HG_MAXSTEP(0xB1, 0xf) HG_MAXSTEP(0x4E, 0xf) HG_MAXSTEP(0x141, 0xf) HG_MAXSTEP(0x140, 0xf) HG_MAXSTEP(0x142, 0xa) HG_MAXSTEP(0x143, 0xc)
+#undef HG_MAXSTEP
   if (lane == 63) {
     auto raise = [](unsigned long long *p, unsigned long long v) {
       if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
     };
-    // {max |x|, max row sum} per slot; the host takes the maximum over the slots.  (One shared pair of
-    // counters cost ~55 us per launch: the ~8 000 waves resident at the start all see the initial zero and
-    // all issue their atomics to the same address, ~12 ns each.)
-    unsigned long long *sl = slots + 2 * (blockIdx.x % PREP_SLOTS);
+    // {max |x|, max row sum, max 2 048-window sum, max 1 024-window sum} per slot; the maximum over the slots is
+    // taken afterwards.  (One shared set of counters cost ~55 us per launch: the ~8 000 waves resident at the
+    // start all see the initial zero and all issue their atomics to the same address, ~12 ns each.)
+    unsigned long long *sl = slots + PREP_SLOT_VALS * (blockIdx.x % PREP_SLOTS);
     raise(&sl[0], (unsigned long long)mx);
     raise(&sl[1], sum);
+    raise(&sl[2], win ? w2 : ~0ull);
+    raise(&sl[3], win ? w1 : ~0ull);
   }
 }
 
-// Exactness verdict of the fast prepass, on the device: 0 when |x| <= 2048 everywhere and the whole-row
-// Cauchy-Schwarz bound keeps every dot product exact in one f32 accumulation window, else 1.
+// Exactness verdict of the fast prepass, on the device.  verdict[0]: 0 = |x| <= 2048 everywhere and, by
+// Cauchy-Schwarz, every dot product is exact in ONE f32 accumulation window; 1 / 2 = exact with windows of
+// 2 048 / 1 024 dims (verdict[1] = window length in K-steps of 64); 3 = none of these.
+__device__ __forceinline__ bool window_safe(unsigned long long a, unsigned long long b) {
+  return a != ~0ull && b != ~0ull && (unsigned __int128)a * b <= ((unsigned __int128)1 << 48);
+}
 __global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *__restrict__ slots_r,
                                                      const unsigned long long *__restrict__ slots_q,
                                                      uint32_t *__restrict__ verdict) {
-  __shared__ unsigned long long s_red[4][256];
-  unsigned long long v[4] = {0, 0, 0, 0};
+  __shared__ unsigned long long s_red[8][256];
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = threadIdx.x; i < PREP_SLOTS; i += 256) {
-    v[0] = max(v[0], slots_r[2 * i]), v[1] = max(v[1], slots_r[2 * i + 1]);
-    v[2] = max(v[2], slots_q[2 * i]), v[3] = max(v[3], slots_q[2 * i + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = max(v[k], slots_r[PREP_SLOT_VALS * i + k]);
+      v[4 + k] = max(v[4 + k], slots_q[PREP_SLOT_VALS * i + k]);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = v[k];
+  for (int k = 0; k < 8; ++k) s_red[k][threadIdx.x] = v[k];
   __syncthreads();
   for (uint32_t o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = max(s_red[k][threadIdx.x], s_red[k][threadIdx.x + o]);
+      for (int k = 0; k < 8; ++k) s_red[k][threadIdx.x] = max(s_red[k][threadIdx.x], s_red[k][threadIdx.x + o]);
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const bool safe = s_red[0][0] <= 2048 && s_red[2][0] <= 2048 &&
-                      (unsigned __int128)s_red[1][0] * s_red[3][0] <= ((unsigned __int128)1 << 48);
-    verdict[0] = safe ? 0u : 1u;
+    uint32_t code = 3, steps = 0;
+    if (s_red[0][0] <= 2048 && s_red[4][0] <= 2048) {
+      if (window_safe(s_red[1][0], s_red[5][0])) code = 0;
+      else if (window_safe(s_red[2][0], s_red[6][0])) code = 1, steps = 2048 / 64;
+      else if (window_safe(s_red[3][0], s_red[7][0])) code = 2, steps = 1024 / 64;
+    }
+    verdict[0] = code, verdict[1] = steps;
   }
 }
 
@@ -315,7 +351,9 @@ struct GemmArgs {
   float pre_c, pre_b;  // phase-0 form of the same bound: dot < pre_c * (nr + nq) + pre_b  =>  rejected
   int symmetric;
   uint32_t tiles_m, tiles_n;  // tile grid
-  const uint32_t *verdict;    // speculative launch: non-zero => this launch must do nothing (see decide_kernel)
+  const uint32_t *verdict;    // speculative launch: runs only if v_lo <= verdict[0] <= v_hi (see decide_kernel);
+  uint32_t v_lo, v_hi;        // with chunk_from_verdict the window length (K-steps) is verdict[1]
+  uint32_t chunk_from_verdict;
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only
@@ -336,7 +374,11 @@ struct GemmArgs {
 template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT>;
-  if (g.verdict && *g.verdict) return;  // uniform
+  if (g.verdict) {  // uniform
+    const uint32_t code = g.verdict[0];
+    if (code < g.v_lo || code > g.v_hi) return;
+    if (CHUNKED && g.chunk_from_verdict) g.chunk_steps = g.verdict[1];
+  }
   static_assert(!GLDS || BIG, "LDS-DMA variant exists for the 256 x 256 geometry only");
   constexpr int LROW = GLDS ? BK : LDS_ROW;  // elements per LDS row
   constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
@@ -755,8 +797,8 @@ static float jaccard_lower_bound(float ani_th, uint32_t ksize) {
   return (float)(j * (1.0 - 1e-4));
 }
 
-hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, bool *speculated) {
-  if (speculated) *speculated = false;
+hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int *speculated) {
+  if (speculated) *speculated = -1;
   const uint32_t Kp = (a.hv_d + BK - 1) / BK * BK;
   // Row pitch of the f16 copies: Kp + 64 elements (+128 B).  With a power-of-two pitch (8 KiB at
   // D = 4096) every workgroup reads the same 128-byte column offset of 256 different rows at the same
@@ -769,7 +811,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   hg_status s;
   if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
   if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * ldk * 2)) != HG_OK) return s;
-  if ((s = hg_ensure(c, c->w_stats, 256 + 4 * PREP_SLOTS * sizeof(unsigned long long))) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_stats, 256 + 2 * PREP_SLOT_VALS * PREP_SLOTS * sizeof(unsigned long long))) != HG_OK) return s;
   auto *fa = static_cast<_Float16 *>(c->w_f16a.p);
   auto *fb = same ? fa : static_cast<_Float16 *>(c->w_f16b.p);
   auto *st = static_cast<unsigned long long *>(c->w_stats.p);
@@ -794,47 +836,50 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   unsigned long long h[2 * (1 + N_CHUNK_CAND)];
   const unsigned long long *hr = h, *hq = same ? h : h + 1 + N_CHUNK_CAND;
   int best_c = -1;
-  bool fast_done = false, spec = false;
-  if (c_whole >= 0) {  // fast prepass: max |x| and the whole-row bound only
-    const size_t slot_bytes = 2 * PREP_SLOTS * sizeof(unsigned long long);
+  bool fast_done = false, spec = false, spec_win = false;
+  (void)hr, (void)hq;
+  int spec_cover = -1;  // speculative schedule: highest verdict code with a guarded launch queued
+  if (c_whole >= 0) {  // fast prepass: max |x|, the whole-row bound and (win) the 2 048- / 1 024-dim window bounds
+    const size_t slot_bytes = PREP_SLOT_VALS * PREP_SLOTS * sizeof(unsigned long long);
     auto *sl = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(st) + 256);
+    auto *slq = same ? sl : sl + PREP_SLOT_VALS * PREP_SLOTS;
+    const uint32_t win = (Kp % 1024 == 0 && Kp / 1024 <= PREP_MAX_WIN && Kp >= 2048) ? 1u : 0u;
     HG_HIP(c, hipMemsetAsync(sl, 0, 2 * slot_bytes, c->stream));
     {
       hg_timed tm(c, HG_T_DIST_PREP);
-      hipLaunchKernelGGL(prep_fast_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, sl);
+      hipLaunchKernelGGL(prep_fast_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, sl, win);
       HG_HIP(c, hipGetLastError());
       if (!same) {
         hipLaunchKernelGGL(prep_fast_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, ldk,
-                           fb, sl + 2 * PREP_SLOTS);
+                           fb, slq, win);
         HG_HIP(c, hipGetLastError());
       }
     }
     if (d_verdict && !a.ani_out) {
-      // speculative schedule: the verdict is formed on the device and guards the GEMM queued right behind
+      // speculative schedule: the verdict is formed on the device and guards the GEMMs queued right behind
       // it; the caller reads it back together with its hit count (no host round trip in between)
-      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, sl, same ? sl : sl + 2 * PREP_SLOTS, d_verdict);
+      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, sl, slq, d_verdict);
       HG_HIP(c, hipGetLastError());
-      best_c = c_whole, fast_done = true, spec = true;
-      if (speculated) *speculated = true;
+      best_c = c_whole, fast_done = true, spec = true, spec_win = win != 0;
     } else {
       hg_status ps = hg_ensure_pinned(c, 2 * slot_bytes);
       if (ps != HG_OK) return ps;
       auto *hs = static_cast<unsigned long long *>(c->h_pin);
       HG_HIP(c, hipMemcpyAsync(hs, sl, (same ? 1 : 2) * slot_bytes, hipMemcpyDeviceToHost, c->stream));
       HG_HIP(c, hipStreamSynchronize(c->stream));
-      std::memset(h, 0, sizeof h);
-      for (int m = 0; m < (same ? 1 : 2); ++m) {
-        unsigned long long *dstp = h + m * (1 + N_CHUNK_CAND);
-        for (uint32_t i = 0; i < PREP_SLOTS; ++i) {
-          dstp[0] = std::max(dstp[0], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i]);
-          dstp[1 + c_whole] = std::max(dstp[1 + c_whole], hs[(size_t)m * 2 * PREP_SLOTS + 2 * i + 1]);
-        }
-      }
-      if (hr[0] <= 2048 && hq[0] <= 2048 &&
-          (unsigned __int128)hr[1 + c_whole] * hq[1 + c_whole] <= ((unsigned __int128)1 << 48))
-        best_c = c_whole, fast_done = true;
-      else if (hr[0] > 2048 || hq[0] > 2048)
-        fast_done = true;  // no f16 path at all: integer kernel below
+      unsigned long long mx[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      for (int m = 0; m < (same ? 1 : 2); ++m)
+        for (uint32_t i = 0; i < PREP_SLOTS; ++i)
+          for (uint32_t k = 0; k < PREP_SLOT_VALS; ++k)
+            mx[m][k] = std::max(mx[m][k], hs[((size_t)m * PREP_SLOTS + i) * PREP_SLOT_VALS + k]);
+      const unsigned long long *r4 = mx[0], *q4 = same ? mx[0] : mx[1];
+      auto safe = [](unsigned long long x, unsigned long long y) {
+        return x != ~0ull && y != ~0ull && (unsigned __int128)x * y <= ((unsigned __int128)1 << 48);
+      };
+      if (r4[0] > 2048 || q4[0] > 2048) fast_done = true;  // no f16 path at all: integer kernel below
+      else if (safe(r4[1], q4[1])) best_c = c_whole, fast_done = true;
+      else if (safe(r4[2], q4[2])) best_c = 5, fast_done = true;  // windows of 2 048 dims (64 << 5)
+      else if (safe(r4[3], q4[3])) best_c = 4, fast_done = true;  // windows of 1 024 dims
     }
   }
   if (!fast_done) {  // every candidate window (also rewrites the f16 copies: same values)
@@ -870,6 +915,10 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
     HG_HIP(c, hipGetLastError());
     return HG_OK;
   }
+  // one GEMM launch for accumulation windows of 64 << bc dims; guard != nullptr: runs only if
+  // v_lo <= guard[0] <= v_hi, and (from_verdict) takes its window length from guard[1]
+  auto gemm = [&](int bc, const uint32_t *guard, uint32_t v_lo, uint32_t v_hi, bool from_verdict) -> hg_status {
+  const int best_c = bc;
   GemmArgs g{};
   g.A = fa, g.B = fb, g.nr = a.ref_n2, g.nq = a.qry_n2;
   g.R = a.R, g.Q = a.Q, g.Kp = Kp, g.ldk = ldk;
@@ -877,7 +926,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   g.kf = kf;
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
   g.ani_th = a.ani_th, g.symmetric = a.symmetric;
-  g.verdict = spec ? d_verdict : nullptr;
+  g.verdict = guard, g.v_lo = v_lo, g.v_hi = v_hi, g.chunk_from_verdict = from_verdict ? 1u : 0u;
   g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
   if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;       // everything goes on to phase 1
   else if (g.j_lo == INFINITY) g.pre_c = 0.f, g.pre_b = INFINITY;    // ANI <= 100 < ani_th: nothing does
@@ -941,5 +990,18 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, boo
   else if (full) le = launch(&dist_mfma_kernel<true, true, false>, TileCfg<false>::THREADS, lds_small);
   else le = launch(&dist_mfma_kernel<true, false, false>, TileCfg<false>::THREADS, lds_small);
   HG_HIP(c, le);
+  return HG_OK;
+  };
+  if (!spec) return gemm(best_c, nullptr, 0, 0, false);
+  // speculative: the one-window kernel for verdict 0 and, where the prepass measured the 2 048 / 1 024 windows,
+  // the windowed kernel for verdicts 1..2 right behind it (whichever is not chosen returns at once)
+  hg_status gs = gemm(c_whole, d_verdict, 0, 0, false);
+  if (gs != HG_OK) return gs;
+  spec_cover = 0;
+  if (spec_win && Kp > 2048) {
+    if ((gs = gemm(4, d_verdict, 1, 2, true)) != HG_OK) return gs;
+    spec_cover = 2;
+  }
+  if (speculated) *speculated = spec_cover;
   return HG_OK;
 }

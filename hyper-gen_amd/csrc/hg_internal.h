@@ -169,7 +169,9 @@ struct hg_dist_args {
   float ani_th;
   int symmetric;
 };
-// d_verdict != nullptr allows the speculative schedule: prepass, on-device exactness verdict (0 = the whole-K
-// f16 path is exact) and the GEMM guarded by it are queued without a host round trip; *speculated tells the
-// caller to read the verdict back with its own results and to call again without d_verdict if it is non-zero.
-hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a, uint32_t *d_verdict = nullptr, bool *speculated = nullptr);
+// d_verdict (two uint32: code, window length) != nullptr allows the speculative schedule: prepass, on-device
+// exactness verdict (0 = one f32 window covers K; 1 / 2 = windows of 2 048 / 1 024 dims; 3 = neither) and the
+// GEMM launches guarded by it are queued without a host round trip.  *speculated = -1 if the call was not
+// speculative, else the highest verdict code a guarded launch covers: the caller reads the verdict back with
+// its own results and calls again without d_verdict if it is larger.
+hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a, uint32_t *d_verdict = nullptr, int *speculated = nullptr);
