@@ -126,17 +126,6 @@ __device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed
   return final64<HAND>(a, b);
 }
 
-// runtime-length variant for the generic kernel (len <= 32), bytes in w[0..3]
-__device__ __forceinline__ uint64_t t1ha2_le32(const uint64_t w[4], uint32_t len, uint64_t seed) {
-  uint64_t a = seed, b = (uint64_t)len;
-  int i = 0;
-  if (len > 24) mixup64<P4>(a, b, w[i++]);
-  if (len > 16) mixup64<P3>(b, a, w[i++]);
-  if (len > 8) mixup64<P2>(a, b, w[i++]);
-  if (len > 0) mixup64<P1>(b, a, w[i++]);
-  return final64(a, b);
-}
-
 template <int... Js, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F &&f) {
   (f(std::integral_constant<int, Js>{}), ...);
@@ -153,13 +142,13 @@ struct Geo {
   static constexpr int TILE = WG * M;
   static constexpr int ITEM = TILE * TILES_PER_ITEM;
 };
-constexpr int GEN_STARTS = 32;                       // generic kernel: starts per lane
+constexpr int GEN_STARTS = 32;                       // long-k kernel: starts per lane
 constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 // k >= FAST64_FROM runs the 64-base-window kernel: with 32-base windows a lane owns only (33 - k) & ~3 k-mer
 // starts (8 at k = 22..25, 4 at k = 26..29).  Measured A/B on one box: k = 22..25 4-6 % faster, k = 26..29
 // 16-17 % faster with the wide window; k <= 21 the two kernels tie.
 constexpr uint32_t FAST64_FROM = 22;
-constexpr bool fast_k(uint32_t k) { return k >= 9 && k < FAST64_FROM; }
+constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
 __device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm, uint32_t g,
                                            uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
@@ -197,7 +186,7 @@ __device__ __forceinline__ void flush_hits(HitStage &st, const hg_genome_meta &g
 }
 
 // =========================================================================================
-// fast kernel: compile-time k in [9, 21] (instantiable up to 29)
+// fast kernel: compile-time k in [1, 21] (instantiable up to 29)
 // =========================================================================================
 template <int K, bool CANON, int VAR = 0>
 __global__ __launch_bounds__(WG) void kmer_sample_fast(
@@ -522,9 +511,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast64(
   flush_hits(stage, gm, g, hits, cnt);
 }
 
-// =========================================================================================
-// generic kernel: any k <= 32 at run time (slow path for unusual k)
-// =========================================================================================
+// 2-bit code of one base (long-k kernel)
 __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
   // 0..3 for ACGT (either case), 4 otherwise
   uint8_t u = c & 0xDF;
@@ -534,51 +521,6 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
   if (u == 'T') return 3;
   if (u2t && u == 'U') return 3;
   return 4;
-}
-
-__global__ __launch_bounds__(WG) void kmer_sample_generic(
-    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
-    const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
-    uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
-  const uint32_t item = blockIdx.x;
-  const uint32_t g = item_genome[item];
-  const hg_genome_meta gm = meta[g];
-  const uint64_t n_bps = gm.n_bps;
-  if (n_bps < ksize) return;
-  const uint64_t n_starts = n_bps - ksize + 1;
-  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
-  const uint64_t s0 = (uint64_t)(item - gm.item_first) * GEN_ITEM + (uint64_t)threadIdx.x * GEN_STARTS;
-  __shared__ HitStage stage;
-  if (threadIdx.x == 0) stage.n = 0;
-  __syncthreads();
-  // lanes past the last k-mer start run an empty range (no early return: the flush below has barriers)
-  const uint64_t s1 = s0 >= n_starts ? s0 : ((s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts);  // starts [s0, s1)
-  const uint64_t i_end = s0 >= n_starts ? s0 : s1 + ksize - 1;
-  const uint64_t mask = (ksize == 32) ? ~0ull : ((1ull << (2 * ksize)) - 1);
-  const char ACGT[4] = {'A', 'C', 'G', 'T'};
-
-  uint64_t fwd = 0, rev = 0;  // MSB-first forward value / reverse-complement value
-  uint32_t run = 0;
-  for (uint64_t i = s0; i < i_end; ++i) {
-    uint32_t c = base_code(gseq[i], u2t);
-    if (c > 3) {
-      run = 0, fwd = rev = 0;
-      continue;
-    }
-    fwd = ((fwd << 2) | c) & mask;
-    rev = (rev >> 2) | ((uint64_t)(3 - c) << (2 * (ksize - 1)));
-    if (++run < ksize) continue;
-    const bool use_rc = canonical && (rev < fwd);
-    const uint64_t v = use_rc ? rev : fwd;  // first base of the chosen strand in the top bits
-    uint64_t w[4] = {0, 0, 0, 0};
-    for (uint32_t b = 0; b < ksize; ++b) {
-      uint32_t code = (uint32_t)(v >> (2 * (ksize - 1 - b))) & 3u;
-      w[b >> 3] |= (uint64_t)(uint8_t)ACGT[code] << (8 * (b & 7));
-    }
-    const uint64_t h = t1ha2_le32(w, ksize, seed);
-    if (h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
-  }
-  flush_hits(stage, gm, g, hits, cnt);
 }
 
 // =========================================================================================
@@ -714,7 +656,8 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
     return launch_fast<KK>(st, canonical, n_items, d_seq, d_meta, d_item_genome, threshold,   \
                            seed, u2t, d_hits, d_cnt);
   if (fast_k(ksize)) switch (ksize) {
-    HG_FAST_CASE(9) HG_FAST_CASE(10) HG_FAST_CASE(11) HG_FAST_CASE(12) HG_FAST_CASE(13)
+    HG_FAST_CASE(1) HG_FAST_CASE(2) HG_FAST_CASE(3) HG_FAST_CASE(4) HG_FAST_CASE(5) HG_FAST_CASE(6) HG_FAST_CASE(7)
+    HG_FAST_CASE(8) HG_FAST_CASE(9) HG_FAST_CASE(10) HG_FAST_CASE(11) HG_FAST_CASE(12) HG_FAST_CASE(13)
     HG_FAST_CASE(14) HG_FAST_CASE(15) HG_FAST_CASE(16) HG_FAST_CASE(17) HG_FAST_CASE(18)
     HG_FAST_CASE(19) HG_FAST_CASE(20) HG_FAST_CASE(21)
     default:
@@ -738,11 +681,8 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
       break;
   }
 #undef HG_FAST64_CASE
-  if (ksize > 32)
-    hipLaunchKernelGGL(kmer_sample_long, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
-                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
-  else
-    hipLaunchKernelGGL(kmer_sample_generic, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
-                       d_item_genome, ksize, threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+  // 33 <= k <= 255 (k <= 32 returned above)
+  hipLaunchKernelGGL(kmer_sample_long, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
+                     threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
   return hipGetLastError();
 }
