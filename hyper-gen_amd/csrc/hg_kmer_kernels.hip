@@ -526,25 +526,32 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
 // =========================================================================================
 // long-k kernel: 33 <= k <= 255 (the CPU path's t1ha2 long-input loop; src/cuda_kernel.cu has none)
 // =========================================================================================
-// Slow, simple and exact: bytes of the chosen strand are fetched on demand.
-struct StrandBytes {
-  const uint8_t *base;  // first base of the window (forward coordinates)
-  uint32_t k;
-  bool rc;
-  uint32_t u2t;
-  __device__ __forceinline__ uint8_t at(uint32_t i) const {
-    const char ACGT[4] = {'A', 'C', 'G', 'T'};
-    const uint32_t c = rc ? 3u - base_code(base[k - 1 - i], u2t) : base_code(base[i], u2t);
-    return (uint8_t)ACGT[c & 3];
+// Run-time k.  A workgroup stages 1 024 k-mer starts' worth of sequence (<= 1 278 bytes) into LDS three
+// ways: the normalised forward strand (upper-case ASCII, 0 for anything that is not a base), its reverse
+// complement (so that the reverse strand of a k-mer is an ascending byte range too), and a running count of
+// invalid bytes (a window is valid iff the count does not change across it).  Each lane then takes four
+// starts: strand choice by the first differing dword of the two byte strings (big-endian compare = the
+// reference's lexicographic compare), hash words cut out of LDS with a run-time v_alignbyte funnel.
+constexpr uint32_t LONG_TILE = 1024;                 // k-mer starts per tile
+constexpr uint32_t LONG_BYTES = 1536;                // staged bytes per tile (>= LONG_TILE + 254), 6 per lane
+constexpr uint32_t LONG_DW = LONG_BYTES / 4 + 4;     // + zero slack for the funnel's second dword
+
+struct LdsStrand {
+  const uint32_t *w32;  // LDS array of bytes, dword view
+  uint32_t byte0;       // first byte of the k-mer in that array
+  __device__ __forceinline__ uint32_t dword(uint32_t i) const {  // bytes [byte0 + 4i, byte0 + 4i + 4)
+    const uint32_t o = byte0 + 4 * i, a = o >> 2;
+    return __builtin_amdgcn_alignbyte(w32[a + 1], w32[a], o & 3u);
   }
-  __device__ __forceinline__ uint64_t word(uint32_t byte_off, uint32_t nbytes) const {  // little endian
-    uint64_t w = 0;
-    for (uint32_t b = 0; b < nbytes; ++b) w |= (uint64_t)at(byte_off + b) << (8 * b);
-    return w;
+  __device__ __forceinline__ uint64_t word(uint32_t byte_off, uint32_t nbytes) const {  // little endian, byte_off % 8 == 0
+    uint32_t lo = dword(byte_off / 4), hi = nbytes > 4 ? dword(byte_off / 4 + 1) : 0u;
+    if (nbytes < 4) lo &= (1u << (8 * nbytes)) - 1;
+    else if (nbytes > 4 && nbytes < 8) hi &= (1u << (8 * (nbytes - 4))) - 1;
+    return mk64(lo, hi);
   }
 };
 
-__device__ __forceinline__ uint64_t t1ha2_long(const StrandBytes &sb, uint32_t len, uint64_t seed) {
+__device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len, uint64_t seed) {
   uint64_t a = seed, b = (uint64_t)len;
   uint32_t off = 0;
   if (len > 32) {  // published t1ha2: lanes c,d, 32 bytes per round, squash
@@ -576,37 +583,83 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
     uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
-  const uint32_t item = blockIdx.x;
+  __shared__ HitStage stage;
+  __shared__ uint32_t s_f[LONG_DW], s_rc[LONG_DW];
+  __shared__ uint16_t s_bad[LONG_BYTES + 8];  // s_bad[i] = invalid bytes among the first i staged bytes
+  __shared__ uint16_t s_scan[WG];
+  const uint32_t item = blockIdx.x, tid = threadIdx.x;
   const uint32_t g = item_genome[item];
   const hg_genome_meta gm = meta[g];
   const uint64_t n_bps = gm.n_bps;
   if (n_bps < ksize) return;
   const uint64_t n_starts = n_bps - ksize + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
-  const uint64_t s0 = (uint64_t)(item - gm.item_first) * GEN_ITEM + (uint64_t)threadIdx.x * GEN_STARTS;
-  __shared__ HitStage stage;
-  if (threadIdx.x == 0) stage.n = 0;
-  __syncthreads();
-  const uint64_t s1 = s0 >= n_starts ? s0 : ((s0 + GEN_STARTS < n_starts) ? s0 + GEN_STARTS : n_starts);
-  const uint64_t i_end = s0 >= n_starts ? s0 : s1 + ksize - 1;
-  uint32_t run = 0;  // valid bases ending at the current position
-  for (uint64_t i = s0; i < i_end; ++i) {
-    run = (base_code(gseq[i], u2t) < 4) ? run + 1 : 0;
-    if (run < ksize) continue;
-    const uint8_t *w = gseq + (i + 1 - ksize);
-    bool use_rc = false;
-    if (canonical) {  // first differing position decides (expected ~1.3 iterations)
-      for (uint32_t t = 0; t < ksize; ++t) {
-        const uint32_t f = base_code(w[t], u2t), r = 3u - base_code(w[ksize - 1 - t], u2t);
-        if (f != r) {
-          use_rc = r < f;
-          break;
-        }
+  const uint64_t item_start = (uint64_t)(item - gm.item_first) * GEN_ITEM;
+  if (tid == 0) stage.n = 0;
+  const uint32_t n_stage = LONG_TILE + ksize - 1;  // bytes a full tile needs
+  uint8_t *fb = reinterpret_cast<uint8_t *>(s_f), *rb = reinterpret_cast<uint8_t *>(s_rc);
+
+  for (uint64_t tile0 = item_start; tile0 < item_start + GEN_ITEM && tile0 < n_starts; tile0 += LONG_TILE) {
+    __syncthreads();  // previous tile's readers are done
+    for (uint32_t i = tid; i < LONG_DW; i += WG) s_f[i] = 0u, s_rc[i] = 0u;
+    __syncthreads();
+    // ---- stage: 6 consecutive bytes per lane
+    uint32_t nbad = 0;
+    uint8_t fbyte[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const uint32_t i = tid * 6 + j;
+      const uint64_t pos = tile0 + i;
+      uint32_t code = 4;
+      if (i < n_stage && pos < n_bps) code = base_code(gseq[pos], u2t);
+      fbyte[j] = code < 4 ? (uint8_t)(0x54474341u >> (8 * code)) : (uint8_t)0;  // "ACGT"
+      nbad += code < 4 ? 0u : 1u;
+      if (i < n_stage) {
+        fb[i] = fbyte[j];
+        rb[n_stage - 1 - i] = code < 4 ? (uint8_t)(0x41434754u >> (8 * code)) : (uint8_t)0;  // "TGCA"
       }
     }
-    const StrandBytes sb{w, ksize, use_rc, u2t};
-    const uint64_t h = t1ha2_long(sb, ksize, seed);
-    if (h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+    // exclusive scan of the per-lane invalid counts (Hillis-Steele over WG entries)
+    s_scan[tid] = (uint16_t)nbad;
+    __syncthreads();
+    for (uint32_t o = 1; o < WG; o <<= 1) {
+      const uint16_t add = tid >= o ? s_scan[tid - o] : (uint16_t)0;
+      __syncthreads();
+      s_scan[tid] = (uint16_t)(s_scan[tid] + add);
+      __syncthreads();
+    }
+    {
+      uint32_t run = (uint32_t)s_scan[tid] - nbad;  // invalid bytes before this lane's first byte
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        s_bad[tid * 6 + j] = (uint16_t)run;
+        run += fbyte[j] ? 0u : 1u;
+      }
+      if (tid == WG - 1) s_bad[LONG_BYTES] = (uint16_t)run;
+    }
+    __syncthreads();
+    // ---- the lane's four starts
+#pragma unroll 1
+    for (uint32_t j = 0; j < LONG_TILE / WG; ++j) {
+      const uint32_t p = tid + WG * j;
+      if (tile0 + p >= n_starts) break;
+      if (s_bad[p + ksize] != s_bad[p]) continue;  // a non-base inside the window
+      const LdsStrand f{s_f, p}, r{s_rc, n_stage - p - ksize};
+      bool use_rc = false;
+      if (canonical) {  // first differing dword decides (big-endian = lexicographic on the bytes)
+        for (uint32_t t = 0; 4 * t < ksize; ++t) {
+          uint32_t fw = __builtin_bswap32(f.dword(t)), rw = __builtin_bswap32(r.dword(t));
+          const uint32_t left = ksize - 4 * t;
+          if (left < 4) fw &= ~0u << (8 * (4 - left)), rw &= ~0u << (8 * (4 - left));
+          if (fw != rw) {
+            use_rc = rw < fw;
+            break;
+          }
+        }
+      }
+      const uint64_t h = t1ha2_long(use_rc ? r : f, ksize, seed);
+      if (h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+    }
   }
   flush_hits(stage, gm, g, hits, cnt);
 }
