@@ -226,6 +226,7 @@ extern "C" void hg_sketch_params_default(hg_sketch_params *p) {
 namespace {
 
 struct BatchPlan {
+  uint32_t max_hits = ~0u;  // largest stored raw hit count of the batch (upper bound of the distinct counts)
   std::vector<std::pair<uint32_t, uint32_t>> big;  // (genome, stored raw hits) with more than HG_ENC_SLAB hits
   std::vector<hg_genome_meta> meta;
   std::vector<uint32_t> item_genome;
@@ -417,8 +418,10 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       if ((s = sort_large_sets(c, pl, h_cnt, n, threshold, d_hits, d_cnt, d_nd)) != HG_OK) return s;
       h_cnt = static_cast<uint32_t *>(c->h_pin);  // (unchanged unless the pinned scratch grew)
       pl.big.clear();
+      pl.max_hits = 0;
       for (size_t g = 0; g < n; ++g) {
         const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
+        pl.max_hits = std::max(pl.max_hits, cnt);
         if (cnt > HG_ENC_SLAB) pl.big.emplace_back((uint32_t)g, cnt);
       }
       if (!reuse) {  // remember this plan for the next call
@@ -488,7 +491,7 @@ extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const 
     hg_timed tm(c, HG_T_ENCODE);
     HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), (uint32_t)n,
                                static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2,
-                               split.n_items ? &split : nullptr));
+                               split.n_items ? &split : nullptr, pl.max_hits));
   }
   if (split.n_items) HG_HIP(c, hipStreamSynchronize(c->stream));  // the pageable item tables must outlive their upload
   HG_HIP(c, hipMemcpyAsync(d_nhash, d_nd, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -654,7 +657,7 @@ extern "C" hg_status hg_hv_encode(hg_ctx *c, const uint64_t *hashes, size_t n, u
   if (n) HG_HIP(c, hipMemcpyAsync(c->w_hits.p, hashes, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), 1,
                              static_cast<uint64_t *>(c->w_hits.p), static_cast<uint32_t *>(c->w_cnt.p), hv_d,
-                             hv_layout, d_hv, d_n2));
+                             hv_layout, d_hv, d_n2, nullptr, nd));
   HG_HIP(c, hipMemcpyAsync(hv_out, d_hv, (size_t)hv_d * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipMemcpyAsync(norm2_out, d_n2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));

@@ -312,13 +312,13 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
     const hg_genome_meta *__restrict__ meta, const uint64_t *__restrict__ hits,
     const uint32_t *__restrict__ ndistinct, uint32_t hv_d, uint32_t layout,
     int16_t *__restrict__ hv_out, int32_t *__restrict__ norm2_out, uint32_t split_over,
-    const uint2 *__restrict__ items, uint32_t *__restrict__ accum) {
+    const uint2 *__restrict__ items, uint32_t *__restrict__ accum, uint32_t wave_max) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];  // [64][n_words + 1]
   __shared__ int32_t s_red[ENC_WAVES];
   const uint32_t g = SPLIT ? items[blockIdx.x].x : blockIdx.x;
   const hg_genome_meta gm = meta[g];
   const uint32_t n_all = ndistinct[g];
-  if (!SPLIT && n_all > split_over) return;
+  if (!SPLIT && (n_all > split_over || n_all <= wave_max)) return;  // split launch / encode_wave_kernel
   const uint32_t slab = SPLIT ? (items[blockIdx.x].y & 0xffffu) : 0u, slot = SPLIT ? (items[blockIdx.x].y >> 16) : 0u;
   const uint32_t h0 = SPLIT ? slab * HG_ENC_SLAB : 0u;
   if (SPLIT && h0 >= n_all) return;  // the plan was made from the raw (pre-unique) count
@@ -435,6 +435,105 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
     for (int w = 0; w < ENC_WAVES; ++w) s += (uint32_t)s_red[w];
     norm2_out[g] = (int32_t)s;
   }
+}
+
+// One WAVE per genome (four genomes per workgroup) for hash sets of at most HG_ENC_WAVE_MAX hashes -- every
+// ordinary genome.  Lane i owns word i of the random stream (hv_d / 64 <= 64 words per pass), so the 64 bit
+// columns of that word are counted entirely inside the lane: bit-sliced carry-save planes over all hashes,
+// expanded once at the end straight into the output row.  No LDS, no atomics, no barrier; the
+// eight-waves-per-genome kernel above (LDS counters, one flush per wave and word) remains for larger sets.
+// (Which genomes it takes: hg_launch_encode.)
+__global__ __launch_bounds__(256) void encode_wave_kernel(
+    const hg_genome_meta *__restrict__ meta, const uint64_t *__restrict__ hits,
+    const uint32_t *__restrict__ ndistinct, uint32_t n_genomes, uint32_t hv_d, uint32_t layout,
+    int16_t *__restrict__ hv_out, int32_t *__restrict__ norm2_out, uint32_t wave_max) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (g >= n_genomes) return;
+  const uint32_t n = ndistinct[g];
+  if (n > wave_max) return;  // encode_kernel handles this genome
+  const uint64_t *__restrict__ hs = hits + meta[g].hit_off;
+  const uint32_t n_words = hv_d / 64;
+  int16_t *__restrict__ out = hv_out + (size_t)g * hv_d;
+  const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(hv_out) & 15) == 0);
+  uint32_t acc = 0;
+  for (uint32_t grp = 0; grp * 64 < n_words; ++grp) {
+    const uint32_t w = grp * 64 + lane;
+    const uint64_t off = (uint64_t)(w + 1) * WY_INC;
+    uint64_t ones = 0, twos = 0, fours = 0, eights = 0;
+    uint64_t hp[HI_PLANES];
+#pragma unroll
+    for (int p = 0; p < HI_PLANES; ++p) hp[p] = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 16) {
+      uint64_t x[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const uint32_t idx = b0 + t;
+        x[t] = (idx < n) ? wy_word(hs[idx], off) : 0ull;  // hs[idx] is wave-uniform
+      }
+      uint64_t twosA, twosB, foursA, foursB, eightsA, eightsB, sixteens;
+      csa(twosA, ones, ones, x[0], x[1]);
+      csa(twosB, ones, ones, x[2], x[3]);
+      csa(foursA, twos, twos, twosA, twosB);
+      csa(twosA, ones, ones, x[4], x[5]);
+      csa(twosB, ones, ones, x[6], x[7]);
+      csa(foursB, twos, twos, twosA, twosB);
+      csa(eightsA, fours, fours, foursA, foursB);
+      csa(twosA, ones, ones, x[8], x[9]);
+      csa(twosB, ones, ones, x[10], x[11]);
+      csa(foursA, twos, twos, twosA, twosB);
+      csa(twosA, ones, ones, x[12], x[13]);
+      csa(twosB, ones, ones, x[14], x[15]);
+      csa(foursB, twos, twos, twosA, twosB);
+      csa(eightsB, fours, fours, foursA, foursB);
+      csa(sixteens, eights, eights, eightsA, eightsB);
+      uint64_t carry = sixteens;
+#pragma unroll
+      for (int p = 0; p < HI_PLANES; ++p) {
+        const uint64_t t = hp[p] & carry;
+        hp[p] ^= carry;
+        carry = t;
+      }
+    }
+    if (w < n_words) {
+      // output position p of the 64-block holds bit j: scalar layout j = p, AVX2 layout j = 16*(p%4) + p/4
+      uint32_t packed[32];
+#pragma unroll
+      for (int p = 0; p < 64; ++p) {
+        const int js = p, ja = 16 * (p & 3) + (p >> 2);
+        auto count = [&](int j) {
+          uint32_t c = (uint32_t)((ones >> j) & 1) | ((uint32_t)((twos >> j) & 1) << 1) | ((uint32_t)((fours >> j) & 1) << 2) |
+                       ((uint32_t)((eights >> j) & 1) << 3);
+#pragma unroll
+          for (int q = 0; q < HI_PLANES; ++q) c |= (uint32_t)((hp[q] >> j) & 1) << (4 + q);
+          return c;
+        };
+        const uint32_t c = (layout == HG_LAYOUT_AVX2) ? count(ja) : count(js);
+        const int16_t v = (int16_t)(uint16_t)(2u * c - n);
+        acc += (uint32_t)((int32_t)v * (int32_t)v);
+        if (p & 1) packed[p >> 1] |= (uint32_t)(uint16_t)v << 16;
+        else packed[p >> 1] = (uint32_t)(uint16_t)v;
+      }
+      int16_t *dst = out + (size_t)w * 64;
+      if (vec_ok) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          reinterpret_cast<uint4 *>(dst)[q] = make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) dst[2 * q] = (int16_t)(packed[q] & 0xffffu), dst[2 * q + 1] = (int16_t)(packed[q] >> 16);
+      }
+    }
+  }
+  // dimensions past the last whole 64-block carry no random bit: count 0
+  for (uint32_t d = n_words * 64 + lane; d < hv_d; d += 64) {
+    const int16_t v = (int16_t)(uint16_t)(0u - n);
+    out[d] = v;
+    acc += (uint32_t)((int32_t)v * (int32_t)v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) norm2_out[g] = (int32_t)acc;
 }
 
 // grid: split genomes.  accum[slot][word * 64 + bit] -> hv (layout, i16 wrapping) + norm
@@ -554,19 +653,32 @@ static hipError_t encode_attr() {
 
 hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                             const uint64_t *d_hits, const uint32_t *d_ndistinct, uint32_t hv_d,
-                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2, const hg_encode_split *split) {
+                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2, const hg_encode_split *split,
+                            uint32_t max_hashes) {
   if (n_genomes == 0) return hipSuccess;
   const size_t lds = (size_t)64 * (hv_d / 64 + 1) * sizeof(uint32_t);
   if (lds > 150 * 1024) return hipErrorInvalidValue;  // hv_d up to ~38k
   hipError_t e = encode_attr();
   if (e != hipSuccess) return e;
   const bool sp = split && split->n_items;
-  hipLaunchKernelGGL(encode_kernel<false>, dim3(n_genomes), dim3(ENC_WG), lds, st, d_meta, d_hits, d_ndistinct, hv_d,
-                     layout, d_hv, d_norm2, sp ? (uint32_t)HG_ENC_SLAB : ~0u, (const uint2 *)nullptr, (uint32_t *)nullptr);
-  if ((e = hipGetLastError()) != hipSuccess || !sp) return e;
+  // One wave per genome does less work per genome (no LDS counters, no per-wave flush) but runs a genome's
+  // hashes serially: it takes everything when the batch alone fills the SIMDs several times over, and only the
+  // tiny sets (where the eight-wave kernel is all overhead) otherwise.  1 000 x 3 333 hashes: 0.18 ms with eight
+  // waves per genome, 0.39 ms with one; 100 000 x 20 hashes: 4.4 ms vs 0.7 ms.
+  const uint32_t wave_max = n_genomes >= 8192 ? (uint32_t)HG_ENC_WAVE_MAX : 256u;
+  hipLaunchKernelGGL(encode_wave_kernel, dim3((n_genomes + 3) / 4), dim3(256), 0, st, d_meta, d_hits, d_ndistinct, n_genomes,
+                     hv_d, layout, d_hv, d_norm2, wave_max);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (max_hashes > wave_max) {  // some genome may exceed what the wave kernel takes
+    hipLaunchKernelGGL(encode_kernel<false>, dim3(n_genomes), dim3(ENC_WG), lds, st, d_meta, d_hits, d_ndistinct, hv_d,
+                       layout, d_hv, d_norm2, sp ? (uint32_t)HG_ENC_SLAB : ~0u, (const uint2 *)nullptr, (uint32_t *)nullptr,
+                       wave_max);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (!sp) return e;
   if ((e = hipMemsetAsync(split->d_accum, 0, (size_t)split->n_genomes * hv_d * sizeof(uint32_t), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(encode_kernel<true>, dim3(split->n_items), dim3(ENC_WG), lds, st, d_meta, d_hits, d_ndistinct, hv_d,
-                     layout, d_hv, d_norm2, ~0u, reinterpret_cast<const uint2 *>(split->d_items), split->d_accum);
+                     layout, d_hv, d_norm2, ~0u, reinterpret_cast<const uint2 *>(split->d_items), split->d_accum, 0u);
   hipLaunchKernelGGL(encode_finalize_kernel, dim3(split->n_genomes), dim3(ENC_WG), 0, st, split->d_genomes, d_ndistinct,
                      split->d_accum, hv_d, layout, d_hv, d_norm2);
   return hipGetLastError();

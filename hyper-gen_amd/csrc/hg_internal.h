@@ -145,6 +145,7 @@ hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, 
 // {genome, slab | slot << 16} for every slab of HG_ENC_SLAB hashes (planned from an upper bound of the distinct
 // count), d_genomes[slot] = genome, d_accum = n_genomes * hv_d uint32 of scratch.  Slabs and slots are < 65536.
 #define HG_ENC_SLAB 32768u
+#define HG_ENC_WAVE_MAX 16368u  // hashes one wave encodes without leaving its bit-sliced counters (16 * 1023)
 struct hg_encode_split {
   const uint32_t *d_items;    // uint2 pairs
   const uint32_t *d_genomes;
@@ -153,7 +154,8 @@ struct hg_encode_split {
 };
 hipError_t hg_launch_encode(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                             const uint64_t *d_hits, const uint32_t *d_ndistinct, uint32_t hv_d,
-                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2, const hg_encode_split *split = nullptr);
+                            uint32_t layout, int16_t *d_hv, int32_t *d_norm2, const hg_encode_split *split = nullptr,
+                            uint32_t max_hashes = ~0u /* upper bound of the distinct counts, if the host knows one */);
 
 // ---- dist kernels ------------------------------------------------------------------------------
 struct hg_dist_args {
