@@ -10,8 +10,9 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("kmer_sample", "sort_unique", "encode_kernel", "dist_mfma", "dist_int", "prep_fast_kernel", "prep_kernel",
-        "decide_kernel", "synth_kernel", "hamming_kernel", "binarize_kernel")
+OURS = ("kmer_sample", "sort_unique", "encode_wave_kernel", "encode_finalize_kernel", "encode_kernel", "bucket_count_kernel",
+        "bucket_scan_kernel", "bucket_scatter_kernel", "bucket_sort_kernel", "bucket_copy_kernel", "dist_mfma", "dist_int",
+        "prep_fast_kernel", "prep_kernel", "decide_kernel", "synth_kernel", "hamming_kernel", "binarize_kernel")
 
 
 def short(name):
