@@ -84,6 +84,10 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   for (auto e : c->t_pool) (void)hipEventDestroy(e);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (auto e : c->copy_events) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (c->pack_buf[i]) (void)hipHostFree(c->pack_buf[i]);
+    if (c->pack_ev[i]) (void)hipEventDestroy(c->pack_ev[i]);
+  }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -503,6 +507,7 @@ extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const 
 // of the sub-batches already on the device, so PCIe transfer and kernels overlap for pinned and for
 // pageable caller memory alike (a pageable hipMemcpyAsync blocks the thread that issues it).
 constexpr uint64_t HG_STAGE_BYTES = 64ull << 20;
+constexpr uint64_t HG_PACK_BYTES = HG_STAGE_BYTES + (2ull << 20);  // a sub-batch of genomes < 1 MiB each fits
 
 extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
                                      const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
@@ -547,8 +552,29 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
   auto upload = [&](size_t first_chunk) {
     hipError_t e = hipSetDevice(c->device);
     for (size_t k = first_chunk; k < n_chunks; ++k) {
-      for (size_t g = cut[k]; g < cut[k + 1] && e == hipSuccess; ++g)
-        if (lens[g]) e = hipMemcpyAsync(d_seq + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, c->copy_stream);
+      const size_t g0 = cut[k], g1 = cut[k + 1];
+      const uint64_t span = offs[g1 - 1] + ((l64[g1 - 1] + 15) & ~(uint64_t)15) - offs[g0];
+      if (g1 - g0 >= 16 && span / (g1 - g0) < ((uint64_t)1 << 20) && span <= HG_PACK_BYTES) {
+        // many small genomes: pack them into pinned memory (device layout) and upload once -- a
+        // hipMemcpyAsync per 2 kbp genome costs more than the genome
+        const int b = (int)(k & 1);
+        if (!c->pack_buf[b]) {
+          e = hipHostMalloc(&c->pack_buf[b], HG_PACK_BYTES, hipHostMallocDefault);
+          if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pack_ev[b], hipEventDisableTiming);
+        }
+        if (e == hipSuccess && c->pack_used[b]) e = hipEventSynchronize(c->pack_ev[b]);
+        if (e == hipSuccess) {
+          auto *pin = static_cast<uint8_t *>(c->pack_buf[b]);
+          for (size_t g = g0; g < g1; ++g)
+            if (lens[g]) std::memcpy(pin + (offs[g] - offs[g0]), seqs[g], lens[g]);
+          e = hipMemcpyAsync(d_seq + offs[g0], pin, span, hipMemcpyHostToDevice, c->copy_stream);
+          if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], c->copy_stream);
+          c->pack_used[b] = true;
+        }
+      } else {
+        for (size_t g = g0; g < g1 && e == hipSuccess; ++g)
+          if (lens[g]) e = hipMemcpyAsync(d_seq + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, c->copy_stream);
+      }
       if (e == hipSuccess) e = hipEventRecord(c->copy_events[k], c->copy_stream);
       std::lock_guard<std::mutex> lk(mu);
       if (e != hipSuccess) copy_err = e;

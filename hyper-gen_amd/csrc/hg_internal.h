@@ -57,6 +57,11 @@ struct hg_ctx {
   // host-fed batches: uploads run on their own stream, one event per sub-batch (hg_sketch_batch)
   hipStream_t copy_stream = nullptr;
   std::vector<hipEvent_t> copy_events;
+  // two pinned staging buffers for sub-batches of many small genomes (one packed upload instead of one
+  // hipMemcpyAsync per genome); pack_ev[i] marks the last upload that read pack_buf[i]
+  void *pack_buf[2] = {nullptr, nullptr};
+  hipEvent_t pack_ev[2] = {nullptr, nullptr};
+  bool pack_used[2] = {false, false};
   // rows [pad_rows, padded rows) of the f16 operand copies are known to be zero (dist tiles hang over)
   const void *pad_a_ptr = nullptr, *pad_b_ptr = nullptr;
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;

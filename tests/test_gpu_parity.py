@@ -490,3 +490,17 @@ def test_symmetric_large(ctx, orc, hg):
     got = {(int(h["ref_idx"]), int(h["qry_idx"])) for h in hits}
     assert {(i, j) for i, j in zip(*np.nonzero((want >= th) & iu & ~near))} <= got
     assert got <= {(i, j) for i, j in zip(*np.nonzero(((want >= th) | near) & iu))}
+
+
+def test_sketch_batch_of_many_small_genomes_is_packed_for_upload(ctx, orc, hg):
+    # >= 16 genomes of < 1 MiB each in a sub-batch take the packed (one upload) path of hg_sketch_batch
+    rng = np.random.default_rng(77)
+    p = hg.default_params(scaled=50)
+    gs = [rand_seq(rng, int(n)) for n in rng.integers(0, 30_000, 200)]
+    gs[7] = gs[7][:5]      # shorter than k
+    gs[8] = gs[8][:0]      # empty
+    for rep in range(2):   # the second call reuses the pinned staging buffers
+        hv, n2, nh = ctx.sketch_batch(gs, p)
+        for i in (0, 1, 7, 8, 9, 57, 199):
+            w_hv, w_n2, w_nh = orc.sketch_genome(gs[i], scaled=50)
+            assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (rep, i)
