@@ -262,7 +262,7 @@ struct Loaded {
   uint8_t ksize = 0;
 };
 
-void load(const std::string &path, Loaded &L) {
+void load(const std::string &path, Loaded &L, unsigned threads) {
   logline("INFO", "Loading sketch from " + path);
   if (hg_sketch_file_read(path.c_str(), &L.f) != HG_OK) die("Opening sketch file failed!");
   L.n = hg_sketch_file_count(L.f);
@@ -273,15 +273,23 @@ void load(const std::string &path, Loaded &L) {
   std::snprintf(buf, sizeof buf, "Decompressing sketch with HV dim=%llu", (unsigned long long)L.hv_d);
   logline("INFO", buf);
   L.hv.resize(L.n * L.hv_d), L.n2.resize(L.n);
-  for (size_t i = 0; i < L.n; ++i) {
-    const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
-    if (r->hv_d != L.hv_d) die("sketches of one file use different HV dimensions");
-    if (r->hv_len * 16 != (uint64_t)r->hv_quant_bits * L.hv_d) die("corrupt sketch payload in " + path);
-    if (hg_hv_unpack(reinterpret_cast<const uint8_t *>(r->hv), (uint32_t)L.hv_d, r->hv_quant_bits,
-                     L.hv.data() + i * L.hv_d) != HG_OK)
-      die("unpack failed");
-    L.n2[i] = r->hv_norm_2;
-  }
+  // decompress_file_sketch is a rayon loop in the reference (src/hd.rs:171-180): -t threads here
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (size_t i; (i = next.fetch_add(1)) < L.n;) {
+      const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
+      if (r->hv_d != L.hv_d) die("sketches of one file use different HV dimensions");
+      if (r->hv_len * 16 != (uint64_t)r->hv_quant_bits * L.hv_d) die("corrupt sketch payload in " + path);
+      if (hg_hv_unpack(reinterpret_cast<const uint8_t *>(r->hv), (uint32_t)L.hv_d, r->hv_quant_bits,
+                       L.hv.data() + i * L.hv_d) != HG_OK)
+        die("unpack failed");
+      L.n2[i] = r->hv_norm_2;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, L.n / 64)); ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
 }
 
 int run_dist(const Cli &c) {
@@ -290,8 +298,8 @@ int run_dist(const Cli &c) {
   const auto t0 = std::chrono::steady_clock::now();
   const bool sym = c.path_r == c.path_q;  // src/dist.rs:13
   Loaded R, Qs;
-  load(c.path_r, R);
-  if (!sym) load(c.path_q, Qs);
+  load(c.path_r, R, c.threads);
+  if (!sym) load(c.path_q, Qs, c.threads);
   const Loaded &Q = sym ? R : Qs;
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
   if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
