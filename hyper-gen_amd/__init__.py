@@ -67,6 +67,7 @@ EXPORTS = [
     "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_read_merge_seq_into", "hg_free",
     "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
     "hg_hv_binarize_dev", "hg_hamming_full_dev", "hg_hamming_search_dev",
+    "hg_ctx_set_debug", "hg_read_fastx_into",
 ]
 
 
@@ -129,6 +130,8 @@ def lib():
         "hg_sketch_file_free": (None, [vp]),
         "hg_read_merge_seq": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz)]),
         "hg_read_merge_seq_into": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
+        "hg_read_fastx_into": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
+        "hg_ctx_set_debug": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "hg_free": (None, [vp]),
         "hg_hv_binarize_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
         "hg_hamming_full_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, vp]),
@@ -191,6 +194,10 @@ class Context:
     def set_stream(self, stream_handle):
         """Run on the given hipStream_t handle; 0 / None is HIP's default stream (torch's default current stream)."""
         self._ck(lib().hg_ctx_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def set_debug(self, key, value):
+        """Development / test hook: force an internal code path of this ctx (hg_ctx_set_debug)."""
+        self._ck(lib().hg_ctx_set_debug(self._h, key.encode(), str(value).encode()))
 
     def reset_stream(self):
         self._ck(lib().hg_ctx_reset_stream(self._h))
@@ -348,11 +355,15 @@ def sort_ani_hits(hits, Q, symmetric=False):
     return hits
 
 
-def read_merge_seq(path):
-    p, n = C.c_void_p(), C.c_size_t(0)
-    st = lib().hg_read_merge_seq(os.fsencode(path), C.byref(p), C.byref(n))
+READ_MERGE, READ_NEEDLETAIL = 0, 1
+
+
+def read_merge_seq(path, mode=READ_MERGE):
+    p, n, cap = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+    st = lib().hg_read_fastx_into(os.fsencode(path), mode, C.byref(p), C.byref(cap), C.byref(n))
     if st != OK:
-        raise HgError(st, "hg_read_merge_seq(%s)" % path)
+        lib().hg_free(p)
+        raise HgError(st, "hg_read_fastx_into(%s)" % path)
     try:
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy() if n.value \
             else np.zeros(0, np.uint8)

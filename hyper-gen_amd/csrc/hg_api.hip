@@ -93,15 +93,34 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   delete c;
 }
 
+// The ctx workspaces (hit buffers, f16 operand copies, counters, the cached batch plan) are ordered by ONE stream.
+// A call may return with its last kernels still running on them, so a switch to another stream first drains the
+// old one: otherwise the next call's kernels could overwrite workspaces the old stream still reads.
+static hg_status switch_stream(hg_ctx *c, hipStream_t to) {
+  if (to == c->stream) return HG_OK;
+  HG_HIP(c, hipSetDevice(c->device));
+  HG_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = to;
+  return HG_OK;
+}
+
 extern "C" hg_status hg_ctx_set_stream(hg_ctx *c, void *hip_stream) {
   if (!c) return HG_ERR_INVALID;
-  c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's default stream, on purpose
-  return HG_OK;
+  return switch_stream(c, reinterpret_cast<hipStream_t>(hip_stream));  // NULL = HIP's default stream, on purpose
 }
 
 extern "C" hg_status hg_ctx_reset_stream(hg_ctx *c) {
   if (!c) return HG_ERR_INVALID;
-  c->stream = c->own_stream;
+  return switch_stream(c, c->own_stream);
+}
+
+extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *value) {
+  if (!c || !key) return HG_ERR_INVALID;
+  const std::string k = key, v = value ? value : "";
+  if (k == "dist_tile") c->dbg_dist_tile = v;
+  else if (k == "sort_test_buckets") c->dbg_sort_buckets = std::atoi(v.c_str());
+  else if (k == "dist_path") c->dbg_dist_path = v;
+  else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;
 }
 
@@ -292,8 +311,8 @@ hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt,
     if (cnt <= HG_SORT_LDS_MAX_KEYS) continue;
     uint32_t P = 2;
     while (P < MAX_BUCKETS && (uint64_t)P * TARGET < cnt) P <<= 1;
-    if (const char *e = std::getenv("HG_SORT_TEST_BUCKETS")) {  // test hook: force overflowing buckets / the fallback
-      P = (uint32_t)std::max(2, std::atoi(e));
+    if (c->dbg_sort_buckets) {  // test hook (hg_ctx_set_debug): force overflowing buckets / the fallback
+      P = (uint32_t)std::max(2, c->dbg_sort_buckets);
     } else if ((uint64_t)P * (HG_SORT_LDS_MAX_KEYS / 2) < cnt) {  // more than ~8 k keys per bucket expected: too many for LDS
       inplace.push_back((uint32_t)g);
       continue;

@@ -151,9 +151,14 @@ int run_sketch(const Cli &c) {
   if (hg_ctx_create(0, &ctx) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
   hg_sketch_params p;
   hg_sketch_params_default(&p);
-  p.ksize = c.ksize, p.canonical = c.canonical, p.scaled = c.scaled, p.seed = c.seed;
+  const bool gpu_mode = c.device == "gpu";
+  p.ksize = c.ksize, p.scaled = c.scaled, p.seed = c.seed;
+  // -C is honoured by the reference's CUDA kernel only (src/cuda_kernel.cu:312-314); its CPU path always takes
+  // needletail's canonical_kmers (src/sketch.rs:89) -- the flag still goes into the .sketch records as given
+  p.canonical = gpu_mode ? (c.canonical ? 1u : 0u) : 1u;
   p.hv_d = (uint32_t)c.hv_d, p.hv_layout = HG_LAYOUT_AVX2;
-  p.norm_mode = c.device == "gpu" ? HG_NORM_ACGT : HG_NORM_U2T;
+  p.norm_mode = gpu_mode ? HG_NORM_ACGT : HG_NORM_U2T;
+  const uint32_t read_mode = gpu_mode ? HG_READ_MERGE : HG_READ_NEEDLETAIL;
 
   std::vector<std::vector<int16_t>> payload(n);
   std::vector<hg_file_sketch> recs(n);
@@ -197,7 +202,7 @@ int run_sketch(const Cli &c) {
     std::atomic<size_t> next{0};
     auto work = [&] {
       for (size_t k; (k = next.fetch_add(1)) < cnt;) {
-        if (hg_read_merge_seq_into(files[b.i0 + k].c_str(), &b.slots[k].p, &b.slots[k].cap, &b.lens[k]) != HG_OK)
+        if (hg_read_fastx_into(files[b.i0 + k].c_str(), read_mode, &b.slots[k].p, &b.slots[k].cap, &b.lens[k]) != HG_OK)
           die("Opening .fna files failed: " + files[b.i0 + k]);
         b.seqs[k] = b.slots[k].p;
       }
@@ -269,6 +274,12 @@ void load(const std::string &path, Loaded &L, unsigned threads) {
   if (L.n == 0) die("empty sketch file " + path);
   const hg_file_sketch *r0 = hg_sketch_file_get(L.f, 0);
   L.hv_d = r0->hv_d, L.ksize = r0->ksize;
+  // validate before sizing anything from the file's own numbers
+  if (L.hv_d == 0 || L.hv_d % 256 || L.hv_d > 65536) die("unsupported HV dimension in " + path);
+  for (size_t i = 0; i < L.n; ++i) {
+    const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
+    if (r->hv_quant_bits < 1 || r->hv_quant_bits > 16) die("corrupt sketch record (quantisation bits) in " + path);
+  }
   char buf[96];
   std::snprintf(buf, sizeof buf, "Decompressing sketch with HV dim=%llu", (unsigned long long)L.hv_d);
   logline("INFO", buf);

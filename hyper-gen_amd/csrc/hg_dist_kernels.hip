@@ -804,8 +804,11 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   // D = 4096) every workgroup reads the same 128-byte column offset of 256 different rows at the same
   // moment, i.e. one L2 / Infinity-Cache channel; the odd 128-byte skew spreads rows over channels.
   const uint32_t ldk = Kp + 64;
-  // padded row counts cover every tile geometry (128, 256 and 320 rows)
-  auto padded = [](uint32_t n) { return std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320); };
+  // padded row counts cover every tile geometry: 128- and 256-row tiles, 320-wide tiles and the 192-wide tiles of
+  // the windowed (CHUNKED) big geometry -- the LDS-DMA reads whole tiles, rows past R / Q must exist and be zero
+  auto padded = [](uint32_t n) {
+    return std::max(std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320), (n + 191) / 192 * 192);
+  };
   const uint32_t Rp = padded(a.R), Qp = padded(a.Q);
   const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
@@ -943,7 +946,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     const uint64_t r4 = (tm * ((a.Q + 255) / 256) + ncu - 1) / ncu, r5 = (tm * ((a.Q + 319) / 320) + ncu - 1) / ncu;
     if (r5 * 5 < r4 * 4) nt = 5;
   }
-  if (const char *e = std::getenv("HG_DIST_TILE")) {  // test hook: force a geometry ("big"/"wide" need !full && whole_k)
+  if (const char *e = c->dbg_dist_tile.empty() ? nullptr : c->dbg_dist_tile.c_str()) {  // test hook (hg_ctx_set_debug): force a geometry
     if (!std::strcmp(e, "big")) big = !full && whole_k, nt = 4;
     else if (!std::strcmp(e, "wide")) big = !full && whole_k, nt = 5;
     else if (!std::strcmp(e, "nt3")) big = !full && whole_k, nt = 3;
@@ -955,7 +958,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   // accumulators double the accumulator registers, so the 256-row geometry narrows to 64 * NT_CHUNKED columns
   constexpr int NT_CHUNKED = 3;
   bool big_chunked = !full && !whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
-  if (const char *e = std::getenv("HG_DIST_TILE")) {
+  if (const char *e = c->dbg_dist_tile.empty() ? nullptr : c->dbg_dist_tile.c_str()) {
     if (!std::strcmp(e, "small")) big_chunked = false;
     else if (!std::strcmp(e, "big") || !std::strcmp(e, "wide")) big_chunked = !full && !whole_k;
   }

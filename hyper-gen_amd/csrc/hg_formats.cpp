@@ -152,10 +152,13 @@ extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out)
   if (!get(p, end, n)) return HG_ERR_IO;
   hg_sketch_file *sf = new (std::nothrow) hg_sketch_file();
   if (!sf) return HG_ERR_OOM;
-  if (n > buf.size()) {  // each record is > 1 byte: cheap sanity bound
+  // a record is at least 47 bytes (31 fixed + two u64 lengths): a count the file cannot hold is corruption,
+  // not an allocation request (a hostile count must not reach resize())
+  if (n > (buf.size() - 8) / 47) {
     delete sf;
     return HG_ERR_IO;
   }
+  try {
   sf->recs.resize(n), sf->names.resize(n), sf->payloads.resize(n);
   for (uint64_t i = 0; i < n; ++i) {
     hg_file_sketch &r = sf->recs[i];
@@ -177,6 +180,10 @@ extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out)
     if (hl) std::memcpy(sf->payloads[i].data(), p, hl * 2);
     p += hl * 2;
     r.hv_len = hl;
+  }
+  } catch (const std::bad_alloc &) {  // nothing may unwind through the C ABI
+    delete sf;
+    return HG_ERR_OOM;
   }
   for (uint64_t i = 0; i < n; ++i) {  // pointers only after the vectors stopped moving
     sf->recs[i].file_str = sf->names[i].c_str();
@@ -216,6 +223,51 @@ size_t merge_in_place(uint8_t *buf, size_t n) {
 }  // namespace
 
 namespace {
+// needletail's view of the same file (the reference's CPU path, src/sketch.rs:76-87): `parse_fastx_file` picks the
+// FASTA or the FASTQ parser from the first byte; a FASTA record's sequence is every line up to the next line that
+// starts with '>', a FASTQ record is four lines (@id, sequence, +, qualities); `normalize(false)` then DROPS
+// blanks, tabs and line ends inside the sequence (u/U -> T and upper-casing happen on the device, HG_NORM_U2T).
+// Output: the read_merge_seq layout ('N' per record start), so that k-mers never span records.
+inline bool nt_blank(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+size_t merge_in_place_needletail(uint8_t *buf, size_t n) {
+  size_t w = 0, i = 0;
+  const bool fastq = n && buf[0] == '@';
+  unsigned line_in_rec = 0;  // FASTQ: 0 = @id, 1 = sequence, 2 = '+', 3 = qualities
+  while (i < n) {
+    const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + i, '\n', n - i));
+    const size_t j = nl ? (size_t)(nl - buf) : n;
+    bool is_seq;
+    if (fastq) {
+      if (line_in_rec == 0) buf[w++] = 'N';
+      is_seq = line_in_rec == 1;
+      line_in_rec = (line_in_rec + 1) & 3;
+    } else {
+      is_seq = buf[i] != '>';
+      if (!is_seq) buf[w++] = 'N';
+    }
+    if (is_seq) {
+      // fast path: no blank inside the line (only a possible trailing '\r')
+      size_t e = j;
+      while (e > i && nt_blank(buf[e - 1])) --e;
+      bool clean = true;
+      for (size_t t = i; t < e; ++t)
+        if (buf[t] == ' ' || buf[t] == '\t' || buf[t] == '\r') {
+          clean = false;
+          break;
+        }
+      if (clean) {
+        std::memmove(buf + w, buf + i, e - i);
+        w += e - i;
+      } else {
+        for (size_t t = i; t < e; ++t)
+          if (!nt_blank(buf[t])) buf[w++] = buf[t];
+      }
+    }
+    i = j < n ? j + 1 : j;
+  }
+  return w;
+}
+
 bool grow(uint8_t *&buf, size_t &cap, size_t need) {
   if (need <= cap) return true;
   uint8_t *nb = static_cast<uint8_t *>(std::realloc(buf, need));
@@ -225,8 +277,8 @@ bool grow(uint8_t *&buf, size_t &cap, size_t need) {
 }
 }  // namespace
 
-extern "C" hg_status hg_read_merge_seq_into(const char *path, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {
-  if (!path || !pbuf || !pcap || !n_bps) return HG_ERR_INVALID;
+extern "C" hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {
+  if (!path || !pbuf || !pcap || !n_bps || mode > HG_READ_NEEDLETAIL) return HG_ERR_INVALID;
   *n_bps = 0;
   uint8_t *buf = *pbuf;
   size_t cap = buf ? *pcap : 0;
@@ -266,10 +318,14 @@ extern "C" hg_status hg_read_merge_seq_into(const char *path, uint8_t **pbuf, si
   }
   *pbuf = buf, *pcap = cap;  // the (possibly moved) buffer stays the caller's, also on error
   if (st != HG_OK) return st;
-  const size_t w = merge_in_place(buf, n);
+  const size_t w = mode == HG_READ_NEEDLETAIL ? merge_in_place_needletail(buf, n) : merge_in_place(buf, n);
   std::memset(buf + w, 0, 64);
   *n_bps = w;
   return HG_OK;
+}
+
+extern "C" hg_status hg_read_merge_seq_into(const char *path, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {
+  return hg_read_fastx_into(path, HG_READ_MERGE, pbuf, pcap, n_bps);
 }
 
 extern "C" hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps) {

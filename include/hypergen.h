@@ -56,11 +56,19 @@ void hg_ctx_destroy(hg_ctx *ctx);
 /* run all subsequent work on an existing hipStream_t (e.g. torch's current stream).  The handle is used as
  * given: NULL is HIP's default (null) stream -- which IS torch's current stream unless the caller changed
  * it -- so that the ctx's kernels are ordered with the caller's own work on that stream.
- * hg_ctx_reset_stream goes back to the ctx's private non-blocking stream (the state after hg_ctx_create). */
+ * hg_ctx_reset_stream goes back to the ctx's private non-blocking stream (the state after hg_ctx_create).
+ * Both first wait for the work already queued on the stream being left (the ctx workspaces are ordered by
+ * one stream at a time). */
 hg_status hg_ctx_set_stream(hg_ctx *ctx, void *hip_stream);
 hg_status hg_ctx_reset_stream(hg_ctx *ctx);
 hg_status hg_ctx_sync(hg_ctx *ctx);
 int hg_device_count(void);
+/* development / test hook (no reference counterpart): force an internal code path of THIS ctx.
+ * keys: "dist_tile" = "" | "small" | "big" | "big_reg" | "wide" | "nt3"   (GEMM tile geometry)
+ *       "dist_path" = "" | "f16" | "i8"                                    (operand format of the ANI GEMM)
+ *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
+ * Nothing in the library reads environment variables. */
+hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
 
 /* per-kernel device timing: when enabled, every kernel launch of the sketch / dist entry
  * points is bracketed by HIP events on the ctx's stream.  hg_ctx_timings waits for the last
@@ -218,6 +226,14 @@ hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps);
  * large enough and realloc'ed otherwise -- a reader thread that recycles its buffers avoids one 5 MB
  * mmap / page-fault / munmap cycle per file */
 hg_status hg_read_merge_seq_into(const char *path, uint8_t **buf, size_t *cap, size_t *n_bps);
+/* mode HG_READ_MERGE: exactly read_merge_seq (every line that does not start with '>' is sequence).
+ * mode HG_READ_NEEDLETAIL: what the reference's CPU path sees through needletail 0.5.1 (src/sketch.rs:76-87):
+ * FASTA or FASTQ chosen by the first byte ('>' / '@'), four-line FASTQ records (only the sequence line is kept),
+ * blanks, tabs and CRs inside sequence lines dropped (`normalize`); still one 'N' per record start.  Both modes
+ * inflate gzip input transparently. */
+#define HG_READ_MERGE 0u
+#define HG_READ_NEEDLETAIL 1u
+hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **buf, size_t *cap, size_t *n_bps);
 void hg_free(void *p);
 
 /* ---- bit-packed hypervectors + Hamming search (extension: BASELINE.json configs[4]) ------------

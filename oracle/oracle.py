@@ -137,6 +137,31 @@ def read_merge_seq(text):
     return out[:n].copy()
 
 
+def read_needletail(text):
+    """What the reference's CPU path feeds its k-mer walk (src/sketch.rs:76-87) for one file, in the
+    read_merge_seq layout ('N' per record start): needletail 0.5.1 `parse_fastx_file` picks FASTA or FASTQ from
+    the first byte; a FASTA record's sequence is every line up to the next '>' line, a FASTQ record is 4 lines;
+    `normalize(false)` drops blanks / tabs / CR / LF inside the sequence (upper-casing, u/U -> T and the
+    non-ACGT breaks are the k-mer walk's NORM_U2T mode).  Restated from the crate's published behaviour:
+    needletail is an un-vendored dependency (Cargo.toml: needletail = "0.5.1"), parity unpinned."""
+    data = bytes(_bytes_arr(text))
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    strip = lambda ln: bytes(c for c in ln if c not in b" \t\r\n")
+    out = bytearray()
+    if data[:1] == b"@":
+        for i, ln in enumerate(lines):
+            if i % 4 == 0:
+                out += b"N"
+            elif i % 4 == 1:
+                out += strip(ln)
+    else:
+        for ln in lines:
+            out += b"N" if ln[:1] == b">" else strip(ln)
+    return np.frombuffer(bytes(out), np.uint8).copy() if out else np.zeros(0, np.uint8)
+
+
 def encode_hv(hashes, hv_d=4096, layout=LAYOUT_AVX2):
     h = np.ascontiguousarray(hashes, dtype=np.uint64)
     hv = np.zeros(hv_d, np.int16)

@@ -115,6 +115,49 @@ def test_read_merge_seq(hg, orc, tmp_path):
     assert bytes(hg.read_merge_seq(str(p))) == b"NAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"
 
 
+def test_read_needletail_mode_fasta_blanks_and_fastq(hg, orc, tmp_path):
+    """-D cpu reads files the way needletail does (src/sketch.rs:76-87): blanks inside sequence lines vanish,
+    FASTQ records contribute their sequence line only; -D gpu keeps read_merge_seq's line semantics."""
+    import gzip
+    fa = b">r1 desc\nAC GT\tAC\r\nacgu \r\n\n>r2\nTT N\r"
+    p = tmp_path / "t.fa"
+    p.write_bytes(fa)
+    got = hg.read_merge_seq(str(p), hg.READ_NEEDLETAIL)
+    assert bytes(got) == b"NACGTACacguNTTN" and (got == orc.read_needletail(fa)).all()
+    assert bytes(hg.read_merge_seq(str(p))) == b"NAC GT\tACacgu NTT N"  # reference GPU reader: lines as they are
+    fq = b"@read1 x\nACGTTGCA\n+\nIIIIIIII\n@read2\nGGGACCC\r\n+read2\n>>>>III\n"
+    p.write_bytes(fq)
+    got = hg.read_merge_seq(str(p), hg.READ_NEEDLETAIL)
+    assert bytes(got) == b"NACGTTGCANGGGACCC" and (got == orc.read_needletail(fq)).all()
+    p.write_bytes(gzip.compress(fq))  # a quality line may start with '>' or '@': the 4-line cadence decides
+    assert bytes(hg.read_merge_seq(str(p), hg.READ_NEEDLETAIL)) == b"NACGTTGCANGGGACCC"
+    rng = np.random.default_rng(5)
+    for trial in range(20):  # random mixes of record lengths, blanks, line ends
+        recs = []
+        for r in range(rng.integers(1, 5)):
+            seq = bytes(rng.choice(list(b"ACGTacgtNn \t"), rng.integers(0, 200)).astype(np.uint8))
+            lines = [seq[i:i + 37] for i in range(0, len(seq), 37)]
+            recs.append(b">h%d\n" % r + (b"\r\n" if trial % 2 else b"\n").join(lines))
+        txt = b"\n".join(recs) + (b"\n" if trial % 3 else b"")
+        p.write_bytes(txt)
+        assert (hg.read_merge_seq(str(p), hg.READ_NEEDLETAIL) == orc.read_needletail(txt)).all(), trial
+
+
+def test_corrupt_sketch_files_are_rejected_not_fatal(hg, tmp_path):
+    path = str(tmp_path / "bad.sketch")
+    for count in (2**63, 2**40, 3):  # record counts the file cannot hold
+        open(path, "wb").write(struct.pack("<Q", count) + b"\x00" * 60)
+        with pytest.raises(hg.HgError):
+            hg.read_sketch_file(path)
+    hdr = struct.pack("<BQBQQBi", 21, 1500, 1, 123, 4096, 6, 0)
+    open(path, "wb").write(struct.pack("<Q", 1) + hdr + struct.pack("<Q", 2**62) + b"ab")  # absurd path length
+    with pytest.raises(hg.HgError):
+        hg.read_sketch_file(path)
+    open(path, "wb").write(struct.pack("<Q", 1) + hdr + struct.pack("<Q", 1) + b"a" + struct.pack("<Q", 2**61))
+    with pytest.raises(hg.HgError):
+        hg.read_sketch_file(path)
+
+
 def test_sort_ani_hits_matches_dump_ani_file_order(hg):
     # model of src/utils.rs:262-269 on the row-major enumeration of src/dist.rs:251-265
     rng = np.random.default_rng(3)

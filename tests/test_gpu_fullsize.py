@@ -139,8 +139,7 @@ def test_dist_10k_thresholded_equals_full_matrix(tile, nhash):
     cap = 4_000_000
     hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
     try:
-        if tile:
-            os.environ["HG_DIST_TILE"] = tile
+        ctx.set_debug("dist_tile", tile)
         for sym, th in ((False, 85.0), (True, 86.5)):
             found, st = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, sym, th,
                                      hits.data_ptr(), cap)
@@ -157,7 +156,47 @@ def test_dist_10k_thresholded_equals_full_matrix(tile, nhash):
             assert bool((got == want).all())
             assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
     finally:
-        os.environ.pop("HG_DIST_TILE", None)
+        ctx.close()
+
+
+def test_dist_windowed_192_wide_tiles_ragged_q():
+    """Q = 4993 needs 5 184 zero-padded query rows for the 192-wide tiles of the windowed big geometry (more than
+    the 256- and 320-row paddings give): the LDS-DMA must read zeros there, not stale memory -- first with a
+    workspace that a larger earlier call sized and filled, then compared with the full-matrix mode."""
+    import bench
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    ctx = hg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        big = bench.clustered_hvs(5600, 0, dev, n=6666)
+        bn2 = (big.int() ** 2).sum(1).int()
+        cap = 4_000_000
+        hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+        # 1) a larger call fills the f16 workspaces with non-zero rows up to 5 600
+        ctx.dist_dev(big.data_ptr(), bn2.data_ptr(), 5600, big.data_ptr(), bn2.data_ptr(), 5600, D, 21, False, 85.0,
+                     hits.data_ptr(), cap)
+        R, Q = 3400, 4993
+        r, q = big[:R].contiguous(), big[200:200 + Q].contiguous()
+        rn, qn = bn2[:R].contiguous(), bn2[200:200 + Q].contiguous()
+        full = torch.empty((R, Q), dtype=torch.float32, device=dev)
+        ctx.dist_full_dev(r.data_ptr(), rn.data_ptr(), R, q.data_ptr(), qn.data_ptr(), Q, D, 21, full.data_ptr())
+        torch.cuda.synchronize()
+        for tile in ("big", ""):
+            ctx.set_debug("dist_tile", tile)
+            found, st = ctx.dist_dev(r.data_ptr(), rn.data_ptr(), R, q.data_ptr(), qn.data_ptr(), Q, D, 21, False, 85.0,
+                                     hits.data_ptr(), cap)
+            torch.cuda.synchronize()
+            assert st == 0 and 0 < found < cap
+            h = hits[: found * 3].view(found, 3)
+            ri, qi, ani = h[:, 0].long(), h[:, 1].long(), h[:, 2].view(torch.float32)
+            want = full >= 85.0
+            assert found == int(want.sum())
+            got = torch.zeros_like(want)
+            got[ri, qi] = True
+            assert bool((got == want).all())
+            assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+    finally:
         ctx.close()
 
 

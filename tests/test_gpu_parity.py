@@ -245,10 +245,10 @@ def test_large_hit_set_hash_set_and_inplace_fallback(ctx, orc):
     g = orc.synth_genome(15, 200_000)
     want = orc.kmer_hash_sample(g, 21, 2)
     try:
-        os.environ["HG_SORT_TEST_BUCKETS"] = "2"
+        ctx.set_debug("sort_test_buckets", "2")
         got = ctx.kmer_hash_sample(g, 21, 2)
     finally:
-        del os.environ["HG_SORT_TEST_BUCKETS"]
+        ctx.set_debug("sort_test_buckets", "0")
     assert want.size > 90_000 and got.size == want.size and (got == want).all()
 
 
@@ -440,16 +440,16 @@ def test_dist_big_tiles_and_chunked_paths(ctx, orc, hg):
     import os
     key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
     try:
-        os.environ["HG_DIST_TILE"] = "big"       # 256 x 256, LDS-DMA staging (swizzled image)
+        ctx.set_debug("dist_tile", "big")       # 256 x 256, LDS-DMA staging (swizzled image)
         hits_big = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
-        os.environ["HG_DIST_TILE"] = "big_reg"   # 256 x 256, register staging
+        ctx.set_debug("dist_tile", "big_reg")   # 256 x 256, register staging
         hits_big_reg = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
-        os.environ["HG_DIST_TILE"] = "wide"      # 256 x 320, LDS-DMA staging
+        ctx.set_debug("dist_tile", "wide")      # 256 x 320, LDS-DMA staging
         hits_wide = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
-        os.environ["HG_DIST_TILE"] = "small"     # 128 x 128
+        ctx.set_debug("dist_tile", "small")     # 128 x 128
         hits = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
     finally:
-        del os.environ["HG_DIST_TILE"]
+        ctx.set_debug("dist_tile", "")
     assert (key(hits_big) == key(hits)).all()      # all geometries: identical hits, bit for bit
     assert (key(hits_big_reg) == key(hits)).all()
     assert (key(hits_wide) == key(hits)).all()
