@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU and step")
     ap.add_argument("--dist-n", type=int, default=10000, help="R = Q of the ANI matrix (0 = skip)")
     ap.add_argument("--hamming-refs", type=int, default=50000, help="refs of the bit-packed D=16384 search (0 = skip)")
+    ap.add_argument("--hamming-queries", type=int, default=10000, help="queries of the bit-packed search")
+    ap.add_argument("--genomes-10k", type=int, default=10000,
+                    help="TOTAL genomes of the configs[2] leg, sharded over the ranks (0 = skip)")
+    ap.add_argument("--hostfed-genomes", type=int, default=256, help="genomes of the host-fed (PCIe) leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -87,23 +91,36 @@ def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100):
     return out
 
 
-def valu_issue(kmer_ms, n_genomes):
-    """Secondary, informative roofline of the k-mer kernel: its VALU instruction rate against the issue rate
-    the same instruction mix reaches in tools/gpu_microbench.hip.  Instruction count and kernel cycles come
-    from the committed PMC passes (profiles/r01_pmc.json: SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this command)."""
+def newest_profile(suffix):
+    """Path of the newest committed profiles/rNN<suffix> (the counters cannot be collected inside this process:
+    rocprofv3 --pmc passes of this very command produce them, tools/profile_gpu.sh)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix)))
+    return c[-1] if c else None
+
+
+def valu_issue(n_genomes):
+    """Secondary, informative roofline of the k-mer kernel: its VALU instruction rate against the issue rate the
+    same instruction mix reaches in tools/gpu_microbench.hip.  Instruction count and kernel cycles: the newest
+    committed PMC passes of this command (SQ_INSTS_VALU, GRBM_GUI_ACTIVE); the slow-class / plain split of the
+    mix: the committed ISA histogram of the kernel (profiles/rNN_kmer_isa.json, tools/count_isa.py)."""
+    ppath, ipath = newest_profile("_pmc.json"), newest_profile("_kmer_isa.json")
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        d = json.load(open(ppath))
         k = [v for name, v in d.items() if name.startswith("kmer_sample_fast")][0]
         insts, cycles = k["SQ_INSTS_VALU"], k["GRBM_GUI_ACTIVE"] / 8.0
+        isa = json.load(open(ipath))
+        slow_frac = isa["per_kmer"]["slow_class"] / isa["per_kmer"]["valu"]
     except Exception:
         return None
     rate = insts / (1024 * cycles)  # wave-instructions per SIMD per cycle, as profiled
-    # mix of the kernel: ~42 slow-class (3.9 cycles) + ~55 plain (2.3 cycles) instructions per k-mer
-    # (profiles/r01_instruction_rates.txt) -> 97 instructions in ~290 cycles
-    bound = 97.0 / (42 * 3.9 + 55 * 2.3)
+    per_kmer = insts * 64.0 / (n_genomes * (L_GENOME + 1 - KSIZE + 1)) if n_genomes == 1000 else None
+    # issue cost of the mix: slow class 3.9 cycles, plain 2.3 cycles per wave-instruction (profiles/r01_instruction_rates.txt)
+    bound = 1.0 / (slow_frac * 3.9 + (1.0 - slow_frac) * 2.3)
     return {"valu_instr_per_simd_cycle": rate, "mix_issue_bound": bound, "frac": rate / bound,
-            "valu_instr_per_kmer": insts * 64.0 / (n_genomes * (L_GENOME + 1 - KSIZE + 1)) if n_genomes == 1000 else None,
-            "source": "profiles/r01_pmc.json (rocprofv3 --pmc of this command), profiles/r01_instruction_rates.txt"}
+            "valu_instr_per_kmer": per_kmer, "slow_class_fraction": slow_frac,
+            "source": "%s (rocprofv3 --pmc of this command), %s (static ISA histogram), "
+                      "profiles/r01_instruction_rates.txt (issue costs)" % (os.path.relpath(ppath, ROOT), os.path.relpath(ipath, ROOT))}
 
 
 def effective_cores():
@@ -167,10 +184,10 @@ def cpu_baseline_dist(hv, n2, seconds, log):
     r, rn = hv[:rows].cpu().numpy(), n2[:rows].cpu().numpy()
     q, qn = hv[:q_rows].cpu().numpy(), n2[:q_rows].cpu().numpy()
     t0 = time.perf_counter()
-    orc.ani_matrix(r, rn, q, qn, KSIZE)
+    block = orc.ani_matrix(r, rn, q, qn, KSIZE)
     dt = time.perf_counter() - t0
     log("cpu dist baseline: %d x %d in %.2f s" % (rows, q_rows, dt))
-    return {"value": rows * q_rows / dt / 1e6, "unit": "M ANI-pairs/sec", "cores": cores, "kind": "port",
+    return block, {"value": rows * q_rows / dt / 1e6, "unit": "M ANI-pairs/sec", "cores": cores, "kind": "port",
             "sample": "%d x %d sub-block of the step's HVs, oracle orc_ani_matrix (src/dist.rs:139-161, scalar "
                       "i16 dot per pair), OpenMP over rows on %d threads, %.2f s" % (rows, q_rows, cores, dt)}
 
@@ -227,8 +244,8 @@ def main():
     bytes_per_launch = N * (L_GENOME + 2 * HV_D)  # L + 2*D algorithmic bytes per genome
     achieved = bytes_per_launch / (kmer_avg_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_kmer_traffic.json")
-    if os.path.exists(tpath):
+    tpath = newest_profile("_kmer_traffic.json")
+    if tpath and N == 1000:
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
@@ -251,10 +268,77 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "nominally a scan, so priced against HBM; the true binder is integer VALU issue "
                              "(~97 VALU instructions per k-mer, ~60 of them the t1ha2 hash; see valu_issue)",
-                     "valu_issue": valu_issue(kmer_avg_ms, N),
+                     "valu_issue": valu_issue(N),
                      "kmer_hashes_per_sec": N * (L_GENOME + 1 - KSIZE + 1) / (kmer_avg_ms * 1e-3)},
         "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in tm.items() if v[1]},
     }
+
+    # ---------------- configs[2]: 10 000 genomes TOTAL, sharded over the ranks -------------------------------
+    # (the headline above is weak-scaled at 1 000 genomes per GPU; this leg is the fixed-size job BASELINE.json
+    # names: rank r sketches genomes shard_range(10 000, r, world), no collective -> "strong" scaling)
+    if a.genomes_10k:
+        from hypergen_amd import shard
+        glo, ghi = shard.shard_range(a.genomes_10k, rank, world)
+        M = ghi - glo
+        seq2 = torch.empty(M * stride + 64, dtype=torch.uint8, device=dev)
+        ctx.synth_genomes_dev(glo, M, L_GENOME, stride, seq2.data_ptr())
+        offs2 = np.arange(M, dtype=np.uint64) * stride
+        lens2 = np.full(M, L_GENOME + 1, np.uint64)
+        hv2 = torch.empty((M, HV_D), dtype=torch.int16, device=dev)
+        n22 = torch.empty(M, dtype=torch.int32, device=dev)
+        nh2 = torch.empty(M, dtype=torch.int32, device=dev)
+
+        def step2():
+            ctx.sketch_batch_dev(seq2.data_ptr(), offs2, lens2, p, hv2.data_ptr(), n22.data_ptr(), nh2.data_ptr())
+
+        step2()
+        steps2 = max(2, min(a.steps, 5))
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(steps2):
+            step2()
+        barrier_sync(world)
+        dt2 = max_over_ranks(time.perf_counter() - t0, world, dev)
+        # genomes [glo, ghi) here and genomes [rank*N, rank*N + N) above overlap on rank 0: same sketches expected
+        same = min(N, M) if rank == 0 else 0
+        if same and not (torch.equal(hv2[:same], hv[:same]) and torch.equal(n22[:same], n2[:same])):
+            raise SystemExit("PARITY GATE FAILED: the 10k-genome leg disagrees with the headline leg on shared genomes")
+        out["sketch_10k"] = {
+            "metric": "genomes/sec sketch (k=21,s=1500,D=4096)", "value": a.genomes_10k * steps2 / dt2,
+            "unit": "genomes/sec", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3, "scaling": "strong",
+            "config": {"workload": "%d synthetic 5 Mbp genomes in total (BASELINE configs[2]), rank r sketches "
+                                   "shard_range(%d, r, %d); inputs resident in HBM (%.1f GB per GPU)" % (
+                                       a.genomes_10k, a.genomes_10k, world, M * stride / 1e9),
+                       "genomes_per_gpu": M, "parallelism": "genome-sharded x%d, no collective" % world}}
+        log("sketch_10k: %.1f genomes/s (%d genomes on this rank, %.1f ms per pass)" % (
+            out["sketch_10k"]["value"], M, dt2 / steps2 * 1e3))
+        del seq2, hv2, n22, nh2
+
+    # ---------------- host-fed: the same sketch path from pinned host memory (PCIe-inclusive, never `value`) ---
+    if a.hostfed_genomes and rank == 0:
+        HF = min(a.hostfed_genomes, N)
+        host = torch.empty((HF, L_GENOME + 1), dtype=torch.uint8).pin_memory()
+        for g in range(HF):
+            host[g].copy_(seq[g * stride: g * stride + L_GENOME + 1])
+        host_rows = [host[g].numpy() for g in range(HF)]
+        own = hg.Context(local)  # its own stream and staging: hg_sketch_batch uploads while it computes
+        h_hv, h_n2, h_nh = own.sketch_batch(host_rows, p)
+        if not (np.array_equal(h_hv, hv[:HF].cpu().numpy()) and np.array_equal(h_n2, n2[:HF].cpu().numpy())):
+            raise SystemExit("PARITY GATE FAILED: host-fed sketches differ from the HBM-resident ones")
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            own.sketch_batch(host_rows, p)
+        hdt_ = time.perf_counter() - t0
+        own.close()
+        gbs = HF * reps * (L_GENOME + 1) / hdt_ / 1e9
+        out["host_fed"] = {"value": HF * reps / hdt_, "unit": "genomes/sec", "pcie_gbs": gbs, "pcie_peak_gbs": 63.0,
+                           "frac_of_pcie": gbs / 63.0,
+                           "config": {"workload": "%d of the step's genomes from pinned host memory through "
+                                                  "hg_sketch_batch (upload overlapped with the kernels), results "
+                                                  "back on the host; rank 0 only" % HF}}
+        log("host-fed: %.0f genomes/s = %.1f GB/s of sequence over PCIe" % (out["host_fed"]["value"], gbs))
+        del host
 
     # ---------------- dist: R x Q ANI matrix, thresholded ------------------------------------------
     if a.dist_n:
@@ -299,8 +383,8 @@ def main():
         flops_per_launch = 2.0 * HV_D * (rows * world) * rows  # 2*D ops per pair
         ach = flops_per_launch / (gemm_ms * 1e-3) / 1e12
         dist_traffic = None  # bytes leaving the XCD L2s per launch (PMC, profiles/): 10 000 x 10 000 only
-        dpath = os.path.join(ROOT, "profiles", "r01_dist_traffic.json")
-        if os.path.exists(dpath) and rows * world == 10000 and world == 1:
+        dpath = newest_profile("_dist_traffic.json")
+        if dpath and rows * world == 10000 and world == 1:
             try:
                 dist_traffic = json.load(open(dpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -319,21 +403,40 @@ def main():
             out["dist"]["value"], gemm_ms, ach, found))
 
     # ---------------- bit-packed D=16384 Hamming search (BASELINE configs[4], extension) -------------------
+    # Sharded database search: the references are sharded by rows, ONE query set lives on rank 0
+    # and is broadcast (RCCL) inside every step, every rank searches its shard, the hit lists (global
+    # indices) are gathered and merged.  N = 1 runs the same code without the collectives.
     if a.hamming_refs:
-        HD, HQ = 16384, 1000
-        refs = a.hamming_refs // world  # the reference database is sharded, the (small) query set replicated
+        from hypergen_amd import shard
+        HD, HQ, HMAX = 16384, a.hamming_queries, 2000
+        words = HD // 32
+        lo, hi = shard.shard_range(a.hamming_refs, rank, world)
+        refs = hi - lo
         gen = torch.Generator(device=dev)
         gen.manual_seed(0x48480000 + rank)
-        rb = torch.randint(-2**31, 2**31 - 1, (refs, HD // 32), dtype=torch.int32, device=dev, generator=gen)
-        qb = rb[:HQ].clone()
-        qb ^= (1 << torch.randint(0, 31, (HQ, HD // 32), device=dev, generator=gen)).int()  # 512 flipped bits
-        hcap = 1 << 20
+        rb = torch.randint(-2**31, 2**31 - 1, (refs, words), dtype=torch.int32, device=dev, generator=gen)
+        qb = torch.zeros((HQ, words), dtype=torch.int32, device=dev)  # only rank 0 fills it
+        src_rows = None
+        if rank == 0:  # queries = rank 0's own rows with one flipped bit per word (512 of 16 384 bits)
+            src_rows = torch.randint(0, refs, (HQ,), device=dev, generator=gen)
+            qb = rb[src_rows] ^ (1 << torch.randint(0, 31, (HQ, words), device=dev, generator=gen)).int()
+            qsrc = qb.clone()
+        hcap = max(1 << 20, 4 * HQ)
         hh = torch.empty(hcap * 3, dtype=torch.int32, device=dev)
-        nfound = 0
+        merged = None
+
+        def search_block(ref_local, ref_lo, queries):
+            n, st = ctx.hamming_search_block_dev(ref_local.data_ptr(), ref_local.shape[0], ref_lo, queries.data_ptr(),
+                                                 queries.shape[0], 0, HD, HMAX, hh.data_ptr(), hcap)
+            if st != 0:
+                raise SystemExit("hamming hit buffer too small")
+            return hh[: 3 * n].cpu().numpy().view(hg.HAM_HIT_DTYPE)
 
         def hstep():
-            nonlocal nfound
-            nfound, _ = ctx.hamming_search_dev(rb.data_ptr(), refs, qb.data_ptr(), HQ, HD, 2000, hh.data_ptr(), hcap)
+            nonlocal merged
+            if world > 1 and rank == 0:
+                qb.copy_(qsrc)  # (the broadcast is in place; rank 0 re-publishes its query set every step)
+            merged = shard.sharded_search(search_block, rb, lo, qb, world, dev)
 
         hstep()
         ctx.enable_timing(True)
@@ -347,25 +450,77 @@ def main():
         htm = ctx.timings()
         ctx.enable_timing(False)
         hms = htm["dist"][0] / max(htm["dist"][1], 1)
+        if rank == 0:  # in-run check: every query finds exactly its source row (global index), at distance 512
+            order = np.argsort(merged["qry_idx"], kind="stable")
+            ok = merged.size == HQ and np.array_equal(merged["qry_idx"][order], np.arange(HQ)) and \
+                np.array_equal(merged["ref_idx"][order], src_rows.cpu().numpy() + lo) and bool((merged["dist"] == words).all())
+            if not ok:
+                raise SystemExit("PARITY GATE FAILED: merged Hamming hits != the queries' source rows")
+        # roofline of the search kernel.  Algorithmic work per launch: one v_xor_b32 + one v_bcnt_u32_b32 per
+        # 32 dims and pair = 2 * R * Q * D/32 lane-ops.  Bound: VALU issue of that pair -- a wave-instruction pair
+        # takes 3.1 ns per SIMD in tools/gpu_microbench.hip (v_bcnt is a VOP3 "slow class" op, profiles/
+        # r01_instruction_rates.txt) -> 1024 SIMDs * 128 lane-ops / 3.1 ns.  Compulsory bytes: every packed row once.
+        word_ops = 2.0 * refs * HQ * words
+        pair_bound = 1024 * 128 / 3.1e-9
         out["hamming"] = {
-            "metric": "M Hamming-pairs/sec (D=16384 bit-packed)", "value": refs * world * HQ * a.steps / hdt / 1e6,
+            "metric": "M Hamming-pairs/sec (D=16384 bit-packed)", "value": a.hamming_refs * HQ * a.steps / hdt / 1e6,
             "unit": "M pairs/sec", "ms_per_step": hdt / a.steps * 1e3, "scaling": "strong",
-            "config": {"workload": "%d ref x %d query sign-binarised D=16384 HVs, popcount(xor) <= 2000 (BASELINE "
-                                   "configs[4]; extension, no reference counterpart)" % (refs * world, HQ),
-                       "hits_per_rank": int(nfound)},
-            "kernel_ms": hms, "word_ops_per_sec": refs * HQ * (HD / 32) / (hms * 1e-3),
+            "config": {"workload": "%d ref x %d query sign-binarised D=16384 HVs, popcount(xor) <= %d (BASELINE "
+                                   "configs[4]; extension, no reference counterpart); refs sharded x%d, one query "
+                                   "set broadcast from rank 0, hits merged" % (a.hamming_refs, HQ, HMAX, world),
+                       "hits_merged": int(merged.size), "refs_per_rank": refs},
+            "roofline": {"bound": "valu", "achieved": word_ops / (hms * 1e-3) / 1e12, "peak": pair_bound / 1e12,
+                         "unit": "T lane-ops/s (xor + popcount)", "frac": word_ops / (hms * 1e-3) / pair_bound,
+                         "kernel": "hamming_kernel", "launch_ms": hms, "algorithmic_lane_ops_per_launch": word_ops,
+                         "compulsory_bytes_per_launch": (refs + HQ) * words * 4,
+                         "compulsory_gbs": (refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, "traffic": None},
+            "kernel_ms": hms,
         }
-        log("hamming: %.0f M pairs/s, kernel %.3f ms, hits/rank %d" % (out["hamming"]["value"], hms, nfound))
+        log("hamming: %.0f M pairs/s, kernel %.3f ms (%.0f %% of the xor+bcnt issue bound), merged hits %d" % (
+            out["hamming"]["value"], hms, 100 * out["hamming"]["roofline"]["frac"], merged.size))
         del rb, qb, hh
 
     # ---------------- CPU baseline (rank 0, single-GPU runs only) ----------------------------------
+    # The same leg is the run's parity gate ("parity gates must pass before any number is
+    # reported"): the oracle's outputs, which it produces anyway, are compared with this run's GPU results
+    # outside every timed region; a mismatch aborts without printing the line.
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle as orc
+        gate = {"sketch_genomes": [], "tolerance_ani": 1e-4}
+        for g in (0, N // 2, N - 1):
+            host = seq[g * stride: g * stride + L_GENOME + 1].cpu().numpy()
+            w_hv, w_n2, w_nh = orc.sketch_genome(host)
+            hs = ctx.kmer_hash_sample(host, KSIZE, SCALED)
+            if not (np.array_equal(hs, orc.kmer_hash_sample(host, KSIZE, SCALED)) and int(nh[g]) == w_nh and
+                    int(n2[g]) == w_n2 and np.array_equal(hv[g].cpu().numpy(), w_hv)):
+                raise SystemExit("PARITY GATE FAILED: sketch of genome %d differs from the CPU oracle" % g)
+            gate["sketch_genomes"].append(g)
         out["cpu_baseline"] = cpu_baseline_sketch(a.cpu_seconds, log)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if a.dist_n:
-            cb = cpu_baseline_dist(mine, mine_n2, min(a.cpu_seconds, 6.0), log)
+            block, cb = cpu_baseline_dist(mine, mine_n2, min(a.cpu_seconds, 6.0), log)
+            br, bq = block.shape
+            gpu_block = torch.empty((br, bq), dtype=torch.float32, device=dev)
+            ctx.dist_full_dev(mine.data_ptr(), mine_n2.data_ptr(), br, mine.data_ptr(), mine_n2.data_ptr(), bq, HV_D, KSIZE,
+                              gpu_block.data_ptr())
+            torch.cuda.synchronize()
+            gb = gpu_block.cpu().numpy()
+            err = float(np.abs(gb - block).max())
+            # ... and the thresholded hits of the timed runs against the same CPU block
+            hh_ = hits[: 3 * found].view(-1, 3)
+            sel = (hh_[:, 0] < br) & (hh_[:, 1] < bq)
+            hr, hq = hh_[sel, 0].long().cpu().numpy(), hh_[sel, 1].long().cpu().numpy()
+            ha = hh_[sel, 2].contiguous().view(torch.float32).cpu().numpy()
+            herr = float(np.abs(ha - block[hr, hq]).max()) if hr.size else 0.0
+            n_cpu_hits = int((block >= 85.0 + 1e-4).sum())
+            if err > 1e-4 or herr > 1e-4 or hr.size < n_cpu_hits:
+                raise SystemExit("PARITY GATE FAILED: ANI block max |gpu - cpu| = %g, hits %g, %d < %d" % (err, herr, hr.size, n_cpu_hits))
+            gate.update(ani_block="%d x %d" % (br, bq), ani_max_abs_err=err, ani_hits_checked=int(hr.size), ani_hits_max_abs_err=herr)
             out["dist"]["cpu_baseline"] = cb
             out["dist"]["speedup_vs_cpu_baseline"] = out["dist"]["value"] / cb["value"]
+        out["parity_gate"] = dict(gate, status="passed")
+    elif rank == 0:
+        out["parity_gate"] = {"status": "skipped (no CPU leg: N > 1 or --no-cpu-baseline); hamming / 10k / host-fed self-checks ran"}
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

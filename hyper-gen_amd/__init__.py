@@ -67,7 +67,9 @@ EXPORTS = [
     "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_read_merge_seq_into", "hg_free",
     "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
     "hg_hv_binarize_dev", "hg_hamming_full_dev", "hg_hamming_search_dev",
-    "hg_ctx_set_debug", "hg_read_fastx_into",
+    "hg_ctx_set_debug", "hg_read_fastx_into", "hg_dist_block_dev", "hg_hamming_search_block_dev",
+    "hg_multi_create", "hg_multi_destroy", "hg_multi_size", "hg_multi_ctx", "hg_multi_last_error", "hg_shard_range",
+    "hg_sketch_batch_multi", "hg_dist_multi", "hg_dist_multi_dev", "hg_hamming_search_multi",
 ]
 
 
@@ -133,6 +135,24 @@ def lib():
         "hg_read_fastx_into": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "hg_ctx_set_debug": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "hg_free": (None, [vp]),
+        "hg_dist_block_dev": (C.c_int, [vp, vp, vp, sz, sz, vp, vp, sz, sz, C.c_uint32, C.c_uint32, C.c_int,
+                                        C.c_float, vp, sz, C.POINTER(sz)]),
+        "hg_hamming_search_block_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, sz, C.c_uint32, C.c_uint32, vp, sz,
+                                                  C.POINTER(sz)]),
+        "hg_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+        "hg_multi_destroy": (None, [vp]),
+        "hg_multi_size": (C.c_int, [vp]),
+        "hg_multi_ctx": (vp, [vp, C.c_int]),
+        "hg_multi_last_error": (C.c_char_p, [vp]),
+        "hg_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
+        "hg_sketch_batch_multi": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(SketchParams),
+                                            vp, vp, vp]),
+        "hg_dist_multi": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
+                                    vp, sz, C.POINTER(sz)]),
+        "hg_dist_multi_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp),
+                                        C.POINTER(vp), C.POINTER(sz), C.c_uint32, C.c_uint32, C.c_int,
+                                        C.c_float, vp, sz, C.POINTER(sz)]),
+        "hg_hamming_search_multi": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, sz, C.POINTER(sz)]),
         "hg_hv_binarize_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
         "hg_hamming_full_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, vp]),
         "hg_hamming_search_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, sz, C.POINTER(sz)]),
@@ -316,12 +336,129 @@ class Context:
         self._ck(lib().hg_dist_full_dev(self._h, _ptr(d_ref), _ptr(d_rn), R, _ptr(d_qry), _ptr(d_qn), Q,
                                         hv_d, ksize, _ptr(d_out)))
 
+    def dist_block_dev(self, d_ref, d_rn, R, ref_off, d_qry, d_qn, Q, qry_off, hv_d, ksize, symmetric, ani_th,
+                       d_out, cap):
+        n = C.c_size_t(0)
+        st = lib().hg_dist_block_dev(self._h, _ptr(d_ref), _ptr(d_rn), R, ref_off, _ptr(d_qry), _ptr(d_qn), Q,
+                                     qry_off, hv_d, ksize, int(symmetric), C.c_float(ani_th), _ptr(d_out), cap,
+                                     C.byref(n))
+        self._ck(st, allow=(ERR_CAPACITY,))
+        return n.value, st
+
+    def hamming_search_block_dev(self, d_ref, R, ref_off, d_qry, Q, qry_off, hv_d, max_dist, d_out, cap):
+        n = C.c_size_t(0)
+        st = lib().hg_hamming_search_block_dev(self._h, _ptr(d_ref), R, ref_off, _ptr(d_qry), Q, qry_off, hv_d,
+                                               max_dist, _ptr(d_out), cap, C.byref(n))
+        self._ck(st, allow=(ERR_CAPACITY,))
+        return n.value, st
+
     def dist_dev(self, d_ref, d_rn, R, d_qry, d_qn, Q, hv_d, ksize, symmetric, ani_th, d_out, cap):
         n = C.c_size_t(0)
         st = lib().hg_dist_dev(self._h, _ptr(d_ref), _ptr(d_rn), R, _ptr(d_qry), _ptr(d_qn), Q, hv_d,
                                ksize, int(symmetric), C.c_float(ani_th), _ptr(d_out), cap, C.byref(n))
         self._ck(st, allow=(ERR_CAPACITY,))
         return n.value, st
+
+
+def shard_range(n, shard, n_shards):
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    lib().hg_shard_range(n, shard, n_shards, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class Multi:
+    """Several GPUs in one process (hg_multi): one hg_ctx per entry of device_ids (ids may repeat)."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        st = lib().hg_multi_create(ids, len(device_ids), C.byref(self._h))
+        if st != OK:
+            raise HgError(st, lib().hg_last_error(None).decode())
+        self.n = len(device_ids)
+
+    def close(self):
+        if self._h:
+            lib().hg_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, st, allow=()):
+        if st != OK and st not in allow:
+            raise HgError(st, lib().hg_multi_last_error(self._h).decode())
+        return st
+
+    def ctx_handle(self, shard):
+        return lib().hg_multi_ctx(self._h, shard)
+
+    def sketch_batch(self, seqs, params=None):
+        p = params or default_params()
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) if isinstance(s, np.ndarray)
+                else np.frombuffer(bytes(s), np.uint8) for s in seqs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * max(n, 1))(*[a.size for a in arrs])
+        hv = np.zeros((n, p.hv_d), np.int16)
+        n2 = np.zeros(n, np.int32)
+        nh = np.zeros(n, np.uint32)
+        self._ck(lib().hg_sketch_batch_multi(self._h, ptrs, lens, n, C.byref(p), _ptr(hv), _ptr(n2), _ptr(nh)))
+        return hv, n2, nh
+
+    def dist(self, ref_hv, ref_n2, qry_hv=None, qry_n2=None, ksize=21, symmetric=False, ani_th=85.0, cap=None):
+        r = np.ascontiguousarray(ref_hv, np.int16)
+        rn = np.ascontiguousarray(ref_n2, np.int32)
+        q = r if qry_hv is None else np.ascontiguousarray(qry_hv, np.int16)
+        qn = rn if qry_hv is None else np.ascontiguousarray(qry_n2, np.int32)
+        cap = cap if cap is not None else max(1024, r.shape[0] * q.shape[0] // 8)
+        while True:
+            out = np.zeros(cap, ANI_HIT_DTYPE)
+            n = C.c_size_t(0)
+            st = lib().hg_dist_multi(self._h, _ptr(r), _ptr(rn), r.shape[0], _ptr(q), _ptr(qn), q.shape[0],
+                                     r.shape[1], ksize, int(symmetric), C.c_float(ani_th), _ptr(out), cap,
+                                     C.byref(n))
+            if st == ERR_CAPACITY:
+                cap = n.value
+                continue
+            self._ck(st)
+            return out[: n.value].copy()
+
+    def dist_dev(self, d_ref, d_rn, ref_rows, d_qry, d_qn, qry_rows, hv_d, ksize=21, symmetric=False, ani_th=85.0,
+                 cap=1 << 20):
+        """d_ref / d_rn (and d_qry / d_qn or None): per-shard device pointers (ints)."""
+        arr = lambda xs: (C.c_void_p * self.n)(*[int(x) for x in xs])
+        szs = lambda xs: (C.c_size_t * self.n)(*[int(x) for x in xs])
+        while True:
+            out = np.zeros(cap, ANI_HIT_DTYPE)
+            n = C.c_size_t(0)
+            st = lib().hg_dist_multi_dev(self._h, arr(d_ref), arr(d_rn), szs(ref_rows),
+                                         arr(d_qry) if d_qry is not None else None,
+                                         arr(d_qn) if d_qry is not None else None,
+                                         szs(qry_rows) if d_qry is not None else None, hv_d, ksize, int(symmetric),
+                                         C.c_float(ani_th), _ptr(out), cap, C.byref(n))
+            if st == ERR_CAPACITY:
+                cap = n.value
+                continue
+            self._ck(st)
+            return out[: n.value].copy()
+
+    def hamming_search(self, ref_bits, qry_bits, hv_d, max_dist, cap=1 << 20):
+        r = np.ascontiguousarray(ref_bits, np.uint32)
+        q = np.ascontiguousarray(qry_bits, np.uint32)
+        while True:
+            out = np.zeros(cap, HAM_HIT_DTYPE)
+            n = C.c_size_t(0)
+            st = lib().hg_hamming_search_multi(self._h, _ptr(r), r.shape[0], _ptr(q), q.shape[0], hv_d, max_dist,
+                                               _ptr(out), cap, C.byref(n))
+            if st == ERR_CAPACITY:
+                cap = n.value
+                continue
+            self._ck(st)
+            return out[: n.value].copy()
 
 
 # ---- host-side formats (no device involved) ------------------------------------------------------

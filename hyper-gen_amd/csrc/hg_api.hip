@@ -741,11 +741,20 @@ extern "C" hg_status hg_dist_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32
                                  const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, uint32_t hv_d,
                                  uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *d_out, size_t cap,
                                  size_t *n_out) {
+  return hg_dist_block_dev(c, d_ref_hv, d_ref_norm2, R, 0, d_qry_hv, d_qry_norm2, Q, 0, hv_d, ksize, symmetric, ani_th,
+                           d_out, cap, n_out);
+}
+
+extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R,
+                                       size_t ref_off, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
+                                       size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
+                                       hg_ani_hit *d_out, size_t cap, size_t *n_out) {
   if (!c) return HG_ERR_INVALID;
   if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
   *n_out = 0;
   hg_status s = check_dist(c, R, Q, hv_d, ksize);
   if (s != HG_OK) return s;
+  if (ref_off + R > 0x7FFFFFFFull || qry_off + Q > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "global indices must be < 2^31");
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   HG_HIP(c, hipSetDevice(c->device));
@@ -758,6 +767,7 @@ extern "C" hg_status hg_dist_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32
   a.hits = d_out, a.hit_count = d_count;
   a.hit_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
   a.ani_th = ani_th, a.symmetric = symmetric;
+  a.ref_off = (uint32_t)ref_off, a.qry_off = (uint32_t)qry_off;
   int spec_cover = -1;
   if ((s = hg_run_dist(c, a, d_count + 1, &spec_cover)) != HG_OK) return s;
   if ((s = hg_ensure_pinned(c, 64)) != HG_OK) return s;

@@ -350,6 +350,7 @@ struct GemmArgs {
   float j_lo;  // conservative Jaccard bound: dot < j_lo * den  =>  ANI < ani_th for sure
   float pre_c, pre_b;  // phase-0 form of the same bound: dot < pre_c * (nr + nq) + pre_b  =>  rejected
   int symmetric;
+  uint32_t ref_off, qry_off;  // global index of row 0 / column 0 (a block of a larger matrix): hits and the i < j test use them
   uint32_t tiles_m, tiles_n;  // tile grid
   const uint32_t *verdict;    // speculative launch: runs only if v_lo <= verdict[0] <= v_hi (see decide_kernel);
   uint32_t v_lo, v_hi;        // with chunk_from_verdict the window length (K-steps) is verdict[1]
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   const uint32_t tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
   if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // padding of the super-tile grid
   const uint32_t row0 = tm * BM, col0 = tn * BN;
-  if (g.symmetric && row0 >= col0 + BN) return;  // tile entirely on/below the diagonal
+  if (g.symmetric && row0 + g.ref_off >= col0 + g.qry_off + BN) return;  // tile entirely on/below the diagonal
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t wm = wave / NWN, wn = wave % NWN;  // 2 x NWN waves, (WTM*16) x 64 each
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   for (uint32_t e = lane; e < (nh); e += 64)                                                           \
     if ((base) + e < g.hit_cap) {                                                                      \
       const uint2 h2 = cand[e];                                                                        \
-      g.hits[(base) + e] = hg_ani_hit{row0 + (h2.x >> 16), col0 + (h2.x & 0xffffu), __uint_as_float(h2.y)}; \
+      g.hits[(base) + e] = hg_ani_hit{row0 + g.ref_off + (h2.x >> 16), col0 + g.qry_off + (h2.x & 0xffffu), __uint_as_float(h2.y)}; \
     }
   // list nearly full in the middle of the tile (dense tiles only): this wave reserves its own range
 #define HG_PROCESS()                                                                                   \
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
         int32_t dot = (int32_t)acc[m][n][r];
         if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
-        bool live = pass && iok && j < g.Q && !(g.symmetric && i >= j);
+        bool live = pass && iok && j < g.Q && !(g.symmetric && i + g.ref_off >= j + g.qry_off);
         if (!FULL) {
           const int32_t den = (int32_t)((uint32_t)nri + (uint32_t)nqv[n] - (uint32_t)dot);
           live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
   __shared__ int16_t sQ[FB_T][FB_K + 2];
   const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const uint32_t i0 = blockIdx.y * FB_T, j0 = blockIdx.x * FB_T;
-  if (a.symmetric && i0 >= j0 + FB_T) return;
+  if (a.symmetric && i0 + a.ref_off >= j0 + a.qry_off + FB_T) return;
   uint32_t acc = 0;
   for (uint32_t k0 = 0; k0 < a.hv_d; k0 += FB_K) {
     __syncthreads();
@@ -775,12 +776,12 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
   }
   const uint32_t i = i0 + ty, j = j0 + tx;
   if (i >= a.R || j >= a.Q) return;
-  if (a.symmetric && i >= j) return;
+  if (a.symmetric && i + a.ref_off >= j + a.qry_off) return;
   const float ani = ani_from_dot((int32_t)acc, a.ref_n2[i], a.qry_n2[j], kf);
   if (a.ani_out) a.ani_out[(size_t)i * a.Q + j] = ani;
   if (a.hit_count && ani >= a.ani_th) {
     const uint32_t idx = atomicAdd(a.hit_count, 1u);
-    if (idx < a.hit_cap) a.hits[idx] = hg_ani_hit{i, j, ani};
+    if (idx < a.hit_cap) a.hits[idx] = hg_ani_hit{i + a.ref_off, j + a.qry_off, ani};
   }
 }
 
@@ -928,7 +929,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   g.chunk_steps = (64u << best_c) / BK;
   g.kf = kf;
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
-  g.ani_th = a.ani_th, g.symmetric = a.symmetric;
+  g.ani_th = a.ani_th, g.symmetric = a.symmetric, g.ref_off = a.ref_off, g.qry_off = a.qry_off;
   g.verdict = guard, g.v_lo = v_lo, g.v_hi = v_hi, g.chunk_from_verdict = from_verdict ? 1u : 0u;
   g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
   if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;       // everything goes on to phase 1

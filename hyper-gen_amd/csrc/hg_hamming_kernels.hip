@@ -39,6 +39,7 @@ struct HamArgs {
   hg_ham_hit *hits;
   uint32_t *hit_count;
   uint32_t hit_cap, max_dist;
+  uint32_t ref_off, qry_off;  // global index of row 0 / column 0 (a shard of a larger database)
 };
 
 __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
       if (bal) {
         const uint32_t pos =
             staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (hit) stage[pos] = hg_ham_hit{r, c, acc[i][j]};
+        if (hit) stage[pos] = hg_ham_hit{r + a.ref_off, c + a.qry_off, acc[i][j]};
         staged += (uint32_t)__popcll(bal);
         if (staged > CAP - 64) {
           HG_HFLUSH()
@@ -160,10 +161,10 @@ extern "C" hg_status hg_hv_binarize_dev(hg_ctx *c, const int16_t *d_hv, size_t n
 
 static hg_status ham_launch(hg_ctx *c, const uint32_t *d_ref, size_t R, const uint32_t *d_qry, size_t Q,
                             uint32_t hv_d, uint32_t *d_dist, hg_ham_hit *d_hits, uint32_t *d_count, uint32_t cap,
-                            uint32_t max_dist) {
+                            uint32_t max_dist, uint32_t ref_off = 0, uint32_t qry_off = 0) {
   const uint32_t words = (hv_d + 31) / 32;
   if (words % 4) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be a multiple of 128 for the packed path");
-  HamArgs a{d_ref, d_qry, (uint32_t)R, (uint32_t)Q, words, d_dist, d_hits, d_count, cap, max_dist};
+  HamArgs a{d_ref, d_qry, (uint32_t)R, (uint32_t)Q, words, d_dist, d_hits, d_count, cap, max_dist, ref_off, qry_off};
   dim3 grid((unsigned)((Q + HT - 1) / HT), (unsigned)((R + HT - 1) / HT));
   if (grid.y > 65535) return hg_fail(c, HG_ERR_UNSUPPORTED, "too many reference rows for one launch");
   hg_timed tm(c, HG_T_DIST);
@@ -184,18 +185,25 @@ extern "C" hg_status hg_hamming_full_dev(hg_ctx *c, const uint32_t *d_ref_bits, 
 extern "C" hg_status hg_hamming_search_dev(hg_ctx *c, const uint32_t *d_ref_bits, size_t R, const uint32_t *d_qry_bits,
                                            size_t Q, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap,
                                            size_t *n_out) {
+  return hg_hamming_search_block_dev(c, d_ref_bits, R, 0, d_qry_bits, Q, 0, hv_d, max_dist, d_out, cap, n_out);
+}
+
+extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_ref_bits, size_t R, size_t ref_off,
+                                                 const uint32_t *d_qry_bits, size_t Q, size_t qry_off, uint32_t hv_d,
+                                                 uint32_t max_dist, hg_ham_hit *d_out, size_t cap, size_t *n_out) {
   if (!c) return HG_ERR_INVALID;
   if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
   *n_out = 0;
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_bits || !d_qry_bits || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  if (ref_off + R > 0xFFFFFFFFull || qry_off + Q > 0xFFFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "global indices must fit 32 bits");
   HG_HIP(c, hipSetDevice(c->device));
   hg_status s;
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
   HG_HIP(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
   s = ham_launch(c, d_ref_bits, R, d_qry_bits, Q, hv_d, nullptr, d_out, d_count,
-                 cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist);
+                 cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist, (uint32_t)ref_off, (uint32_t)qry_off);
   if (s != HG_OK) return s;
   uint32_t found = 0;
   HG_HIP(c, hipMemcpyAsync(&found, d_count, sizeof found, hipMemcpyDeviceToHost, c->stream));

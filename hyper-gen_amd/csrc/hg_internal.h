@@ -178,6 +178,7 @@ struct hg_dist_args {
   uint32_t hit_cap;
   float ani_th;
   int symmetric;
+  uint32_t ref_off = 0, qry_off = 0;  // global indices of row 0 / column 0 when the call is a block of a larger matrix
 };
 // d_verdict (two uint32: code, window length) != nullptr allows the speculative schedule: prepass, on-device
 // exactness verdict (0 = one f32 window covers K; 1 / 2 = windows of 2 048 / 1 024 dims; 3 = neither) and the

@@ -54,7 +54,7 @@ __device__ __forceinline__ uint64_t rot64(uint64_t v, unsigned s) {
 // partial words; here the third product takes the second as its 64-bit addend and hands its carry
 // out in an SGPR pair, and that carry plus the caller's addend are folded into the addend of the
 // last product with three 32-bit ops.
-template <uint64_t P, bool ZERO_ADDEND = false>
+template <uint64_t P, bool ZERO_ADDEND = false, bool UNI_ADDEND = false>
 __device__ __forceinline__ uint64_t mul128_lo_hiadd(uint64_t x, uint64_t addend, uint64_t &hi_plus) {
   constexpr uint32_t p0 = (uint32_t)P, p1 = (uint32_t)(P >> 32);
   const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
@@ -62,29 +62,35 @@ __device__ __forceinline__ uint64_t mul128_lo_hiadd(uint64_t x, uint64_t addend,
   const uint64_t T = (uint64_t)x1 * p0 + (A >> 32);  // cannot overflow
   uint64_t W, cm;                                     // W = x0*p1 + T (mod 2^64), cm = carry-out lanes
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(W), "=s"(cm) : "v"(x0), "s"(p1), "v"(T));
-  // S = addend + {hi32(W), carry}
-  uint32_t slo, shi;
-  if (ZERO_ADDEND) {
+  if (ZERO_ADDEND) {  // S = {hi32(W), carry}
+    uint32_t shi;
     asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(shi) : "s"(cm));
-    slo = (uint32_t)(W >> 32);
+    hi_plus = (uint64_t)x1 * p1 + mk64((uint32_t)(W >> 32), shi);
   } else {
-    asm("v_cndmask_b32_e64 %1, 0, 1, %4\n\t"
-        "v_add_co_u32_e32 %0, vcc, %2, %3\n\t"
-        "v_addc_co_u32_e32 %1, vcc, %5, %1, vcc"
-        : "=&v"(slo), "=&v"(shi)
-        : "v"((uint32_t)addend), "v"((uint32_t)(W >> 32)), "s"(cm), "v"((uint32_t)(addend >> 32))
-        : "vcc");
+    // hi64 + addend = x1*p1 + (addend + hi32(W)) + (carry << 32): the 64-bit sum addend + hi32(W) is ONE
+    // v_mad_u64_u32 (hi32(W) * 1 + addend; it lands in an aligned register pair, which three 32-bit carry ops
+    // do not -- the compiler then paid v_movs to pair them), and the carry goes into the high half of the last
+    // product with one v_addc that takes it straight from the SGPR pair.  All of this is mod 2^64, like b += hi.
+    // (UNI_ADDEND: the addend is wave-uniform -- the seed in the first mixup -- and is read from its SGPR pair)
+    uint64_t t, junk;
+    if (UNI_ADDEND)
+      asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(t), "=s"(junk) : "v"((uint32_t)(W >> 32)), "s"(addend));
+    else
+      asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(t), "=s"(junk) : "v"((uint32_t)(W >> 32)), "v"(addend));
+    const uint64_t hp = (uint64_t)x1 * p1 + t;
+    uint32_t hph = (uint32_t)(hp >> 32);
+    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(hph), "+s"(cm));
+    hi_plus = mk64((uint32_t)hp, hph);
   }
-  hi_plus = (uint64_t)x1 * p1 + mk64(slo, shi);
   return mk64((uint32_t)A, (uint32_t)W);
 }
 
 // src/cuda_kernel.cu:136-141 with the prime as a template argument
-template <uint64_t P, bool HAND = true>
+template <uint64_t P, bool HAND = true, bool UNI_B = false>
 __device__ __forceinline__ void mixup64(uint64_t &a, uint64_t &b, uint64_t v) {
   if (HAND) {
     uint64_t nb;
-    a ^= mul128_lo_hiadd<P>(b + v, b, nb);
+    a ^= mul128_lo_hiadd<P, false, UNI_B>(b + v, b, nb);
     b = nb;
   } else {
     unsigned __int128 m = (unsigned __int128)(b + v) * P;
@@ -126,6 +132,19 @@ __device__ __forceinline__ uint64_t t1ha2_fixed(const uint32_t *d, uint64_t seed
   return final64<HAND>(a, b);
 }
 
+// the same on 8-byte words w[0..ceil(K/8)) (unused bytes of the last word zero)
+template <int K>
+__device__ __forceinline__ uint64_t t1ha2_fixed_w(const uint64_t *w, uint64_t seed) {
+  // the first mixup's `b` operand is wave-uniform (the seed or the length)
+  uint64_t a = seed, b = (uint64_t)K;
+  int i = 0;
+  if (K > 24) mixup64<P4, true, true>(a, b, w[i++]);
+  if (K > 16) mixup64<P3, true, (K <= 24)>(b, a, w[i++]);
+  if (K > 8) mixup64<P2, true, (K <= 16)>(a, b, w[i++]);
+  if (K > 0) mixup64<P1, true, (K <= 8)>(b, a, w[i++]);
+  return final64(a, b);
+}
+
 template <int... Js, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F &&f) {
   (f(std::integral_constant<int, Js>{}), ...);
@@ -148,6 +167,10 @@ constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 // starts (8 at k = 22..25, 4 at k = 26..29).  Measured A/B on one box: k = 22..25 4-6 % faster, k = 26..29
 // 16-17 % faster with the wide window; k <= 21 the two kernels tie.
 constexpr uint32_t FAST64_FROM = 22;
+// canonical fast kernels: 4 = chosen strand fetched from an LDS image of the window, 0 = register extraction + mux
+#ifndef HG_KMER_DEFAULT_VAR
+#define HG_KMER_DEFAULT_VAR 4
+#endif
 constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
 __device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm, uint32_t g,
@@ -207,6 +230,18 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
   __shared__ HitStage stage;
+  // VAR & 4 (canonical strand only): the lane's window goes to LDS twice -- forward ASCII F[0..32) and its reverse
+  // complement R[i] = comp(F[31 - i]) -- so that BOTH strands of k-mer j are ascending byte ranges of one 64-byte
+  // image (forward: [j, j+K), reverse: [64-K-j, 64-j)) and the chosen strand's hash words are fetched with
+  // (unaligned) ds_read_b64 from a run-time offset.  That replaces, per k-mer, the v_alignbyte / v_perm
+  // extraction of both strands and the six-dword v_bitop3 mux (~12 VALU instructions) by one v_cndmask + one
+  // add and three LDS reads, which issue beside the VALU stream.  Lanes only read what they wrote themselves:
+  // no barrier.  72-byte lane pitch: conflict-free ds_write_b64 / ds_read_b64, and the up-to-7-byte overshoot
+  // of the last word stays inside the lane's own pad.
+  constexpr bool LDSWIN = CANON && (VAR & 4) != 0;
+  constexpr int WIN_PITCH = 72;
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[LDSWIN ? WG * WIN_PITCH + 16 : 16];
+  uint8_t *const mywin = s_win + threadIdx.x * WIN_PITCH;
   if (threadIdx.x == 0) stage.n = 0;
   __syncthreads();
 
@@ -285,11 +320,56 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
       if (rem < 32) inv |= (rem == 0) ? ~0u : (~0u << rem);
     }
 
+    if (LDSWIN) {
+      uint2 *w2 = reinterpret_cast<uint2 *>(mywin);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        w2[t] = make_uint2(FA[2 * t], FA[2 * t + 1]);
+        // R dword t = bytes comp(F[31-4t]), comp(F[30-4t]), ... = CA[7 - t] byte-reversed
+        w2[4 + t] = make_uint2(__builtin_amdgcn_perm(0u, CA[7 - 2 * t], 0x00010203u),
+                               __builtin_amdgcn_perm(0u, CA[6 - 2 * t], 0x00010203u));
+      }
+    }
+
+    // strand choice + hash words of k-mer jj (LDS image variant)
+    constexpr int NW = (K + 7) / 8, TB = K - 8 * (NW - 1);  // 8-byte words of a k-mer, bytes used in the last one
+    uint64_t wq[2][NW];
+    auto fetch_words = [&](auto jjc, uint64_t *w) {
+      constexpr int jj = decltype(jjc)::value;
+      const uint64_t fv = (Gm >> (2 * (32 - K - jj))) & MASK2K;
+      const uint64_t rv = (Gc >> (2 * jj)) & MASK2K;
+      uint64_t lt;
+      uint32_t off;
+      asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(jj), "n"(64 - K - jj), "s"(lt));
+      const uint8_t *src = mywin + off;
+#pragma unroll
+      for (int m = 0; m < NW - 1; ++m) __builtin_memcpy(&w[m], src + 8 * m, 8);
+      if constexpr (TB <= 4) {  // last word: TB bytes
+        uint32_t lo;
+        __builtin_memcpy(&lo, src + 8 * (NW - 1), 4);
+        if constexpr (TB < 4) lo &= (1u << (8 * (TB & 3))) - 1;
+        w[NW - 1] = lo;
+      } else {
+        __builtin_memcpy(&w[NW - 1], src + 8 * (NW - 1), 8);
+        if constexpr (TB < 8) w[NW - 1] &= (1ull << (8 * (TB & 7))) - 1;
+      }
+    };
+
     // ---- the lane's M k-mers ------------------------------------------------------------------
     static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
       constexpr int j = decltype(jc)::value;
       constexpr int q = j >> 2, r = j & 3;
       const bool valid = ((inv >> j) & MASKK) == 0;
+
+      if constexpr (LDSWIN) {
+        // two-deep software pipeline: the words of k-mer j+1 are requested before k-mer j is hashed
+        if constexpr (j == 0) fetch_words(jc, wq[0]);
+        if constexpr (j + 1 < M) fetch_words(std::integral_constant<int, j + 1>{}, wq[(j + 1) & 1]);
+        const uint64_t h = t1ha2_fixed_w<K>(wq[j & 1], seed);
+        if (valid && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+        return;
+      }
 
       // strand choice as an all-ones / all-zeros VGPR mask.  The obvious `use_rc ? rcw : f` becomes
       // v_cmp + 6 x v_cndmask_b32 ... vcc, and that VOP2/VCC form measures ~14-20 cycles per
@@ -677,12 +757,12 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
     hipLaunchKernelGGL((kmer_sample_fast<21, true, VV>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                              \
     return hipGetLastError();
-    switch (v) { HG_V(1) HG_V(2) HG_V(3) default: break; }
+    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) default: break; }
 #undef HG_V
   }
 #endif
   if (canonical)
-    hipLaunchKernelGGL((kmer_sample_fast<K, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
+    hipLaunchKernelGGL((kmer_sample_fast<K, true, HG_KMER_DEFAULT_VAR>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);
   else
     hipLaunchKernelGGL((kmer_sample_fast<K, false>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,

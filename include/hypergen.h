@@ -186,6 +186,14 @@ hg_status hg_dist_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *d_ref
                       uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
                       hg_ani_hit *d_out, size_t cap, size_t *n_out);
 
+/* One block of a larger R x Q matrix (multi-GPU decomposition): rows ref_off.. and columns
+ * qry_off.. of the global enumeration.  Hits carry GLOBAL indices and `symmetric` keeps global ref < global qry,
+ * so the union over the blocks of a partition equals the one-call result. */
+hg_status hg_dist_block_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R,
+                            size_t ref_off, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
+                            size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
+                            hg_ani_hit *d_out, size_t cap, size_t *n_out);
+
 /* order of dump_ani_file (src/utils.rs:262-269): stable ascending sort by ANI over the
  * reference's pair enumeration, then reversed.  Host side. */
 void hg_sort_ani_hits(hg_ani_hit *hits, size_t n, size_t Q, int symmetric);
@@ -253,6 +261,58 @@ hg_status hg_hamming_full_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R,
 hg_status hg_hamming_search_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R, const uint32_t *d_qry_bits,
                                 size_t Q, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap,
                                 size_t *n_out);
+
+/* one shard of a sharded reference database: hits carry ref_off + local row, qry_off + local column */
+hg_status hg_hamming_search_block_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R, size_t ref_off,
+                                      const uint32_t *d_qry_bits, size_t Q, size_t qry_off, uint32_t hv_d,
+                                      uint32_t max_dist, hg_ham_hit *d_out, size_t cap, size_t *n_out);
+
+/* ---- several GPUs in one process -------------------------------------------------------------------
+ * The reference drives one CudaDevice::new(0) from all rayon workers (src/sketch_cuda.rs:52,82).  hg_multi
+ * owns one hg_ctx per entry of device_ids (1..8 GPUs of one node; ids may repeat -- two logical shards on one
+ * GPU, which is how a single-GPU box tests the sharded path) and one host thread per shard for the duration
+ * of each call.  Partitioning follows SURVEY.md 8(e):
+ *   sketch : genomes are independent units -> contiguous genome blocks per shard, no exchange;
+ *   dist   : every shard needs ALL reference HVs -> the shards' row blocks are all-gathered device to
+ *            device (hipMemcpyPeerAsync: every GPU pulls its 7 peers' blocks over its 7 xGMI links at
+ *            once), then shard s computes the block (all refs) x (its query rows); hits are merged on
+ *            the host with global indices;
+ *   search : the bit-packed reference database is sharded by rows, the (small) query set is broadcast,
+ *            per-shard hits are merged on the host.
+ * Results equal the single-ctx calls (same kernels, same arithmetic); hit order is unspecified. */
+typedef struct hg_multi hg_multi;
+hg_status hg_multi_create(const int *device_ids, int n, hg_multi **out);
+void hg_multi_destroy(hg_multi *m);
+int hg_multi_size(const hg_multi *m);
+hg_ctx *hg_multi_ctx(hg_multi *m, int shard); /* borrowed: valid until hg_multi_destroy */
+const char *hg_multi_last_error(const hg_multi *m);
+/* contiguous block [*lo, *hi) of n units owned by `shard` of n_shards; sizes differ by at most one */
+void hg_shard_range(size_t n, int shard, int n_shards, size_t *lo, size_t *hi);
+
+/* hg_sketch_batch over all shards: genome g goes to the shard whose hg_shard_range contains g */
+hg_status hg_sketch_batch_multi(hg_multi *m, const uint8_t *const *seqs, const size_t *lens, size_t n,
+                                const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
+                                uint32_t *nhash_out);
+/* hg_dist over all shards, host buffers in and out.  Each reference row crosses PCIe once (to its shard's
+ * GPU) and is replicated over xGMI; query rows go to their shard only.  qry_hv == ref_hv with Q == R is the
+ * all-vs-all case: every GPU then holds every row, and with `symmetric` the column ranges are balanced by
+ * pair count (boundaries at Q * sqrt(s / n)) instead of by row count. */
+hg_status hg_dist_multi(hg_multi *m, const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
+                        const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q, uint32_t hv_d,
+                        uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *out, size_t cap,
+                        size_t *n_out);
+/* the same for sketches that are already resident: shard s holds ref_rows[s] consecutive reference rows at
+ * d_ref_hv[s] / d_ref_norm2[s] on ITS device (e.g. the output of hg_sketch_batch_dev on hg_multi_ctx(m, s)),
+ * global row order = shard order.  d_qry_hv == NULL: the query set is the reference set (all-vs-all). */
+hg_status hg_dist_multi_dev(hg_multi *m, const int16_t *const *d_ref_hv, const int32_t *const *d_ref_norm2,
+                            const size_t *ref_rows, const int16_t *const *d_qry_hv,
+                            const int32_t *const *d_qry_norm2, const size_t *qry_rows, uint32_t hv_d,
+                            uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *out, size_t cap,
+                            size_t *n_out);
+/* bit-packed database search (host buffers): ref_bits is R x words, qry_bits Q x words, words = hv_d / 32 */
+hg_status hg_hamming_search_multi(hg_multi *m, const uint32_t *ref_bits, size_t R, const uint32_t *qry_bits,
+                                  size_t Q, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *out, size_t cap,
+                                  size_t *n_out);
 
 /* ---- synthetic genomes (benchmark / test utility, not part of the reference surface) -----
  * Genome g = first_genome + i is written at d_out + i * stride as 'N' followed by L bases

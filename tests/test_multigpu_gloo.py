@@ -49,6 +49,69 @@ def _worker(rank, world, port, n_genomes, out_dir):
     dist.destroy_process_group()
 
 
+def _search_worker(rank, world, port, n_refs, n_qry, words, max_dist, out_dir):
+    """configs[4] decomposition: refs sharded by rows, ONE query set broadcast from rank 0, hits merged."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hypergen_amd as hg
+    from hypergen_amd import shard
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1234)            # the database exists "on disk": every rank cuts its own rows
+    refs = rng.integers(0, 2**32, (n_refs, words), dtype=np.uint64).astype(np.uint32)
+    lo, hi = shard.shard_range(n_refs, rank, world)
+    # only rank 0 knows the queries; the other ranks start from garbage that the broadcast must replace
+    if rank == 0:
+        q = refs[rng.integers(0, n_refs, n_qry)].copy()
+        q ^= (np.uint32(1) << rng.integers(0, 32, q.shape).astype(np.uint32))
+        np.save(os.path.join(out_dir, "queries.npy"), q)
+    else:
+        q = np.full((n_qry, words), 0xDEADBEEF, np.uint32)
+    qt = torch.from_numpy(q)
+
+    def search_block(ref_local, ref_lo, queries):  # the CPU oracle stands in for hg_hamming_search_block_dev
+        d = orc.hamming_matrix(ref_local, queries.numpy())
+        ri, qi = np.nonzero(d <= max_dist)
+        h = np.zeros(ri.size, hg.HAM_HIT_DTYPE)
+        h["ref_idx"], h["qry_idx"], h["dist"] = ri + ref_lo, qi, d[ri, qi]
+        return h
+
+    merged = shard.sharded_search(search_block, refs[lo:hi], lo, qt, world)
+    np.save(os.path.join(out_dir, "merged%d.npy" % rank), merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_search_broadcasts_queries_and_merges_hits(tmp_path, orc):
+    import hypergen_amd as hg
+    n_refs, n_qry, words, max_dist, world = 301, 23, 16, 40, 2
+    mp.spawn(_search_worker, args=(world, _free_port(), n_refs, n_qry, words, max_dist, str(tmp_path)), nprocs=world,
+             join=True)
+    rng = np.random.default_rng(1234)
+    refs = rng.integers(0, 2**32, (n_refs, words), dtype=np.uint64).astype(np.uint32)
+    q = np.load(tmp_path / "queries.npy")
+    d = orc.hamming_matrix(refs, q)               # single-process oracle on the whole database
+    ri, qi = np.nonzero(d <= max_dist)
+    want = sorted(zip(ri.tolist(), qi.tolist(), d[ri, qi].tolist()))
+    assert len(want) >= n_qry                     # every query finds at least its source row
+    for r in range(world):                        # every rank holds the same merged list
+        m = np.load(tmp_path / ("merged%d.npy" % r))
+        assert m.dtype == hg.HAM_HIT_DTYPE
+        assert sorted(zip(m["ref_idx"].tolist(), m["qry_idx"].tolist(), m["dist"].tolist())) == want
+
+
+def test_hg_shard_range_matches_the_python_rule():
+    sys.path.insert(0, ROOT)
+    import hypergen_amd as hg
+    from hypergen_amd import shard
+    for n in (0, 1, 7, 8, 1000, 10001):
+        for w in (1, 2, 3, 8):
+            for k in range(w):
+                assert hg.shard_range(n, k, w) == shard.shard_range(n, k, w)
+
+
 def test_shard_range_covers_everything():
     sys.path.insert(0, ROOT)
     import hypergen_amd  # noqa: F401
