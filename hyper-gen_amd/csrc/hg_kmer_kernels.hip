@@ -167,9 +167,10 @@ constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 // starts (8 at k = 22..25, 4 at k = 26..29).  Measured A/B on one box: k = 22..25 4-6 % faster, k = 26..29
 // 16-17 % faster with the wide window; k <= 21 the two kernels tie.
 constexpr uint32_t FAST64_FROM = 22;
-// canonical fast kernels: 4 = chosen strand fetched from an LDS image of the window, 0 = register extraction + mux
+// canonical fast kernels: 4 = chosen strand fetched from an LDS image of the window (| 8: dword-aligned reads +
+// run-time v_alignbyte; without it byte-offset ds_reads), 0 = register extraction of both strands + mux
 #ifndef HG_KMER_DEFAULT_VAR
-#define HG_KMER_DEFAULT_VAR 4
+#define HG_KMER_DEFAULT_VAR 12
 #endif
 constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
@@ -342,6 +343,26 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
       uint32_t off;
       asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
       asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(jj), "n"(64 - K - jj), "s"(lt));
+      if constexpr ((VAR & 8) != 0) {
+        // dword-aligned reads + run-time v_alignbyte (it takes the byte shift from off[1:0]): a ds_read at an
+        // address that is not a multiple of 4 is executed lane by lane on gfx950 (measured: ~64 cycles per wave
+        // instruction, the kernel took 16.8 ms instead of 10.3 with byte-offset ds_read_b64/b128)
+        constexpr int NDR = (K + 3 + 3) / 4;  // aligned dwords that cover any K bytes starting at shift 0..3
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(mywin + (off & ~3u), 4));
+        uint32_t t[NDR + 1], d[2 * NW];
+#pragma unroll
+        for (int m = 0; m < NDR; ++m) t[m] = src[m];
+        t[NDR] = 0;
+#pragma unroll
+        for (int m = 0; m < 2 * NW; ++m) {
+          if (m < ND) d[m] = __builtin_amdgcn_alignbyte(t[m + 1 < NDR ? m + 1 : NDR], t[m], off);
+          else d[m] = 0;
+        }
+        if constexpr (NB < 4) d[ND - 1] &= (1u << (8 * (NB & 3))) - 1;
+#pragma unroll
+        for (int m = 0; m < NW; ++m) w[m] = mk64(d[2 * m], d[2 * m + 1]);
+        return;
+      }
       const uint8_t *src = mywin + off;
 #pragma unroll
       for (int m = 0; m < NW - 1; ++m) __builtin_memcpy(&w[m], src + 8 * m, 8);
@@ -757,7 +778,7 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
     hipLaunchKernelGGL((kmer_sample_fast<21, true, VV>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                              \
     return hipGetLastError();
-    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) default: break; }
+    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) HG_V(12) default: break; }
 #undef HG_V
   }
 #endif

@@ -25,7 +25,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "hyper-gen_amd", "csrc", "hg_kmer_kernels.hip")
-KERNEL = "kmer_sample_fastILi21ELb1ELi4E"  # <K = 21, CANON = true, VAR = HG_KMER_DEFAULT_VAR>
+KERNEL = "kmer_sample_fastILi21ELb1ELi%sE" % os.environ.get("HG_ISA_VAR", "12")  # <K = 21, CANON = true, VAR = HG_KMER_DEFAULT_VAR>
 M = 12
 
 SLOW = ("v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_perm_b32", "v_alignbyte_b32",
@@ -56,7 +56,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm",
-                               "-amdgpu-atomic-optimizer-strategy=None", "-S", "--cuda-device-only", "-o", f.name, SRC],
+                               "-amdgpu-atomic-optimizer-strategy=None", "-DHG_KMER_EXPERIMENT", "-S", "--cuda-device-only", "-o", f.name, SRC],
                               stderr=subprocess.DEVNULL)
         lines = open(f.name).read().split("\n")
     start = [i for i, l in enumerate(lines) if l.startswith("_Z") and ":" in l and KERNEL in l.split(":")[0]][0]
