@@ -178,6 +178,28 @@ def encode_hv_avx2_emulated(hashes, hv_d=4096):
     return hv
 
 
+def has_avx2_build():
+    """True when libhg_oracle_avx2.so exists and this CPU executes AVX2."""
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return " avx2" in flags and os.path.exists(os.path.join(_HERE, "libhg_oracle_avx2.so"))
+
+
+def encode_hv_avx2_intrinsics(hashes, hv_d=4096):
+    """src/hd.rs:14-92 executed with the real AVX2 intrinsics (oracle/hg_oracle_avx2.c)."""
+    lib()
+    L = C.CDLL(os.path.join(_HERE, "libhg_oracle_avx2.so"))
+    L.orc_encode_hv_avx2_intrinsics.restype = None
+    L.orc_encode_hv_avx2_intrinsics.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.POINTER(C.c_int16)]
+    h = np.ascontiguousarray(hashes, dtype=np.uint64)
+    hv = np.zeros(hv_d, np.int16)
+    buf = h if h.size else np.zeros(1, np.uint64)
+    L.orc_encode_hv_avx2_intrinsics(_p(buf, C.c_uint64), h.size, hv_d, _p(hv, C.c_int16))
+    return hv
+
+
 def hv_norm2(hv):
     hv = np.ascontiguousarray(hv, dtype=np.int16)
     return int(lib().orc_hv_norm2(_p(hv, C.c_int16), hv.size))

@@ -1,6 +1,7 @@
 """The reference's OWN kernel (src/cuda_kernel.cu built in place by hipcc into oracle/_ref/) run on
 the MI355X next to the oracle and the product: three-way agreement on the sampled hash sets.
-(k <= 24 only: the reference kernel itself faults at k = 31 / 32 when built for gfx950.)"""
+k <= 24 with the -O3 build of the reference source, k = 25..32 (the `default:` branch of its t1ha2_atonce: the
+prime_4 stage) with the -O0 build of the same source -- optimised builds of the reference kernel fault there."""
 import os
 import subprocess
 import tempfile
@@ -12,14 +13,15 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 REF = os.path.join(ROOT, "oracle", "_ref")
-HAVE_REF = os.path.exists(os.path.join(REF, "ref_kmer_runner")) and os.path.exists(os.path.join(REF, "ref_cuda_kernel.hsaco"))
+HAVE_REF = all(os.path.exists(os.path.join(REF, f)) for f in ("ref_kmer_runner", "ref_cuda_kernel.hsaco", "ref_cuda_kernel_O0.hsaco"))
 
 
 def run_ref(seq, k, scaled, seed=123, canonical=True, slots=0):
     with tempfile.TemporaryDirectory() as td:
         fi, fo = os.path.join(td, "s.bin"), os.path.join(td, "o.bin")
         np.ascontiguousarray(seq, np.uint8).tofile(fi)
-        subprocess.check_call([os.path.join(REF, "ref_kmer_runner"), os.path.join(REF, "ref_cuda_kernel.hsaco"),
+        hsaco = "ref_cuda_kernel.hsaco" if k <= 24 else "ref_cuda_kernel_O0.hsaco"
+        subprocess.check_call([os.path.join(REF, "ref_kmer_runner"), os.path.join(REF, hsaco),
                                fi, str(k), str(scaled), str(seed), "1" if canonical else "0", str(slots), fo])
         return np.fromfile(fo, np.uint64)
 
@@ -32,6 +34,10 @@ def run_ref(seq, k, scaled, seed=123, canonical=True, slots=0):
     (14, 80_000, 12, 20, True, 128),
     (15, 80_000, 24, 20, True, 128),
     (16, 80_000, 16, 3, True, 256),
+    (17, 60_000, 25, 20, True, 128),      # k >= 25: reference kernel built -O0
+    (18, 60_000, 27, 5, False, 256),
+    (19, 60_000, 31, 20, True, 128),
+    (20, 60_000, 32, 1, True, 520),
 ])
 def test_three_way_hash_sets(orc, g, L, k, scaled, canon, slots):
     import hypergen_amd as hg

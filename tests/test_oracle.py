@@ -105,6 +105,29 @@ def test_hv_layouts(orc, n, d):
     assert orc.hv_norm2(sc) == orc.hv_norm2(av) == int((sc.astype(np.int64) ** 2).sum())
 
 
+def test_avx2_layout_with_the_real_intrinsics(orc):
+    """src/hd.rs:14-92 followed statement by statement with <immintrin.h> (oracle/hg_oracle_avx2.c, gcc -mavx2):
+    the CPU's own vpshufb / vphaddw / vpermq define the AVX2 output order; the closed-form ORC_LAYOUT_AVX2 and
+    the scalar emulation must both equal it -- including the zero-padded last batch (n % 4 != 0), n = 0, a
+    production-sized set and the i16 wrap of n > 32 767."""
+    if not orc.has_avx2_build():
+        pytest.skip("host CPU without AVX2 (or libhg_oracle_avx2.so not built)")
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 2, 3, 4, 5, 7, 8, 50, 3333, 40_000):
+        for d in ((256, 4096) if n < 1000 else (4096 if n == 3333 else 256,)):
+            hs = np.unique(rng.integers(0, 2**64, n, dtype=np.uint64))
+            real = orc.encode_hv_avx2_intrinsics(hs, d)
+            assert (real == orc.encode_hv(hs, d, orc.LAYOUT_AVX2)).all(), (n, d)
+            if n <= 3333:
+                assert (real == orc.encode_hv_avx2_emulated(hs, d)).all(), (n, d)
+    # the permutation itself, on a single hash: scalar dim 64i + j  ->  AVX2 dim 64i + 4*(j & 15) + (j >> 4)
+    h = np.array([0x0123456789ABCDEF], np.uint64)
+    sc, av = orc.encode_hv(h, 256, orc.LAYOUT_SCALAR), orc.encode_hv_avx2_intrinsics(h, 256)
+    for i in range(4):
+        for j in range(64):
+            assert av[64 * i + 4 * (j & 15) + (j >> 4)] == sc[64 * i + j]
+
+
 def test_pack_roundtrip_and_width(orc):
     rng = np.random.default_rng(3)
     for amp in (5, 31, 32, 33, 200, 600, 5000, 16000):

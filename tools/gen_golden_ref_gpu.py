@@ -24,7 +24,9 @@ def run_ref(seq, k, scaled, seed=123, canonical=True, slots=0):
     with tempfile.TemporaryDirectory() as td:
         fi, fo = os.path.join(td, "s.bin"), os.path.join(td, "o.bin")
         np.ascontiguousarray(seq, np.uint8).tofile(fi)
-        subprocess.check_call([os.path.join(REF, "ref_kmer_runner"), os.path.join(REF, "ref_cuda_kernel.hsaco"),
+        # k >= 25: the -O0 build of the same reference source (the optimised builds fault there, oracle/Makefile)
+        hsaco = "ref_cuda_kernel.hsaco" if k <= 24 else "ref_cuda_kernel_O0.hsaco"
+        subprocess.check_call([os.path.join(REF, "ref_kmer_runner"), os.path.join(REF, hsaco),
                                fi, str(k), str(scaled), str(seed), "1" if canonical else "0", str(slots), fo])
         return np.fromfile(fo, np.uint64)
 
@@ -43,8 +45,12 @@ def main():
         ("g2_200k_k24_s50", 5, 200_000, 24, 50, True, 64),
         ("g2_50k_k9_s20", 7, 50_000, 9, 20, True, 128),
         ("g2_50k_k12_s20", 8, 50_000, 12, 20, True, 128),
-        # k = 25 probes the reference kernel's `default:` branch (k=31/32 fault on gfx950)
+        # k = 25..32: the reference kernel's `default:` branch = t1ha2's prime_4 stage (-O0 build, see run_ref)
         ("g2_50k_k25_s20", 9, 50_000, 25, 20, True, 128),
+        ("g2_50k_k28_s20", 10, 50_000, 28, 20, True, 128),
+        ("g2_50k_k31_s20", 11, 50_000, 31, 20, True, 128),
+        ("g2_50k_k32_s7_noncanon", 12, 50_000, 32, 7, False, 256),
+        ("g2_100k_k29_s1", 13, 100_000, 29, 1, True, 520),
     ]:
         seq = orc.synth_genome(g, L)
         if "100k" in name:  # sprinkle non-bases and lower case
