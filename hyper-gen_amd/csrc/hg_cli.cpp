@@ -121,8 +121,20 @@ Cli parse(int argc, char **argv) {
   return c;
 }
 
-void ck(hg_ctx *ctx, hg_status s, const char *what) {
-  if (s != HG_OK) die(std::string(what) + ": " + hg_status_str(s) + " (" + hg_last_error(ctx) + ")");
+void ckm(hg_multi *m, hg_status s, const char *what) {
+  if (s != HG_OK) die(std::string(what) + ": " + hg_status_str(s) + " (" + hg_multi_last_error(m) + ")");
+}
+
+// every GPU the process can see (HIP_VISIBLE_DEVICES narrows it); the reference opens device 0 only
+// (src/sketch_cuda.rs:52)
+hg_multi *open_all_devices() {
+  const int n = hg_device_count();
+  if (n <= 0) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  std::vector<int> ids(n);
+  for (int i = 0; i < n; ++i) ids[i] = i;
+  hg_multi *m = nullptr;
+  if (hg_multi_create(ids.data(), n, &m) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  return m;
 }
 
 // get_fasta_files (src/utils.rs:208-221): *.fna, *.fa, *.fasta, in that order
@@ -147,8 +159,7 @@ int run_sketch(const Cli &c) {
   const auto t0 = std::chrono::steady_clock::now();
   if (c.scaled == 0) die("scaled must be >= 1");
   if (c.hv_d % 256) die("hv_d must be a multiple of 256 (bit-packed sketch blocks, src/hd.rs:143-153)");
-  hg_ctx *ctx = nullptr;
-  if (hg_ctx_create(0, &ctx) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  hg_multi *multi = open_all_devices();
   hg_sketch_params p;
   hg_sketch_params_default(&p);
   const bool gpu_mode = c.device == "gpu";
@@ -224,7 +235,8 @@ int run_sketch(const Cli &c) {
     std::vector<int16_t> hv(nb * c.hv_d);
     std::vector<int32_t> n2(nb);
     std::vector<uint32_t> nh(nb);
-    ck(ctx, hg_sketch_batch(ctx, cur.seqs.data(), cur.lens.data(), nb, &p, hv.data(), n2.data(), nh.data()), "sketch");
+    // genomes shard over every visible GPU (contiguous blocks, no exchange: SURVEY.md 8e)
+    ckm(multi, hg_sketch_batch_multi(multi, cur.seqs.data(), cur.lens.data(), nb, &p, hv.data(), n2.data(), nh.data()), "sketch");
     {
       std::lock_guard<std::mutex> lk(pool_mu);
       for (auto &sl : cur.slots) pool.push_back(sl);
@@ -254,7 +266,7 @@ int run_sketch(const Cli &c) {
   for (auto &r : recs) total += 47 + std::strlen(r.file_str) + r.hv_len * 2;
   std::snprintf(buf, sizeof buf, "Dump sketch file to %s with size %.2f MB", c.out.c_str(), total / 1024.0 / 1024.0);
   logline("INFO", buf);
-  hg_ctx_destroy(ctx);
+  hg_multi_destroy(multi);
   return 0;
 }
 
@@ -315,19 +327,19 @@ int run_dist(const Cli &c) {
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
   if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
   logline("INFO", "Computing ANI..");
-  hg_ctx *ctx = nullptr;
-  if (hg_ctx_create(0, &ctx) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  hg_multi *multi = open_all_devices();
   const size_t total = sym ? R.n * (Q.n - 1) / 2 : R.n * Q.n;
   std::vector<hg_ani_hit> hits(std::max<size_t>(1024, total / 16));
   size_t found = 0;
   for (;;) {
-    hg_status s = hg_dist(ctx, R.hv.data(), R.n2.data(), R.n, Q.hv.data(), Q.n2.data(), Q.n, (uint32_t)R.hv_d, R.ksize,
-                          sym, c.ani_th, hits.data(), hits.size(), &found);
+    // reference rows are all-gathered over xGMI, query rows stay on their shard's GPU
+    hg_status s = hg_dist_multi(multi, R.hv.data(), R.n2.data(), R.n, Q.hv.data(), Q.n2.data(), Q.n, (uint32_t)R.hv_d,
+                                R.ksize, sym, c.ani_th, hits.data(), hits.size(), &found);
     if (s == HG_ERR_CAPACITY) {
       hits.resize(found);
       continue;
     }
-    ck(ctx, s, "dist");
+    ckm(multi, s, "dist");
     break;
   }
   hits.resize(found);
@@ -359,7 +371,7 @@ int run_dist(const Cli &c) {
   logline("INFO", buf);
   hg_sketch_file_free(R.f);
   if (!sym) hg_sketch_file_free(Qs.f);
-  hg_ctx_destroy(ctx);
+  hg_multi_destroy(multi);
   return 0;
 }
 

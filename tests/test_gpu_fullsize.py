@@ -232,3 +232,137 @@ def test_work_is_ordered_with_the_callers_stream():
             assert found == want, (use_side_stream, found, want)
     finally:
         ctx.close()
+
+
+def test_config2_sketch_10k_x_5mbp_resident_and_sharded(orc):
+    """BASELINE configs[2]: 10 000 synthetic 5 Mbp genomes (50 GB resident on one MI355X).  Checked through
+    size-independent properties + sampled oracle parity, then as the 8-way sharded job: the shard a rank would own
+    (shard_range(10 000, r, 8)), sketched on its own from its own generator call, must equal the same rows of the
+    one-GPU run bit for bit; finally the 10 000 real sketches go through dist (configs[3] on real data)."""
+    import hypergen_amd as hg
+    from hypergen_amd import shard
+    dev = torch.device("cuda:0")
+    n10 = 10_000
+    ctx = hg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        stride = (L + 1 + 15) // 16 * 16
+        seq = torch.empty(n10 * stride + 64, dtype=torch.uint8, device=dev)
+        ctx.synth_genomes_dev(0, n10, L, stride, seq.data_ptr())
+        offs = np.arange(n10, dtype=np.uint64) * stride
+        lens = np.full(n10, L + 1, np.uint64)
+        p = hg.default_params()
+        hv = torch.empty((n10, D), dtype=torch.int16, device=dev)
+        n2 = torch.empty(n10, dtype=torch.int32, device=dev)
+        nh = torch.empty(n10, dtype=torch.int32, device=dev)
+        ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+        torch.cuda.synchronize()
+        nhc = nh.cpu().numpy()
+        assert 3050 < nhc.min() and nhc.max() < 3650 and abs(nhc.mean() - (L - 20) / 1500) < 30
+        assert torch.equal((hv.int() ** 2).sum(1).int(), n2)
+        assert bool(((hv.int() - nh[:, None]) % 2 == 0).all())
+        for g in (0, 2_345, 5_000, 7_777, 9_999):  # sampled full parity with the CPU oracle
+            host = orc.synth_genome(g, L)
+            assert np.array_equal(seq[g * stride: g * stride + L + 1].cpu().numpy(), host)
+            w_hv, w_n2, w_nh = orc.sketch_genome(host)
+            assert nhc[g] == w_nh and int(n2[g]) == w_n2 and np.array_equal(hv[g].cpu().numpy(), w_hv), g
+        # the sharded job, ranks 0, 3 and 7 of 8 (each from scratch: own generator call, own batch plan)
+        for r in (0, 3, 7):
+            lo, hi = shard.shard_range(n10, r, 8)
+            m = hi - lo
+            s_seq = torch.empty(m * stride + 64, dtype=torch.uint8, device=dev)
+            ctx.synth_genomes_dev(lo, m, L, stride, s_seq.data_ptr())
+            s_hv = torch.empty((m, D), dtype=torch.int16, device=dev)
+            s_n2 = torch.empty(m, dtype=torch.int32, device=dev)
+            s_nh = torch.empty(m, dtype=torch.int32, device=dev)
+            ctx.sketch_batch_dev(s_seq.data_ptr(), offs[:m], lens[:m], p, s_hv.data_ptr(), s_n2.data_ptr(), s_nh.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(s_hv, hv[lo:hi]) and torch.equal(s_n2, n2[lo:hi]) and torch.equal(s_nh, nh[lo:hi]), r
+            del s_seq, s_hv
+        del seq
+        # dist of the 10 000 real sketches: thresholded output == thresholded full matrix on a 2 048-row block
+        cap = 4_000_000
+        hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+        found, st = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), n10, hv.data_ptr(), n2.data_ptr(), n10, D, 21, True, 90.0,
+                                 hits.data_ptr(), cap)
+        torch.cuda.synchronize()
+        assert st == 0 and 100_000 < found < cap  # 100 clusters x ~C(100,2) close pairs
+        blk = 2048
+        full = torch.empty((blk, n10), dtype=torch.float32, device=dev)
+        ctx.dist_full_dev(hv.data_ptr(), n2.data_ptr(), blk, hv.data_ptr(), n2.data_ptr(), n10, D, 21, full.data_ptr())
+        torch.cuda.synchronize()
+        h = hits[: found * 3].view(found, 3)
+        sel = h[:, 0] < blk
+        ri, qi, ani = h[sel, 0].long(), h[sel, 1].long(), h[sel, 2].contiguous().view(torch.float32)
+        want = torch.triu(full >= 90.0, diagonal=1)
+        got = torch.zeros_like(want)
+        got[ri, qi] = True
+        assert int(sel.sum()) == int(want.sum()) and bool((got == want).all())
+        assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+        # estimator sanity on real data: member m of cluster 0 vs its root
+        est = full[0, 1:100].cpu().numpy()
+        assert np.abs(est - 100.0 * (1.0 - 0.001 * np.arange(1, 100))).max() < 1.0
+    finally:
+        ctx.close()
+
+
+def test_config4_hamming_search_50k_refs_fullsize(orc):
+    """BASELINE configs[4] at full size: 50 000 bit-packed D = 16384 references x 1 000 queries.  The hit list is
+    compared (a) with the CPU oracle's popcount matrix on a 2 000 x 1 000 slice, (b) for ALL 5*10^7 pairs with an
+    independent brute-force evaluation (+-1 bf16 GEMM in torch: hamming = (D - dot) / 2, exact in the f32
+    accumulator), and (c) with the same search run as 8 reference shards with global indices (the 8-GPU
+    decomposition), which must give the identical hit set."""
+    import hypergen_amd as hg
+    from hypergen_amd import shard
+    dev = torch.device("cuda:0")
+    HD, R, Q, MAXD = 16384, 50_000, 1_000, 7_400
+    words = HD // 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    refs = torch.randint(-2**31, 2**31 - 1, (R, words), dtype=torch.int32, device=dev, generator=g)
+    src = torch.randint(0, R, (Q,), device=dev, generator=g)
+    # queries: a source row with a random 0..100 % of its WORDS replaced -> distances from 0 up to the random-pair 8 192
+    frac = torch.rand((Q, 1), device=dev, generator=g)
+    noise = torch.randint(-2**31, 2**31 - 1, (Q, words), dtype=torch.int32, device=dev, generator=g)
+    qry = torch.where(torch.rand((Q, words), device=dev, generator=g) < frac, noise, refs[src])
+    ctx = hg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        cap = 1 << 20
+        out = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+        n, st = ctx.hamming_search_dev(refs.data_ptr(), R, qry.data_ptr(), Q, HD, MAXD, out.data_ptr(), cap)
+        torch.cuda.synchronize()
+        assert st == 0 and Q // 2 < n < cap  # ~90 % of the queries keep their source within MAXD
+        h = out[: 3 * n].view(n, 3).clone()
+        # (b) brute force over all pairs
+        def pm1(x):  # bits -> +-1 bf16, LSB first
+            sh = torch.arange(32, device=dev, dtype=torch.int32)
+            return (((x[:, :, None] >> sh) & 1).to(torch.bfloat16) * 2 - 1).reshape(x.shape[0], -1)
+        qf = pm1(qry)
+        dist_all = torch.empty((R, Q), dtype=torch.int32, device=dev)
+        for r0 in range(0, R, 5000):
+            dot = pm1(refs[r0:r0 + 5000]).float() @ qf.float().T  # f32 GEMM: sums of +-1 are exact
+            dist_all[r0:r0 + 5000] = ((HD - dot) / 2).round().int()
+        want = dist_all <= MAXD
+        assert n == int(want.sum())
+        got = torch.zeros_like(want)
+        got[h[:, 0].long(), h[:, 1].long()] = True
+        assert bool((got == want).all())
+        assert bool((dist_all[h[:, 0].long(), h[:, 1].long()] == h[:, 2]).all())
+        # (a) the CPU oracle on a slice
+        sl = orc.hamming_matrix(refs[:2000].cpu().numpy().view(np.uint32), qry.cpu().numpy().view(np.uint32))
+        assert np.array_equal(sl, dist_all[:2000].cpu().numpy().astype(np.uint32))
+        # (c) 8 reference shards with global indices
+        parts = []
+        for r in range(8):
+            lo, hi = shard.shard_range(R, r, 8)
+            m, st = ctx.hamming_search_block_dev(refs[lo:hi].data_ptr(), hi - lo, lo, qry.data_ptr(), Q, 0, HD, MAXD,
+                                                 out.data_ptr(), cap)
+            assert st == 0
+            parts.append(out[: 3 * m].view(m, 3).clone())
+        hs = torch.cat(parts)
+        key = lambda t: t[:, 0].long() * Q + t[:, 1].long()
+        a, b = h[key(h).argsort()], hs[key(hs).argsort()]
+        assert a.shape == b.shape and bool((a == b).all())
+    finally:
+        ctx.close()
