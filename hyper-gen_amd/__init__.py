@@ -70,6 +70,7 @@ EXPORTS = [
     "hg_ctx_set_debug", "hg_read_fastx_into", "hg_dist_block_dev", "hg_hamming_search_block_dev",
     "hg_multi_create", "hg_multi_destroy", "hg_multi_size", "hg_multi_ctx", "hg_multi_last_error", "hg_shard_range",
     "hg_sketch_batch_multi", "hg_dist_multi", "hg_dist_multi_dev", "hg_hamming_search_multi",
+    "hg_sort_ani_hits_dev", "hg_sort_ani_hits_staged", "hg_topk_per_query_dev",
 ]
 
 
@@ -135,6 +136,9 @@ def lib():
         "hg_read_fastx_into": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "hg_ctx_set_debug": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "hg_free": (None, [vp]),
+        "hg_sort_ani_hits_dev": (C.c_int, [vp, vp, sz, sz]),
+        "hg_sort_ani_hits_staged": (C.c_int, [vp, vp, sz, sz]),
+        "hg_topk_per_query_dev": (C.c_int, [vp, vp, sz, sz, C.c_uint32, vp, vp]),
         "hg_dist_block_dev": (C.c_int, [vp, vp, vp, sz, sz, vp, vp, sz, sz, C.c_uint32, C.c_uint32, C.c_int,
                                         C.c_float, vp, sz, C.POINTER(sz)]),
         "hg_hamming_search_block_dev": (C.c_int, [vp, vp, sz, sz, vp, sz, sz, C.c_uint32, C.c_uint32, vp, sz,
@@ -351,6 +355,17 @@ class Context:
                                                max_dist, _ptr(d_out), cap, C.byref(n))
         self._ck(st, allow=(ERR_CAPACITY,))
         return n.value, st
+
+    def sort_ani_hits_dev(self, d_hits, n, Q):
+        self._ck(lib().hg_sort_ani_hits_dev(self._h, _ptr(d_hits), n, Q))
+
+    def sort_ani_hits_staged(self, hits, Q):
+        hits = np.ascontiguousarray(hits, ANI_HIT_DTYPE).copy()
+        self._ck(lib().hg_sort_ani_hits_staged(self._h, _ptr(hits), hits.size, Q))
+        return hits
+
+    def topk_per_query_dev(self, d_hits, n, Q, k, d_out, d_counts):
+        self._ck(lib().hg_topk_per_query_dev(self._h, _ptr(d_hits), n, Q, k, _ptr(d_out), _ptr(d_counts)))
 
     def dist_dev(self, d_ref, d_rn, R, d_qry, d_qn, Q, hv_d, ksize, symmetric, ani_th, d_out, cap):
         n = C.c_size_t(0)

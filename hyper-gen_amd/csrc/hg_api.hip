@@ -77,7 +77,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort,
                          &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
-                         &c->w_n2a, &c->w_n2b};
+                         &c->w_n2a, &c->w_n2b, &c->w_sorthits};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &t : c->t_pending) (void)hipEventDestroy(t.e0), (void)hipEventDestroy(t.e1);

@@ -40,7 +40,7 @@ void logline(const char *lvl, const std::string &msg) {
 
 struct Cli {
   std::string mode, path = "1", path_r = "1", path_q = "1", out, method = "t1ha2", device = "cpu";
-  unsigned threads = 16, ksize = 21;
+  unsigned threads = 16, ksize = 21, top_n = 1;
   bool canonical = true;
   unsigned long long seed = 123, scaled = 1500, hv_d = 4096;
   float quant_scale = 1.0f, ani_th = 85.0f;
@@ -57,7 +57,8 @@ Cli parse(int argc, char **argv) {
   if (c.mode == "--help" || c.mode == "-h") {
     std::printf("HyperGen: Fast and memory-efficient genome sketching in hyperdimensional space (MI355X build)\n\n"
                 "  hyper-gen sketch -p {fna_path} -o {output_sketch_file}\n"
-                "  hyper-gen dist -r {ref_sketch} -q {query_sketch} -o {output_ANI_results}\n\n"
+                "  hyper-gen dist -r {ref_sketch} -q {query_sketch} -o {output_ANI_results}\n"
+                "  hyper-gen search -r {ref_sketch} -q {query_sketch} -o {top_hits_per_query} [-n top_n]\n\n"
                 "options: -p --path, -r --path_r, -q --path_q, -o --out, -t --thread [16], -m --sketch_method,\n"
                 "         -C --canonical [true], -k --ksize [21], -S --seed [123], -s --scaled [1500], -d --hv_d [4096],\n"
                 "         -Q --quant_scale [1.0], -a --ani_th [85.0], -D --device [cpu]\n");
@@ -68,7 +69,7 @@ Cli parse(int argc, char **argv) {
   static const std::map<std::string, char> longs = {
       {"path", 'p'}, {"path_r", 'r'}, {"path_q", 'q'}, {"out", 'o'}, {"thread", 't'}, {"sketch_method", 'm'},
       {"canonical", 'C'}, {"ksize", 'k'}, {"seed", 'S'}, {"scaled", 's'}, {"hv_d", 'd'}, {"quant_scale", 'Q'},
-      {"ani_th", 'a'}, {"device", 'D'}};
+      {"ani_th", 'a'}, {"device", 'D'}, {"top_n", 'n'}};
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i], val;
     char key = 0;
@@ -115,12 +116,16 @@ Cli parse(int argc, char **argv) {
       case 'Q': c.quant_scale = std::strtof(val.c_str(), nullptr); break;
       case 'a': c.ani_th = std::strtof(val.c_str(), nullptr); break;
       case 'D': c.device = val; break;
+      case 'n': c.top_n = (unsigned)u(1u << 20); break;  // search only (extension: the reference's search is a stub)
       default: die("unexpected argument '" + a + "'");
     }
   }
   return c;
 }
 
+void ck(hg_ctx *ctx, hg_status s, const char *what) {
+  if (s != HG_OK) die(std::string(what) + ": " + hg_status_str(s) + " (" + hg_last_error(ctx) + ")");
+}
 void ckm(hg_multi *m, hg_status s, const char *what) {
   if (s != HG_OK) die(std::string(what) + ": " + hg_status_str(s) + " (" + hg_multi_last_error(m) + ")");
 }
@@ -343,7 +348,9 @@ int run_dist(const Cli &c) {
     break;
   }
   hits.resize(found);
-  hg_sort_ani_hits(hits.data(), hits.size(), Q.n, sym);
+  // dump_ani_file's order (src/utils.rs:262-269), produced on the device: two stable radix passes instead of a
+  // comparison sort of up to 10^6..10^8 triples on one host core
+  ck(hg_multi_ctx(multi, 0), hg_sort_ani_hits_staged(hg_multi_ctx(multi, 0), hits.data(), hits.size(), Q.n), "sort");
   std::string tsv;
   char line[64];
   for (const auto &h : hits) {
@@ -375,11 +382,76 @@ int run_dist(const Cli &c) {
   return 0;
 }
 
+// `search`: the reference parses the subcommand and does nothing (src/main.rs:22-24, "TODO: support for search").
+// Here: every query sketch against the reference database, the top_n (-n, default 1) references per query with
+// ANI >= ani_th, one line "query<TAB>reference<TAB>ani" per result, queries in file order, best first.
+// Without -r / -q / -o it stays the reference's no-op.
+int run_search(const Cli &c) {
+  if (c.path_r == "1" || c.path_q == "1" || c.out.empty()) return 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  Loaded R, Q;
+  load(c.path_r, R, c.threads);
+  load(c.path_q, Q, c.threads);
+  if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
+  if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
+  logline("INFO", "Searching..");
+  hg_multi *multi = open_all_devices();
+  std::vector<hg_ani_hit> hits(std::max<size_t>(1024, R.n * Q.n / 16));
+  size_t found = 0;
+  for (;;) {
+    hg_status s = hg_dist_multi(multi, R.hv.data(), R.n2.data(), R.n, Q.hv.data(), Q.n2.data(), Q.n, (uint32_t)R.hv_d,
+                                R.ksize, 0, c.ani_th, hits.data(), hits.size(), &found);
+    if (s == HG_ERR_CAPACITY) {
+      hits.resize(found);
+      continue;
+    }
+    ckm(multi, s, "search");
+    break;
+  }
+  hg_ctx *ctx = hg_multi_ctx(multi, 0);
+  const uint32_t k = std::max(1u, c.top_n);
+  void *d_hits = nullptr, *d_out = nullptr, *d_cnt = nullptr;
+  ck(ctx, hg_dev_alloc(ctx, std::max<size_t>(found, 1) * sizeof(hg_ani_hit), &d_hits), "alloc");
+  ck(ctx, hg_dev_alloc(ctx, Q.n * (size_t)k * sizeof(hg_ani_hit), &d_out), "alloc");
+  ck(ctx, hg_dev_alloc(ctx, Q.n * sizeof(uint32_t), &d_cnt), "alloc");
+  if (found) ck(ctx, hg_copy_h2d(ctx, d_hits, hits.data(), found * sizeof(hg_ani_hit)), "upload");
+  ck(ctx, hg_topk_per_query_dev(ctx, static_cast<hg_ani_hit *>(d_hits), found, Q.n, k, static_cast<hg_ani_hit *>(d_out),
+                                static_cast<uint32_t *>(d_cnt)), "top-k");
+  std::vector<hg_ani_hit> best(Q.n * (size_t)k);
+  std::vector<uint32_t> cnt(Q.n);
+  ck(ctx, hg_copy_d2h(ctx, best.data(), d_out, best.size() * sizeof(hg_ani_hit)), "download");
+  ck(ctx, hg_copy_d2h(ctx, cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t)), "download");
+  hg_dev_free(ctx, d_hits), hg_dev_free(ctx, d_out), hg_dev_free(ctx, d_cnt);
+  std::string tsv;
+  char line[64];
+  size_t reported = 0;
+  for (size_t q = 0; q < Q.n; ++q)
+    for (uint32_t r = 0; r < cnt[q]; ++r) {
+      const hg_ani_hit &h = best[q * k + r];
+      tsv += hg_sketch_file_get(Q.f, q)->file_str;
+      tsv += '\t';
+      tsv += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
+      std::snprintf(line, sizeof line, "\t%.3f\n", (double)h.ani);
+      tsv += line;
+      ++reported;
+    }
+  FILE *f = std::fopen(c.out.c_str(), "wb");
+  if (!f || (tsv.size() && std::fwrite(tsv.data(), 1, tsv.size(), f) != tsv.size())) die("Dump search file failed!");
+  std::fclose(f);
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "Searched %zu queries against %zu references: %zu results (top %u, ANI >= %.1f) took %.3fs",
+                Q.n, R.n, reported, k, c.ani_th, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  logline("INFO", buf);
+  hg_sketch_file_free(R.f), hg_sketch_file_free(Q.f);
+  hg_multi_destroy(multi);
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
   const Cli c = parse(argc, argv);
   if (c.mode == "sketch") return run_sketch(c);
   if (c.mode == "dist") return run_dist(c);
-  return 0;  // search: parsed but a no-op in the reference too (src/main.rs:22-24)
+  return run_search(c);
 }

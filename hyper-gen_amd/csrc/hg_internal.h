@@ -37,6 +37,7 @@ struct hg_ctx {
   Buf w_ani;      // staged ANI output (host entry points)
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
+  Buf w_sorthits; // keys / permutations / scratch of the device-side hit ordering
   // optional per-kernel timing (hg_ctx_enable_timing)
   bool timing = false;
   struct TimedLaunch {

@@ -103,3 +103,60 @@ def test_cli_reference_fixture(tmp_path):
     tsv = str(tmp_path / "t.tsv")
     r = subprocess.run([hg.CLI_PATH, "dist", "-r", out, "-q", out, "-o", tsv], capture_output=True, text=True)
     assert r.returncode == 0 and open(tsv).read() == ""  # one record, symmetric -> zero pairs
+
+
+def test_cli_search_topn_and_cpu_mode_reader(tmp_path, orc):
+    """`search` (a stub in the reference) = top-n references per query; `-D cpu` (default) reads files the way
+    needletail does (FASTQ records, blanks dropped) and ignores `-C false` like src/sketch.rs:89; `-D gpu` honours it."""
+    import hypergen_amd as hg
+    d = tmp_path / "db"
+    d.mkdir()
+    L = 200_000
+    gen = {"a000.fna": 0, "a005.fna": 5, "a020.fna": 20, "b100.fna": 100, "b107.fna": 107}
+    for name, g in gen.items():
+        write_fasta(str(d / name), orc.synth_genome(g, L)[1:], name)
+    db = str(tmp_path / "db.sketch")
+    assert subprocess.run([hg.CLI_PATH, "sketch", "-p", str(d), "-o", db, "-s", "100"], capture_output=True).returncode == 0
+    qd = tmp_path / "q"
+    qd.mkdir()
+    # queries: a FASTQ file with blanks in the sequence line and a gapped FASTA of the same genomes
+    s3 = bytes(orc.synth_genome(3, L)[1:]).decode()
+    (qd / "q003.fna").write_text("@read one\n" + s3[:1000] + " " + s3[1000:] + "\r\n+\n" + "I" * (L + 1) + "\n")
+    s104 = bytes(orc.synth_genome(104, L)[1:]).decode()
+    (qd / "q104.fa").write_text(">x\n" + "\n".join(s104[i:i + 61] + ("\t" if i % 3 == 0 else "") for i in range(0, L, 61)) + "\n")
+    qs = str(tmp_path / "q.sketch")
+    r = subprocess.run([hg.CLI_PATH, "sketch", "-p", str(qd), "-o", qs, "-s", "100", "-C", "false"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    recs = hg.read_sketch_file(qs)
+    assert [os.path.basename(x["file_str"]) for x in recs] == ["q003.fna", "q104.fa"]
+    for x, g in zip(recs, (3, 104)):  # CPU mode: canonical k-mers although -C false was given; flag stored as given
+        w_hv, w_n2, _ = orc.sketch_genome(orc.synth_genome(g, L), scaled=100, canonical=True, norm=orc.NORM_U2T)
+        assert x["canonical"] is False and x["hv_norm_2"] == w_n2
+        assert (hg.hv_unpack(x["hv"].view(np.uint8), 4096, x["hv_quant_bits"]) == w_hv).all()
+    out = str(tmp_path / "top.tsv")
+    r = subprocess.run([hg.CLI_PATH, "search", "-r", db, "-q", qs, "-o", out, "-a", "80", "-n", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split("\t") for l in open(out).read().splitlines()]
+    names = [(os.path.basename(a), os.path.basename(b)) for a, b, _ in rows]
+    # genome 3 is closest to members 0 and 5 of cluster 0, genome 104 to 107 / 100 of cluster 1 (0.1 % per member step)
+    assert names == [("q003.fna", "a000.fna"), ("q003.fna", "a005.fna"), ("q104.fa", "b107.fna"), ("q104.fa", "b100.fna")]
+    anis = [float(v) for _, _, v in rows]
+    assert anis[0] >= anis[1] > 98.0 and anis[2] >= anis[3] > 98.0
+    hvs = np.stack([hg.hv_unpack(x["hv"].view(np.uint8), 4096, x["hv_quant_bits"]) for x in hg.read_sketch_file(db)])
+    n2s = np.array([x["hv_norm_2"] for x in hg.read_sketch_file(db)], np.int32)
+    qh = np.stack([hg.hv_unpack(x["hv"].view(np.uint8), 4096, x["hv_quant_bits"]) for x in recs])
+    qn = np.array([x["hv_norm_2"] for x in recs], np.int32)
+    model = orc.ani_matrix(hvs, n2s, qh, qn, 21)
+    assert abs(anis[0] - float(model[0, 0])) <= 1e-3 + 1e-4 and abs(anis[2] - float(model[4, 1])) <= 1e-3 + 1e-4
+    # -D gpu honours -C false (src/cuda_kernel.cu:312-314) and reads lines as they are (plain FASTA only)
+    gq = tmp_path / "gq"
+    gq.mkdir()
+    write_fasta(str(gq / "g.fna"), orc.synth_genome(3, L)[1:], "g")
+    gs = str(tmp_path / "g.sketch")
+    r = subprocess.run([hg.CLI_PATH, "sketch", "-p", str(gq), "-o", gs, "-s", "100", "-C", "false", "-D", "gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    x = hg.read_sketch_file(gs)[0]
+    w_hv, w_n2, _ = orc.sketch_genome(orc.synth_genome(3, L), scaled=100, canonical=False)
+    assert x["hv_norm_2"] == w_n2 and (hg.hv_unpack(x["hv"].view(np.uint8), 4096, x["hv_quant_bits"]) == w_hv).all()
+    # without -r / -q / -o `search` stays the reference's no-op
+    assert subprocess.run([hg.CLI_PATH, "search"], capture_output=True).returncode == 0
