@@ -77,7 +77,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort,
                          &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
-                         &c->w_n2a, &c->w_n2b, &c->w_sorthits};
+                         &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &t : c->t_pending) (void)hipEventDestroy(t.e0), (void)hipEventDestroy(t.e1);
@@ -113,6 +113,8 @@ extern "C" hg_status hg_ctx_reset_stream(hg_ctx *c) {
   if (!c) return HG_ERR_INVALID;
   return switch_stream(c, c->own_stream);
 }
+
+extern "C" int hg_ctx_last_dist_path(const hg_ctx *c) { return c ? c->last_dist_path : -1; }
 
 extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *value) {
   if (!c || !key) return HG_ERR_INVALID;
@@ -759,8 +761,9 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   HG_HIP(c, hipSetDevice(c->device));
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
-  auto *d_count = static_cast<uint32_t *>(c->w_misc.p);  // [0] hit counter, [1] exactness verdict, [2] its window length
-  HG_HIP(c, hipMemsetAsync(d_count, 0, 4 * sizeof(uint32_t), c->stream));
+  // [0] hit counter, [1] exactness verdict, [2] its window length, [4..12] control words of the i8 operand attempt
+  auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
+  HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
   hg_dist_args a{};
   a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
   a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
@@ -772,9 +775,12 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if ((s = hg_run_dist(c, a, d_count + 1, &spec_cover)) != HG_OK) return s;
   if ((s = hg_ensure_pinned(c, 64)) != HG_OK) return s;
   auto *h_res = static_cast<uint32_t *>(c->h_pin);
-  HG_HIP(c, hipMemcpyAsync(h_res, d_count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HG_HIP(c, hipMemcpyAsync(h_res, d_count, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));
-  if (spec_cover >= 0 && (int)h_res[1] > spec_cover) {  // no guarded launch applied: statistics-driven schedule
+  const bool i8_tried = h_res[9] != 0;  // the i8 prepass wrote its K-step count
+  if (i8_tried && h_res[8] != 1u) c->i8_skip = 16;  // vetoed on the device: f16 ran; do not probe again for a while
+  if (h_res[8] == 1u) c->last_dist_path = 1;
+  if (h_res[8] != 1u && spec_cover >= 0 && (int)h_res[1] > spec_cover) {  // no guarded launch applied: statistics-driven schedule
     HG_HIP(c, hipMemsetAsync(d_count, 0, 4 * sizeof(uint32_t), c->stream));
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
     h_res = static_cast<uint32_t *>(c->h_pin);  // the pinned scratch may have grown meanwhile

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "hg_internal.h"
@@ -162,7 +163,9 @@ __device__ __forceinline__ unsigned long long dpp_get64(unsigned long long v) {
 __global__ __launch_bounds__(256) void prep_fast_kernel(const int16_t *__restrict__ hv, uint32_t rows,
                                                         uint32_t hv_d, uint32_t kp, uint32_t ldk,
                                                         _Float16 *__restrict__ out,
-                                                        unsigned long long *__restrict__ slots, uint32_t win) {
+                                                        unsigned long long *__restrict__ slots, uint32_t win,
+                                                        const uint32_t *__restrict__ veto) {
+  if (veto && veto[0] == 1u) return;  // the i8 operand path queued before this prepass is valid: nothing to do
   // win != 0 (kp a multiple of 1024, at most PREP_MAX_WIN windows): the row's sum of squares per aligned
   // 1024-dim window is collected too (per-wave LDS accumulators), for the 2 048- and 1 024-dim bounds
   __shared__ unsigned long long s_win[4][PREP_MAX_WIN];
@@ -284,8 +287,12 @@ __device__ __forceinline__ bool window_safe(unsigned long long a, unsigned long 
 }
 __global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *__restrict__ slots_r,
                                                      const unsigned long long *__restrict__ slots_q,
-                                                     uint32_t *__restrict__ verdict) {
+                                                     uint32_t *__restrict__ verdict, const uint32_t *__restrict__ veto) {
   __shared__ unsigned long long s_red[8][256];
+  if (veto && veto[0] == 1u) {  // uniform: the i8 path did the work; report "covered" to the host
+    if (threadIdx.x == 0) verdict[0] = 0, verdict[1] = 0;
+    return;
+  }
   unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = threadIdx.x; i < PREP_SLOTS; i += 256) {
 #pragma unroll
@@ -312,6 +319,170 @@ __global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *_
       else if (window_safe(s_red[3][0], s_red[7][0])) code = 2, steps = 1024 / 64;
     }
     verdict[0] = code, verdict[1] = steps;
+  }
+}
+
+// ---- i8 operand path -----------------------------------------------------------------------------------
+// A sketch HV is hv[d] = 2*count[d] - n (src/hd.rs:29,84-87): all entries of a row have the parity e = n & 1, so
+//     x = 2*c - e,   c = (x + e) >> 1   (exact; c is the bit count centred on n/2, sigma = sqrt(n)/2),
+//     dot(r, q) = 4*sum c_r*c_q - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q,     S = sum_d c[d].
+// For sketches of up to ~3 500 hashes (genomes up to ~5 Mbp at scaled = 1500) c fits a signed byte for all but a
+// ~1e-5 fraction of the entries, so G = sum a_r*a_q (a = c clamped to [-127, 127]) runs on
+// v_mfma_i32_16x16x64_i8: twice the K per instruction AND half the operand bytes of the f16 path (the kernel is
+// co-limited by the L2 -> LDS feed), exact in the i32 accumulator without any window logic.  The few clamped
+// entries ("outliers", residual b = c - a) are repaired exactly, outside the GEMM:
+//     sum c_i*c_j = G + sum_{d in out(i)} b_i[d]*c_j[d] + sum_{d in out(j)} a_i[d]*b_j[d]
+// Both sums are evaluated in the epilogue, only for the few candidates that survive the threshold pre-filter AND sit
+// in a row / column that has clamped entries (~4 % of the rows): a row's entries (dim, b) are consecutive in a sorted
+// list, c_j[d] and a_i[d] are read back from the original i16 matrices.  Rows of mixed
+// parity, residuals beyond a byte, more than I8_ENT_CAP outlier entries or a row with more than 255 of them veto
+// the path on the device and the f16 kernels queued behind it run instead; the dot product is the same integer
+// either way.
+constexpr uint32_t I8_ENT_CAP = 1024;
+struct I8Outlier {
+  uint32_t row;
+  uint16_t d;
+  int8_t b;
+  uint8_t side;  // 0 = reference matrix, 1 = query matrix
+};
+// ctrl words (device): [0] outlier count, [1] failure bits, [2] phase-0 slack of the GEMM epilogue, [3] entries of side 0,
+//                      [4] verdict (1 = i8 path valid), [5] K-steps of 128 bytes
+__global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict__ hv, uint32_t rows, uint32_t hv_d,
+                                                      uint32_t kp8, uint32_t ldk8, int8_t *__restrict__ out_a,
+                                                      int32_t *__restrict__ rowinfo, int32_t *__restrict__ rowslot,
+                                                      I8Outlier *__restrict__ list, uint32_t *__restrict__ ctrl,
+                                                      uint32_t *__restrict__ maxs_slots, uint32_t side) {
+  const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // whole wave
+  const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
+  const int32_t x0 = src[0], e = x0 & 1;
+  int32_t S = 0;
+  uint32_t par = 0, bad = 0;
+  const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  const uint32_t nchunks = (kp8 + 511) / 512;
+  for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {  // four 16-byte loads in flight per lane
+    uint32_t d0s[4];
+    uint4 raw[4];
+    bool vec[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // chunk order rotated by the row index: a power-of-two row pitch otherwise sends every wave to the same channels
+      d0s[t] = q0 + t < nchunks ? ((q0 + t + row) % nchunks) * 512 + lane * 8 : kp8;
+      vec[t] = vec_ok && d0s[t] + 8 <= hv_d;
+      raw[t] = make_uint4(0, 0, 0, 0);
+      if (vec[t]) raw[t] = *reinterpret_cast<const uint4 *>(src + d0s[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t d0 = d0s[t];
+      if (d0 >= kp8) continue;
+      int32_t x[8];
+      if (vec[t]) {
+        const uint32_t w[4] = {raw[t].x, raw[t].y, raw[t].z, raw[t].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[2 * i] = (int16_t)(w[i] & 0xffffu), x[2 * i + 1] = (int16_t)(w[i] >> 16);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = d0 + i < hv_d ? (int32_t)src[d0 + i] : -e;  // padding: c = 0
+      }
+      uint32_t pk[2] = {0, 0};
+      const bool all_real = d0 + 8 <= hv_d;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        par |= (all_real || d0 + i < hv_d) ? (uint32_t)((x[i] ^ x0) & 1) : 0u;
+        const int32_t cc = (x[i] + e) >> 1;
+        S += cc;
+        const int32_t a = cc > 127 ? 127 : (cc < -127 ? -127 : cc), b = cc - a;
+        if (b != 0) {
+          if (b > 127 || b < -127) bad |= 4u;
+          const uint32_t idx = atomicAdd(&ctrl[0], 1u);
+          if (idx < I8_ENT_CAP) list[idx] = I8Outlier{row, (uint16_t)(d0 + i), (int8_t)b, (uint8_t)side};
+        }
+        pk[i >> 2] |= (uint32_t)(uint8_t)(int8_t)a << (8 * (i & 3));
+      }
+      *reinterpret_cast<uint2 *>(out_a + (size_t)row * ldk8 + d0) = make_uint2(pk[0], pk[1]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+  const bool anypar = __any(par != 0), anybad = __any(bad != 0);
+  if (lane == 0) {
+    rowinfo[row] = 2 * S + e;
+    rowslot[row] = 0;  // "no outlier entries" until i8_entries_kernel says otherwise
+    const uint32_t fl = (anypar ? 1u : 0u) | (anybad ? 4u : 0u);
+    if (fl) atomicOr(&ctrl[1], fl);
+    // max |S| over the rows, in one of 1 024 slots (folded by i8_entries_kernel): a single counter would take one
+    // same-address atomic from every wave resident at the start (they all see the initial zero), ~12 ns each
+    const uint32_t as = (uint32_t)(S < 0 ? -S : S);
+    uint32_t *sl = &maxs_slots[blockIdx.x % PREP_SLOTS];
+    if (as > __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sl, as);
+  }
+}
+
+// One workgroup: the outlier entries sorted by (side, row, dim) so that a row's entries are consecutive; per row
+// (first entry | count | sum |b|) into rowslot; the verdict into ctrl.
+__global__ __launch_bounds__(1024) void i8_entries_kernel(const I8Outlier *__restrict__ list, I8Outlier *__restrict__ sorted,
+                                                          uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ maxs_slots,
+                                                          int32_t *__restrict__ slot_r, int32_t *__restrict__ slot_q,
+                                                          uint32_t kp8, uint32_t hv_d) {
+  __shared__ unsigned long long s_key[I8_ENT_CAP];
+  __shared__ uint32_t s_mx, s_bsum, s_bad, s_n0;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_mx = 0, s_bsum = 0, s_bad = 0, s_n0 = 0;
+  __syncthreads();
+  {
+    const uint32_t v = maxs_slots[tid];  // PREP_SLOTS == blockDim.x
+    if (v) atomicMax(&s_mx, v);
+  }
+  const uint32_t n_raw = ctrl[0];
+  const uint32_t n = n_raw < I8_ENT_CAP ? n_raw : I8_ENT_CAP;
+  bool bad = ctrl[1] != 0 || n_raw > I8_ENT_CAP || kp8 > 65535;
+  // key: side | row | dim | residual byte  (ascending = grouped by side, then row)
+  unsigned long long key = ~0ull;
+  if (tid < n) {
+    const I8Outlier o = list[tid];
+    key = ((unsigned long long)(o.side & 1) << 63) | ((unsigned long long)(o.row & 0x7fffffffu) << 24) |
+          ((unsigned long long)o.d << 8) | (uint8_t)o.b;
+    if (o.side == 0) atomicAdd(&s_n0, 1u);
+  }
+  s_key[tid] = key;
+  __syncthreads();
+  for (uint32_t k = 2; k <= I8_ENT_CAP; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t ixj = tid ^ j;
+      if (ixj > tid) {
+        const unsigned long long x = s_key[tid], y = s_key[ixj];
+        const bool up = (tid & k) == 0;
+        if ((x > y) == up) s_key[tid] = y, s_key[ixj] = x;
+      }
+      __syncthreads();
+    }
+  const uint32_t n0 = s_n0;
+  if (tid < n) {
+    const unsigned long long kk = s_key[tid];
+    const uint32_t side = (uint32_t)(kk >> 63), row = (uint32_t)(kk >> 24) & 0x7fffffffu;
+    sorted[tid] = I8Outlier{row, (uint16_t)(kk >> 8), (int8_t)(uint8_t)kk, (uint8_t)side};
+    const bool first = tid == 0 || (s_key[tid - 1] >> 24) != (kk >> 24);
+    if (first) {  // run length and sum |b| of this row's entries
+      uint32_t cnt = 0, bs = 0;
+      for (uint32_t t = tid; t < n && (s_key[t] >> 24) == (kk >> 24); ++t) {
+        const int32_t bb = (int8_t)(uint8_t)s_key[t];
+        ++cnt, bs += (uint32_t)(bb < 0 ? -bb : bb);
+      }
+      if (cnt > 255 || bs >= (1u << 14)) atomicOr(&s_bad, 1u);
+      atomicMax(&s_bsum, bs);
+      const uint32_t first_idx = side ? tid - n0 : tid;  // index inside this side's correction table
+      // slot word: first entry (10 bits) | entries (8 bits) | sum |b| of the row (14 bits: the epilogue's per-row slack)
+      (side ? slot_q : slot_r)[row] = (int32_t)((first_idx << 22) | ((cnt & 255u) << 14) | (bs & 0x3fffu));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bad = bad || s_bad != 0;
+    ctrl[2] = 4u * s_mx + hv_d + 64u + 8u * s_bsum * 254u;  // (global form of the epilogue's slack; informational)
+    ctrl[3] = n0;
+    ctrl[4] = bad ? 0u : 1u;
+    ctrl[5] = kp8 / 128;
   }
 }
 
@@ -355,6 +526,14 @@ struct GemmArgs {
   const uint32_t *verdict;    // speculative launch: runs only if v_lo <= verdict[0] <= v_hi (see decide_kernel);
   uint32_t v_lo, v_hi;        // with chunk_from_verdict the window length (K-steps) is verdict[1]
   uint32_t chunk_from_verdict;
+  const uint32_t *veto;       // f16 kernels queued behind an i8 attempt: return at once if *veto == 1 (i8 path valid)
+  // i8 operand path (I8 instantiations): row / column info words 2*S + e, control words of the i8 prepass
+  const int32_t *info_r, *info_q;
+  const int32_t *slot_r, *slot_q;  // first entry (10 bits) | entries (8) | sum |b| (14) per row / column, 0 = none
+  const I8Outlier *ents;           // clamped entries sorted by (side, row, dim)
+  const int16_t *raw_r, *raw_q;    // the original i16 matrices (rows of hv_d)
+  const uint32_t *i8ctrl;          // [3] entries of side 0, [4] verdict, [5] K-steps
+  uint32_t hv_d, same_set;
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only
@@ -372,9 +551,16 @@ struct GemmArgs {
 // LDS image is unpadded [row][8 chunks of 16 B] and bank conflicts are removed by an XOR swizzle of the
 // chunk index with (row >> 1) & 7 -- applied to the per-lane SOURCE address when loading and to the
 // fragment address when reading (same involution on both sides).
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4>
+typedef int int4v __attribute__((ext_vector_type(4)));
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT>;
+  static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
+  if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
+  if (I8) {
+    if (g.i8ctrl[4] != 1u) return;
+    g.Kp = g.i8ctrl[5] * BK;  // K-steps of 128 bytes = BK two-byte units, extra columns included
+  }
   if (g.verdict) {  // uniform
     const uint32_t code = g.verdict[0];
     if (code < g.v_lo || code > g.v_hi) return;
@@ -414,12 +600,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   const uint32_t wm = wave / NWN, wn = wave % NWN;  // 2 x NWN waves, (WTM*16) x 64 each
   const uint32_t fr = lane & 15, fq = lane >> 4;
 
-  float4v acc[WTM][NT];
+  typedef typename std::conditional<I8, int4v, float4v>::type acc_t;  // i8 operands accumulate in exact i32
+  acc_t acc[WTM][NT];
   int32_t iacc[CHUNKED ? WTM : 1][CHUNKED ? NT : 1][4];
 #pragma unroll
   for (int m = 0; m < WTM; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{};
   if (CHUNKED) {
 #pragma unroll
     for (int m = 0; m < WTM; ++m)
@@ -487,8 +674,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // up behind the workgroup's burst cannot issue MFMAs meanwhile, and with every wave loading right after the
   // barrier both waves of a SIMD sit in that queue together while the matrix pipe idles.  With one loader
   // per SIMD its partner keeps the pipe busy and the loader catches up while the partner waits at the barrier.
+  // HG_DMA_SPREAD (A/B switch): instead of one burst by four loader waves right after the barrier, ALL waves issue
+  // the pieces of tile k+1 spread over the first four phases of step k, a couple per phase between MFMA groups.
+#ifndef HG_DMA_SPREAD
+#define HG_DMA_SPREAD 0
+#endif
 #ifndef HG_DMA_LOADER_WAVES
-#define HG_DMA_LOADER_WAVES 4
+#define HG_DMA_LOADER_WAVES (HG_DMA_SPREAD ? 8 : 4)
 #endif
   constexpr int LW = HG_DMA_LOADER_WAVES, LT = LW * 64;  // loader waves / threads
   constexpr int PA = BM * 8 / LT, PB = BN * 8 / LT;      // 16-byte pieces per loader thread, A / B tile
@@ -520,6 +712,17 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
+  // pieces [lo, hi) of the same transfer (spread schedule)
+#define HG_DMA_PART(stage, k0, lo, hi)                                                                      \
+  if (wave < (uint32_t)LW) {                                                                                \
+    _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8;                                          \
+    _Pragma("unroll") for (int i = (lo); i < (hi); ++i) {                                                   \
+      if (i < PA)                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
+      if (i < PB)                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
+    }                                                                                                       \
+  }
   constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
   half8 bfr[2][NT], afr[2][2];
   // fragments of phase (kk, mp) of the stage whose fragment bases are pa / pb, into buffer set `buf`
@@ -543,7 +746,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     }
   }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
-  if (GLDS && nsteps > 1) HG_DMA(1, BK)
+  if (GLDS && nsteps > 1 && !HG_DMA_SPREAD) HG_DMA(1, BK)
   if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
@@ -560,13 +763,17 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #pragma unroll
     for (int t = 0; t < PHASES; ++t) {
       const int kk = t / MP, mp = t % MP;
+      if (GLDS && HG_DMA_SPREAD && t < 4 && ks + 1 < nsteps) {  // tile ks+1 -> the stage freed by the last barrier
+        constexpr int PMAX_ = PA > PB ? PA : PB, Q4 = (PMAX_ + 3) / 4;
+        HG_DMA_PART(cur ^ 1, (ks + 1) * BK, t * Q4, (t + 1) * Q4 < PMAX_ ? (t + 1) * Q4 : PMAX_)
+      }
       if (t + 1 < PHASES) {
         if (!HG_EXP(2) && !(HG_EXP(32) && ks)) HG_FRAGS((t + 1) & 1, fA, fB, (t + 1) / MP, (t + 1) % MP)
       } else {
         // every fragment read of this stage must have returned before another wave may refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!HG_EXP(16)) __syncthreads();
-        if (GLDS && ks + 2 < nsteps && !HG_EXP(1)) HG_DMA(cur, (ks + 2) * BK)
+        if (GLDS && ks + 2 < nsteps && !HG_EXP(1) && !HG_DMA_SPREAD) HG_DMA(cur, (ks + 2) * BK)
         if (ks + 1 < nsteps && !HG_EXP(2) && !HG_EXP(32)) HG_FRAGS(0, nA, nB, 0, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -580,8 +787,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[2 * mp + i][n] =
-                __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
+            if constexpr (I8)  // the same 16-byte fragments hold 16 k-consecutive bytes per lane: one instruction covers K = 64
+              acc[2 * mp + i][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(int4v, afr[t & 1][i]),
+                                                                         __builtin_bit_cast(int4v, bfr[kk & 1][n]),
+                                                                         acc[2 * mp + i][n], 0, 0, 0);
+            else
+              acc[2 * mp + i][n] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -593,7 +805,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] += (int32_t)acc[m][n][r];
-          acc[m][n] = (float4v){0.f, 0.f, 0.f, 0.f};
+          acc[m][n] = acc_t{};
         }
     }
   }
@@ -603,15 +815,23 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   constexpr uint32_t CAND_CAP = 2048;  // 16 KiB per wave
   int32_t *s_nr = reinterpret_cast<int32_t *>(reinterpret_cast<uint2 *>(sAB) + (THREADS / 64) * CAND_CAP), *s_nq = s_nr + BM;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_nq + BN);  // per-wave hit counts + the workgroup's base
+  int32_t *s_ir = reinterpret_cast<int32_t *>(s_cnt + THREADS / 64 + 1), *s_iq = s_ir + BM;  // i8 path: 2*S + e per row / column
+  int32_t *s_sr = s_iq + BN, *s_sq = s_sr + BM;                                             // ... and the outlier-entry slots
   for (uint32_t t = tid; t < (uint32_t)(BM + BN); t += THREADS) {
     const bool is_r = t < (uint32_t)BM;
     const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
-    s_nr[t] = idx < (is_r ? g.R : g.Q) ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
+    const bool in = idx < (is_r ? g.R : g.Q);
+    s_nr[t] = in ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
+    if (I8) {
+      s_ir[t] = in ? (is_r ? g.info_r[idx] : g.info_q[idx]) : 0;
+      s_sr[t] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
+    }
   }
   __syncthreads();
 #undef HG_GLOAD
 #undef HG_LSTORE
 #undef HG_DMA
+#undef HG_DMA_PART
 #undef HG_FRAGS
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
@@ -635,6 +855,28 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   }
   uint2 *cand = reinterpret_cast<uint2 *>(sAB) + wave * CAND_CAP;
   uint32_t staged = 0;  // wave-uniform
+  // i8 operands: G = sum a_r*a_q  ->  the exact dot product.  First the tabulated products of the clamped entries of
+  // row i / column j (rare: ~4 % of the rows have one), then dot = 4*sum c_r*c_q - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q
+  // (info word = 2*S + e).  Runs per candidate in phase 2, outside the unrolled accumulator sweep.
+  auto i8_exact_dot = [&](int32_t G, uint32_t li, uint32_t lj, uint32_t gi, uint32_t gj) -> int32_t {
+    const int32_t sr = s_sr[li], sq = s_sq[lj];
+    const uint32_t ur_ = (uint32_t)sr, uq_ = (uint32_t)sq;  // first (10) | count (8) | sum |b| (14)
+    const int32_t ir = s_ir[li], iq = s_iq[lj];
+    const int32_t er = ir & 1, eq = iq & 1;
+    for (uint32_t t = 0; t < ((ur_ >> 14) & 255u); ++t) {  // b_i[d] * c_j[d], c = the true centred count of column j
+      const I8Outlier o = g.ents[(ur_ >> 22) + t];
+      G += (int32_t)o.b * (((int32_t)g.raw_q[(size_t)gj * g.hv_d + o.d] + eq) >> 1);
+    }
+    if ((uq_ >> 14) & 255u) {
+      const uint32_t qbase = g.same_set ? 0u : g.i8ctrl[3];
+      for (uint32_t t = 0; t < ((uq_ >> 14) & 255u); ++t) {  // a_i[d] * b_j[d], a = the clamped byte of row i
+        const I8Outlier o = g.ents[qbase + (uq_ >> 22) + t];
+        const int32_t cc = ((int32_t)g.raw_r[(size_t)gi * g.hv_d + o.d] + er) >> 1;
+        G += (int32_t)o.b * (cc > 127 ? 127 : (cc < -127 ? -127 : cc));
+      }
+    }
+    return 4 * G - eq * (ir - er) - er * (iq - eq) + (er & eq) * (int32_t)g.hv_d;
+  };
   // phase 2 on cand[0 .. staged): exact ANI, hits compacted to cand[0 .. nh)
 #define HG_PHASE2(nh)                                                                                  \
   {                                                                                                    \
@@ -646,8 +888,9 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       if (e < staged) {                                                                                \
         c2 = cand[e];                                                                                  \
         const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);                         \
+        if constexpr (I8) c2.y = (uint32_t)i8_exact_dot((int32_t)c2.y, c2.x >> 16, c2.x & 0xffffu, gi, gj); \
         ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);               \
-        if (FULL && g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;                                 \
+        if constexpr (FULL) { if (g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani; }                 \
         hit = g.hit_count && ani >= g.ani_th;                                                          \
       }                                                                                                \
       const unsigned long long bal = __ballot(hit);                                                    \
@@ -686,11 +929,26 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   constexpr int32_t NORM_SAFE = 1 << 29;
   int32_t nqv[NT];
   float tq[NT];
+  // i8 path: the accumulator holds G = sum a_r*a_q and
+  //   dot = 4*G + 4*corrR(i,j) + 4*corrQ(i,j) - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q,
+  // so dot <= 4*G + [2|S_r| + 1016*B_i] + [2|S_q| + 508*B_j] + D  (B = the row's sum |b| over its clamped entries:
+  // |corrR| <= B_i*254, |corrQ| <= B_j*127).  Phase 0 stays one convert + add + compare per element: the bracketed
+  // per-row / per-column slacks are folded into the row and column thresholds (+64 for the i32 -> f32 rounding);
+  // rows without clamped entries, the normal case, only pay 2|S|.  Phase 2 evaluates the exact integer.
+  const float p0_scale = I8 ? 0.25f : 1.f;
+  auto i8_row_slack = [&](int32_t info, int32_t slot, float per_b) -> float {
+    const int32_t s2 = info - (info & 1);  // 2*S
+    return (float)(s2 < 0 ? -s2 : s2) + per_b * (float)(slot & 0x3fff);
+  };
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const uint32_t j = col0 + wn * (NT * 16) + n * 16 + fr;
     nqv[n] = s_nq[wn * (NT * 16) + n * 16 + fr];
-    tq[n] = j >= g.Q ? INFINITY : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY : g.pre_c * (float)nqv[n] + g.pre_b);
+    float slack = 0.f;
+    if (I8) slack = i8_row_slack(s_iq[wn * (NT * 16) + n * 16 + fr], s_sq[wn * (NT * 16) + n * 16 + fr], 508.f) + (float)g.hv_d + 64.f;
+    tq[n] = j >= g.Q ? INFINITY
+                     : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY
+                                                           : (g.pre_c * (float)nqv[n] + g.pre_b - slack) * p0_scale);
   }
 #pragma unroll
   for (int m = 0; m < WTM; ++m) {
@@ -699,10 +957,12 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
       const bool iok = i < g.R;
       const int32_t nri = s_nr[li];
-      const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : g.pre_c * (float)nri);
+      float rslack = 0.f;
+      if (I8) rslack = i8_row_slack(s_ir[li], s_sr[li], 1016.f);
+      const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : (g.pre_c * (float)nri - rslack) * p0_scale);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        float d = acc[m][n][r];
+        float d = (float)acc[m][n][r];
         if (CHUNKED) d += (float)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
         const bool pass = FULL || d >= ur + tq[n];
         if (__ballot(pass) == 0) continue;  // wave-uniform: typically > 80 % of the element slots
@@ -710,7 +970,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         int32_t dot = (int32_t)acc[m][n][r];
         if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
         bool live = pass && iok && j < g.Q && !(g.symmetric && i + g.ref_off >= j + g.qry_off);
-        if (!FULL) {
+        if (!FULL && !I8) {  // (i8 operands: the list carries the raw G, phase 2 forms the exact dot product)
           const int32_t den = (int32_t)((uint32_t)nri + (uint32_t)nqv[n] - (uint32_t)dot);
           live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
         }
@@ -813,6 +1073,92 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const uint32_t Rp = padded(a.R), Qp = padded(a.Q);
   const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
+  // ---- i8 operand attempt (thresholded, large problems): queued first; every f16 kernel below carries its verdict
+  // word as a veto and returns at once when the i8 kernels did the work.  After a failed attempt the next few calls
+  // go straight to f16 (large sketches never qualify; probing them every time would cost ~50 us per call).
+  const uint32_t *veto = nullptr;
+  const bool want_i8 = c->dbg_dist_path != "f16" && d_verdict && !a.ani_out && a.hits && a.hv_d <= 8192 && a.hv_d % 8 == 0 &&
+                       ((uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256 || c->dbg_dist_path == "i8") &&
+                       (c->i8_skip == 0 || c->dbg_dist_path == "i8");
+  if (!want_i8 && c->i8_skip) --c->i8_skip;
+  if (want_i8) {
+    const uint32_t kp8 = (a.hv_d + 127) / 128 * 128, ldk8 = kp8 + 128;
+    if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
+    if (!same && (s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldk8)) != HG_OK) return s;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // misc block: info_r, info_q, slot_r, slot_q, raw + sorted entry lists, max |S| slots
+    const size_t o_iq = al((size_t)a.R * 4), o_sr = o_iq + al((size_t)a.Q * 4), o_sq = o_sr + al((size_t)a.R * 4);
+    const size_t o_list = o_sq + al((size_t)a.Q * 4), o_sorted = o_list + al(I8_ENT_CAP * sizeof(I8Outlier));
+    const size_t o_slots = o_sorted + al(I8_ENT_CAP * sizeof(I8Outlier));
+    if ((s = hg_ensure(c, c->w_i8misc, o_slots + al(PREP_SLOTS * 4) + 256)) != HG_OK) return s;
+    auto *a8 = static_cast<int8_t *>(c->w_i8a.p), *b8 = same ? a8 : static_cast<int8_t *>(c->w_i8b.p);
+    auto *mb = static_cast<uint8_t *>(c->w_i8misc.p);
+    auto *info_r = reinterpret_cast<int32_t *>(mb), *info_q = same ? info_r : reinterpret_cast<int32_t *>(mb + o_iq);
+    auto *slot_r = reinterpret_cast<int32_t *>(mb + o_sr), *slot_q = same ? slot_r : reinterpret_cast<int32_t *>(mb + o_sq);
+    auto *list = reinterpret_cast<I8Outlier *>(mb + o_list), *sorted = reinterpret_cast<I8Outlier *>(mb + o_sorted);
+    auto *maxs = reinterpret_cast<uint32_t *>(mb + o_slots);
+    HG_HIP(c, hipMemsetAsync(maxs, 0, PREP_SLOTS * 4, c->stream));
+    uint32_t *ctrl = d_verdict + 3;  // words 4.. of the caller's result block (zeroed by the caller, read back with the hit count)
+    if (Rp > a.R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)a.R * ldk8, 0, (size_t)(Rp - a.R) * ldk8, c->stream));
+    if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)a.Q * ldk8, 0, (size_t)(Qp - a.Q) * ldk8, c->stream));
+    {
+      hg_timed tmp(c, HG_T_DIST_PREP);
+      static_assert(PREP_SLOTS == 1024, "i8_entries_kernel folds one slot per thread");
+      hipLaunchKernelGGL(prep_i8_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, kp8, ldk8, a8,
+                         info_r, slot_r, list, ctrl, maxs, 0u);
+      HG_HIP(c, hipGetLastError());
+      if (!same) {
+        hipLaunchKernelGGL(prep_i8_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, kp8, ldk8, b8,
+                           info_q, slot_q, list, ctrl, maxs, 1u);
+        HG_HIP(c, hipGetLastError());
+      }
+      hipLaunchKernelGGL(i8_entries_kernel, dim3(1), dim3(1024), 0, c->stream, list, sorted, ctrl, maxs, slot_r, slot_q, kp8,
+                         a.hv_d);
+      HG_HIP(c, hipGetLastError());
+    }
+    GemmArgs g{};
+    g.A = reinterpret_cast<const _Float16 *>(a8), g.B = reinterpret_cast<const _Float16 *>(b8);
+    g.nr = a.ref_n2, g.nq = a.qry_n2, g.R = a.R, g.Q = a.Q;
+    g.Kp = kp8 / 2, g.ldk = ldk8 / 2;  // in two-byte units, like the f16 operands (a K-step is 128 bytes either way)
+    g.chunk_steps = ~0u, g.kf = (float)a.ksize;
+    g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap, g.ani_th = a.ani_th;
+    g.symmetric = a.symmetric, g.ref_off = a.ref_off, g.qry_off = a.qry_off;
+    g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
+    if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;
+    else if (g.j_lo == INFINITY) g.pre_c = 0.f, g.pre_b = INFINITY;
+    else g.pre_c = (float)((double)g.j_lo / (1.0 + (double)g.j_lo) * (1.0 - 1e-5)), g.pre_b = 0.f;
+    g.info_r = info_r, g.info_q = info_q, g.slot_r = slot_r, g.slot_q = slot_q, g.ents = sorted;
+    g.raw_r = a.ref_hv, g.raw_q = a.qry_hv, g.i8ctrl = ctrl, g.hv_d = a.hv_d, g.same_set = same ? 1u : 0u;
+    int nt = 4;
+    {
+      const uint64_t tm = (a.R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
+      const uint64_t r4 = (tm * ((a.Q + 255) / 256) + ncu - 1) / ncu, r5 = (tm * ((a.Q + 319) / 320) + ncu - 1) / ncu;
+      if (r5 * 5 < r4 * 4) nt = 5;
+      if (c->dbg_dist_tile == "big") nt = 4;
+      else if (c->dbg_dist_tile == "wide") nt = 5;
+    }
+    g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
+    const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+    const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 128)
+                               : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 128);
+    const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
+                             : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
+    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+      HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->lds_attr_done.push_back(fp);
+    }
+    {
+      hg_timed tmg(c, HG_T_DIST);
+      if (nt == 5)
+        hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
+                           c->stream, g);
+      else
+        hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true>), dim3(n_tiles), dim3(TileCfg<true, 4>::THREADS), lds,
+                           c->stream, g);
+      HG_HIP(c, hipGetLastError());
+    }
+    veto = ctrl + 4;
+  }
   if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
   if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * ldk * 2)) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_stats, 256 + 2 * PREP_SLOT_VALS * PREP_SLOTS * sizeof(unsigned long long))) != HG_OK) return s;
@@ -851,18 +1197,18 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     HG_HIP(c, hipMemsetAsync(sl, 0, 2 * slot_bytes, c->stream));
     {
       hg_timed tm(c, HG_T_DIST_PREP);
-      hipLaunchKernelGGL(prep_fast_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, sl, win);
+      hipLaunchKernelGGL(prep_fast_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, Kp, ldk, fa, sl, win, veto);
       HG_HIP(c, hipGetLastError());
       if (!same) {
         hipLaunchKernelGGL(prep_fast_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, Kp, ldk,
-                           fb, slq, win);
+                           fb, slq, win, veto);
         HG_HIP(c, hipGetLastError());
       }
     }
     if (d_verdict && !a.ani_out) {
       // speculative schedule: the verdict is formed on the device and guards the GEMMs queued right behind
       // it; the caller reads it back together with its hit count (no host round trip in between)
-      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, sl, slq, d_verdict);
+      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, sl, slq, d_verdict, veto);
       HG_HIP(c, hipGetLastError());
       best_c = c_whole, fast_done = true, spec = true, spec_win = win != 0;
     } else {
@@ -913,6 +1259,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   }
   const float kf = (float)a.ksize;
   hg_timed tm(c, HG_T_DIST);
+  c->last_dist_path = best_c < 0 ? 2 : 0;  // (a valid i8 attempt overrides this after the caller's read-back)
   if (best_c < 0) {  // values too large for the f16 path: exact integer kernel
     dim3 grid((a.Q + FB_T - 1) / FB_T, (a.R + FB_T - 1) / FB_T);
     hipLaunchKernelGGL(dist_int_kernel, grid, dim3(FB_T * FB_T), 0, c->stream, a.ref_hv, a.qry_hv, a, kf);
@@ -931,6 +1278,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   g.ani_out = a.ani_out, g.hits = a.hits, g.hit_count = a.hit_count, g.hit_cap = a.hit_cap;
   g.ani_th = a.ani_th, g.symmetric = a.symmetric, g.ref_off = a.ref_off, g.qry_off = a.qry_off;
   g.verdict = guard, g.v_lo = v_lo, g.v_hi = v_hi, g.chunk_from_verdict = from_verdict ? 1u : 0u;
+  g.veto = veto;
   g.j_lo = jaccard_lower_bound(a.ani_th, a.ksize);
   if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;       // everything goes on to phase 1
   else if (g.j_lo == INFINITY) g.pre_c = 0.f, g.pre_b = INFINITY;    // ANI <= 100 < ani_th: nothing does
@@ -980,10 +1328,11 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16), lds_big = 2 * (256 + 256) * LDS_ROW * sizeof(_Float16);
   hipError_t le;
   // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
-  const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 4 + 64);
-  const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 4 + 64);
+  // (+ the same number of info words for the i8 operand path)
+  const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 128);
+  const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 128);
   const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
-                                              8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 4 + 64);
+                                              8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 128);
   if (big_chunked) le = launch(&dist_mfma_kernel<true, false, true, true, NT_CHUNKED>, TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
   else if (big && dma && nt == 3) le = launch(&dist_mfma_kernel<false, false, true, true, 3>, TileCfg<true, 3>::THREADS, lds_chunked);
   else if (big && dma && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);

@@ -37,6 +37,9 @@ struct hg_ctx {
   Buf w_ani;      // staged ANI output (host entry points)
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
+  Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
+  int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA, 1 i8 MFMA, 2 integer VALU
+  uint32_t i8_skip = 0;         // calls left that skip the i8 attempt after it was vetoed
   Buf w_sorthits; // keys / permutations / scratch of the device-side hit ordering
   // optional per-kernel timing (hg_ctx_enable_timing)
   bool timing = false;

@@ -194,6 +194,11 @@ hg_status hg_dist_block_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t 
                             size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
                             hg_ani_hit *d_out, size_t cap, size_t *n_out);
 
+/* Which exact operand path the last hg_dist / hg_dist_dev / hg_dist_block_dev call of this ctx took (all give the same
+ * integers): 0 = f16 operands on v_mfma_f32_16x16x32_f16 (exact f32 windows), 1 = centred i8 operands on
+ * v_mfma_i32_16x16x64_i8 (sketches of up to ~3 500 hashes; decided on the device), 2 = integer VALU fallback; -1 = none yet. */
+int hg_ctx_last_dist_path(const hg_ctx *ctx);
+
 /* order of dump_ani_file (src/utils.rs:262-269): stable ascending sort by ANI over the
  * reference's pair enumeration, then reversed.  Host side. */
 void hg_sort_ani_hits(hg_ani_hit *hits, size_t n, size_t Q, int symmetric);

@@ -504,3 +504,84 @@ def test_sketch_batch_of_many_small_genomes_is_packed_for_upload(ctx, orc, hg):
         for i in (0, 1, 7, 8, 9, 57, 199):
             w_hv, w_n2, w_nh = orc.sketch_genome(gs[i], scaled=50)
             assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (rep, i)
+
+
+def _sketch_like(rng, rows, D, n, base=None, share=0.6):
+    """HVs with the structure of real sketches: hv = 2*count - n (uniform parity per row), count ~ Binomial."""
+    cnt = rng.binomial(n, 0.5, (rows, D))
+    if base is not None:
+        k = int(n * share)
+        cnt = base[rng.integers(0, base.shape[0], rows)] + rng.binomial(n - k, 0.5, (rows, D))
+    return (2 * cnt - n).astype(np.int16)
+
+
+@pytest.mark.parametrize("same", [True, False])
+def test_dist_i8_operand_path_equals_f16_and_oracle(ctx, orc, same):
+    """The i8 operand path (centred counts on v_mfma_i32_16x16x64_i8, outlier entries as extra K columns, parity /
+    row-sum correction in the epilogue) must give the integers of the f16 path: identical hits, identical floats.
+    Rows carry planted outliers (|count - n/2| > 127) -- alone in their dimension, shared by two rows, and at the
+    same dimension on both sides -- odd and even n, a ragged D."""
+    rng = np.random.default_rng(77 if same else 78)
+    D = 4096 - 8 * 5
+    n_odd, n_even = 3333, 3000
+    base = rng.binomial(int(n_odd * 0.6), 0.5, (6, D))
+    R, Q = 900, 900 if same else 700
+    r = _sketch_like(rng, R, D, n_odd, base)
+    r[::3] = _sketch_like(rng, len(r[::3]), D, n_even, rng.binomial(int(n_even * 0.6), 0.5, (6, D)))
+    q = r if same else _sketch_like(rng, Q, D, n_odd, base)
+    # planted outliers: +-(300..480) keeps |x| <= 509 (residual fits a byte) and the row parity
+    def plant(m, row, d, v):
+        m[row, d] = v if (v - m[row, 0]) % 2 == 0 else v + 1
+    plant(r, 5, 17, 401), plant(r, 5, 3000, -455), plant(r, 77, 17, 377), plant(r, 400, 4000, 480), plant(r, 899, 0, -300)
+    if not same:
+        plant(q, 9, 17, -391), plant(q, 9, 2222, 333), plant(q, 650, 4000, 445)
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = rn if same else np.array([orc.hv_norm2(x) for x in q], np.int32)
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
+    try:
+        for sym in ((False, True) if same else (False,)):
+            ctx.set_debug("dist_path", "f16")
+            h16 = key(ctx.dist(r, rn, q, qn, 21, symmetric=sym, ani_th=60.0))
+            ctx.set_debug("dist_path", "i8")
+            h8 = key(ctx.dist(r, rn, q, qn, 21, symmetric=sym, ani_th=60.0))
+            assert h8.size == h16.size > 1000 and np.array_equal(h8, h16), (same, sym)
+            got = np.zeros_like(want)
+            got[h8["ref_idx"], h8["qry_idx"]] = h8["ani"]
+            sel = want >= 60.0 + 1e-4
+            if sym:
+                sel = np.triu(sel, 1)
+            assert (got[sel] > 0).all() and np.abs(got[sel] - want[sel]).max() <= 1e-4
+            # pairs through the planted outliers, including the diagonal of an outlier row
+            for (i, j) in ((5, 77), (5, 5), (400, 400), (899, 3)) if same else ((5, 9), (400, 650), (77, 9)):
+                if want[i, j] >= 60.0 and (not sym or i < j):
+                    assert abs(got[i, j] - want[i, j]) <= 1e-4, (i, j)
+    finally:
+        ctx.set_debug("dist_path", "")
+
+
+def test_dist_i8_vetoed_inputs_fall_back_to_f16(ctx, orc):
+    """Inputs the i8 path must refuse on the device -- a row of mixed parity, a residual beyond a byte, more outlier
+    dims than extra columns -- still give the f16 result (the f16 kernels queued behind the attempt run)."""
+    rng = np.random.default_rng(79)
+    D, R = 4096, 700
+    base = rng.binomial(2000, 0.5, (5, D))
+    for kind in ("mixed_parity", "huge_value", "too_many_outliers"):
+        r = _sketch_like(rng, R, D, 3333, base)
+        if kind == "mixed_parity":
+            r[123, 77] += 1
+        elif kind == "huge_value":
+            r[5, 9] = 1201 if r[5, 0] % 2 else 1200
+        else:
+            r[:, ::3] = (r[:, ::3].astype(np.int32) * 3 + (r[:, :1].astype(np.int32) % 2) * -2).astype(np.int16)  # sigma x3, parity kept
+        rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+        want = orc.ani_matrix(r, rn, r, rn, 21)
+        ctx.set_debug("dist_path", "i8")
+        try:
+            h = ctx.dist(r, rn, r, rn, 21, symmetric=True, ani_th=70.0)
+        finally:
+            ctx.set_debug("dist_path", "")
+        got = np.zeros_like(want)
+        got[h["ref_idx"], h["qry_idx"]] = h["ani"]
+        sel = np.triu(want >= 70.0 + 1e-4, 1)
+        assert h.size >= int(sel.sum()) > 100 and np.abs(got[sel] - want[sel]).max() <= 1e-4, kind
