@@ -48,6 +48,9 @@ def parse():
                     help="TOTAL genomes of the configs[2] leg, sharded over the ranks (0 = skip)")
     ap.add_argument("--hostfed-genomes", type=int, default=256, help="genomes of the host-fed (PCIe) leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
+                                                      "multi-rank logic on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses device 0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -62,6 +65,8 @@ def barrier_sync(world):
 def max_over_ranks(x, world, dev):
     if world == 1:
         return x
+    if torch.distributed.get_backend() != "nccl":
+        dev = torch.device("cpu")
     t = torch.tensor([x], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return float(t.item())
@@ -200,10 +205,17 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # tensors handed to collectives live on the GPU for RCCL; gloo (testing aid) gets host copies
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(a.backend)
 
     def log(msg):
         if rank == 0:
@@ -357,9 +369,15 @@ def main():
             nonlocal found
             if world > 1:  # the path's one exchange step: all-gather the reference HV matrix (RCCL/xGMI)
                 # as raw bytes: RCCL has no int16 datatype and the payload is opaque to the collective
-                torch.distributed.all_gather_into_tensor(ref_all.view(torch.uint8).view(-1),
-                                                         mine.view(torch.uint8).view(-1))
-                torch.distributed.all_gather_into_tensor(ref_n2, mine_n2)
+                if a.backend == "nccl":
+                    torch.distributed.all_gather_into_tensor(ref_all.view(torch.uint8).view(-1),
+                                                             mine.view(torch.uint8).view(-1))
+                    torch.distributed.all_gather_into_tensor(ref_n2, mine_n2)
+                else:  # gloo (testing aid): the same collective on host copies
+                    h_all, h_n2 = torch.empty(ref_all.shape, dtype=torch.int16), torch.empty(ref_n2.shape, dtype=torch.int32)
+                    torch.distributed.all_gather_into_tensor(h_all.view(torch.uint8).view(-1), mine.cpu().view(torch.uint8).view(-1))
+                    torch.distributed.all_gather_into_tensor(h_n2, mine_n2.cpu())
+                    ref_all.copy_(h_all), ref_n2.copy_(h_n2)
                 r, rn, nr = ref_all, ref_n2, ref_all.shape[0]
             else:
                 r, rn, nr = mine, mine_n2, rows
@@ -443,7 +461,13 @@ def main():
             nonlocal merged
             if world > 1 and rank == 0:
                 qb.copy_(qsrc)  # (the broadcast is in place; rank 0 re-publishes its query set every step)
-            merged = shard.sharded_search(search_block, rb, lo, qb, world, dev)
+            if a.backend == "nccl" or world == 1:
+                merged = shard.sharded_search(search_block, rb, lo, qb, world, dev)
+            else:  # gloo (testing aid): broadcast / gather on host copies
+                hq = qb.cpu()
+                shard.broadcast_rows(hq, world, 0)
+                qb.copy_(hq)
+                merged = shard.gather_records(search_block(rb, lo, qb), world, cdev)
 
         hstep()
         ctx.enable_timing(True)

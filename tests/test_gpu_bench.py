@@ -30,3 +30,29 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert j["dist"]["roofline"]["bound"] == "mfma" and j["dist"]["value"] > 0
     assert j["hamming"]["value"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 logic on a one-GPU box: two ranks (torch.distributed.run, gloo, both on device 0) run the real
+    kernels through the sharded code paths -- weak-scaled sketch, the 10k-style strong-scaled leg, the all-gathered
+    reference matrix of dist, the sharded Hamming search with ONE broadcast query set and merged hits (rank 0 verifies
+    that every query finds its source row by global index).  RCCL itself is what the driver's 8-GPU run exercises."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--genomes", "24", "--genomes-10k", "50", "--dist-n", "2048", "--hamming-refs", "6001",
+                        "--hamming-queries", "300", "--backend", "gloo", "--share-gpu"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "cpu_baseline" not in j
+    assert j["sketch_10k"]["config"]["genomes_per_gpu"] == 25 and j["sketch_10k"]["scaling"] == "strong"
+    assert j["dist"]["value"] > 0 and j["dist"]["config"]["hits_per_rank"] > 0
+    assert j["hamming"]["config"]["hits_merged"] == 300 and j["hamming"]["config"]["refs_per_rank"] == 3001
