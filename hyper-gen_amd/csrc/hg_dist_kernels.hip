@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "hg_internal.h"
@@ -552,6 +553,10 @@ struct GemmArgs {
 // chunk index with (row >> 1) & 7 -- applied to the per-lane SOURCE address when loading and to the
 // fragment address when reading (same involution on both sides).
 typedef int int4v __attribute__((ext_vector_type(4)));
+template <int... Js, class F>
+__device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...>, F &&f) {
+  (f(std::integral_constant<int, Js>{}), ...);
+}
 template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT>;
@@ -827,6 +832,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       s_sr[t] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
     }
   }
+  if (tid == 0) reinterpret_cast<uint32_t *>(s_sq + BN)[THREADS / 64] = 0u;  // "some candidate list is nearly full"
   __syncthreads();
 #undef HG_GLOAD
 #undef HG_LSTORE
@@ -858,7 +864,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // i8 operands: G = sum a_r*a_q  ->  the exact dot product.  First the tabulated products of the clamped entries of
   // row i / column j (rare: ~4 % of the rows have one), then dot = 4*sum c_r*c_q - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q
   // (info word = 2*S + e).  Runs per candidate in phase 2, outside the unrolled accumulator sweep.
-  auto i8_exact_dot = [&](int32_t G, uint32_t li, uint32_t lj, uint32_t gi, uint32_t gj) -> int32_t {
+  auto i8_exact_dot = [&](int32_t G, uint32_t li, uint32_t lj, uint32_t gi, uint32_t gj) __attribute__((always_inline)) -> int32_t {
     const int32_t sr = s_sr[li], sq = s_sq[lj];
     const uint32_t ur_ = (uint32_t)sr, uq_ = (uint32_t)sq;  // first (10) | count (8) | sum |b| (14)
     const int32_t ir = s_ir[li], iq = s_iq[lj];
@@ -878,49 +884,80 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     return 4 * G - eq * (ir - er) - er * (iq - eq) + (er & eq) * (int32_t)g.hv_d;
   };
   // phase 2 on cand[0 .. staged): exact ANI, hits compacted to cand[0 .. nh)
-#define HG_PHASE2(nh)                                                                                  \
-  {                                                                                                    \
-    for (uint32_t b = 0; b < staged; b += 64) {                                                        \
-      const uint32_t e = b + lane;                                                                     \
-      bool hit = false;                                                                                \
-      uint2 c2 = make_uint2(0u, 0u);                                                                   \
-      float ani = 0.f;                                                                                 \
-      if (e < staged) {                                                                                \
-        c2 = cand[e];                                                                                  \
-        const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);                         \
-        if constexpr (I8) c2.y = (uint32_t)i8_exact_dot((int32_t)c2.y, c2.x >> 16, c2.x & 0xffffu, gi, gj); \
-        ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);               \
-        if constexpr (FULL) { if (g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani; }                 \
-        hit = g.hit_count && ani >= g.ani_th;                                                          \
-      }                                                                                                \
-      const unsigned long long bal = __ballot(hit);                                                    \
-      if (hit) {                                                                                       \
-        const uint32_t pos = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),                     \
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)); \
-        cand[pos] = make_uint2(c2.x, __float_as_uint(ani)); /* pos <= e: never ahead of an unread entry */ \
-      }                                                                                                \
-      nh += (uint32_t)__popcll(bal);                                                                   \
-    }                                                                                                  \
-    staged = 0;                                                                                        \
-  }
-#define HG_WRITE_HITS(base, nh)                                                                        \
-  for (uint32_t e = lane; e < (nh); e += 64)                                                           \
-    if ((base) + e < g.hit_cap) {                                                                      \
-      const uint2 h2 = cand[e];                                                                        \
-      g.hits[(base) + e] = hg_ani_hit{row0 + g.ref_off + (h2.x >> 16), col0 + g.qry_off + (h2.x & 0xffffu), __uint_as_float(h2.y)}; \
+  // Phase 2 is latency bound (a chain of LDS reads, a log and three divisions per batch, two waves per SIMD to hide it
+  // behind: a tile with a dense block of hits used to take twice as long as a sparse one).  Every batch of 64
+  // candidates therefore touches only ITS OWN list entries -- the ANI overwrites the dot product in place, a miss is
+  // marked 0xFFFFFFFF (no non-negative float has that pattern) -- so batches are independent: several are in flight
+  // per wave, and at the end of the tile the batches of ALL eight lists are dealt round-robin to the eight waves (a
+  // cluster's block of hits sits in two or three waves' lists).  The compaction happens on the way out, after the
+  // range has been reserved.
+  auto phase2_batch = [&](uint2 *cl, uint32_t b, uint32_t n_list) __attribute__((always_inline)) -> uint32_t {  // returns the batch's hit count
+    const uint32_t e = b + lane;
+    bool hit = false;
+    if (e < n_list) {
+      uint2 c2 = cl[e];
+      const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);
+      if constexpr (I8) c2.y = (uint32_t)i8_exact_dot((int32_t)c2.y, c2.x >> 16, c2.x & 0xffffu, gi, gj);
+      const float ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);
+      if constexpr (FULL) {
+        if (g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;
+      }
+      hit = g.hit_count && ani >= g.ani_th;
+      cl[e].y = hit ? __float_as_uint(ani) : 0xFFFFFFFFu;
     }
-  // list nearly full in the middle of the tile (dense tiles only): this wave reserves its own range
-#define HG_PROCESS()                                                                                   \
-  {                                                                                                    \
-    uint32_t nh = 0;                                                                                   \
-    HG_PHASE2(nh)                                                                                      \
-    if (nh) {                                                                                          \
-      uint32_t base = 0;                                                                               \
-      if (lane == 0) base = atomicAdd(g.hit_count, nh);                                                \
-      base = __builtin_amdgcn_readfirstlane(base);                                                     \
-      HG_WRITE_HITS(base, nh)                                                                          \
-    }                                                                                                  \
-  }
+    return (uint32_t)__popcll(__ballot(hit));
+  };
+  auto write_batch = [&](const uint2 *cl, uint32_t b, uint32_t n_list, uint32_t off) __attribute__((always_inline)) -> uint32_t {  // hits written
+    const uint32_t e = b + lane;
+    uint2 h2 = make_uint2(0u, 0xFFFFFFFFu);
+    if (e < n_list) h2 = cl[e];
+    const bool hit = h2.y != 0xFFFFFFFFu;
+    const unsigned long long bal = __ballot(hit);
+    const uint32_t pos = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (hit && pos < g.hit_cap)
+      g.hits[pos] = hg_ani_hit{row0 + g.ref_off + (h2.x >> 16), col0 + g.qry_off + (h2.x & 0xffffu), __uint_as_float(h2.y)};
+    return (uint32_t)__popcll(bal);
+  };
+  // Emptying the lists: ONE reservation per workgroup (same-address returning atomics serialise at ~12 ns; with noise
+  // hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round, and one atomic per
+  // wave kept every CU waiting ~25 us per round), and the batches of all lists dealt round-robin to the waves.
+  constexpr uint32_t NW_ = THREADS / 64;
+  uint32_t *s_len = reinterpret_cast<uint32_t *>(s_sq + BN);  // the list lengths + the "some list is nearly full" flag
+  auto flush_all = [&]() __attribute__((always_inline)) {
+    if (lane == 0) s_len[wave] = staged;
+    __syncthreads();
+    uint2 *all = reinterpret_cast<uint2 *>(sAB);
+    uint32_t nh = 0, kglob = 0;
+    for (uint32_t l = 0; l < NW_; ++l) {
+      const uint32_t n_list = s_len[l];
+      uint2 *cl = all + l * CAND_CAP;
+      const uint32_t nb = (n_list + 63) / 64, first = (wave + NW_ - (kglob % NW_)) % NW_;  // my first batch of this list
+      for (uint32_t k = first; k < nb; k += NW_) nh += phase2_batch(cl, k * 64, n_list);
+      kglob += nb;
+    }
+    if (lane == 0) s_cnt[wave] = nh;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < NW_; ++w) total += s_cnt[w];
+      s_cnt[NW_] = total ? atomicAdd(g.hit_count, total) : 0u;
+      s_len[NW_] = 0u;
+    }
+    __syncthreads();
+    uint32_t off = s_cnt[NW_];
+    for (uint32_t w = 0; w < wave; ++w) off += s_cnt[w];
+    kglob = 0;
+    for (uint32_t l = 0; l < NW_; ++l) {  // the same batches again: compact them into this wave's part of the range
+      const uint32_t n_list = s_len[l];
+      const uint2 *cl = all + l * CAND_CAP;
+      const uint32_t nb = (n_list + 63) / 64, first = (wave + NW_ - (kglob % NW_)) % NW_;
+      for (uint32_t k = first; k < nb; k += NW_) off += write_batch(cl, k * 64, n_list, off);
+      kglob += nb;
+    }
+    staged = 0;
+    __syncthreads();  // the lists may be refilled only after every wave has read them
+  };
   // Phase 0 (thresholded mode): dot >= j_lo * (nr + nq - dot) rewritten as dot >= c * (nr + nq) with
   // c = j_lo / (1 + j_lo) shaved by 1e-5, evaluated in f32 straight from the accumulator: one add, one
   // compare and one wave-uniform branch per element slot.  Only slots where some lane passes (a superset
@@ -936,7 +973,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   // per-row / per-column slacks are folded into the row and column thresholds (+64 for the i32 -> f32 rounding);
   // rows without clamped entries, the normal case, only pay 2|S|.  Phase 2 evaluates the exact integer.
   const float p0_scale = I8 ? 0.25f : 1.f;
-  auto i8_row_slack = [&](int32_t info, int32_t slot, float per_b) -> float {
+  auto i8_row_slack = [&](int32_t info, int32_t slot, float per_b) __attribute__((always_inline)) -> float {
     const int32_t s2 = info - (info & 1);  // 2*S
     return (float)(s2 < 0 ? -s2 : s2) + per_b * (float)(slot & 0x3fff);
   };
@@ -950,22 +987,24 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
                      : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY
                                                            : (g.pre_c * (float)nqv[n] + g.pre_b - slack) * p0_scale);
   }
-#pragma unroll
-  for (int m = 0; m < WTM; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+  // (compile-time m, r, n: the accumulator registers must be indexed statically whatever the optimiser thinks of the
+  // size of the unrolled body -- a loop it declines to unroll sends all 160 accumulators through scratch)
+  dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
       const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
       const bool iok = i < g.R;
       const int32_t nri = s_nr[li];
       float rslack = 0.f;
       if (I8) rslack = i8_row_slack(s_ir[li], s_sr[li], 1016.f);
       const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : (g.pre_c * (float)nri - rslack) * p0_scale);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
+      dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
+        constexpr int n = decltype(nc)::value;
         float d = (float)acc[m][n][r];
         if (CHUNKED) d += (float)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
         const bool pass = FULL || d >= ur + tq[n];
-        if (__ballot(pass) == 0) continue;  // wave-uniform: typically > 80 % of the element slots
+        if (__ballot(pass) == 0) return;  // wave-uniform: typically > 80 % of the element slots
         const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
         int32_t dot = (int32_t)acc[m][n][r];
         if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
@@ -981,33 +1020,18 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
           cand[pos] = make_uint2((li << 16) | lj, (uint32_t)dot);
         }
         staged += (uint32_t)__popcll(bal);
-      }
+      });
+    });
+    // At most 4 * NT * 64 candidates per m and wave.  A list that might overflow in the next m (dense blocks of hits
+    // only) is emptied by the WHOLE workgroup: the decision is made uniform through LDS, one barrier per m.
+    if constexpr (m + 1 < WTM) {
+      if (lane == 0 && staged > CAND_CAP - 4 * NT * 64) s_len[NW_] = 1u;
+      __syncthreads();
+      const bool any_full = s_len[NW_] != 0u;
+      if (any_full) flush_all();
     }
-    // at most 4 * NT * 64 candidates per m: one overflow check per m is enough
-    if (staged > CAND_CAP - 4 * NT * 64) HG_PROCESS()
-  }
-  // end of the tile: ONE reservation per workgroup.  Same-address returning atomics serialise at ~12 ns;
-  // with noise hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round,
-  // and one atomic per wave kept every CU waiting ~25 us per round (0.09 ms of a 0.74 ms launch).
-  {
-    uint32_t nh = 0;
-    HG_PHASE2(nh)
-    if (lane == 0) s_cnt[wave] = nh;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t total = 0;
-#pragma unroll
-      for (int w = 0; w < THREADS / 64; ++w) total += s_cnt[w];
-      s_cnt[THREADS / 64] = total ? atomicAdd(g.hit_count, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_cnt[THREADS / 64];
-    for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
-    HG_WRITE_HITS(base, nh)
-  }
-#undef HG_PROCESS
-#undef HG_PHASE2
-#undef HG_WRITE_HITS
+  });
+  flush_all();  // end of the tile
 }
 
 // ---- always-exact integer fallback -------------------------------------------------------------------
@@ -1139,8 +1163,8 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
     const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
-    const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 128)
-                               : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 128);
+    const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
+                               : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
     const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
                              : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
     if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
@@ -1329,10 +1353,10 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   hipError_t le;
   // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
   // (+ the same number of info words for the i8 operand path)
-  const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 128);
-  const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 128);
+  const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
+  const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256);
   const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
-                                              8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 128);
+                                              8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 256);
   if (big_chunked) le = launch(&dist_mfma_kernel<true, false, true, true, NT_CHUNKED>, TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
   else if (big && dma && nt == 3) le = launch(&dist_mfma_kernel<false, false, true, true, 3>, TileCfg<true, 3>::THREADS, lds_chunked);
   else if (big && dma && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
