@@ -779,9 +779,16 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   HG_HIP(c, hipStreamSynchronize(c->stream));
   const bool i8_tried = h_res[9] != 0;  // the i8 prepass wrote its K-step count
   if (i8_tried && h_res[8] != 1u) c->i8_skip = 16;  // vetoed on the device: f16 ran; do not probe again for a while
-  if (h_res[8] == 1u) c->last_dist_path = 1;
-  if (h_res[8] != 1u && spec_cover >= 0 && (int)h_res[1] > spec_cover) {  // no guarded launch applied: statistics-driven schedule
-    HG_HIP(c, hipMemsetAsync(d_count, 0, 4 * sizeof(uint32_t), c->stream));
+  if (h_res[8] == 1u) {
+    c->last_dist_path = 1;
+    c->i8_sig_ref = d_ref_hv, c->i8_sig_qry = d_qry_hv, c->i8_sig_r = (uint32_t)R, c->i8_sig_q = (uint32_t)Q, c->i8_sig_d = hv_d;
+  } else {
+    c->i8_sig_ref = c->i8_sig_qry = nullptr;
+  }
+  // no guarded launch applied (or the f16 chain was not queued behind a trusted i8 attempt that failed after all):
+  // statistics-driven schedule
+  if (h_res[8] != 1u && (spec_cover == -2 || (spec_cover >= 0 && (int)h_res[1] > spec_cover))) {
+    HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
     h_res = static_cast<uint32_t *>(c->h_pin);  // the pinned scratch may have grown meanwhile
     HG_HIP(c, hipMemcpyAsync(h_res, d_count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -1182,6 +1182,13 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
       HG_HIP(c, hipGetLastError());
     }
     veto = ctrl + 4;
+    // The previous call on exactly these operands took the i8 path: the f16 fallback chain (five launches that would
+    // all return at once) is not queued again.  Should the verdict come back negative after all, the caller reruns
+    // the statistics-driven f16 schedule (*speculated == -2).
+    if (c->i8_sig_ref == a.ref_hv && c->i8_sig_qry == a.qry_hv && c->i8_sig_r == a.R && c->i8_sig_q == a.Q && c->i8_sig_d == a.hv_d) {
+      if (speculated) *speculated = -2;
+      return HG_OK;
+    }
   }
   if ((s = hg_ensure(c, c->w_f16a, (size_t)Rp * ldk * 2)) != HG_OK) return s;
   if (!same && (s = hg_ensure(c, c->w_f16b, (size_t)Qp * ldk * 2)) != HG_OK) return s;

@@ -39,6 +39,8 @@ struct hg_ctx {
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
   int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA, 1 i8 MFMA, 2 integer VALU
+  const void *i8_sig_ref = nullptr, *i8_sig_qry = nullptr;  // operands of the last call that took the i8 path
+  uint32_t i8_sig_r = 0, i8_sig_q = 0, i8_sig_d = 0;
   uint32_t i8_skip = 0;         // calls left that skip the i8 attempt after it was vetoed
   Buf w_sorthits; // keys / permutations / scratch of the device-side hit ordering
   // optional per-kernel timing (hg_ctx_enable_timing)

@@ -237,10 +237,13 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
   // (unaligned) ds_read_b64 from a run-time offset.  That replaces, per k-mer, the v_alignbyte / v_perm
   // extraction of both strands and the six-dword v_bitop3 mux (~12 VALU instructions) by one v_cndmask + one
   // add and three LDS reads, which issue beside the VALU stream.  Lanes only read what they wrote themselves:
-  // no barrier.  72-byte lane pitch: conflict-free ds_write_b64 / ds_read_b64, and the up-to-7-byte overshoot
-  // of the last word stays inside the lane's own pad.
+  // no barrier.  Lane pitch: 68 bytes = 17 dwords for the dword-aligned variant (VAR & 8) -- its ds_read2_b32 /
+  // ds_write2_b32 are banked over 32 banks per half wave, and 17 is odd (the first version used 72 bytes: 18 l mod 32
+  // repeats after 16 lanes, every access was a 2-way conflict and SQ_LDS_BANK_CONFLICT was 68 % of the LDS-active
+  // cycles, with the LDS pipe busy 60 % of the kernel); 72 bytes for the byte-offset variant (b64 / b128 accesses).
+  // The overshoot of the last word stays inside the lane's own pad.
   constexpr bool LDSWIN = CANON && (VAR & 4) != 0;
-  constexpr int WIN_PITCH = 72;
+  constexpr int WIN_PITCH = (VAR & 8) ? 68 : 72;
   __shared__ __attribute__((aligned(16))) uint8_t s_win[LDSWIN ? WG * WIN_PITCH + 16 : 16];
   uint8_t *const mywin = s_win + threadIdx.x * WIN_PITCH;
   if (threadIdx.x == 0) stage.n = 0;
@@ -322,13 +325,22 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     }
 
     if (LDSWIN) {
-      uint2 *w2 = reinterpret_cast<uint2 *>(mywin);
+      // R dword t = bytes comp(F[31-4t]), comp(F[30-4t]), ... = CA[7 - t] byte-reversed
+      if constexpr ((VAR & 8) != 0) {
+        uint32_t *w1 = reinterpret_cast<uint32_t *>(mywin);  // 4-byte aligned pitch: dword stores (paired by the compiler)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        w2[t] = make_uint2(FA[2 * t], FA[2 * t + 1]);
-        // R dword t = bytes comp(F[31-4t]), comp(F[30-4t]), ... = CA[7 - t] byte-reversed
-        w2[4 + t] = make_uint2(__builtin_amdgcn_perm(0u, CA[7 - 2 * t], 0x00010203u),
-                               __builtin_amdgcn_perm(0u, CA[6 - 2 * t], 0x00010203u));
+        for (int t = 0; t < 8; ++t) {
+          w1[t] = FA[t];
+          w1[8 + t] = __builtin_amdgcn_perm(0u, CA[7 - t], 0x00010203u);
+        }
+      } else {
+        uint2 *w2 = reinterpret_cast<uint2 *>(mywin);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          w2[t] = make_uint2(FA[2 * t], FA[2 * t + 1]);
+          w2[4 + t] = make_uint2(__builtin_amdgcn_perm(0u, CA[7 - 2 * t], 0x00010203u),
+                                 __builtin_amdgcn_perm(0u, CA[6 - 2 * t], 0x00010203u));
+        }
       }
     }
 

@@ -566,9 +566,13 @@ def test_dist_i8_vetoed_inputs_fall_back_to_f16(ctx, orc):
     rng = np.random.default_rng(79)
     D, R = 4096, 700
     base = rng.binomial(2000, 0.5, (5, D))
-    for kind in ("mixed_parity", "huge_value", "too_many_outliers"):
+    for kind in ("clean", "mixed_parity", "clean", "huge_value", "too_many_outliers"):
+        # ("clean" in between: a successful i8 call makes the next call on the same buffers trust the i8 path and
+        # queue no f16 fallback -- the vetoed input right after it must then be rerun through the f16 schedule)
         r = _sketch_like(rng, R, D, 3333, base)
-        if kind == "mixed_parity":
+        if kind == "clean":
+            pass
+        elif kind == "mixed_parity":
             r[123, 77] += 1
         elif kind == "huge_value":
             r[5, 9] = 1201 if r[5, 0] % 2 else 1200
@@ -585,3 +589,4 @@ def test_dist_i8_vetoed_inputs_fall_back_to_f16(ctx, orc):
         got[h["ref_idx"], h["qry_idx"]] = h["ani"]
         sel = np.triu(want >= 70.0 + 1e-4, 1)
         assert h.size >= int(sel.sum()) > 100 and np.abs(got[sel] - want[sel]).max() <= 1e-4, kind
+        assert ctx.last_dist_path() == (1 if kind == "clean" else 0), kind

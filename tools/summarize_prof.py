@@ -12,7 +12,8 @@ from collections import defaultdict
 
 OURS = ("kmer_sample", "sort_unique", "encode_wave_kernel", "encode_finalize_kernel", "encode_kernel", "bucket_count_kernel",
         "bucket_scan_kernel", "bucket_scatter_kernel", "bucket_sort_kernel", "bucket_copy_kernel", "dist_mfma", "dist_int",
-        "prep_fast_kernel", "prep_kernel", "decide_kernel", "synth_kernel", "hamming_kernel", "binarize_kernel")
+        "prep_fast_kernel", "prep_i8_kernel", "i8_entries_kernel", "prep_kernel", "decide_kernel", "synth_kernel",
+        "hamming_kernel", "binarize_kernel", "gather_keys_kernel", "permute_hits_kernel", "topk_kernel")
 
 
 def short(name):
