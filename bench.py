@@ -480,19 +480,34 @@ def main():
         hdt = max_over_ranks(time.perf_counter() - t0, world, dev)
         htm = ctx.timings()
         ctx.enable_timing(False)
-        hms = htm["dist"][0] / max(htm["dist"][1], 1)
         if rank == 0:  # in-run check: every query finds exactly its source row (global index), at distance 512
             order = np.argsort(merged["qry_idx"], kind="stable")
             ok = merged.size == HQ and np.array_equal(merged["qry_idx"][order], np.arange(HQ)) and \
                 np.array_equal(merged["ref_idx"][order], src_rows.cpu().numpy() + lo) and bool((merged["dist"] == words).all())
             if not ok:
                 raise SystemExit("PARITY GATE FAILED: merged Hamming hits != the queries' source rows")
-        # roofline of the search kernel.  Algorithmic work per launch: one v_xor_b32 + one v_bcnt_u32_b32 per
-        # 32 dims and pair = 2 * R * Q * D/32 lane-ops.  Bound: VALU issue of that pair -- a wave-instruction pair
-        # takes 3.1 ns per SIMD in tools/gpu_microbench.hip (v_bcnt is a VOP3 "slow class" op, profiles/
-        # r01_instruction_rates.txt) -> 1024 SIMDs * 128 lane-ops / 3.1 ns.  Compulsory bytes: every packed row once.
-        word_ops = 2.0 * refs * HQ * words
-        pair_bound = 1024 * 128 / 3.1e-9
+        # roofline of the search.  The library runs large searches as an exact +-1 byte GEMM on the matrix pipe
+        # (G = D - 2*distance, v_mfma_i32_16x16x64_i8): algorithmic flops = 2 * D per pair against the dense i8 MFMA
+        # peak (2x the f16 peak, MI355X_MICROARCH.md).  The xor + popcount kernel (small searches) is priced in lane-ops:
+        # one v_xor_b32 + one v_bcnt_u32_b32 per 32 dims and pair against the issue rate of that pair
+        # (3.1 ns per wave-instruction pair and SIMD, tools/gpu_microbench.hip).  Compulsory bytes: every packed row once.
+        hpath = ctx.last_hamming_path()
+        prep_ms = htm["dist_prep"][0] / max(a.steps, 1)
+        hms = htm["dist"][0] / max(a.steps, 1)
+        if hpath == 1:
+            flops = 2.0 * HD * refs * HQ
+            hroof = {"bound": "mfma", "achieved": flops / (hms * 1e-3) / 1e12, "peak": 2 * MFMA_F16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / (hms * 1e-3) / 1e12 / (2 * MFMA_F16_PEAK_TFLOPS),
+                     "peak_dtype": "i8 dense MFMA", "kernel": "dist_mfma_kernel (+-1 byte operands, Hamming epilogue)",
+                     "launch_ms": hms, "expand_ms": prep_ms, "algorithmic_flops_per_launch": flops}
+        else:
+            word_ops = 2.0 * refs * HQ * words
+            pair_bound = 1024 * 128 / 3.1e-9
+            hroof = {"bound": "valu", "achieved": word_ops / (hms * 1e-3) / 1e12, "peak": pair_bound / 1e12,
+                     "unit": "T lane-ops/s (xor + popcount)", "frac": word_ops / (hms * 1e-3) / pair_bound,
+                     "kernel": "hamming_kernel", "launch_ms": hms, "algorithmic_lane_ops_per_launch": word_ops}
+        hroof.update(compulsory_bytes_per_launch=(refs + HQ) * words * 4,
+                     compulsory_gbs=(refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, traffic=None)
         out["hamming"] = {
             "metric": "M Hamming-pairs/sec (D=16384 bit-packed)", "value": a.hamming_refs * HQ * a.steps / hdt / 1e6,
             "unit": "M pairs/sec", "ms_per_step": hdt / a.steps * 1e3, "scaling": "strong",
@@ -500,15 +515,11 @@ def main():
                                    "configs[4]; extension, no reference counterpart); refs sharded x%d, one query "
                                    "set broadcast from rank 0, hits merged" % (a.hamming_refs, HQ, HMAX, world),
                        "hits_merged": int(merged.size), "refs_per_rank": refs},
-            "roofline": {"bound": "valu", "achieved": word_ops / (hms * 1e-3) / 1e12, "peak": pair_bound / 1e12,
-                         "unit": "T lane-ops/s (xor + popcount)", "frac": word_ops / (hms * 1e-3) / pair_bound,
-                         "kernel": "hamming_kernel", "launch_ms": hms, "algorithmic_lane_ops_per_launch": word_ops,
-                         "compulsory_bytes_per_launch": (refs + HQ) * words * 4,
-                         "compulsory_gbs": (refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, "traffic": None},
-            "kernel_ms": hms,
+            "roofline": hroof, "kernel_ms": hms,
         }
-        log("hamming: %.0f M pairs/s, kernel %.3f ms (%.0f %% of the xor+bcnt issue bound), merged hits %d" % (
-            out["hamming"]["value"], hms, 100 * out["hamming"]["roofline"]["frac"], merged.size))
+        log("hamming: %.0f M pairs/s, kernel %.3f ms (%s, %.0f %% of its bound), merged hits %d" % (
+            out["hamming"]["value"], hms, "matrix pipe" if hpath == 1 else "xor+popcount",
+            100 * out["hamming"]["roofline"]["frac"], merged.size))
         del rb, qb, hh
 
     # ---------------- CPU baseline (rank 0, single-GPU runs only) ----------------------------------

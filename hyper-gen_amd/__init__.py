@@ -71,6 +71,7 @@ EXPORTS = [
     "hg_multi_create", "hg_multi_destroy", "hg_multi_size", "hg_multi_ctx", "hg_multi_last_error", "hg_shard_range",
     "hg_sketch_batch_multi", "hg_dist_multi", "hg_dist_multi_dev", "hg_hamming_search_multi",
     "hg_sort_ani_hits_dev", "hg_sort_ani_hits_staged", "hg_topk_per_query_dev", "hg_ctx_last_dist_path",
+    "hg_ctx_last_hamming_path",
 ]
 
 
@@ -137,6 +138,7 @@ def lib():
         "hg_ctx_set_debug": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "hg_free": (None, [vp]),
         "hg_ctx_last_dist_path": (C.c_int, [vp]),
+        "hg_ctx_last_hamming_path": (C.c_int, [vp]),
         "hg_sort_ani_hits_dev": (C.c_int, [vp, vp, sz, sz]),
         "hg_sort_ani_hits_staged": (C.c_int, [vp, vp, sz, sz]),
         "hg_topk_per_query_dev": (C.c_int, [vp, vp, sz, sz, C.c_uint32, vp, vp]),
@@ -360,6 +362,10 @@ class Context:
     def last_dist_path(self):
         """0 = f16 MFMA, 1 = i8 MFMA, 2 = integer VALU (all exact), -1 = no thresholded dist call yet."""
         return int(lib().hg_ctx_last_dist_path(self._h))
+
+    def last_hamming_path(self):
+        """0 = xor + popcount kernel, 1 = +-1 byte GEMM on the matrix pipe (same integers), -1 = none yet."""
+        return int(lib().hg_ctx_last_hamming_path(self._h))
 
     def sort_ani_hits_dev(self, d_hits, n, Q):
         self._ck(lib().hg_sort_ani_hits_dev(self._h, _ptr(d_hits), n, Q))

@@ -535,6 +535,7 @@ struct GemmArgs {
   const int16_t *raw_r, *raw_q;    // the original i16 matrices (rows of hv_d)
   const uint32_t *i8ctrl;          // [3] entries of side 0, [4] verdict, [5] K-steps
   uint32_t hv_d, same_set;
+  int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only
@@ -557,12 +558,15 @@ template <int... Js, class F>
 __device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...>, F &&f) {
   (f(std::integral_constant<int, Js>{}), ...);
 }
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false>
+// HAM (with I8): the operands are +-1 bytes expanded from bit-packed hypervectors, G = D - 2*hamming; the epilogue
+// keeps G >= ham_thr and reports {ref, qry, (D - G) / 2} -- the bit-packed search on the matrix pipe.
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false>
 __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT>;
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
+  static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
-  if (I8) {
+  if (I8 && !HAM) {
     if (g.i8ctrl[4] != 1u) return;
     g.Kp = g.i8ctrl[5] * BK;  // K-steps of 128 bytes = BK two-byte units, extra columns included
   }
@@ -826,8 +830,8 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     const bool is_r = t < (uint32_t)BM;
     const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
     const bool in = idx < (is_r ? g.R : g.Q);
-    s_nr[t] = in ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
-    if (I8) {
+    s_nr[t] = (in && !HAM) ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
+    if (I8 && !HAM) {
       s_ir[t] = in ? (is_r ? g.info_r[idx] : g.info_q[idx]) : 0;
       s_sr[t] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
     }
@@ -896,14 +900,19 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     bool hit = false;
     if (e < n_list) {
       uint2 c2 = cl[e];
-      const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);
-      if constexpr (I8) c2.y = (uint32_t)i8_exact_dot((int32_t)c2.y, c2.x >> 16, c2.x & 0xffffu, gi, gj);
-      const float ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);
-      if constexpr (FULL) {
-        if (g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;
+      if constexpr (HAM) {  // G = D - 2 * hamming; the pre-filter was exact
+        hit = true;
+        cl[e].y = (uint32_t)((int32_t)g.hv_d - (int32_t)c2.y) >> 1;
+      } else {
+        const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);
+        if constexpr (I8) c2.y = (uint32_t)i8_exact_dot((int32_t)c2.y, c2.x >> 16, c2.x & 0xffffu, gi, gj);
+        const float ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);
+        if constexpr (FULL) {
+          if (g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;
+        }
+        hit = g.hit_count && ani >= g.ani_th;
+        cl[e].y = hit ? __float_as_uint(ani) : 0xFFFFFFFFu;
       }
-      hit = g.hit_count && ani >= g.ani_th;
-      cl[e].y = hit ? __float_as_uint(ani) : 0xFFFFFFFFu;
     }
     return (uint32_t)__popcll(__ballot(hit));
   };
@@ -982,7 +991,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     const uint32_t j = col0 + wn * (NT * 16) + n * 16 + fr;
     nqv[n] = s_nq[wn * (NT * 16) + n * 16 + fr];
     float slack = 0.f;
-    if (I8) slack = i8_row_slack(s_iq[wn * (NT * 16) + n * 16 + fr], s_sq[wn * (NT * 16) + n * 16 + fr], 508.f) + (float)g.hv_d + 64.f;
+    if (I8 && !HAM) slack = i8_row_slack(s_iq[wn * (NT * 16) + n * 16 + fr], s_sq[wn * (NT * 16) + n * 16 + fr], 508.f) + (float)g.hv_d + 64.f;
     tq[n] = j >= g.Q ? INFINITY
                      : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY
                                                            : (g.pre_c * (float)nqv[n] + g.pre_b - slack) * p0_scale);
@@ -997,13 +1006,14 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       const bool iok = i < g.R;
       const int32_t nri = s_nr[li];
       float rslack = 0.f;
-      if (I8) rslack = i8_row_slack(s_ir[li], s_sr[li], 1016.f);
+      if (I8 && !HAM) rslack = i8_row_slack(s_ir[li], s_sr[li], 1016.f);
       const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : (g.pre_c * (float)nri - rslack) * p0_scale);
       dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
         constexpr int n = decltype(nc)::value;
         float d = (float)acc[m][n][r];
         if (CHUNKED) d += (float)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
-        const bool pass = FULL || d >= ur + tq[n];
+        bool pass = FULL || d >= ur + tq[n];
+        if constexpr (HAM) pass = (int32_t)acc[m][n][r] >= g.ham_thr;
         if (__ballot(pass) == 0) return;  // wave-uniform: typically > 80 % of the element slots
         const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
         int32_t dot = (int32_t)acc[m][n][r];
@@ -1070,6 +1080,91 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
 }
 
 }  // namespace
+
+// ---- bit-packed Hamming search on the matrix pipe ---------------------------------------------------------------
+// bits -> +-1 bytes (bit 1 -> +1, bit 0 -> -1), one lane per 32-bit word: per nibble the four bits are spread to the
+// low bit of four bytes by one multiply ((x * 0x00204081) & 0x01010101: the partial products never collide) and
+// turned into 0x01 / 0xFF by a byte permute from a two-entry table.
+__global__ __launch_bounds__(256) void expand_bits_kernel(const uint32_t *__restrict__ bits, uint32_t rows, uint32_t words,
+                                                          uint32_t ldk8, int8_t *__restrict__ out) {
+  const uint32_t row = blockIdx.y;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) {
+    const uint32_t v = bits[(size_t)row * words + w];
+    uint32_t d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t m = (((v >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u;
+      d[i] = __builtin_amdgcn_perm(0u, 0x000001FFu, m);  // selector byte 0 -> 0xFF (-1), 1 -> 0x01 (+1)
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)row * ldk8 + (size_t)w * 32);
+    dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+  }
+}
+
+hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R, const uint32_t *d_qry_bits, uint32_t Q,
+                              uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_hits, uint32_t *d_count, uint32_t cap,
+                              uint32_t ref_off, uint32_t qry_off) {
+  static_assert(sizeof(hg_ham_hit) == sizeof(hg_ani_hit), "the GEMM epilogue writes 12-byte records");
+  const uint32_t words = hv_d / 32, ldk8 = hv_d + 128;  // hv_d is a multiple of 128 (checked by the caller)
+  auto padded = [](uint32_t n) { return std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320); };
+  const uint32_t Rp = padded(R), Qp = padded(Q);
+  hg_status s;
+  if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldk8)) != HG_OK) return s;
+  auto *a8 = static_cast<int8_t *>(c->w_i8a.p), *b8 = static_cast<int8_t *>(c->w_i8b.p);
+  c->i8_sig_ref = c->i8_sig_qry = nullptr;  // the dist path's operand copies are gone
+  if (Rp > R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)R * ldk8, 0, (size_t)(Rp - R) * ldk8, c->stream));
+  if (Qp > Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)Q * ldk8, 0, (size_t)(Qp - Q) * ldk8, c->stream));
+  {
+    hg_timed tp(c, HG_T_DIST_PREP);
+    const unsigned gx = (words + 255) / 256;
+    for (uint32_t r0 = 0; r0 < R; r0 += 65535) {
+      const uint32_t m = std::min<uint32_t>(65535, R - r0);
+      hipLaunchKernelGGL(expand_bits_kernel, dim3(gx, m), dim3(256), 0, c->stream, d_ref_bits + (size_t)r0 * words, m, words, ldk8,
+                         a8 + (size_t)r0 * ldk8);
+      HG_HIP(c, hipGetLastError());
+    }
+    for (uint32_t q0 = 0; q0 < Q; q0 += 65535) {
+      const uint32_t m = std::min<uint32_t>(65535, Q - q0);
+      hipLaunchKernelGGL(expand_bits_kernel, dim3(gx, m), dim3(256), 0, c->stream, d_qry_bits + (size_t)q0 * words, m, words, ldk8,
+                         b8 + (size_t)q0 * ldk8);
+      HG_HIP(c, hipGetLastError());
+    }
+  }
+  GemmArgs g{};
+  g.A = reinterpret_cast<const _Float16 *>(a8), g.B = reinterpret_cast<const _Float16 *>(b8);
+  g.R = R, g.Q = Q, g.Kp = hv_d / 2, g.ldk = ldk8 / 2, g.chunk_steps = ~0u;
+  g.hits = reinterpret_cast<hg_ani_hit *>(d_hits), g.hit_count = d_count, g.hit_cap = cap;
+  g.ref_off = ref_off, g.qry_off = qry_off, g.hv_d = hv_d;
+  // dist <= max  <=>  G = D - 2*dist >= D - 2*max  (max >= D: everything is a hit)
+  g.ham_thr = max_dist >= hv_d ? -(int32_t)hv_d - 1 : (int32_t)hv_d - 2 * (int32_t)max_dist;
+  int nt = 4;
+  {
+    const uint64_t tm = (R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
+    const uint64_t r4 = (tm * ((Q + 255) / 256) + ncu - 1) / ncu, r5 = (tm * ((Q + 319) / 320) + ncu - 1) / ncu;
+    if (r5 * 5 < r4 * 4) nt = 5;
+  }
+  g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
+  const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+  const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
+                             : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
+  const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true, true>)
+                           : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, true>);
+  if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+    HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->lds_attr_done.push_back(fp);
+  }
+  hg_timed tg(c, HG_T_DIST);
+  if (nt == 5)
+    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
+                       c->stream, g);
+  else
+    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true, true>), dim3(n_tiles), dim3(TileCfg<true, 4>::THREADS), lds,
+                       c->stream, g);
+  HG_HIP(c, hipGetLastError());
+  return HG_OK;
+}
 
 // ANI >= th  <=>  J >= x/(2-x) with x = exp(k*(th/100-1)).  Returned with a relative safety
 // margin far above the float32 rounding of the device-side test (3 roundings of 2^-24), so a pair

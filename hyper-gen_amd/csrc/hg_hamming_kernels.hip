@@ -173,6 +173,8 @@ static hg_status ham_launch(hg_ctx *c, const uint32_t *d_ref, size_t R, const ui
   return HG_OK;
 }
 
+extern "C" int hg_ctx_last_hamming_path(const hg_ctx *c) { return c ? c->last_ham_path : -1; }
+
 extern "C" hg_status hg_hamming_full_dev(hg_ctx *c, const uint32_t *d_ref_bits, size_t R, const uint32_t *d_qry_bits,
                                          size_t Q, uint32_t hv_d, uint32_t *d_dist_out) {
   if (!c) return HG_ERR_INVALID;
@@ -202,8 +204,18 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
   HG_HIP(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
-  s = ham_launch(c, d_ref_bits, R, d_qry_bits, Q, hv_d, nullptr, d_out, d_count,
-                 cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist, (uint32_t)ref_off, (uint32_t)qry_off);
+  // Large searches run as an exact +-1 byte GEMM on the matrix pipe (hg_run_hamming_mfma: G = D - 2 * distance, the
+  // ANI kernel's tiles and hit lists); small ones -- and everything when the hook says "popc" -- on the xor + popcount
+  // kernel above.  Both give the same integers.
+  const bool mfma = c->dbg_ham_path != "popc" && hv_d % 128 == 0 && hv_d <= 65536 && R < 0x7FFFFFFFull && Q < 0x7FFFFFFFull &&
+                    ((uint64_t)R * Q >= (uint64_t)1 << 24 || c->dbg_ham_path == "mfma");
+  c->last_ham_path = mfma ? 1 : 0;
+  if (mfma)
+    s = hg_run_hamming_mfma(c, d_ref_bits, (uint32_t)R, d_qry_bits, (uint32_t)Q, hv_d, max_dist, d_out, d_count,
+                            cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, (uint32_t)ref_off, (uint32_t)qry_off);
+  else
+    s = ham_launch(c, d_ref_bits, R, d_qry_bits, Q, hv_d, nullptr, d_out, d_count,
+                   cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist, (uint32_t)ref_off, (uint32_t)qry_off);
   if (s != HG_OK) return s;
   uint32_t found = 0;
   HG_HIP(c, hipMemcpyAsync(&found, d_count, sizeof found, hipMemcpyDeviceToHost, c->stream));

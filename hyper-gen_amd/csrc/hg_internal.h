@@ -38,6 +38,7 @@ struct hg_ctx {
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
+  int last_ham_path = -1;       // last Hamming search: 0 xor + popcount kernel, 1 +-1 byte GEMM on the matrix pipe
   int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA, 1 i8 MFMA, 2 integer VALU
   const void *i8_sig_ref = nullptr, *i8_sig_qry = nullptr;  // operands of the last call that took the i8 path
   uint32_t i8_sig_r = 0, i8_sig_q = 0, i8_sig_d = 0;
@@ -73,7 +74,7 @@ struct hg_ctx {
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // development / test hooks (hg_ctx_set_debug); never read from the environment
-  std::string dbg_dist_tile, dbg_dist_path;
+  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path;
   int dbg_sort_buckets = 0;
   // pinned host scratch
   void *h_pin = nullptr;
@@ -192,3 +193,10 @@ struct hg_dist_args {
 // speculative, else the highest verdict code a guarded launch covers: the caller reads the verdict back with
 // its own results and calls again without d_verdict if it is larger.
 hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a, uint32_t *d_verdict = nullptr, int *speculated = nullptr);
+
+// Bit-packed Hamming search as an exact i8 GEMM on the matrix pipe (+-1 byte operands expanded from the bits; the
+// ANI GEMM's tiles, LDS-DMA staging and hit lists): all pairs with distance <= max_dist appended to d_hits through
+// *d_count (zeroed by the caller).  hv_d must be a multiple of 128.
+hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R, const uint32_t *d_qry_bits, uint32_t Q,
+                              uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_hits, uint32_t *d_count, uint32_t cap,
+                              uint32_t ref_off, uint32_t qry_off);

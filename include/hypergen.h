@@ -66,6 +66,7 @@ int hg_device_count(void);
 /* development / test hook (no reference counterpart): force an internal code path of THIS ctx.
  * keys: "dist_tile" = "" | "small" | "big" | "big_reg" | "wide" | "nt3"   (GEMM tile geometry)
  *       "dist_path" = "" | "f16" | "i8"                                    (operand format of the ANI GEMM)
+ *       "ham_path"  = "" | "popc" | "mfma"                                 (Hamming search: xor+popcount or +-1 byte GEMM)
  *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
  * Nothing in the library reads environment variables. */
 hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
@@ -280,6 +281,10 @@ hg_status hg_hamming_search_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t 
                                 size_t Q, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap,
                                 size_t *n_out);
 
+/* Searches of 2^24 pairs or more (hv_d a multiple of 128) run as an exact +-1 byte GEMM on the matrix pipe
+ * (G = D - 2 * distance on v_mfma_i32_16x16x64_i8, the ANI kernel's tiles and hit lists), smaller ones on the
+ * xor + popcount kernel; both give the same integers.  hg_ctx_last_hamming_path: 0 = popcount, 1 = matrix pipe. */
+int hg_ctx_last_hamming_path(const hg_ctx *ctx);
 /* one shard of a sharded reference database: hits carry ref_off + local row, qry_off + local column */
 hg_status hg_hamming_search_block_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R, size_t ref_off,
                                       const uint32_t *d_qry_bits, size_t Q, size_t qry_off, uint32_t hv_d,

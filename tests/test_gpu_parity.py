@@ -358,10 +358,24 @@ def test_binarize_and_hamming(ctx, orc, R, Q, d):
     max_dist = int(np.percentile(want, 30))
     cap = R * Q
     hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
-    n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, max_dist, hits.data_ptr(), cap)
+    exp = {(i, j, int(want[i, j])) for i, j in zip(*np.nonzero(want <= max_dist))}
+    for path in ("popc", "mfma"):  # xor + popcount kernel / +-1 byte GEMM on the matrix pipe: the same integers
+        ctx.set_debug("ham_path", path)
+        try:
+            n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, max_dist, hits.data_ptr(), cap)
+        finally:
+            ctx.set_debug("ham_path", "")
+        got = hits.cpu().numpy().view(np.uint32)[: 3 * n].reshape(-1, 3)
+        assert st == 0 and n == len(exp), path
+        assert {(int(a), int(b), int(c)) for a, b, c in got} == exp, path
+    # every pair is a hit when max_dist >= D, none of the padded rows / columns leaks in
+    ctx.set_debug("ham_path", "mfma")
+    try:
+        n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, d, hits.data_ptr(), cap)
+    finally:
+        ctx.set_debug("ham_path", "")
     got = hits.cpu().numpy().view(np.uint32)[: 3 * n].reshape(-1, 3)
-    assert st == 0 and n == int((want <= max_dist).sum())
-    assert {(int(a), int(b), int(c)) for a, b, c in got} == {(i, j, int(want[i, j])) for i, j in zip(*np.nonzero(want <= max_dist))}
+    assert st == 0 and n == R * Q and {(int(a), int(b), int(c)) for a, b, c in got} == {(i, j, int(want[i, j])) for i in range(R) for j in range(Q)}
 
 
 def test_hamming_of_d16384_sketches(ctx, orc, hg):
