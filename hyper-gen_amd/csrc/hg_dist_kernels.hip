@@ -711,8 +711,13 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
   }
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
+#ifndef HG_DMA_PRIO
+#define HG_DMA_PRIO 0  /* A/B switch: 1 = the loader waves issue their burst at raised priority */
+#endif
 #define HG_DMA(stage, k0)                                                                                   \
+  {                                                                                                         \
   if (wave < (uint32_t)LW) {                                                                                \
+    if (HG_DMA_PRIO == 1) __builtin_amdgcn_s_setprio(3);                                                    \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
     _Pragma("unroll") for (int i = 0; i < (PA > PB ? PA : PB); ++i) {                                       \
       if (i < PA)                                                                                           \
@@ -720,6 +725,10 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       if (i < PB)                                                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
     }                                                                                                       \
+    if (HG_DMA_PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                    \
+  } else if (HG_DMA_PRIO == 2) {                                                                            \
+    __builtin_amdgcn_s_setprio(1); /* 2 = static priority for the non-loading half */                       \
+  }                                                                                                         \
   }
   // pieces [lo, hi) of the same transfer (spread schedule)
 #define HG_DMA_PART(stage, k0, lo, hi)                                                                      \
