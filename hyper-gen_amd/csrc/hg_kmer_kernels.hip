@@ -168,9 +168,10 @@ constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 // 16-17 % faster with the wide window; k <= 21 the two kernels tie.
 constexpr uint32_t FAST64_FROM = 22;
 // canonical fast kernels: 4 = chosen strand fetched from an LDS image of the window (| 8: dword-aligned reads +
-// run-time v_alignbyte; without it byte-offset ds_reads), 0 = register extraction of both strands + mux
+// run-time v_alignbyte; without it byte-offset ds_reads; | 16: a second copy of the k-mer loop without the validity
+// test for waves that saw only bases), 0 = register extraction of both strands + mux
 #ifndef HG_KMER_DEFAULT_VAR
-#define HG_KMER_DEFAULT_VAR 12
+#define HG_KMER_DEFAULT_VAR 28
 #endif
 constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     const int64_t rem64 = (int64_t)n_bps - (int64_t)p0;
     const uint32_t rem = rem64 >= 32 ? 32u : (rem64 <= 0 ? 0u : (uint32_t)rem64);
     uint32_t inv = 0;  // bit b set <=> base b of the window cannot be part of a k-mer
-    if (__any((dacc != 0) | (rem < 32))) {
+    const bool wave_dirty = __any((dacc != 0) | (rem < 32));  // wave-uniform
+    if (wave_dirty) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         uint32_t xv = x[t];
@@ -390,10 +392,14 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     };
 
     // ---- the lane's M k-mers ------------------------------------------------------------------
+    // VAR & 16: two copies of the loop -- waves that saw only bases (the normal case: the validity mask is zero for
+    // every lane) run one without the per-k-mer validity test
+    auto run_kmers = [&](auto checkc) {
+    constexpr bool CHECK = decltype(checkc)::value;
     static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
       constexpr int j = decltype(jc)::value;
       constexpr int q = j >> 2, r = j & 3;
-      const bool valid = ((inv >> j) & MASKK) == 0;
+      const bool valid = !CHECK || ((inv >> j) & MASKK) == 0;
 
       if constexpr (LDSWIN) {
         // two-deep software pipeline: the words of k-mer j+1 are requested before k-mer j is hashed
@@ -455,6 +461,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
       const uint64_t h = t1ha2_fixed<K, !(VAR & 1)>(d, seed);
       if (valid && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
     });
+    };
+    if ((VAR & 16) != 0 && !wave_dirty) run_kmers(std::false_type{});
+    else run_kmers(std::true_type{});
   }
   flush_hits(stage, gm, g, hits, cnt);
 }
@@ -790,7 +799,7 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
     hipLaunchKernelGGL((kmer_sample_fast<21, true, VV>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                              \
     return hipGetLastError();
-    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) HG_V(12) default: break; }
+    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) HG_V(12) HG_V(28) default: break; }
 #undef HG_V
   }
 #endif
