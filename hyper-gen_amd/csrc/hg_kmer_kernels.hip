@@ -351,8 +351,17 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     uint64_t wq[2][NW];
     auto fetch_words = [&](auto jjc, uint64_t *w) {
       constexpr int jj = decltype(jjc)::value;
-      const uint64_t fv = (Gm >> (2 * (32 - K - jj))) & MASK2K;
-      const uint64_t rv = (Gc >> (2 * jj)) & MASK2K;
+      uint64_t fv, rv;
+      if constexpr ((K & 1) != 0) {
+        // odd K: a k-mer never equals its reverse complement (the middle base would have to pair with itself), so the
+        // compare is decided inside the 2K bits and the two values only have to be TOP-aligned -- the bits below them
+        // (codes of neighbouring bases) never matter and need no masking
+        fv = Gm << (2 * jj);
+        rv = Gc << (2 * (32 - K - jj));
+      } else {
+        fv = (Gm >> (2 * (32 - K - jj))) & MASK2K;
+        rv = (Gc >> (2 * jj)) & MASK2K;
+      }
       uint64_t lt;
       uint32_t off;
       asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
