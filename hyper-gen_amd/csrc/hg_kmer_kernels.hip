@@ -261,6 +261,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     for (int t = 0; t < 8; ++t) xn[t] = src[t];
   };
 
+  // VAR & 32: the next tile's window is requested while the current one is hashed (the LDS-image variants leave
+  // the registers for it)
+  constexpr bool PREFETCH = (VAR & 32) != 0;
+  if (PREFETCH && item_start < n_starts) load_window(item_start);
 #pragma unroll 1
   for (int tile = 0; tile < TILES_PER_ITEM; ++tile) {
     const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
@@ -268,9 +272,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * M;
 
     uint32_t x[8];
-    load_window(tile_start);
+    if (!PREFETCH) load_window(tile_start);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = xn[t];
+    if (PREFETCH && tile + 1 < TILES_PER_ITEM && tile_start + G::TILE < n_starts) load_window(tile_start + G::TILE);
 
     // ---- classify 4 bases per dword -----------------------------------------------------
     uint32_t FA[8], CA[8];      // upper-case ASCII, complement ASCII (same byte order)
@@ -808,7 +813,7 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
     hipLaunchKernelGGL((kmer_sample_fast<21, true, VV>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                              \
     return hipGetLastError();
-    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) HG_V(12) HG_V(28) default: break; }
+    switch (v) { HG_V(0) HG_V(1) HG_V(2) HG_V(3) HG_V(4) HG_V(12) HG_V(28) HG_V(60) default: break; }
 #undef HG_V
   }
 #endif
