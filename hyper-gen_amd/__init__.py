@@ -12,6 +12,7 @@ Note for processes that also use PyTorch-ROCm: import torch BEFORE this module l
 """
 import ctypes as C
 import os
+import threading
 import subprocess
 
 import numpy as np
@@ -71,7 +72,9 @@ EXPORTS = [
     "hg_multi_create", "hg_multi_destroy", "hg_multi_size", "hg_multi_ctx", "hg_multi_last_error", "hg_shard_range",
     "hg_sketch_batch_multi", "hg_dist_multi", "hg_dist_multi_dev", "hg_hamming_search_multi",
     "hg_sort_ani_hits_dev", "hg_sort_ani_hits_staged", "hg_topk_per_query_dev", "hg_ctx_last_dist_path",
-    "hg_ctx_last_hamming_path",
+    "hg_ctx_last_hamming_path", "hg_read_fastx_pinned", "hg_pinned_free",
+    "hg_sketch_stream_open", "hg_sketch_stream_push", "hg_sketch_stream_pop", "hg_sketch_stream_finish",
+    "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node",
 ]
 
 
@@ -137,6 +140,17 @@ def lib():
         "hg_read_fastx_into": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "hg_ctx_set_debug": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "hg_free": (None, [vp]),
+        "hg_read_fastx_pinned": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
+        "hg_pinned_free": (None, [vp]),
+        "hg_device_numa_node": (C.c_int, [C.c_int]),
+        "hg_sketch_stream_open": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(SketchParams), C.POINTER(vp)]),
+        "hg_sketch_stream_push": (C.c_int, [vp, vp, sz, C.c_uint64]),
+        "hg_sketch_stream_pop": (C.c_int, [vp, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_int)]),
+        "hg_sketch_stream_finish": (C.c_int, [vp]),
+        "hg_sketch_stream_last_error": (C.c_char_p, [vp]),
+        "hg_sketch_stream_close": (None, [vp]),
+        "hg_sketch_stream_stats": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
         "hg_ctx_last_dist_path": (C.c_int, [vp]),
         "hg_ctx_last_hamming_path": (C.c_int, [vp]),
         "hg_sort_ani_hits_dev": (C.c_int, [vp, vp, sz, sz]),
@@ -532,6 +546,93 @@ def read_merge_seq(path, mode=READ_MERGE):
             else np.zeros(0, np.uint8)
     finally:
         lib().hg_free(p)
+
+
+class PinnedReader:
+    """Page-locked read buffers (hg_read_fastx_pinned): read(path) returns a uint8 view that stays valid until
+    the next read into the same slot or close(); what the CLI's reader threads use to feed hg_sketch_batch."""
+
+    def __init__(self, slots=1):
+        self._p = [C.c_void_p() for _ in range(slots)]
+        self._cap = [C.c_size_t(0) for _ in range(slots)]
+
+    def read(self, path, slot=0, mode=READ_MERGE):
+        n = C.c_size_t(0)
+        st = lib().hg_read_fastx_pinned(os.fsencode(path), mode, C.byref(self._p[slot]), C.byref(self._cap[slot]), C.byref(n))
+        if st != OK:
+            raise HgError(st, "hg_read_fastx_pinned(%s)" % path)
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(C.cast(self._p[slot], C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    def close(self):
+        for p in self._p:
+            if p:
+                lib().hg_pinned_free(p)
+                p.value = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class SketchStream:
+    """Continuous host-fed sketching (hg_sketch_stream_*): push(seq, tag) from any thread, pop() -> (tag, hv, norm2,
+    nhash) in completion order (None once finish() was called and everything has been popped).  The arrays pushed
+    are kept alive until their result is popped."""
+
+    def __init__(self, device_ids=(0,), params=None):
+        self.params = params or default_params()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        st = lib().hg_sketch_stream_open(ids, len(device_ids), C.byref(self.params), C.byref(self._h))
+        if st != OK:
+            raise HgError(st, "hg_sketch_stream_open: " + lib().hg_last_error(None).decode())
+        self._keep = {}
+        self._lock = threading.Lock()
+
+    def _check(self, st, what):
+        if st != OK:
+            raise HgError(st, what + ": " + lib().hg_sketch_stream_last_error(self._h).decode())
+
+    def push(self, seq, tag):
+        a = np.ascontiguousarray(seq, np.uint8)
+        with self._lock:
+            self._keep[tag] = a
+        self._check(lib().hg_sketch_stream_push(self._h, _ptr(a), a.size, tag), "hg_sketch_stream_push")
+
+    def finish(self):
+        self._check(lib().hg_sketch_stream_finish(self._h), "hg_sketch_stream_finish")
+
+    def pop(self):
+        tag, n2, nh, got = C.c_uint64(), C.c_int32(), C.c_uint32(), C.c_int()
+        hv = np.empty(self.params.hv_d, np.int16)
+        self._check(lib().hg_sketch_stream_pop(self._h, C.byref(tag), _ptr(hv), C.byref(n2), C.byref(nh), C.byref(got)),
+                    "hg_sketch_stream_pop")
+        if not got.value:
+            return None
+        with self._lock:
+            self._keep.pop(tag.value, None)
+        return tag.value, hv, n2.value, nh.value
+
+    def stats(self, engine=0):
+        out = (C.c_double * 6)()
+        self._check(lib().hg_sketch_stream_stats(self._h, engine, out), "hg_sketch_stream_stats")
+        return dict(zip(("uploader_idle_s", "uploader_no_chunk_s", "uploader_copy_s", "compute_idle_s", "compute_busy_s",
+                         "chunks"), out))
+
+    def close(self):
+        if self._h:
+            lib().hg_sketch_stream_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def write_sketch_file(path, records):

@@ -6,15 +6,19 @@
 // `-D cpu|gpu` only selects which of the reference's two base-normalisation behaviours is
 // reproduced (cpu: needletail, u/U -> T; gpu: src/cuda_kernel.cu, ACGTacgt only).
 #include <glob.h>
+#include <sched.h>
 #include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,6 +35,26 @@ void logline(const char *lvl, const std::string &msg) {
   std::strftime(ts, sizeof ts, "%Y-%m-%d-%H:%M:%S", std::localtime(&t));  // src/utils.rs:17-29
   std::printf("%s [%s] - %s\n", ts, lvl, msg.c_str());
   std::fflush(stdout);
+}
+
+// RUST_LOG=debug (the reference logs through env_logger) adds per-stage timings
+bool debug_log() {
+  static const bool on = [] {
+    const char *e = std::getenv("RUST_LOG");
+    return e && std::strstr(e, "debug") != nullptr;
+  }();
+  return on;
+}
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void debugf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void debugf(const char *fmt, ...) {
+  if (!debug_log()) return;
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  logline("DEBUG", buf);
 }
 
 [[noreturn]] void die(const std::string &msg) {
@@ -142,6 +166,32 @@ hg_multi *open_all_devices() {
   return m;
 }
 
+// Reader thread -> the CPUs of the NUMA node its device hangs off (the thread's page-locked buffers are then local
+// to the device's socket: the DMA engine fetches them ~25 % faster than from the other socket).  Best effort.
+void bind_thread_to_node(int node, size_t threads_sharing) {
+  if (node < 0) return;
+  FILE *f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+  if (!f) return;
+  char line[4096] = {0};
+  const bool ok = std::fgets(line, sizeof line, f) != nullptr;
+  std::fclose(f);
+  if (!ok) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int cpus = 0;
+  for (char *q = line; *q;) {  // "0-63,128-191"
+    char *end = nullptr;
+    const long lo = std::strtol(q, &end, 10);
+    if (end == q) break;
+    long hi = lo;
+    if (*end == '-') hi = std::strtol(end + 1, &end, 10);
+    for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &set), ++cpus;
+    q = *end == ',' ? end + 1 : end;
+    if (*end != ',') break;
+  }
+  if (cpus && (size_t)cpus >= threads_sharing) (void)sched_setaffinity(0, sizeof set, &set);  // never oversubscribe a node
+}
+
 // get_fasta_files (src/utils.rs:208-221): *.fna, *.fa, *.fasta, in that order
 std::vector<std::string> fasta_files(const std::string &dir) {
   std::vector<std::string> out;
@@ -164,7 +214,6 @@ int run_sketch(const Cli &c) {
   const auto t0 = std::chrono::steady_clock::now();
   if (c.scaled == 0) die("scaled must be >= 1");
   if (c.hv_d % 256) die("hv_d must be a multiple of 256 (bit-packed sketch blocks, src/hd.rs:143-153)");
-  hg_multi *multi = open_all_devices();
   hg_sketch_params p;
   hg_sketch_params_default(&p);
   const bool gpu_mode = c.device == "gpu";
@@ -178,90 +227,106 @@ int run_sketch(const Cli &c) {
 
   std::vector<std::vector<int16_t>> payload(n);
   std::vector<hg_file_sketch> recs(n);
-  const size_t budget = (size_t)1 << 30;  // bytes of sequence per device batch (read ahead of the device)
 
-  // Reader side.  Batches are cut by on-disk size (about `budget` bytes each); inside a batch -t persistent
-  // worker threads pull file indices from an atomic counter (no per-wave join), and every file is read into
-  // a recycled buffer: a batch returns its buffers to a pool once the device has consumed it, so after the
-  // first two batches no reader thread allocates (one 5 MB mmap / page-fault / munmap cycle per file made
-  // 16 readers contend on the process's address-space lock: 18 ms per file and thread instead of 4).
+  // Reader side: -t persistent threads pull file indices from one counter; every thread owns S page-locked buffers
+  // and fills them round robin (hg_read_fastx_pinned: the device then fetches the sequence by DMA at the PCIe rate
+  // -- malloc'ed buffers went through the runtime's bounce buffer at a quarter of it), pushing each genome into the
+  // sketch stream.  A thread waits when its S buffers are all in flight, so the page-locked footprint stays at T*S
+  // genomes however many files there are (locking pages costs ~0.25 ms per MB) and after its first S files no
+  // thread allocates.  The buffers are per thread on purpose: a ring shared by all readers made every file land in
+  // memory last written on another core complex or socket -- 2x (16 threads) to 5x (32) slower reads on the
+  // 2-socket host.
+  // Device side: hg_sketch_stream (one uploader + one compute thread per visible GPU, genomes go to the least
+  // loaded one: SURVEY.md 8e, no exchange); this thread collects the results, which arrive in completion order
+  // and are stored by file index.
+  const size_t T = std::max<size_t>(1, std::min<size_t>(c.threads, std::max<size_t>(n, 1)));
+  const size_t S = std::max<size_t>(4, (64 + T - 1) / T);
   struct Slot {
     uint8_t *p = nullptr;
-    size_t cap = 0;
+    size_t cap = 0, len = 0;
+    bool busy = false;  // pushed, result not collected yet
   };
-  struct Batch {
-    size_t i0 = 0, i1 = 0;
-    std::vector<Slot> slots;
-    std::vector<const uint8_t *> seqs;
-    std::vector<size_t> lens;
-  };
-  std::vector<Slot> pool;
-  std::mutex pool_mu;
-  std::vector<uint64_t> fsize(n);
-  for (size_t i = 0; i < n; ++i) {
-    struct stat sb;
-    fsize[i] = ::stat(files[i].c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 0;
-    const std::string &f = files[i];
-    if (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0) fsize[i] *= 4;  // rough inflated size
-  }
-  auto read_batch = [&](size_t i0) {
-    Batch b;
-    b.i0 = b.i1 = i0;
-    uint64_t bytes = 0;
-    while (b.i1 < n && (b.i1 == i0 || bytes + fsize[b.i1] <= budget)) bytes += fsize[b.i1++];
-    const size_t cnt = b.i1 - b.i0;
-    b.slots.resize(cnt), b.seqs.resize(cnt), b.lens.resize(cnt);
-    {
-      std::lock_guard<std::mutex> lk(pool_mu);
-      for (size_t k = 0; k < cnt && !pool.empty(); ++k) b.slots[k] = pool.back(), pool.pop_back();
-    }
-    std::atomic<size_t> next{0};
-    auto work = [&] {
-      for (size_t k; (k = next.fetch_add(1)) < cnt;) {
-        if (hg_read_fastx_into(files[b.i0 + k].c_str(), read_mode, &b.slots[k].p, &b.slots[k].cap, &b.lens[k]) != HG_OK)
-          die("Opening .fna files failed: " + files[b.i0 + k]);
-        b.seqs[k] = b.slots[k].p;
+  std::vector<Slot> slots(T * S);
+  std::vector<Slot *> slot_of(n, nullptr);
+  std::mutex mu;
+  std::condition_variable cv_space, cv_stream;
+  hg_sketch_stream *stream = nullptr;
+  std::atomic<size_t> next{0};
+  std::atomic<uint64_t> read_ns{0};
+  std::vector<int> dev_node;
+  auto reader = [&](size_t tid) {
+    bind_thread_to_node(dev_node[tid % dev_node.size()], T);
+    size_t k = 0;
+    for (size_t i; (i = next.fetch_add(1)) < n; k = (k + 1) % S) {
+      Slot &sl = slots[tid * S + k];
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_space.wait(lk, [&] { return !sl.busy; });
       }
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < std::min<size_t>(std::max(1u, c.threads), cnt); ++t) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-    return b;
+      const double tr0 = now_s();
+      if (hg_read_fastx_pinned(files[i].c_str(), read_mode, &sl.p, &sl.cap, &sl.len) != HG_OK)
+        die("Opening .fna files failed: " + files[i]);
+      read_ns.fetch_add((uint64_t)((now_s() - tr0) * 1e9));
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        sl.busy = true, slot_of[i] = &sl;
+        cv_stream.wait(lk, [&] { return stream != nullptr; });  // the devices are opened while the first files are read
+      }
+      if (hg_sketch_stream_push(stream, sl.p, sl.len, i) != HG_OK) die(std::string("sketch: ") + hg_sketch_stream_last_error(stream));
+    }
   };
-
-  // two-stage pipeline: the host reads (and inflates) batch i+1 while the device sketches batch i
-  Batch cur = n ? read_batch(0) : Batch{};
-  while (cur.i1 > cur.i0) {
-    Batch nxt;
-    std::thread reader;
-    if (cur.i1 < n) reader = std::thread([&] { nxt = read_batch(cur.i1); });
-    const size_t nb = cur.i1 - cur.i0;
-    std::vector<int16_t> hv(nb * c.hv_d);
-    std::vector<int32_t> n2(nb);
-    std::vector<uint32_t> nh(nb);
-    // genomes shard over every visible GPU (contiguous blocks, no exchange: SURVEY.md 8e)
-    ckm(multi, hg_sketch_batch_multi(multi, cur.seqs.data(), cur.lens.data(), nb, &p, hv.data(), n2.data(), nh.data()), "sketch");
-    {
-      std::lock_guard<std::mutex> lk(pool_mu);
-      for (auto &sl : cur.slots) pool.push_back(sl);
-    }
-    for (size_t k = 0; k < nb; ++k) {
-      const int16_t *v = hv.data() + k * c.hv_d;
-      const uint32_t q = hg_hv_quant_bits(v, (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
-      payload[cur.i0 + k].resize((size_t)q * c.hv_d / 16);
-      if (hg_hv_pack(v, (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[cur.i0 + k].data())) != HG_OK) die("pack");
-      hg_file_sketch &r = recs[cur.i0 + k];
-      std::memset(&r, 0, sizeof r);
-      r.ksize = (uint8_t)c.ksize, r.canonical = c.canonical, r.hv_quant_bits = (uint8_t)q, r.hv_norm_2 = n2[k];
-      r.scaled = c.scaled, r.seed = c.seed, r.hv_d = c.hv_d;
-      r.file_str = files[cur.i0 + k].c_str();
-      r.hv = payload[cur.i0 + k].data(), r.hv_len = payload[cur.i0 + k].size();
-    }
-    if (reader.joinable()) reader.join();
-    cur = std::move(nxt);
+  const double td0 = now_s();
+  const int nd = hg_device_count();  // (brings the HIP runtime up: the readers' page-locked buffers need it too)
+  if (nd <= 0) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  for (int i = 0; i < nd; ++i) dev_node.push_back(hg_device_numa_node(i));
+  std::vector<std::thread> readers;
+  for (size_t t = 0; t < T && n; ++t) readers.emplace_back(reader, t);
+  {
+    std::vector<int> ids(nd);
+    for (int i = 0; i < nd; ++i) ids[i] = i;
+    hg_sketch_stream *st = nullptr;
+    if (hg_sketch_stream_open(ids.data(), nd, &p, &st) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+    debugf("%d device(s) opened in %.1f ms", nd, (now_s() - td0) * 1e3);
+    std::lock_guard<std::mutex> lk(mu);
+    stream = st;
+    cv_stream.notify_all();
   }
-  for (auto &sl : pool) hg_free(sl.p);
+  std::vector<int16_t> hv(c.hv_d);
+  double t_wait = 0, t_pack = 0;
+  for (size_t done = 0; done < n; ++done) {
+    uint64_t f = 0;
+    int32_t n2 = 0;
+    uint32_t nh = 0;
+    int got = 0;
+    const double tw0 = now_s();
+    if (hg_sketch_stream_pop(stream, &f, hv.data(), &n2, &nh, &got) != HG_OK || !got)
+      die(std::string("sketch: ") + hg_sketch_stream_last_error(stream));
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      slot_of[f]->busy = false;  // the sequence is not needed any more
+    }
+    cv_space.notify_all();
+    const double ts1 = now_s();
+    const uint32_t q = hg_hv_quant_bits(hv.data(), (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
+    payload[f].resize((size_t)q * c.hv_d / 16);
+    if (hg_hv_pack(hv.data(), (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[f].data())) != HG_OK) die("pack");
+    hg_file_sketch &r = recs[f];
+    std::memset(&r, 0, sizeof r);
+    r.ksize = (uint8_t)c.ksize, r.canonical = c.canonical, r.hv_quant_bits = (uint8_t)q, r.hv_norm_2 = n2;
+    r.scaled = c.scaled, r.seed = c.seed, r.hv_d = c.hv_d;
+    r.file_str = files[f].c_str();
+    r.hv = payload[f].data(), r.hv_len = payload[f].size();
+    t_wait += ts1 - tw0, t_pack += now_s() - ts1;
+  }
+  for (auto &t : readers) t.join();
+  if (debug_log()) {
+    double st[6];
+    for (int e = 0; hg_sketch_stream_stats(stream, e, st) == HG_OK; ++e)
+      debugf("device engine %d: uploader idle %.1f ms, waiting for a chunk %.1f ms, in copy calls %.1f ms; compute idle "
+             "%.1f ms, busy %.1f ms; %.0f chunks", e, st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5]);
+  }
+  debugf("collector: waited %.1f ms for results, sketch compression %.1f ms; readers: %.2f ms per file and thread",
+         t_wait * 1e3, t_pack * 1e3, n ? read_ns.load() / 1e6 / n : 0.0);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   char buf[256];
   std::snprintf(buf, sizeof buf, "Sketching %zu files took %.2fs - Speed: %.1f files/s", n, secs, n / std::max(secs, 1e-9));
@@ -271,7 +336,10 @@ int run_sketch(const Cli &c) {
   for (auto &r : recs) total += 47 + std::strlen(r.file_str) + r.hv_len * 2;
   std::snprintf(buf, sizeof buf, "Dump sketch file to %s with size %.2f MB", c.out.c_str(), total / 1024.0 / 1024.0);
   logline("INFO", buf);
-  hg_multi_destroy(multi);
+  const double tf0 = now_s();
+  hg_sketch_stream_close(stream);
+  for (auto &sl : slots) hg_pinned_free(sl.p);
+  debugf("released buffers and devices in %.1f ms", (now_s() - tf0) * 1e3);
   return 0;
 }
 

@@ -7,6 +7,9 @@
 // reference-produced .sketch file exists in this environment, so byte compatibility with the
 // Rust binary is UNPINNED ("parity status").
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -17,6 +20,7 @@
 #include <vector>
 
 #include "../../include/hypergen.h"
+#include "hg_host.h"
 
 extern "C" uint32_t hg_hv_quant_bits(const int16_t *hv, uint32_t hv_d) {
   if (!hv || hv_d == 0) return 6;
@@ -229,13 +233,28 @@ namespace {
 // blanks, tabs and line ends inside the sequence (u/U -> T and upper-casing happen on the device, HG_NORM_U2T).
 // Output: the read_merge_seq layout ('N' per record start), so that k-mers never span records.
 inline bool nt_blank(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+
+// first position in [i, n) whose byte is below 0x21 (line ends, blanks, tabs and the other control characters) or,
+// read as a signed char, negative; n if there is none.  A sequence line that is clean up to its '\n' is found with
+// this ONE scan, 16 bytes per step (all the needletail mode costs over read_merge_seq's memchr).
+inline size_t find_ctl(const uint8_t *buf, size_t i, size_t n) {
+#if defined(__SSE2__)
+  const __m128i lim = _mm_set1_epi8(0x21);
+  for (; i + 16 <= n; i += 16) {
+    const int m = _mm_movemask_epi8(_mm_cmplt_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(buf + i)), lim));
+    if (m) return i + (size_t)__builtin_ctz((unsigned)m);
+  }
+#endif
+  for (; i < n; ++i)
+    if (buf[i] < 0x21 || buf[i] >= 0x80) return i;
+  return n;
+}
+
 size_t merge_in_place_needletail(uint8_t *buf, size_t n) {
   size_t w = 0, i = 0;
   const bool fastq = n && buf[0] == '@';
   unsigned line_in_rec = 0;  // FASTQ: 0 = @id, 1 = sequence, 2 = '+', 3 = qualities
   while (i < n) {
-    const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + i, '\n', n - i));
-    const size_t j = nl ? (size_t)(nl - buf) : n;
     bool is_seq;
     if (fastq) {
       if (line_in_rec == 0) buf[w++] = 'N';
@@ -245,30 +264,30 @@ size_t merge_in_place_needletail(uint8_t *buf, size_t n) {
       is_seq = buf[i] != '>';
       if (!is_seq) buf[w++] = 'N';
     }
+    size_t j;
     if (is_seq) {
-      // fast path: no blank inside the line (only a possible trailing '\r')
-      size_t e = j;
-      while (e > i && nt_blank(buf[e - 1])) --e;
-      bool clean = true;
-      for (size_t t = i; t < e; ++t)
-        if (buf[t] == ' ' || buf[t] == '\t' || buf[t] == '\r') {
-          clean = false;
-          break;
-        }
-      if (clean) {
-        std::memmove(buf + w, buf + i, e - i);
-        w += e - i;
+      const size_t t = find_ctl(buf, i, n);
+      if (t == n || buf[t] == '\n') {  // fast path: nothing to drop inside the line
+        j = t;
+        std::memmove(buf + w, buf + i, j - i);
+        w += j - i;
       } else {
-        for (size_t t = i; t < e; ++t)
-          if (!nt_blank(buf[t])) buf[w++] = buf[t];
+        const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + t, '\n', n - t));
+        j = nl ? (size_t)(nl - buf) : n;
+        for (size_t u = i; u < j; ++u)
+          if (!nt_blank(buf[u])) buf[w++] = buf[u];
       }
+    } else {
+      const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(buf + i, '\n', n - i));
+      j = nl ? (size_t)(nl - buf) : n;
     }
     i = j < n ? j + 1 : j;
   }
   return w;
 }
 
-bool grow(uint8_t *&buf, size_t &cap, size_t need) {
+// default growth: realloc (the buffer is the caller's malloc memory)
+bool grow_malloc(uint8_t *&buf, size_t &cap, size_t need, size_t /*keep*/, void *) {
   if (need <= cap) return true;
   uint8_t *nb = static_cast<uint8_t *>(std::realloc(buf, need));
   if (!nb) return false;
@@ -277,7 +296,10 @@ bool grow(uint8_t *&buf, size_t &cap, size_t need) {
 }
 }  // namespace
 
-extern "C" hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {
+// The reader proper; `grow(buf, cap, need, keep, user)` enlarges the buffer keeping its first `keep` bytes
+// (realloc here, page-locked memory in hg_api.hip's hg_read_fastx_pinned).
+hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, size_t *pcap, size_t *n_bps,
+                             hg_grow_fn grow, void *user) {
   if (!path || !pbuf || !pcap || !n_bps || mode > HG_READ_NEEDLETAIL) return HG_ERR_INVALID;
   *n_bps = 0;
   uint8_t *buf = *pbuf;
@@ -295,11 +317,11 @@ extern "C" hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t
     gzFile f = gzopen(path, "rb");
     if (!f) return HG_ERR_IO;
     gzbuffer(f, 1 << 20);
-    if (!grow(buf, cap, ((size_t)16 << 20) + 64)) st = HG_ERR_OOM;
+    if (!grow(buf, cap, ((size_t)16 << 20) + 64, 0, user)) st = HG_ERR_OOM;
     int got = 0;
     while (st == HG_OK && (got = gzread(f, buf + n, (unsigned)std::min<size_t>(cap - 64 - n, 1u << 30))) > 0) {
       n += (size_t)got;
-      if (n == cap - 64 && !grow(buf, cap, 2 * cap)) st = HG_ERR_OOM;
+      if (n == cap - 64 && !grow(buf, cap, 2 * cap, n, user)) st = HG_ERR_OOM;
     }
     if (st == HG_OK && got < 0) st = HG_ERR_IO;
     gzclose(f);
@@ -308,7 +330,7 @@ extern "C" hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t
     long sz = -1;
     if (std::fseek(fp, 0, SEEK_END) == 0) sz = std::ftell(fp);
     if (sz < 0) st = HG_ERR_IO;
-    else if (!grow(buf, cap, (size_t)sz + 64)) st = HG_ERR_OOM;
+    else if (!grow(buf, cap, (size_t)sz + 64, 0, user)) st = HG_ERR_OOM;
     if (st == HG_OK) {
       std::rewind(fp);
       n = sz ? std::fread(buf, 1, (size_t)sz, fp) : 0;
@@ -322,6 +344,10 @@ extern "C" hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t
   std::memset(buf + w, 0, 64);
   *n_bps = w;
   return HG_OK;
+}
+
+extern "C" hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {
+  return hg_read_fastx_impl(path, mode, pbuf, pcap, n_bps, grow_malloc, nullptr);
 }
 
 extern "C" hg_status hg_read_merge_seq_into(const char *path, uint8_t **pbuf, size_t *pcap, size_t *n_bps) {

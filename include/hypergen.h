@@ -246,6 +246,33 @@ size_t hg_sketch_file_count(const hg_sketch_file *f);
 const hg_file_sketch *hg_sketch_file_get(const hg_sketch_file *f, size_t i);
 void hg_sketch_file_free(hg_sketch_file *f);
 
+/* ---- continuous host-fed sketching ------------------------------------------------------------------------
+ * The streaming form of hg_sketch_batch for hosts that produce genomes one at a time (reader threads walking a
+ * file list, src/sketch_cuda.rs:120-166): one uploader and one compute thread per device keep the PCIe link and the
+ * kernels busy without the caller collecting batches.  Results are bit-identical to hg_sketch_batch.
+ *   open    one engine per entry of device_ids (an id may repeat); params are fixed for the stream's lifetime
+ *   push    any thread; `seq` must stay valid and unchanged until the genome's result has been popped; page-locked
+ *           memory (hg_read_fastx_pinned) is fetched by DMA at the link rate, other memory is staged by the runtime;
+ *           blocks while 4096 results are outstanding
+ *   pop     any thread; blocks until a result is ready (completion order, identified by `tag`); *got = 0 with
+ *           HG_OK once hg_sketch_stream_finish was called and every pushed genome has been popped; hv_out holds
+ *           hv_d int16, any output pointer may be NULL
+ *   finish  no more pushes; partial chunks are flushed
+ *   close   joins the threads and frees everything (outstanding results are dropped)
+ * After a failure every call returns its status; hg_sketch_stream_last_error has the text. */
+typedef struct hg_sketch_stream hg_sketch_stream;
+hg_status hg_sketch_stream_open(const int *device_ids, int n_devices, const hg_sketch_params *p, hg_sketch_stream **out);
+hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t n_bps, uint64_t tag);
+hg_status hg_sketch_stream_pop(hg_sketch_stream *s, uint64_t *tag, int16_t *hv_out, int32_t *norm2_out,
+                               uint32_t *nhash_out, int *got);
+hg_status hg_sketch_stream_finish(hg_sketch_stream *s);
+const char *hg_sketch_stream_last_error(hg_sketch_stream *s);
+/* diagnostics of one engine, seconds since open: out[0] uploader waiting for input, [1] uploader waiting for a free
+ * chunk (the kernels lag), [2] uploader inside the copy calls, [3] compute thread waiting for a chunk, [4] compute
+ * thread from "chunk taken" to "results queued" (includes waiting for the chunk's upload); out[5] = chunks so far */
+hg_status hg_sketch_stream_stats(hg_sketch_stream *s, int engine, double out[6]);
+void hg_sketch_stream_close(hg_sketch_stream *s);
+
 /* ---- FASTA ingest (host side; src/fastx_reader.rs:6-29) ------------------------------- */
 /* read_merge_seq: returns a malloc'ed buffer (free with hg_free) and its length */
 hg_status hg_read_merge_seq(const char *path, uint8_t **out, size_t *n_bps);
@@ -261,6 +288,14 @@ hg_status hg_read_merge_seq_into(const char *path, uint8_t **buf, size_t *cap, s
 #define HG_READ_MERGE 0u
 #define HG_READ_NEEDLETAIL 1u
 hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **buf, size_t *cap, size_t *n_bps);
+/* same, but the buffer is page-locked host memory owned by the library (hipHostMalloc, visible to every device;
+ * *buf NULL or from an earlier call, release with hg_pinned_free): hg_sketch_batch uploads such sequences by DMA at
+ * the PCIe rate, while malloc'ed memory goes through the runtime's bounce buffer at a fraction of it.  Needs a HIP
+ * device like every compute entry point. */
+hg_status hg_read_fastx_pinned(const char *path, uint32_t mode, uint8_t **buf, size_t *cap, size_t *n_bps);
+void hg_pinned_free(void *p);
+/* NUMA node of a device (-1 unknown): host threads that fill page-locked buffers for it should run there */
+int hg_device_numa_node(int device_id);
 void hg_free(void *p);
 
 /* ---- bit-packed hypervectors + Hamming search (extension: BASELINE.json configs[4]) ------------

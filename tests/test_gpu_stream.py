@@ -1,0 +1,103 @@
+"""hg_sketch_stream_* (continuous host-fed sketching: uploader + compute thread per device) against hg_sketch_batch
+and the oracle: same bits whatever the chunking, the pushing thread, the memory kind or the number of engines."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hg():
+    import hypergen_amd
+    return hypergen_amd
+
+
+def _drain(st, n):
+    out = {}
+    while True:
+        r = st.pop()
+        if r is None:
+            break
+        assert r[0] not in out
+        out[r[0]] = r[1:]
+    assert len(out) == n
+    return out
+
+
+def test_stream_equals_batch_mixed_sizes(hg, orc):
+    # empty, shorter than k, exactly k, tiny (staged together), mid-size, 5 Mbp, and one genome larger than a chunk
+    lens = [0, 10, 21, 22, 2_000, 2_000, 30_000, 255_000, 300_000, 1_200_000, 5_000_000, 70_000_000, 4_000, 900]
+    genomes = [orc.synth_genome(g, L)[1:] if L else np.zeros(0, np.uint8) for g, L in enumerate(lens)]
+    genomes[6] = genomes[6].copy()
+    genomes[6][1000:1040] = ord("N")
+    p = hg.default_params(scaled=200)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch(genomes, p)
+    for devs in ((0,), (0, 0)):
+        with hg.SketchStream(devs, p) as st:
+            def pusher(idx):
+                for i in idx:
+                    st.push(genomes[i], i)
+            th = [threading.Thread(target=pusher, args=(range(t, len(genomes), 3),)) for t in range(3)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            st.finish()
+            out = _drain(st, len(genomes))
+        for i in range(len(genomes)):
+            assert out[i][2] == nh[i] and out[i][1] == n2[i] and np.array_equal(out[i][0], hv[i]), (devs, i)
+    for i in (4, 7):
+        w_hv, w_n2, w_nh = orc.sketch_genome(genomes[i], scaled=200)
+        assert nh[i] == w_nh and n2[i] == w_n2 and np.array_equal(hv[i], w_hv)
+
+
+def test_stream_many_small_genomes_and_interleaved_pops(hg, orc):
+    """more genomes than one chunk may hold (4096), pops interleaved with pushes, page-locked and plain memory"""
+    import torch
+    n = 6000
+    base = orc.synth_genome(7, 400_000)[1:]
+    rng = np.random.default_rng(3)
+    starts = rng.integers(0, base.size - 3000, n)
+    sizes = rng.integers(500, 3000, n)
+    genomes = [base[s:s + m] for s, m in zip(starts, sizes)]
+    pinned = torch.from_numpy(base.copy()).pin_memory().numpy()
+    p = hg.default_params(scaled=20)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch(genomes, p)
+    with hg.SketchStream((0,), p) as st:
+        got = {}
+        for i in range(n):
+            src = pinned if i % 2 else base
+            st.push(src[starts[i]:starts[i] + sizes[i]], i)
+            if i % 1000 == 999:  # results outstanding: pop some while pushing
+                for _ in range(500):
+                    r = st.pop()
+                    got[r[0]] = r[1:]
+        st.finish()
+        got.update(_drain(st, n - len(got)))
+    assert len(got) == n
+    for i in range(n):
+        assert got[i][2] == nh[i] and got[i][1] == n2[i] and np.array_equal(got[i][0], hv[i]), i
+
+
+def test_stream_params_and_errors(hg, orc):
+    g = orc.synth_genome(3, 200_000)[1:]
+    p = hg.default_params(ksize=16, scaled=50, hv_d=1024, canonical=0)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch([g], p)
+    with hg.SketchStream((0,), p) as st:
+        st.push(g, 77)
+        st.finish()
+        tag, shv, sn2, snh = st.pop()
+        assert tag == 77 and snh == nh[0] and sn2 == n2[0] and np.array_equal(shv, hv[0])
+        assert st.pop() is None and st.pop() is None
+        with pytest.raises(hg.HgError):
+            st.push(g, 1)  # after finish
+    bad = hg.default_params(hv_d=0)
+    with pytest.raises(hg.HgError):
+        hg.SketchStream((0,), bad)
+    with pytest.raises(hg.HgError):
+        hg.SketchStream((99,), p)
