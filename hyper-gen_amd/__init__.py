@@ -75,6 +75,7 @@ EXPORTS = [
     "hg_ctx_last_hamming_path", "hg_read_fastx_pinned", "hg_pinned_free",
     "hg_sketch_stream_open", "hg_sketch_stream_push", "hg_sketch_stream_pop", "hg_sketch_stream_finish",
     "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node",
+    "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
 ]
 
 
@@ -147,6 +148,10 @@ def lib():
         "hg_sketch_stream_push": (C.c_int, [vp, vp, sz, C.c_uint64]),
         "hg_sketch_stream_pop": (C.c_int, [vp, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_int)]),
+        "hg_sketch_stream_push_packed": (C.c_int, [vp, vp, sz, C.c_uint64]),
+        "hg_pack2_size": (sz, [sz]),
+        "hg_pack2": (C.c_int, [vp, sz, C.c_uint32, vp]),
+        "hg_unpack2_dev": (C.c_int, [vp, vp, sz, vp]),
         "hg_sketch_stream_finish": (C.c_int, [vp]),
         "hg_sketch_stream_last_error": (C.c_char_p, [vp]),
         "hg_sketch_stream_close": (None, [vp]),
@@ -274,6 +279,10 @@ class Context:
                 continue
             self._ck(st)
             return out[: n.value].copy()
+
+    def unpack2_dev(self, d_blob, n_bps, d_out):
+        """hg_unpack2_dev on device pointers (ints)"""
+        self._ck(lib().hg_unpack2_dev(self._h, C.c_void_p(d_blob), n_bps, C.c_void_p(d_out)))
 
     def hv_encode(self, hashes, hv_d=4096, layout=LAYOUT_AVX2):
         h = np.ascontiguousarray(hashes, dtype=np.uint64)
@@ -548,6 +557,24 @@ def read_merge_seq(path, mode=READ_MERGE):
         lib().hg_free(p)
 
 
+def pack2(seq, norm_mode=0, in_place=False):
+    """hg_pack2: uint8 blob of hg_pack2_size(len(seq)) bytes (2-bit codes + not-a-base bits)."""
+    a = np.ascontiguousarray(seq, np.uint8)
+    n = a.size
+    size = lib().hg_pack2_size(n)
+    if in_place:
+        buf = np.zeros(max(n, size), np.uint8)
+        buf[:n] = a
+        st = lib().hg_pack2(_ptr(buf), n, norm_mode, _ptr(buf))
+        out = buf[:size]
+    else:
+        out = np.empty(size, np.uint8)
+        st = lib().hg_pack2(_ptr(a), n, norm_mode, _ptr(out))
+    if st != OK:
+        raise HgError(st, "hg_pack2")
+    return out
+
+
 class PinnedReader:
     """Page-locked read buffers (hg_read_fastx_pinned): read(path) returns a uint8 view that stays valid until
     the next read into the same slot or close(); what the CLI's reader threads use to feed hg_sketch_batch."""
@@ -602,6 +629,13 @@ class SketchStream:
         with self._lock:
             self._keep[tag] = a
         self._check(lib().hg_sketch_stream_push(self._h, _ptr(a), a.size, tag), "hg_sketch_stream_push")
+
+    def push_packed(self, blob, n_bps, tag):
+        a = np.ascontiguousarray(blob, np.uint8)
+        assert a.size >= lib().hg_pack2_size(n_bps)
+        with self._lock:
+            self._keep[tag] = a
+        self._check(lib().hg_sketch_stream_push_packed(self._h, _ptr(a), n_bps, tag), "hg_sketch_stream_push_packed")
 
     def finish(self):
         self._check(lib().hg_sketch_stream_finish(self._h), "hg_sketch_stream_finish")

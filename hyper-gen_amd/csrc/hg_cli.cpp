@@ -254,25 +254,36 @@ int run_sketch(const Cli &c) {
   std::atomic<size_t> next{0};
   std::atomic<uint64_t> read_ns{0};
   std::vector<int> dev_node;
+  // 2-bit packing (hg_pack2: 3 bits per base over the link) costs a reader ~0.3 ms per 5 Mbp and only pays when
+  // the link is what limits, so every reader decides per file: if at least two of its own buffers are still in
+  // flight when it starts on a file, the device side lags behind the readers -> pack this one.
+  std::atomic<size_t> n_packed{0};
+  const uint32_t pack_flags = HG_READ_PACK2 | (p.norm_mode == HG_NORM_U2T ? HG_READ_PACK2_U2T : 0u);
   auto reader = [&](size_t tid) {
     bind_thread_to_node(dev_node[tid % dev_node.size()], T);
     size_t k = 0;
     for (size_t i; (i = next.fetch_add(1)) < n; k = (k + 1) % S) {
       Slot &sl = slots[tid * S + k];
+      bool pack;
       {
         std::unique_lock<std::mutex> lk(mu);
+        size_t in_flight = 0;
+        for (size_t q = 0; q < S; ++q) in_flight += slots[tid * S + q].busy ? 1 : 0;
+        pack = in_flight >= 2;
         cv_space.wait(lk, [&] { return !sl.busy; });
       }
       const double tr0 = now_s();
-      if (hg_read_fastx_pinned(files[i].c_str(), read_mode, &sl.p, &sl.cap, &sl.len) != HG_OK)
+      if (hg_read_fastx_pinned(files[i].c_str(), read_mode | (pack ? pack_flags : 0u), &sl.p, &sl.cap, &sl.len) != HG_OK)
         die("Opening .fna files failed: " + files[i]);
       read_ns.fetch_add((uint64_t)((now_s() - tr0) * 1e9));
+      if (pack) n_packed.fetch_add(1);
       {
         std::unique_lock<std::mutex> lk(mu);
         sl.busy = true, slot_of[i] = &sl;
         cv_stream.wait(lk, [&] { return stream != nullptr; });  // the devices are opened while the first files are read
       }
-      if (hg_sketch_stream_push(stream, sl.p, sl.len, i) != HG_OK) die(std::string("sketch: ") + hg_sketch_stream_last_error(stream));
+      const hg_status ps = pack ? hg_sketch_stream_push_packed(stream, sl.p, sl.len, i) : hg_sketch_stream_push(stream, sl.p, sl.len, i);
+      if (ps != HG_OK) die(std::string("sketch: ") + hg_sketch_stream_last_error(stream));
     }
   };
   const double td0 = now_s();
@@ -325,8 +336,9 @@ int run_sketch(const Cli &c) {
       debugf("device engine %d: uploader idle %.1f ms, waiting for a chunk %.1f ms, in copy calls %.1f ms; compute idle "
              "%.1f ms, busy %.1f ms; %.0f chunks", e, st[0] * 1e3, st[1] * 1e3, st[2] * 1e3, st[3] * 1e3, st[4] * 1e3, st[5]);
   }
-  debugf("collector: waited %.1f ms for results, sketch compression %.1f ms; readers: %.2f ms per file and thread",
-         t_wait * 1e3, t_pack * 1e3, n ? read_ns.load() / 1e6 / n : 0.0);
+  debugf("collector: waited %.1f ms for results, sketch compression %.1f ms; readers: %.2f ms per file and thread, "
+         "%zu of %zu files sent 2-bit packed", t_wait * 1e3, t_pack * 1e3, n ? read_ns.load() / 1e6 / n : 0.0,
+         n_packed.load(), n);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   char buf[256];
   std::snprintf(buf, sizeof buf, "Sketching %zu files took %.2fs - Speed: %.1f files/s", n, secs, n / std::max(secs, 1e-9));

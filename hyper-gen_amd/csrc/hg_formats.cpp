@@ -7,8 +7,8 @@
 // reference-produced .sketch file exists in this environment, so byte compatibility with the
 // Rust binary is UNPINNED ("parity status").
 #include <zlib.h>
-#if defined(__SSE2__)
-#include <emmintrin.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
 #endif
 
 #include <algorithm>
@@ -203,6 +203,84 @@ extern "C" const hg_file_sketch *hg_sketch_file_get(const hg_sketch_file *f, siz
 }
 extern "C" void hg_sketch_file_free(hg_sketch_file *f) { delete f; }
 
+// ---- 2-bit packing of sequence for the PCIe link ------------------------------------------------------------
+// Blob layout for n bases: codes, 4 bases per byte (base i in bits 2(i&3)..2(i&3)+1 of byte i>>2; A,C,G,T = 0..3,
+// the device's own code ((x>>1)^(x>>2))&3), padded to a multiple of 16 bytes; then the NOT-a-base mask, 1 bit per
+// base (bit i&7 of byte i>>3), padded likewise.  3 bits per base = 0.375 of the ASCII bytes; hg_unpack2_dev turns
+// it back into the ASCII the k-mer kernels classify the same way ('A','C','G','T' / 'N'), so results cannot differ.
+namespace {
+inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+inline void pack2_scalar(const uint8_t *seq, size_t i0, size_t i1, bool u2t, uint8_t *codes, uint8_t *mask) {
+  for (size_t i = i0; i < i1; ++i) {  // i0 is a multiple of 8
+    const uint8_t x = seq[i], u = x & 0xDF;
+    const bool ok = u == 'A' || u == 'C' || u == 'G' || u == 'T' || (u2t && u == 'U');
+    const uint8_t c = ok ? (uint8_t)(((x >> 1) ^ (x >> 2)) & 3) : 0;
+    if ((i & 3) == 0) codes[i >> 2] = 0;
+    if ((i & 7) == 0) mask[i >> 3] = 0;
+    codes[i >> 2] |= (uint8_t)(c << (2 * (i & 3)));
+    mask[i >> 3] |= (uint8_t)((ok ? 0 : 1) << (i & 7));
+  }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) size_t pack2_avx2(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes, uint8_t *mask) {
+  const __m256i up = _mm256_set1_epi8((char)0xDF), three = _mm256_set1_epi8(3);
+  const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+  const __m256i cU = _mm256_set1_epi8(u2t ? 'U' : 'T');
+  const __m256i w14 = _mm256_set1_epi16(0x0401), w116 = _mm256_set1_epi32(0x00100001);
+  const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                        0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(seq + i));
+    const __m256i u = _mm256_and_si256(x, up);
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)),
+                                       _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)),
+                                                       _mm256_cmpeq_epi8(u, cU)));
+    __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(x, 1), _mm256_srli_epi16(x, 2)), three);
+    c = _mm256_and_si256(c, ok);  // non-bases carry code 0
+    const __m256i q = _mm256_madd_epi16(_mm256_maddubs_epi16(c, w14), w116);  // c0 + 4 c1 + 16 c2 + 64 c3 per dword
+    const __m256i b = _mm256_shuffle_epi8(q, pick);
+    const uint32_t lo = (uint32_t)_mm256_cvtsi256_si32(b), hi = (uint32_t)_mm256_extract_epi32(b, 4);
+    const uint32_t bad = ~(uint32_t)_mm256_movemask_epi8(ok);
+    // the stores stay behind the loads also when codes == seq (8 + 4 bytes written per 32 read)
+    std::memcpy(codes + (i >> 2), &lo, 4), std::memcpy(codes + (i >> 2) + 4, &hi, 4);
+    std::memcpy(mask + (i >> 3), &bad, 4);
+  }
+  return i;
+}
+#endif
+}  // namespace
+
+extern "C" size_t hg_pack2_size(size_t n_bps) { return al16((n_bps + 3) / 4) + al16((n_bps + 7) / 8); }
+
+// `out` may be `seq` itself (packing in place): the codes trail the reads, the mask is collected aside.
+extern "C" hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out) {
+  if ((n_bps && !seq) || !out || norm_mode > HG_NORM_U2T) return HG_ERR_INVALID;
+  const bool u2t = norm_mode == HG_NORM_U2T;
+  const size_t cb = al16((n_bps + 3) / 4), mb = al16((n_bps + 7) / 8);
+  // collected aside (so that packing in place works); kept per thread: a fresh 0.6 MB block per 5 Mbp genome is an
+  // mmap / page-fault / munmap cycle each time, and reader threads then queue on the address-space lock
+  static thread_local std::vector<uint8_t> mask;
+  try {
+    if (mask.size() < mb) mask.resize(mb + mb / 4);
+  } catch (const std::bad_alloc &) {
+    return HG_ERR_OOM;
+  }
+  if (mb) std::memset(mask.data() + (mb - 16), 0, 16);  // the padding tail; everything below is overwritten
+  size_t done = 0;
+#if defined(__x86_64__)
+  if (__builtin_cpu_supports("avx2")) done = pack2_avx2(seq, n_bps, u2t, out, mask.data());
+#endif
+  const size_t tail_codes = (done >> 2);
+  pack2_scalar(seq, done, n_bps, u2t, out, mask.data());
+  const size_t used = n_bps > done ? (n_bps + 3) / 4 : tail_codes;
+  if (cb > used) std::memset(out + used, 0, cb - used);
+  std::memcpy(out + cb, mask.data(), mb);
+  return HG_OK;
+}
+
 // ---- FASTA -----------------------------------------------------------------------------------------------
 namespace {
 // in-place merge of FASTA text held in buf[0..n): header lines become one 'N', sequence lines lose their
@@ -300,7 +378,9 @@ bool grow_malloc(uint8_t *&buf, size_t &cap, size_t need, size_t /*keep*/, void 
 // (realloc here, page-locked memory in hg_api.hip's hg_read_fastx_pinned).
 hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, size_t *pcap, size_t *n_bps,
                              hg_grow_fn grow, void *user) {
-  if (!path || !pbuf || !pcap || !n_bps || mode > HG_READ_NEEDLETAIL) return HG_ERR_INVALID;
+  const uint32_t base_mode = mode & 0xFu;
+  if (!path || !pbuf || !pcap || !n_bps || base_mode > HG_READ_NEEDLETAIL || (mode & ~(0xFu | HG_READ_PACK2 | HG_READ_PACK2_U2T)))
+    return HG_ERR_INVALID;
   *n_bps = 0;
   uint8_t *buf = *pbuf;
   size_t cap = buf ? *pcap : 0;
@@ -340,9 +420,11 @@ hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, si
   }
   *pbuf = buf, *pcap = cap;  // the (possibly moved) buffer stays the caller's, also on error
   if (st != HG_OK) return st;
-  const size_t w = mode == HG_READ_NEEDLETAIL ? merge_in_place_needletail(buf, n) : merge_in_place(buf, n);
+  const size_t w = base_mode == HG_READ_NEEDLETAIL ? merge_in_place_needletail(buf, n) : merge_in_place(buf, n);
   std::memset(buf + w, 0, 64);
   *n_bps = w;
+  if (mode & HG_READ_PACK2)  // the buffer (file size + 64 bytes) holds the blob: hg_pack2_size(w) <= max(w, 32) + 32
+    return hg_pack2(buf, w, (mode & HG_READ_PACK2_U2T) ? HG_NORM_U2T : HG_NORM_ACGT, buf);
   return HG_OK;
 }
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -29,12 +30,23 @@ constexpr size_t CHUNK_BYTES = 64ull << 20;  // device bytes a chunk aims at (on
 constexpr size_t CHUNK_GENOMES = 4096;       // bounds the HV read-back of a chunk of tiny genomes (32 MiB at D = 4096)
 constexpr size_t SMALL_BYTES = 256u << 10;   // genomes below this are packed into page-locked staging and uploaded together
 constexpr int N_CHUNKS = 3;
+// compute threads (each with its own ctx) per device.  A/B at 2 (+ a 4th chunk): 7.3-7.8 k files/s instead of
+// 8.3-9.6 k -- two contexts' small kernels and synchronisations get in each other's way; kept configurable
+constexpr int N_WORKERS = 1;
 
 struct Item {
-  const uint8_t *seq;
-  size_t len;
+  const uint8_t *seq;  // ASCII sequence, or a hg_pack2 blob when packed
+  size_t len;          // bases
   uint64_t tag;
+  bool packed;
 };
+
+// one packed genome of a chunk: where its blob sits in the chunk's packed area, where its ASCII goes
+struct UnpackJob {
+  uint64_t pk_off, out_off, n_bps;
+  uint32_t first_block, pad;
+};
+constexpr uint32_t UNPACK_GROUPS_PER_BLOCK = 1024;  // 256 threads x 4 groups of 16 bases
 
 struct Chunk {
   uint8_t *d = nullptr;  // device sequence buffer
@@ -44,6 +56,11 @@ struct Chunk {
   std::vector<uint64_t> offs, lens, tags;
   size_t bytes = 0;
   hipEvent_t uploaded = nullptr;
+  // hg_pack2 blobs (hg_sketch_stream_push_packed): their own device area, expanded into `d` by unpack2_kernel
+  uint8_t *dpk = nullptr;
+  size_t pk_cap = 0, pk_bytes = 0;
+  UnpackJob *h_jobs = nullptr, *d_jobs = nullptr;  // CHUNK_GENOMES entries each (page-locked / device), lazily allocated
+  uint32_t n_jobs = 0, n_blocks = 0;
 };
 
 struct Done {  // the results of one chunk
@@ -56,21 +73,73 @@ struct Done {  // the results of one chunk
 
 }  // namespace
 
+namespace {
+// 16 bases per step: 4 code bytes -> 16 ASCII bytes through a v_perm table ("ACGT"), non-bases -> 'N'
+__device__ __forceinline__ void unpack2_group(const uint8_t *__restrict__ blob, size_t code_bytes, uint8_t *__restrict__ out,
+                                              uint64_t grp) {
+  const uint32_t codes = *reinterpret_cast<const uint32_t *>(blob + 4 * grp);
+  const uint32_t bad = *reinterpret_cast<const uint16_t *>(blob + code_bytes + 2 * grp);
+  uint32_t w[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const uint32_t c = (codes >> (8 * b)) & 0xFFu;
+    const uint32_t sel = (c & 3u) | ((c & 0xCu) << 6) | ((c & 0x30u) << 12) | ((c & 0xC0u) << 18);  // 2-bit fields -> bytes
+    const uint32_t ascii = __builtin_amdgcn_perm(0u, 0x54474341u, sel);  // selector 0..3 -> 'A','C','G','T'
+    const uint32_t m = ((((bad >> (4 * b)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;  // mask bits -> byte masks
+    w[b] = (ascii & ~m) | (0x4E4E4E4Eu & m);
+  }
+  *reinterpret_cast<uint4 *>(out + 16 * grp) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void unpack2_kernel(const uint8_t *__restrict__ pk, uint8_t *__restrict__ out,
+                                                      const UnpackJob *__restrict__ jobs, uint32_t n_jobs) {
+  uint32_t lo = 0, hi = n_jobs;  // the last job whose first block is <= blockIdx.x
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+    else hi = mid;
+  }
+  const UnpackJob jb = jobs[lo];
+  const uint64_t groups = (jb.n_bps + 15) / 16;
+  const size_t code_bytes = (((size_t)jb.n_bps + 3) / 4 + 15) & ~(size_t)15;
+  const uint64_t g0 = (uint64_t)(blockIdx.x - jb.first_block) * UNPACK_GROUPS_PER_BLOCK + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t g = g0 + 256u * r;
+    if (g < groups) unpack2_group(pk + jb.pk_off, code_bytes, out + jb.out_off, g);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack2_one_kernel(const uint8_t *__restrict__ blob, uint8_t *__restrict__ out, uint64_t n_bps) {
+  const uint64_t groups = (n_bps + 15) / 16;
+  const size_t code_bytes = (((size_t)n_bps + 3) / 4 + 15) & ~(size_t)15;
+  const uint64_t g0 = (uint64_t)blockIdx.x * UNPACK_GROUPS_PER_BLOCK + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t g = g0 + 256u * r;
+    if (g < groups) unpack2_group(blob, code_bytes, out, g);
+  }
+}
+}  // namespace
+
 struct hg_sketch_stream {
   struct Engine {
     int device = 0;
-    hg_ctx *ctx = nullptr;
+    struct Worker {  // one compute thread: its own ctx (workspaces, stream) and result areas
+      hg_ctx *ctx = nullptr;
+      int16_t *d_hv = nullptr;
+      int32_t *d_n2 = nullptr;
+      uint32_t *d_nh = nullptr;
+      uint8_t *h_res = nullptr;  // page-locked read-back area
+      std::thread th;
+    } w[N_WORKERS];
     hipStream_t copy = nullptr;
     Chunk chunk[N_CHUNKS];
     std::deque<Item> in;
     std::deque<int> free_chunks, full_chunks;
     size_t load = 0;  // bytes pushed to this engine whose results are not out yet
     bool uploader_done = false;
-    int16_t *d_hv = nullptr;
-    int32_t *d_n2 = nullptr;
-    uint32_t *d_nh = nullptr;
-    uint8_t *h_res = nullptr;  // page-locked read-back area
-    std::thread up, comp;
+    std::thread up;
     // diagnostics (hg_sketch_stream_stats): seconds spent per phase, chunks handed over
     double t_up_idle = 0, t_up_nochunk = 0, t_up_copy = 0, t_comp_idle = 0, t_comp_run = 0;
     size_t n_chunks = 0;
@@ -118,6 +187,7 @@ bool flush_run(hg_sketch_stream *s, Engine &e, Chunk &c) {
 bool hand_over(hg_sketch_stream *s, Engine &e, int ci) {
   Chunk &c = e.chunk[ci];
   if (!flush_run(s, e, c)) return false;
+  if (c.n_jobs) ST_HIP(s, hipMemcpyAsync(c.d_jobs, c.h_jobs, c.n_jobs * sizeof(UnpackJob), hipMemcpyHostToDevice, e.copy));
   ST_HIP(s, hipEventRecord(c.uploaded, e.copy));
   std::lock_guard<std::mutex> lk(s->mu);
   e.full_chunks.push_back(ci);
@@ -161,6 +231,7 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         Chunk &c = e.chunk[cur];
         c.offs.clear(), c.lens.clear(), c.tags.clear();
         c.bytes = 0, c.run_lo = c.run_hi = 0;
+        c.pk_bytes = 0, c.n_jobs = 0, c.n_blocks = 0;
       }
       Chunk &c = e.chunk[cur];
       if (c.bytes + padded + 64 > c.cap) {  // one genome larger than the chunk (bytes == 0 here): the chunk grows
@@ -175,7 +246,32 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         c.cap = want;
       }
       const double tc = now_s();
-      if (it.len) {
+      if (it.len && it.packed) {
+        const size_t blob = hg_pack2_size(it.len);
+        if (c.pk_bytes + blob > c.pk_cap) {  // the packed area grows between chunks' uses (nothing of this chunk is in flight
+          // unless earlier genomes of it are: wait for their copies before the old block goes away)
+          ST_HIP(s, hipStreamSynchronize(e.copy));
+          uint8_t *nb = nullptr;
+          const size_t want = std::max(c.pk_bytes + blob + blob / 8, (size_t)(CHUNK_BYTES * 3 / 8 + (1u << 20)));
+          hipError_t he = hipMalloc(reinterpret_cast<void **>(&nb), want);
+          if (he != hipSuccess) {
+            fail(s, HG_ERR_OOM, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(he));
+            return false;
+          }
+          if (c.dpk && c.pk_bytes) ST_HIP(s, hipMemcpy(nb, c.dpk, c.pk_bytes, hipMemcpyDeviceToDevice));
+          if (c.dpk) ST_HIP(s, hipFree(c.dpk));
+          c.dpk = nb, c.pk_cap = want;
+        }
+        if (!c.h_jobs) {
+          ST_HIP(s, hipHostMalloc(reinterpret_cast<void **>(&c.h_jobs), CHUNK_GENOMES * sizeof(UnpackJob), hipHostMallocDefault));
+          ST_HIP(s, hipMalloc(reinterpret_cast<void **>(&c.d_jobs), CHUNK_GENOMES * sizeof(UnpackJob)));
+        }
+        ST_HIP(s, hipMemcpyAsync(c.dpk + c.pk_bytes, it.seq, blob, hipMemcpyHostToDevice, e.copy));
+        UnpackJob &jb = c.h_jobs[c.n_jobs++];
+        jb.pk_off = c.pk_bytes, jb.out_off = c.bytes, jb.n_bps = it.len, jb.first_block = c.n_blocks, jb.pad = 0;
+        c.n_blocks += (uint32_t)(((it.len + 15) / 16 + UNPACK_GROUPS_PER_BLOCK - 1) / UNPACK_GROUPS_PER_BLOCK);
+        c.pk_bytes += blob;
+      } else if (it.len) {
         if (it.len < SMALL_BYTES && c.bytes + padded <= CHUNK_BYTES) {
           if (!c.stage) ST_HIP(s, hipHostMalloc(reinterpret_cast<void **>(&c.stage), CHUNK_BYTES, hipHostMallocDefault));
           if (c.run_hi == c.run_lo) c.run_lo = c.run_hi = c.bytes;
@@ -191,7 +287,8 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
       c.offs.push_back(c.bytes), c.lens.push_back(it.len), c.tags.push_back(it.tag);
       c.bytes += padded;
       // hand the chunk on when it is full -- or when nothing else is waiting: the kernels start at once and the
-      // next genome opens a new chunk
+      // next genome opens a new chunk.  (A/B: keeping the chunk open while the kernels are busy halves the number of
+      // chunks and is 7-10 % slower end to end -- results come back later, the readers' buffers free up later.)
       if (idle_after || c.bytes >= CHUNK_BYTES || c.tags.size() >= CHUNK_GENOMES) {
         if (!hand_over(s, e, cur)) return false;
         cur = -1;
@@ -206,8 +303,9 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
   s->cv_chunk.notify_all();
 }
 
-void computer(hg_sketch_stream *s, Engine *ep) {
+void computer(hg_sketch_stream *s, Engine *ep, int wi) {
   Engine &e = *ep;
+  Engine::Worker &w = e.w[wi];
   auto body = [&]() -> bool {
     ST_HIP(s, hipSetDevice(e.device));
     const size_t D = s->p.hv_d;
@@ -226,23 +324,27 @@ void computer(hg_sketch_stream *s, Engine *ep) {
       Chunk &c = e.chunk[ci];
       const size_t m = c.tags.size();
       const double tr = now_s();
-      ST_HIP(s, hipStreamWaitEvent(e.ctx->stream, c.uploaded, 0));
-      const hg_status st = hg_sketch_batch_dev(e.ctx, c.d, c.offs.data(), c.lens.data(), m, &s->p, e.d_hv, e.d_n2, e.d_nh);
+      ST_HIP(s, hipStreamWaitEvent(w.ctx->stream, c.uploaded, 0));
+      if (c.n_jobs) {
+        hipLaunchKernelGGL(unpack2_kernel, dim3(c.n_blocks), dim3(256), 0, w.ctx->stream, c.dpk, c.d, c.d_jobs, c.n_jobs);
+        ST_HIP(s, hipGetLastError());
+      }
+      const hg_status st = hg_sketch_batch_dev(w.ctx, c.d, c.offs.data(), c.lens.data(), m, &s->p, w.d_hv, w.d_n2, w.d_nh);
       if (st != HG_OK) {
-        fail(s, st, std::string("device ") + std::to_string(e.device) + ": " + hg_last_error(e.ctx));
+        fail(s, st, std::string("device ") + std::to_string(e.device) + ": " + hg_last_error(w.ctx));
         return false;
       }
       const size_t hvb = m * D * sizeof(int16_t), hvb_al = (CHUNK_GENOMES * D * sizeof(int16_t) + 63) & ~(size_t)63;
-      ST_HIP(s, hipMemcpyAsync(e.h_res, e.d_hv, hvb, hipMemcpyDeviceToHost, e.ctx->stream));
-      ST_HIP(s, hipMemcpyAsync(e.h_res + hvb_al, e.d_n2, m * 4, hipMemcpyDeviceToHost, e.ctx->stream));
-      ST_HIP(s, hipMemcpyAsync(e.h_res + hvb_al + CHUNK_GENOMES * 4, e.d_nh, m * 4, hipMemcpyDeviceToHost, e.ctx->stream));
-      ST_HIP(s, hipStreamSynchronize(e.ctx->stream));
+      ST_HIP(s, hipMemcpyAsync(w.h_res, w.d_hv, hvb, hipMemcpyDeviceToHost, w.ctx->stream));
+      ST_HIP(s, hipMemcpyAsync(w.h_res + hvb_al, w.d_n2, m * 4, hipMemcpyDeviceToHost, w.ctx->stream));
+      ST_HIP(s, hipMemcpyAsync(w.h_res + hvb_al + CHUNK_GENOMES * 4, w.d_nh, m * 4, hipMemcpyDeviceToHost, w.ctx->stream));
+      ST_HIP(s, hipStreamSynchronize(w.ctx->stream));
       Done d;
       d.tags = c.tags;
-      d.hv.assign(reinterpret_cast<int16_t *>(e.h_res), reinterpret_cast<int16_t *>(e.h_res) + m * D);
-      d.n2.assign(reinterpret_cast<int32_t *>(e.h_res + hvb_al), reinterpret_cast<int32_t *>(e.h_res + hvb_al) + m);
-      d.nh.assign(reinterpret_cast<uint32_t *>(e.h_res + hvb_al + CHUNK_GENOMES * 4),
-                  reinterpret_cast<uint32_t *>(e.h_res + hvb_al + CHUNK_GENOMES * 4) + m);
+      d.hv.assign(reinterpret_cast<int16_t *>(w.h_res), reinterpret_cast<int16_t *>(w.h_res) + m * D);
+      d.n2.assign(reinterpret_cast<int32_t *>(w.h_res + hvb_al), reinterpret_cast<int32_t *>(w.h_res + hvb_al) + m);
+      d.nh.assign(reinterpret_cast<uint32_t *>(w.h_res + hvb_al + CHUNK_GENOMES * 4),
+                  reinterpret_cast<uint32_t *>(w.h_res + hvb_al + CHUNK_GENOMES * 4) + m);
       std::lock_guard<std::mutex> lk(s->mu);
       e.t_comp_run += now_s() - tr, ++e.n_chunks;
       e.load -= std::min(e.load, c.bytes);
@@ -266,18 +368,29 @@ void destroy(hg_sketch_stream *s) {
   }
   for (Engine *e : s->eng) {
     if (e->up.joinable()) e->up.join();
-    if (e->comp.joinable()) e->comp.join();
+    for (auto &w : e->w)
+      if (w.th.joinable()) w.th.join();
+    if (!e->w[0].ctx) {  // never opened (bad device id): nothing to release, and no HIP call that would leave an error behind
+      delete e;
+      continue;
+    }
     (void)hipSetDevice(e->device);
     if (e->copy) (void)hipStreamSynchronize(e->copy);
     for (Chunk &c : e->chunk) {
       if (c.d) (void)hipFree(c.d);
       if (c.stage) (void)hipHostFree(c.stage);
+      if (c.dpk) (void)hipFree(c.dpk);
+      if (c.h_jobs) (void)hipHostFree(c.h_jobs);
+      if (c.d_jobs) (void)hipFree(c.d_jobs);
       if (c.uploaded) (void)hipEventDestroy(c.uploaded);
     }
-    if (e->d_hv) (void)hipFree(e->d_hv);
-    if (e->h_res) (void)hipHostFree(e->h_res);
+    for (auto &w : e->w) {
+      if (w.d_hv) (void)hipFree(w.d_hv);
+      if (w.h_res) (void)hipHostFree(w.h_res);
+    }
     if (e->copy) (void)hipStreamDestroy(e->copy);
-    if (e->ctx) hg_ctx_destroy(e->ctx);
+    for (auto &w : e->w)
+      if (w.ctx) hg_ctx_destroy(w.ctx);
     delete e;
   }
   delete s;
@@ -304,7 +417,7 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
     }
     s->eng.push_back(e);
     e->device = device_ids[i];
-    hg_status st = hg_ctx_create(device_ids[i], &e->ctx);
+    hg_status st = hg_ctx_create(device_ids[i], &e->w[0].ctx);
     hipError_t he = hipSuccess;
     if (st == HG_OK) {
       if ((he = hipSetDevice(e->device)) == hipSuccess)
@@ -314,13 +427,15 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
           e->chunk[k].cap = CHUNK_BYTES + 64, he = hipEventCreateWithFlags(&e->chunk[k].uploaded, hipEventDisableTiming);
         e->free_chunks.push_back(k);
       }
-      void *dres = nullptr;
-      if (he == hipSuccess) he = hipMalloc(&dres, hvb_al + CHUNK_GENOMES * 8);
-      if (he == hipSuccess) {
-        e->d_hv = static_cast<int16_t *>(dres);
-        e->d_n2 = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dres) + hvb_al);
-        e->d_nh = reinterpret_cast<uint32_t *>(e->d_n2 + CHUNK_GENOMES);
-        he = hipHostMalloc(reinterpret_cast<void **>(&e->h_res), hvb_al + CHUNK_GENOMES * 8, hipHostMallocDefault);
+      for (int wi = 0; wi < N_WORKERS && he == hipSuccess && st == HG_OK; ++wi) {
+        Engine::Worker &w = e->w[wi];
+        if (wi && (st = hg_ctx_create(device_ids[i], &w.ctx)) != HG_OK) break;
+        void *dres = nullptr;
+        if ((he = hipMalloc(&dres, hvb_al + CHUNK_GENOMES * 8)) != hipSuccess) break;
+        w.d_hv = static_cast<int16_t *>(dres);
+        w.d_n2 = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(dres) + hvb_al);
+        w.d_nh = reinterpret_cast<uint32_t *>(w.d_n2 + CHUNK_GENOMES);
+        he = hipHostMalloc(reinterpret_cast<void **>(&w.h_res), hvb_al + CHUNK_GENOMES * 8, hipHostMallocDefault);
       }
     }
     if (st != HG_OK || he != hipSuccess) {
@@ -331,13 +446,23 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
   }
   for (Engine *e : s->eng) {
     e->up = std::thread(uploader, s, e);
-    e->comp = std::thread(computer, s, e);
+    for (int wi = 0; wi < N_WORKERS; ++wi) e->w[wi].th = std::thread(computer, s, e, wi);
   }
   *out = s;
   return HG_OK;
 }
 
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed);
+
 extern "C" hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag) {
+  return push_item(s, seq, len, tag, false);
+}
+
+extern "C" hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag) {
+  return push_item(s, blob, n_bps, tag, true);
+}
+
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed) {
   if (!s || (len && !seq)) return HG_ERR_INVALID;
   std::unique_lock<std::mutex> lk(s->mu);
   if (s->finishing) return HG_ERR_INVALID;
@@ -346,7 +471,7 @@ extern "C" hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *s
   Engine *best = s->eng[0];
   for (Engine *e : s->eng)
     if (e->load < best->load) best = e;
-  best->in.push_back(Item{seq, len, tag});
+  best->in.push_back(Item{seq, len, tag, packed});
   best->load += (len + 15) & ~(size_t)15;
   ++s->pushed;
   s->cv_in.notify_all();
@@ -386,6 +511,19 @@ extern "C" const char *hg_sketch_stream_last_error(hg_sketch_stream *s) {
   if (!s) return "";
   std::lock_guard<std::mutex> lk(s->mu);
   return s->msg.c_str();
+}
+
+extern "C" hg_status hg_unpack2_dev(hg_ctx *c, const uint8_t *d_blob, size_t n_bps, uint8_t *d_seq_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (n_bps == 0) return HG_OK;
+  if (!d_blob || !d_seq_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  if (((uintptr_t)d_blob | (uintptr_t)d_seq_out) & 15) return hg_fail(c, HG_ERR_INVALID, "hg_unpack2_dev: pointers must be 16-byte aligned");
+  HG_HIP(c, hipSetDevice(c->device));
+  const uint64_t groups = (n_bps + 15) / 16;
+  hipLaunchKernelGGL(unpack2_one_kernel, dim3((unsigned)((groups + UNPACK_GROUPS_PER_BLOCK - 1) / UNPACK_GROUPS_PER_BLOCK)),
+                     dim3(256), 0, c->stream, d_blob, d_seq_out, (uint64_t)n_bps);
+  HG_HIP(c, hipGetLastError());
+  return HG_OK;
 }
 
 extern "C" hg_status hg_sketch_stream_stats(hg_sketch_stream *s, int engine, double out[6]) {

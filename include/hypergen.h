@@ -263,6 +263,10 @@ void hg_sketch_file_free(hg_sketch_file *f);
 typedef struct hg_sketch_stream hg_sketch_stream;
 hg_status hg_sketch_stream_open(const int *device_ids, int n_devices, const hg_sketch_params *p, hg_sketch_stream **out);
 hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t n_bps, uint64_t tag);
+/* the same genome as a hg_pack2 blob (3 bits per base over the link instead of 8; expanded on the device into the
+ * ASCII the kernels would have classified the same way: results are bit-identical).  The blob must have been
+ * packed with the stream's norm_mode. */
+hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
 hg_status hg_sketch_stream_pop(hg_sketch_stream *s, uint64_t *tag, int16_t *hv_out, int32_t *norm2_out,
                                uint32_t *nhash_out, int *got);
 hg_status hg_sketch_stream_finish(hg_sketch_stream *s);
@@ -272,6 +276,16 @@ const char *hg_sketch_stream_last_error(hg_sketch_stream *s);
  * thread from "chunk taken" to "results queued" (includes waiting for the chunk's upload); out[5] = chunks so far */
 hg_status hg_sketch_stream_stats(hg_sketch_stream *s, int engine, double out[6]);
 void hg_sketch_stream_close(hg_sketch_stream *s);
+
+/* ---- 2-bit packing for the PCIe link (optional) ----------------------------------------------------
+ * hg_pack2 writes hg_pack2_size(n_bps) bytes: 2-bit codes (A,C,G,T = 0..3, 4 bases per byte, LSB first) padded to
+ * 16 bytes, then a not-a-base bit per position padded to 16 bytes.  Bases are what the kernels accept under
+ * `norm_mode` (ACGTacgt, plus Uu -> T under HG_NORM_U2T).  `out` may equal `seq` when the buffer holds
+ * max(n_bps, hg_pack2_size(n_bps)) bytes.  hg_unpack2_dev is the device inverse ('A','C','G','T' / 'N'; 16-byte
+ * aligned device pointers, d_seq_out with room for n_bps rounded up to 16), in stream order on the ctx's stream. */
+size_t hg_pack2_size(size_t n_bps);
+hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out);
+hg_status hg_unpack2_dev(hg_ctx *ctx, const uint8_t *d_blob, size_t n_bps, uint8_t *d_seq_out);
 
 /* ---- FASTA ingest (host side; src/fastx_reader.rs:6-29) ------------------------------- */
 /* read_merge_seq: returns a malloc'ed buffer (free with hg_free) and its length */
@@ -287,6 +301,10 @@ hg_status hg_read_merge_seq_into(const char *path, uint8_t **buf, size_t *cap, s
  * inflate gzip input transparently. */
 #define HG_READ_MERGE 0u
 #define HG_READ_NEEDLETAIL 1u
+/* OR-ed into the mode: the buffer comes back as the hg_pack2 blob of the merged sequence (*n_bps = its bases),
+ * packed for HG_NORM_ACGT, or for HG_NORM_U2T with HG_READ_PACK2_U2T as well -- for hg_sketch_stream_push_packed */
+#define HG_READ_PACK2 16u
+#define HG_READ_PACK2_U2T 32u
 hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **buf, size_t *cap, size_t *n_bps);
 /* same, but the buffer is page-locked host memory owned by the library (hipHostMalloc, visible to every device;
  * *buf NULL or from an earlier call, release with hg_pinned_free): hg_sketch_batch uploads such sequences by DMA at

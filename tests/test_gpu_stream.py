@@ -101,3 +101,69 @@ def test_stream_params_and_errors(hg, orc):
         hg.SketchStream((0,), bad)
     with pytest.raises(hg.HgError):
         hg.SketchStream((99,), p)
+
+
+def _dirty(orc, g, L, rng):
+    seq = orc.synth_genome(g, L)[1:].copy() if L else np.zeros(0, np.uint8)
+    if L > 100:
+        seq[rng.choice(L, max(1, L // 5000), replace=False)] = ord("N")
+        a = int(rng.integers(0, L - 60))
+        seq[a:a + 50] = np.char.lower(seq[a:a + 50].view("S1")).view(np.uint8)
+        b = int(rng.integers(0, L - 60))
+        seq[b:b + 40] = rng.choice(np.frombuffer(b"UuRYKM-*", np.uint8), 40)
+    return seq
+
+
+@pytest.mark.parametrize("norm", [0, 1])
+def test_unpack2_dev_is_the_normalised_ascii(hg, orc, norm):
+    """pack on the host, expand on the device: 'A','C','G','T' where the kernels see a base (u/U -> T under U2T), 'N' elsewhere"""
+    import torch
+    rng = np.random.default_rng(11 + norm)
+    with hg.Context(0) as ctx:
+        for L in (1, 15, 16, 17, 4095, 4096, 16_385, 1_000_003):
+            seq = _dirty(orc, 5, L, rng) if L > 100 else rng.choice(np.frombuffer(b"ACGTNacgtU", np.uint8), L)
+            blob = torch.from_numpy(hg.pack2(seq, norm)).cuda()
+            out = torch.full(((L + 15) // 16 * 16,), 0x7F, dtype=torch.uint8, device="cuda")
+            ctx.unpack2_dev(blob.data_ptr(), L, out.data_ptr())
+            ctx.sync()
+            up = seq & 0xDF
+            ok = (up == 65) | (up == 67) | (up == 71) | (up == 84) | ((up == 85) if norm else np.zeros(L, bool))
+            want = np.where(ok, np.where(up == 85, 84, up), ord("N")).astype(np.uint8)
+            assert np.array_equal(out.cpu().numpy()[:L], want), L
+
+
+@pytest.mark.parametrize("norm", [0, 1])
+def test_stream_packed_equals_ascii(hg, orc, norm):
+    rng = np.random.default_rng(21 + norm)
+    lens = [0, 5, 21, 40, 3_000, 100_000, 777_777, 5_000_000, 70_000_000, 2_222]
+    genomes = [_dirty(orc, 30 + i, L, rng) for i, L in enumerate(lens)]
+    p = hg.default_params(scaled=300, norm_mode=norm)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch(genomes, p)
+    with hg.SketchStream((0,), p) as st:
+        for i, g in enumerate(genomes):
+            if i % 3 == 2:
+                st.push(g, i)  # mixed chunks: ASCII and packed genomes side by side
+            else:
+                st.push_packed(hg.pack2(g, norm), g.size, i)
+        st.finish()
+        out = _drain(st, len(genomes))
+    for i in range(len(genomes)):
+        assert out[i][2] == nh[i] and out[i][1] == n2[i] and np.array_equal(out[i][0], hv[i]), i
+    w_hv, w_n2, w_nh = orc.sketch_genome(genomes[5], scaled=300, norm=norm)
+    assert nh[5] == w_nh and n2[5] == w_n2 and np.array_equal(hv[5], w_hv)
+
+
+def test_read_fastx_pinned_pack_flag(hg, orc, tmp_path):
+    seq = _dirty(orc, 9, 200_000, np.random.default_rng(2))
+    f = tmp_path / "g.fna"
+    body = seq.tobytes()
+    f.write_bytes(b">g\n" + b"\n".join(body[j:j + 70] for j in range(0, len(body), 70)) + b"\n")
+    merged = hg.read_merge_seq(str(f))
+    with hg.PinnedReader() as rd:
+        for mode, norm in ((hg.READ_MERGE | 16, 0), (hg.READ_NEEDLETAIL | 16 | 32, 1)):
+            blob = rd.read(str(f), mode=mode)
+            n = merged.size
+            assert blob.size == n  # the view is n_bps long; the blob occupies its first hg_pack2_size(n) bytes
+            size = hg.lib().hg_pack2_size(n)
+            assert np.array_equal(blob[:size], hg.pack2(merged, norm))
