@@ -167,3 +167,52 @@ def test_read_fastx_pinned_pack_flag(hg, orc, tmp_path):
             assert blob.size == n  # the view is n_bps long; the blob occupies its first hg_pack2_size(n) bytes
             size = hg.lib().hg_pack2_size(n)
             assert np.array_equal(blob[:size], hg.pack2(merged, norm))
+
+
+def test_stream_concurrent_push_pop_and_early_close(hg, orc):
+    """four pushers and two poppers at once; then a stream that is closed with results outstanding must not hang"""
+    base = orc.synth_genome(12, 600_000)[1:]
+    rng = np.random.default_rng(8)
+    n = 3000
+    starts = rng.integers(0, base.size - 20_000, n)
+    sizes = rng.integers(30, 20_000, n)
+    p = hg.default_params(scaled=50)
+    genomes = [base[s:s + m] for s, m in zip(starts, sizes)]
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch(genomes, p)
+    got, lock = {}, threading.Lock()
+    with hg.SketchStream((0, 0), p) as st:
+        def pusher(t):
+            for i in range(t, n, 4):
+                if i % 5 == 0:
+                    st.push_packed(hg.pack2(genomes[i]), genomes[i].size, i)
+                else:
+                    st.push(genomes[i], i)
+
+        def popper():
+            while True:
+                with lock:
+                    if len(got) >= n:
+                        return
+                r = st.pop()
+                if r is None:
+                    return
+                with lock:
+                    got[r[0]] = r[1:]
+        pu = [threading.Thread(target=pusher, args=(t,)) for t in range(4)]
+        po = [threading.Thread(target=popper) for _ in range(2)]
+        for t in pu + po:
+            t.start()
+        for t in pu:
+            t.join()
+        st.finish()
+        for t in po:
+            t.join()
+    assert len(got) == n
+    for i in range(n):
+        assert got[i][2] == nh[i] and got[i][1] == n2[i] and np.array_equal(got[i][0], hv[i]), i
+    st = hg.SketchStream((0,), p)
+    for i in range(200):
+        st.push(genomes[i], i)
+    st.pop()
+    st.close()  # 199 results dropped
