@@ -7,6 +7,7 @@
 // reproduced (cpu: needletail, u/U -> T; gpu: src/cuda_kernel.cu, ACGTacgt only).
 #include <glob.h>
 #include <sched.h>
+#include <unistd.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -59,7 +60,8 @@ void debugf(const char *fmt, ...) {
 
 [[noreturn]] void die(const std::string &msg) {
   std::fprintf(stderr, "error: %s\n", msg.c_str());
-  std::exit(2);
+  std::fflush(nullptr);
+  _exit(2);  // not exit(): reader threads, or a thread that is bringing the HIP runtime up, may still be running
 }
 
 struct Cli {
@@ -406,13 +408,22 @@ int run_dist(const Cli &c) {
   const auto t0 = std::chrono::steady_clock::now();
   const bool sym = c.path_r == c.path_q;  // src/dist.rs:13
   Loaded R, Qs;
+  double tp = now_s();
+  hg_multi *multi = nullptr;
+  std::thread opener([&] {  // the HIP runtime comes up (~0.2 s) while the sketch files are read and decompressed
+    const double td = now_s();
+    multi = open_all_devices();
+    debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
+  });
   load(c.path_r, R, c.threads);
   if (!sym) load(c.path_q, Qs, c.threads);
+  debugf("sketch files loaded and decompressed in %.1f ms", (now_s() - tp) * 1e3);
+  opener.join();
   const Loaded &Q = sym ? R : Qs;
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
   if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
   logline("INFO", "Computing ANI..");
-  hg_multi *multi = open_all_devices();
+  tp = now_s();
   const size_t total = sym ? R.n * (Q.n - 1) / 2 : R.n * Q.n;
   std::vector<hg_ani_hit> hits(std::max<size_t>(1024, total / 16));
   size_t found = 0;
@@ -428,21 +439,45 @@ int run_dist(const Cli &c) {
     break;
   }
   hits.resize(found);
+  debugf("ANI matrix (%zu hits) in %.1f ms", found, (now_s() - tp) * 1e3);
+  tp = now_s();
   // dump_ani_file's order (src/utils.rs:262-269), produced on the device: two stable radix passes instead of a
   // comparison sort of up to 10^6..10^8 triples on one host core
   ck(hg_multi_ctx(multi, 0), hg_sort_ani_hits_staged(hg_multi_ctx(multi, 0), hits.data(), hits.size(), Q.n), "sort");
-  std::string tsv;
-  char line[64];
-  for (const auto &h : hits) {
-    tsv += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
-    tsv += '\t';
-    tsv += hg_sketch_file_get(Q.f, h.qry_idx)->file_str;
-    std::snprintf(line, sizeof line, "\t%.3f\n", (double)h.ani);  // "{}\t{}\t{:.3}\n", src/utils.rs:277-282
-    tsv += line;
+  debugf("hits ordered in %.1f ms", (now_s() - tp) * 1e3);
+  tp = now_s();
+  // "{}\t{}\t{:.3}\n" (src/utils.rs:277-282), formatted by -t threads over contiguous ranges of the ordered hits
+  const size_t FT = std::max<size_t>(1, std::min<size_t>(c.threads, hits.size() / 4096 + 1));
+  std::vector<std::string> part(FT);
+  {
+    auto fmt = [&](size_t t) {
+      const size_t lo = hits.size() * t / FT, hi = hits.size() * (t + 1) / FT;
+      std::string &o = part[t];
+      o.reserve((hi - lo) * 96);
+      char line[64];
+      for (size_t i = lo; i < hi; ++i) {
+        const hg_ani_hit &h = hits[i];
+        o += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
+        o += '\t';
+        o += hg_sketch_file_get(Q.f, h.qry_idx)->file_str;
+        o.append(line, (size_t)std::snprintf(line, sizeof line, "\t%.3f\n", (double)h.ani));
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < FT; ++t) th.emplace_back(fmt, t);
+    fmt(0);
+    for (auto &t : th) t.join();
   }
+  size_t tsv_bytes = 0;
+  for (const auto &o : part) tsv_bytes += o.size();
+  debugf("TSV formatted (%.1f MB) in %.1f ms", tsv_bytes / 1e6, (now_s() - tp) * 1e3);
+  tp = now_s();
   FILE *f = std::fopen(c.out.c_str(), "wb");
-  if (!f || (tsv.size() && std::fwrite(tsv.data(), 1, tsv.size(), f) != tsv.size())) die("Dump ANI file failed!");
-  std::fclose(f);
+  if (!f) die("Dump ANI file failed!");
+  for (const auto &o : part)
+    if (o.size() && std::fwrite(o.data(), 1, o.size(), f) != o.size()) die("Dump ANI file failed!");
+  if (std::fclose(f) != 0) die("Dump ANI file failed!");
+  debugf("TSV written in %.1f ms", (now_s() - tp) * 1e3);
   char buf[512];
   const double perc = total ? 100.0 * found / total : 0.0;
   if (perc < 5.0) {
@@ -470,12 +505,14 @@ int run_search(const Cli &c) {
   if (c.path_r == "1" || c.path_q == "1" || c.out.empty()) return 0;
   const auto t0 = std::chrono::steady_clock::now();
   Loaded R, Q;
+  hg_multi *multi = nullptr;
+  std::thread opener([&] { multi = open_all_devices(); });  // the HIP runtime comes up while the files are read
   load(c.path_r, R, c.threads);
   load(c.path_q, Q, c.threads);
+  opener.join();
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
   if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
   logline("INFO", "Searching..");
-  hg_multi *multi = open_all_devices();
   std::vector<hg_ani_hit> hits(std::max<size_t>(1024, R.n * Q.n / 16));
   size_t found = 0;
   for (;;) {

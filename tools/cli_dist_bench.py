@@ -37,9 +37,12 @@ try:
     for rep in range(2):
         out = os.path.join(d, "ani.tsv")
         t0 = time.time()
-        subprocess.check_call([exe, "dist", "-r", sk, "-q", sk, "-o", out, "-t", str(a.threads)],
-                              stdout=subprocess.DEVNULL, stderr=None if rep else subprocess.DEVNULL)
+        o = subprocess.run([exe, "dist", "-r", sk, "-q", sk, "-o", out, "-t", str(a.threads)], check=True,
+                           stdout=subprocess.PIPE, stderr=None if rep else subprocess.DEVNULL,
+                           env=dict(os.environ, RUST_LOG="debug")).stdout.decode()
         dt = time.time() - t0
+        if rep:
+            print("\n".join(l.split(" - ", 1)[1] for l in o.splitlines() if " - " in l))
         lines = sum(1 for _ in open(out))
         print("hyper-gen dist %d x %d: %.2f s, %d TSV lines (%.1f MB)" % (a.n, a.n, dt, lines, os.path.getsize(out) / 1e6))
 finally:
