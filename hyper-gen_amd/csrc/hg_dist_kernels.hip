@@ -496,10 +496,16 @@ constexpr uint32_t ST = 8;       // super-tile edge, in tiles
 //   big  : 256 x 256, 8 waves, 144 KiB LDS, 1 workgroup / CU  -- half the LDS and L2 bytes per flop
 //   wide : 256 x 320 (NT = 5, LDS-DMA only): chosen when it divides the tile grid into fewer rounds over the
 //          CUs (10 000 x 10 000: 1 280 tiles = 5.0 rounds of 256 instead of 1 600 = 6.25 -> 7)
-template <bool BIG, int NT = 4>
+//   w4   : 256 x 256 on FOUR waves of 128 x 128 (NT = 8, 256 accumulators per lane pinned to AGPRs, one wave per SIMD):
+//          a wave reads (128 + 128) x 128 B of fragments per K-step for 128 MFMAs where the 8-wave shape reads
+//          (128 + 64) x 128 B for 64 -- at K = 16384 the 8-wave shape sits at the LDS read rate (126 B/clk/CU, 67 %
+//          matrix-pipe busy).  NEGATIVE so far: 8.2 ms against 6.5 ms on the Hamming search (256 x 192: 8.5 ms); with
+//          a single wave per SIMD nothing covers the per-step barrier and the fragment latency.  Kept behind the
+//          Hamming test hook "mfma4".
+template <bool BIG, int NT = 4, bool W4 = false>
 struct TileCfg {
   static constexpr int WTM = BIG ? 8 : 4;   // 16-row MFMA tiles per wave in M
-  static constexpr int NWN = BIG ? 4 : 2;   // waves in N
+  static constexpr int NWN = W4 ? 2 : (BIG ? 4 : 2);   // waves in N
   static constexpr int BM = 2 * WTM * 16, BN = NWN * NT * 16;  // NT = 16-column MFMA tiles per wave in N
   static constexpr int THREADS = 2 * NWN * 64;
   static constexpr int LOADS = BM * BK * 2 / 16 / THREADS;    // 16-byte pieces per thread, A operand
@@ -560,9 +566,10 @@ __device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...
 }
 // HAM (with I8): the operands are +-1 bytes expanded from bit-packed hypervectors, G = D - 2*hamming; the epilogue
 // keeps G >= ham_thr and reports {ref, qry, (D - G) / 2} -- the bit-packed search on the matrix pipe.
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false>
-__global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmArgs g) {
-  using TC = TileCfg<BIG, NT>;
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool W4 = false>
+__global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kernel(GemmArgs g) {
+  using TC = TileCfg<BIG, NT, W4>;
+  static_assert(!W4 || (BIG && GLDS && I8 && (NT == 6 || NT == 8)), "the four-wave shape exists for the i8 LDS-DMA path");
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
   static_assert(!GLDS || BIG, "LDS-DMA variant exists for the 256 x 256 geometry only");
   constexpr int LROW = GLDS ? BK : LDS_ROW;  // elements per LDS row
   constexpr int BM = TC::BM, BN = TC::BN, WTM = TC::WTM, NWN = TC::NWN, THREADS = TC::THREADS, LOADS = TC::LOADS;
-  static_assert(LOADS == 4 && (GLDS || TC::LOADS_B == 4), "staging macros move 4 pieces per operand");
+  static_assert(GLDS || (LOADS == 4 && TC::LOADS_B == 4), "staging macros move 4 pieces per operand");
   static_assert(NT == 4 || GLDS, "wide tiles exist for the LDS-DMA variant only");
   // two LDS stages of (A tile + B tile)
   extern __shared__ __attribute__((aligned(16))) _Float16 sAB[];
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
 #ifndef HG_DMA_LOADER_WAVES
 #define HG_DMA_LOADER_WAVES (HG_DMA_SPREAD ? 8 : 4)
 #endif
-  constexpr int LW = HG_DMA_LOADER_WAVES, LT = LW * 64;  // loader waves / threads
+  constexpr int LW = HG_DMA_LOADER_WAVES < THREADS / 64 ? HG_DMA_LOADER_WAVES : THREADS / 64, LT = LW * 64;  // loader waves / threads
   constexpr int PA = BM * 8 / LT, PB = BN * 8 / LT;      // 16-byte pieces per loader thread, A / B tile
   // byte offsets of this thread's pieces inside the A / B row block (fixed-size arrays: a template-sized
   // array here makes hipcc drop the kernel's host stub without a diagnostic)
@@ -741,8 +748,11 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }
-  constexpr int MP = WTM / 2, PHASES = (BK / 32) * MP;
-  half8 bfr[2][NT], afr[2][2];
+  // A fragments per phase: 2 (x NT B fragments = 8..10 MFMAs, another wave of the SIMD covers the fragment latency) or,
+  // with one wave per SIMD (W4), 4 x 8 = 32 MFMAs = 512 cycles between a fragment's request and its first use
+  constexpr int AF = W4 ? 4 : 2;
+  constexpr int MP = WTM / AF, PHASES = (BK / 32) * MP;
+  half8 bfr[2][NT], afr[2][AF];
   // fragments of phase (kk, mp) of the stage whose fragment bases are pa / pb, into buffer set `buf`
 #define HG_FRAGS(buf, pa, pb, kk, mp)                                                                       \
   {                                                                                                         \
@@ -751,8 +761,8 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                         \
           bfr[(kk) & 1][n] = *reinterpret_cast<const half8 *>((pb) + n * 16 * LROW + ko_);                  \
     }                                                                                                       \
-    afr[buf][0] = *reinterpret_cast<const half8 *>((pa) + (2 * (mp)) * 16 * LROW + ko_);                    \
-    afr[buf][1] = *reinterpret_cast<const half8 *>((pa) + (2 * (mp) + 1) * 16 * LROW + ko_);                \
+    _Pragma("unroll") for (int i_ = 0; i_ < AF; ++i_)                                                       \
+        afr[buf][i_] = *reinterpret_cast<const half8 *>((pa) + (AF * (mp) + i_) * 16 * LROW + ko_);         \
   }
   if (GLDS) {
     HG_DMA(0, 0)
@@ -797,21 +807,26 @@ __global__ __launch_bounds__(TileCfg<BIG>::THREADS) void dist_mfma_kernel(GemmAr
       __builtin_amdgcn_sched_barrier(0);
       if (HG_EXP(8)) {  // fragment reads without the MFMAs
 #pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(afr[t & 1][i]));
+        for (int i = 0; i < AF; ++i) asm volatile("" ::"v"(afr[t & 1][i]));
 #pragma unroll
         for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(bfr[kk & 1][n]));
       } else if (!HG_EXP(2)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < AF; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            if constexpr (I8)  // the same 16-byte fragments hold 16 k-consecutive bytes per lane: one instruction covers K = 64
-              acc[2 * mp + i][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(int4v, afr[t & 1][i]),
-                                                                         __builtin_bit_cast(int4v, bfr[kk & 1][n]),
-                                                                         acc[2 * mp + i][n], 0, 0, 0);
+            if constexpr (W4)  // > 256 live registers: pin the accumulators to AGPRs (the register allocator otherwise
+              // shuttles them between the two files inside the loop: 280 v_accvgpr moves per 96 MFMAs)
+              asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0"
+                           : "+a"(acc[AF * mp + i][n])
+                           : "v"(__builtin_bit_cast(int4v, afr[t & 1][i])), "v"(__builtin_bit_cast(int4v, bfr[kk & 1][n])));
+            else if constexpr (I8)  // the same 16-byte fragments hold 16 k-consecutive bytes per lane: one instruction covers K = 64
+              acc[AF * mp + i][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(int4v, afr[t & 1][i]),
+                                                                          __builtin_bit_cast(int4v, bfr[kk & 1][n]),
+                                                                          acc[AF * mp + i][n], 0, 0, 0);
             else
-              acc[2 * mp + i][n] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[2 * mp + i][n], 0, 0, 0);
+              acc[AF * mp + i][n] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[AF * mp + i][n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1116,7 +1131,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
                               uint32_t ref_off, uint32_t qry_off) {
   static_assert(sizeof(hg_ham_hit) == sizeof(hg_ani_hit), "the GEMM epilogue writes 12-byte records");
   const uint32_t words = hv_d / 32, ldk8 = hv_d + 128;  // hv_d is a multiple of 128 (checked by the caller)
-  auto padded = [](uint32_t n) { return std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320); };
+  auto padded = [](uint32_t n) { return std::max({(n + 255) / 256 * 256, (n + 319) / 320 * 320, (n + 191) / 192 * 192}); };
   const uint32_t Rp = padded(R), Qp = padded(Q);
   hg_status s;
   if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
@@ -1148,24 +1163,32 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   g.ref_off = ref_off, g.qry_off = qry_off, g.hv_d = hv_d;
   // dist <= max  <=>  G = D - 2*dist >= D - 2*max  (max >= D: everything is a hit)
   g.ham_thr = max_dist >= hv_d ? -(int32_t)hv_d - 1 : (int32_t)hv_d - 2 * (int32_t)max_dist;
-  int nt = 4;
-  {
+  // eight waves of 128 x 64 / 128 x 80; the four-wave shape of 128 x 128 (TileCfg) only through the test hook "mfma4":
+  // A/B on 50 000 x 10 000 x 16384: 8.2 ms against 6.5 ms
+  const bool w4 = c->dbg_ham_path == "mfma4";
+  int nt = w4 ? 8 : 4;
+  if (!w4) {
     const uint64_t tm = (R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
     const uint64_t r4 = (tm * ((Q + 255) / 256) + ncu - 1) / ncu, r5 = (tm * ((Q + 319) / 320) + ncu - 1) / ncu;
     if (r5 * 5 < r4 * 4) nt = 5;
   }
-  g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
+  const uint32_t bn = w4 ? 256u : (uint32_t)nt * 64;
+  g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
                              : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
-  const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true, true>)
-                           : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, true>);
+  const void *fp = w4        ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 8, true, true, true>)
+                   : nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true, true>)
+                             : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, true>);
   if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
     HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     c->lds_attr_done.push_back(fp);
   }
   hg_timed tg(c, HG_T_DIST);
-  if (nt == 5)
+  if (w4)
+    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 8, true, true, true>), dim3(n_tiles),
+                       dim3(TileCfg<true, 8, true>::THREADS), lds, c->stream, g);
+  else if (nt == 5)
     hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
                        c->stream, g);
   else
