@@ -817,7 +817,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
           for (int n = 0; n < NT; ++n)
             if constexpr (W4)  // > 256 live registers: pin the accumulators to AGPRs (the register allocator otherwise
               // shuttles them between the two files inside the loop: 280 v_accvgpr moves per 96 MFMAs)
-              asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0"
+              asm("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0"
                            : "+a"(acc[AF * mp + i][n])
                            : "v"(__builtin_bit_cast(int4v, afr[t & 1][i])), "v"(__builtin_bit_cast(int4v, bfr[kk & 1][n])));
             else if constexpr (I8)  // the same 16-byte fragments hold 16 k-consecutive bytes per lane: one instruction covers K = 64
