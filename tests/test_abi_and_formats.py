@@ -184,3 +184,60 @@ def test_cli_surface(hg):
     bad = subprocess.run([cli, "sketch", "-p", "/tmp", "-o", "/tmp/x", "-t", "300"], capture_output=True, text=True)
     assert bad.returncode != 0 and "invalid value" in bad.stderr  # -t is u8 (src/utils.rs:54-56)
     assert subprocess.run([cli, "frobnicate"], capture_output=True).returncode != 0
+
+
+def test_reader_blocks_equal_whole_file_semantics(hg, orc, tmp_path):
+    """The reader works through a file in 256 KiB blocks of whole lines: line ends, CRs, headers, FASTQ records and a
+    line longer than a block must come out as if the file had been merged in one piece (the oracle's whole-buffer
+    restatement), in both read modes, also 2-bit packed, also gzip-ed."""
+    import gzip
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTacgtNnU", np.uint8)
+
+    def seq(n):
+        return rng.choice(alpha, n, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .01, .01]).tobytes()
+
+    def fasta(total, width, crlf=False, blanks=False):
+        out, left = [], total
+        while left > 0:
+            out.append(b">rec %d\n" % len(out))
+            m = min(left, int(rng.integers(1, 400_000)))
+            body = seq(m)
+            for j in range(0, m, width):
+                line = body[j:j + width]
+                if blanks and rng.random() < 0.01 and len(line) > 4:
+                    line = line[:2] + b" \t" + line[2:]
+                out.append(line + (b"\r\n" if crlf else b"\n"))
+            left -= m
+        return b"".join(out)
+
+    def fastq(records):
+        out = []
+        for r in range(records):
+            m = int(rng.integers(20, 3000))
+            out.append(b"@r%d\n" % r + seq(m) + b"\n+\n" + bytes(rng.integers(33, 74, m, dtype=np.uint8)) + b"\n")
+        return b"".join(out)
+
+    cases = {
+        "w80": fasta(1_500_000, 80), "w61_crlf": fasta(900_000, 61, crlf=True), "blanks": fasta(700_000, 70, blanks=True),
+        "one_long_line": b">x\n" + seq(1_200_000) + b"\n>y\n" + seq(300_000),  # no trailing newline either
+        "exact_block": b">a\n" + seq((256 << 10) - 4) + b"\n" + seq(5000) + b"\n",  # a '\\n' as the block's last byte
+        "fastq": fastq(900), "tiny": b">t\nACGT", "empty": b"",
+    }
+    for name, txt in cases.items():
+        for gz in (False, True):
+            f = tmp_path / ("%s%s.fna" % (name, "_gz" if gz else ""))
+            f.write_bytes(gzip.compress(txt, 1) if gz else txt)
+            for mode, want, norm in ((hg.READ_MERGE, orc.read_merge_seq(txt), 0), (hg.READ_NEEDLETAIL, orc.read_needletail(txt), 1)):
+                got = hg.read_merge_seq(str(f), mode)
+                assert got.size == want.size and (got == want).all(), (name, gz, mode)
+                p, n, cap = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+                flags = mode | 16 | (32 if norm else 0)
+                assert hg.lib().hg_read_fastx_into(str(f).encode(), flags, C.byref(p), C.byref(cap), C.byref(n)) == 0
+                try:
+                    assert n.value == want.size
+                    size = hg.lib().hg_pack2_size(n.value)
+                    blob = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(size, 1),))[:size]
+                    assert (blob == hg.pack2(want, norm)).all(), (name, gz, mode, "packed")
+                finally:
+                    hg.lib().hg_free(p)
