@@ -112,7 +112,7 @@ def valu_issue(n_genomes):
     ppath, ipath = newest_profile("_pmc.json"), newest_profile("_kmer_isa.json")
     try:
         d = json.load(open(ppath))
-        k = [v for name, v in d.items() if name.startswith("kmer_sample_fast")][0]
+        k = max((v for name, v in d.items() if name.startswith("kmer_sample_")), key=lambda v: v.get("GRBM_GUI_ACTIVE", 0))
         insts, cycles = k["SQ_INSTS_VALU"], k["GRBM_GUI_ACTIVE"] / 8.0
         isa = json.load(open(ipath))
         slow_frac = isa["per_kmer"]["slow_class"] / isa["per_kmer"]["valu"]
@@ -276,10 +276,10 @@ def main():
                    "genomes_per_gpu": N, "genome_bp": L_GENOME, "parallelism": "genome-sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "kmer_sample_fast<21,true>", "launch_ms": kmer_avg_ms,
+                     "kernel": "kmer_sample_grouped<21>", "launch_ms": kmer_avg_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "nominally a scan, so priced against HBM; the true binder is integer VALU issue "
-                             "(~97 VALU instructions per k-mer, ~60 of them the t1ha2 hash; see valu_issue)",
+                             "(~80 VALU instructions per k-mer, ~51 of them the t1ha2 hash; see valu_issue)",
                      "valu_issue": valu_issue(N),
                      "kmer_hashes_per_sec": N * (L_GENOME + 1 - KSIZE + 1) / (kmer_avg_ms * 1e-3)},
         "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in tm.items() if v[1]},

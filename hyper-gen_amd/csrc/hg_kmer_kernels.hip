@@ -152,10 +152,13 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F 
 
 // ---- geometry ---------------------------------------------------------------------------
 constexpr int WG = 256;        // lanes per workgroup
-constexpr int TILES_PER_ITEM = 8;
+// tiles of a work item: 8, or 9 where a lane owns 12 starts per tile (k = 18..21) -- the grouped kernel walks the
+// same item as 3 tiles of 3 x 12 starts per lane
+constexpr int tiles_per_item(int k) { return (((33 - k) & ~3) == 12) ? 9 : 8; }
 template <int K>
 struct Geo {
   static constexpr int M = (33 - K) & ~3;  // k-mer starts per lane, multiple of 4 (dword stride)
+  static constexpr int TILES_PER_ITEM = tiles_per_item(K);
   static constexpr int ND = (K + 3) / 4;   // dwords of one k-mer
   static constexpr int NB = K - 4 * (ND - 1);  // bytes used in the last dword (1..4)
   static constexpr int TILE = WG * M;
@@ -172,6 +175,12 @@ constexpr uint32_t FAST64_FROM = 22;
 // test for waves that saw only bases), 0 = register extraction of both strands + mux
 #ifndef HG_KMER_DEFAULT_VAR
 #define HG_KMER_DEFAULT_VAR 28
+#endif
+#ifndef HG_U2T_HOIST
+#define HG_U2T_HOIST 1  /* the u/U -> T rewrite behind one branch per window (0: one branch per dword) */
+#endif
+#ifndef HG_KMER_GROUPED
+#define HG_KMER_GROUPED 1  /* canonical k = 19, 21: kmer_sample_grouped instead of kmer_sample_fast (A/B: -DHG_KMER_GROUPED=0) */
 #endif
 constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
   constexpr bool PREFETCH = (VAR & 32) != 0;
   if (PREFETCH && item_start < n_starts) load_window(item_start);
 #pragma unroll 1
-  for (int tile = 0; tile < TILES_PER_ITEM; ++tile) {
+  for (int tile = 0; tile < G::TILES_PER_ITEM; ++tile) {
     const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
     if (tile_start >= n_starts) break;  // uniform
     const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * M;
@@ -275,20 +284,32 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     if (!PREFETCH) load_window(tile_start);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = xn[t];
-    if (PREFETCH && tile + 1 < TILES_PER_ITEM && tile_start + G::TILE < n_starts) load_window(tile_start + G::TILE);
+    if (PREFETCH && tile + 1 < G::TILES_PER_ITEM && tile_start + G::TILE < n_starts) load_window(tile_start + G::TILE);
 
     // ---- classify 4 bases per dword -----------------------------------------------------
     uint32_t FA[8], CA[8];      // upper-case ASCII, complement ASCII (same byte order)
     uint32_t dacc = 0;          // != 0  <=> some byte of the window is not ACGTacgt
     uint32_t Glo = 0, Ghi = 0;  // 2-bit codes, base b at bits [2b, 2b+1]
+#if HG_U2T_HOIST
+    if (u2t) {  // needletail normalize: u/U -> T  ('U' ^ 'T' == 1); ONE uniform branch per window
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t e = (x[t] & 0xDFDFDFDFu) ^ 0x55555555u;
+        const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
+        x[t] ^= (~nz & 0x80808080u) >> 7;
+      }
+    }
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      uint32_t xv = x[t];
-      if (u2t) {  // needletail normalize: u/U -> T  ('U' ^ 'T' == 1)
-        uint32_t e = (xv & 0xDFDFDFDFu) ^ 0x55555555u;
-        uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
-        xv ^= (~nz & 0x80808080u) >> 7;
+#if !HG_U2T_HOIST
+      if (u2t) {
+        const uint32_t e = (x[t] & 0xDFDFDFDFu) ^ 0x55555555u;
+        const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;
+        x[t] ^= (~nz & 0x80808080u) >> 7;
       }
+#endif
+      const uint32_t xv = x[t];
       uint32_t u = xv & 0xDFDFDFDFu;
       uint32_t tt = xv ^ (xv >> 1);
       uint32_t cd = (tt >> 1) & 0x03030303u;  // A,C,G,T -> 0,1,2,3 per byte
@@ -317,12 +338,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     if (wave_dirty) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        uint32_t xv = x[t];
-        if (u2t) {
-          uint32_t e = (xv & 0xDFDFDFDFu) ^ 0x55555555u;
-          uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;
-          xv ^= (~nz & 0x80808080u) >> 7;
-        }
+        const uint32_t xv = x[t];  // (u/U already turned into T above)
         uint32_t d = (xv & 0xDFDFDFDFu) ^ FA[t];
         uint32_t z = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
         uint32_t nib = (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
@@ -478,6 +494,199 @@ __global__ __launch_bounds__(WG) void kmer_sample_fast(
     };
     if ((VAR & 16) != 0 && !wave_dirty) run_kmers(std::false_type{});
     else run_kmers(std::true_type{});
+  }
+  flush_hits(stage, gm, g, hits, cnt);
+}
+
+// =========================================================================================
+// grouped kernel: canonical k = 18..21 (12 k-mer starts per 32-base window)
+// =========================================================================================
+// kmer_sample_fast spends 12.5 of its 75 VALU instructions per k-mer on what happens once per tile and lane -- loading
+// and classifying the 32-base window, packing its 2-bit codes, writing the LDS image -- for only 12 k-mers, whose
+// windows overlap their neighbours' by 20 bases.  Here a lane owns a 56-base window and three GROUPS of 12 k-mers:
+// the window is loaded, classified and written to LDS (forward image + reverse complement, 112 bytes) once, and each
+// group runs the same 12-k-mer body on its own 32-base slice -- the code words of the slice come out of the window's
+// 112-bit code streams with four v_alignbit each, its LDS offsets are the image offsets -/+ 12 g bytes (a multiple
+// of 4: the run-time byte shift of the hash words does not change), taken through one selected base pointer.
+// The group loop is a real loop (three unrolled copies of 2 x 12 hash bodies would not fit the instruction cache).
+template <int K>
+__global__ __launch_bounds__(WG) void kmer_sample_grouped(
+    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
+    const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
+    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  using G = Geo<K>;
+  static_assert(G::M == 12 && (K & 1), "written for 12 starts per slice and odd k (unmasked strand compare)");
+  constexpr int M = 12, GROUPS = 3, MB = M * GROUPS, BW = (GROUPS - 1) * M + 32, NDW = BW / 4;  // 36 starts, 56 bases, 14 dwords
+  constexpr int ND = G::ND, NB = G::NB, NW = (K + 7) / 8;
+  constexpr int PITCH = 2 * BW + 4;  // 116 bytes = 29 dwords: odd, the lanes' dword accesses spread over the banks
+  constexpr int TILE = WG * MB, TILES = G::ITEM / TILE;
+  static_assert(TILES * TILE == G::ITEM, "the work item is a whole number of grouped tiles");
+  constexpr uint32_t MASKK = (1u << K) - 1;
+
+  const uint32_t item = blockIdx.x;
+  const uint32_t g = item_genome[item];
+  const hg_genome_meta gm = meta[g];
+  const uint64_t n_bps = gm.n_bps;
+  if (n_bps < (uint64_t)K) return;
+  const uint64_t n_starts = n_bps - K + 1;
+  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+  __shared__ HitStage stage;
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[WG * PITCH + 16];
+  uint8_t *const mywin = s_win + threadIdx.x * PITCH;
+  if (threadIdx.x == 0) stage.n = 0;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int tile = 0; tile < TILES; ++tile) {
+    const uint64_t tile_start = item_start + (uint64_t)tile * TILE;
+    if (tile_start >= n_starts) break;  // uniform
+    const uint64_t p0 = tile_start + (uint64_t)threadIdx.x * MB;
+    uint32_t x[NDW];
+    {
+      // 56 bytes; a window that would run more than 32 bytes past the genome end (the slack every caller provides) is
+      // read from the genome start instead and, if it holds bases at all, refilled byte by byte
+      const bool in = p0 + BW <= n_bps + 32;
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(gseq + (in ? p0 : 0));
+#pragma unroll
+      for (int t = 0; t < NDW; ++t) x[t] = src[t];
+      if (!in && p0 < n_bps) {
+#pragma unroll 1
+        for (int t = 0; t < NDW; ++t) {
+          uint32_t w = 0;
+          for (int bb = 0; bb < 4; ++bb) {
+            const uint64_t pos = p0 + 4 * t + bb;
+            w |= (uint32_t)(pos < n_bps ? gseq[pos] : (uint8_t)'N') << (8 * bb);
+          }
+          x[t] = w;
+        }
+      }
+    }
+    // ---- classify 4 bases per dword; code streams of the window: W LSB-first (base b at bits 2b..2b+1 of the
+    // 128-bit value), V MSB-first (base 0 in the top two bits) --------------------------------------------------
+    uint32_t FA[NDW], CA[NDW];
+    uint32_t dacc = 0;
+    uint32_t W[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+#if HG_U2T_HOIST
+    if (u2t) {  // needletail normalize: u/U -> T  ('U' ^ 'T' == 1); ONE uniform branch per window
+#pragma unroll
+      for (int t = 0; t < NDW; ++t) {
+        const uint32_t e = (x[t] & 0xDFDFDFDFu) ^ 0x55555555u;
+        const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
+        x[t] ^= (~nz & 0x80808080u) >> 7;
+      }
+    }
+#endif
+#pragma unroll
+    for (int t = 0; t < NDW; ++t) {
+#if !HG_U2T_HOIST
+      if (u2t) {
+        const uint32_t e = (x[t] & 0xDFDFDFDFu) ^ 0x55555555u;
+        const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;
+        x[t] ^= (~nz & 0x80808080u) >> 7;
+      }
+#endif
+      const uint32_t xv = x[t];
+      const uint32_t u = xv & 0xDFDFDFDFu;
+      const uint32_t tt = xv ^ (xv >> 1);
+      const uint32_t cd = (tt >> 1) & 0x03030303u;  // A,C,G,T -> 0,1,2,3 per byte
+      FA[t] = __builtin_amdgcn_perm(0u, 0x54474341u, cd);  // "ACGT"[code]
+      CA[t] = __builtin_amdgcn_perm(0u, 0x41434754u, cd);  // "TGCA"[code]
+      dacc |= u ^ FA[t];
+      const uint32_t pl = __builtin_amdgcn_udot4(cd, 0x40100401u, 0u, false);  // c0 | c1<<2 | c2<<4 | c3<<6
+      const uint32_t pm = __builtin_amdgcn_udot4(cd, 0x01041040u, 0u, false);  // c0<<6 | c1<<4 | c2<<2 | c3
+      W[t >> 2] |= pl << (8 * (t & 3));
+      V[3 - (t >> 2)] |= pm << (24 - 8 * (t & 3));  // V[3] holds bases 0..15, base 0 on top
+    }
+    // ---- validity: rare path, taken only by waves that see a non-base or the genome end ----
+    const int64_t rem64 = (int64_t)n_bps - (int64_t)p0;
+    const uint32_t rem = rem64 >= BW ? (uint32_t)BW : (rem64 <= 0 ? 0u : (uint32_t)rem64);
+    uint64_t inv = 0;  // bit b set <=> base b of the window cannot be part of a k-mer
+    const bool wave_dirty = __any((dacc != 0) | (rem < (uint32_t)BW));  // wave-uniform
+    if (wave_dirty) {
+      uint32_t iv[2] = {0, 0};
+#pragma unroll
+      for (int t = 0; t < NDW; ++t) {
+        const uint32_t d = (x[t] & 0xDFDFDFDFu) ^ FA[t];
+        const uint32_t z = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+        const uint32_t nib = (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+        iv[t >> 3] |= nib << (4 * (t & 7));
+      }
+      inv = mk64(iv[0], iv[1]);
+      if (rem < (uint32_t)BW) inv |= (rem == 0) ? ~0ull : (~0ull << rem);
+    }
+    // ---- LDS image: F[0..56) then R[i] = comp(F[55 - i]); both strands of the k-mer at window position J are
+    // ascending byte ranges: forward [J, J+K), reverse [112 - K - J, 112 - J) ---------------------------------
+    {
+      uint32_t *w1 = reinterpret_cast<uint32_t *>(mywin);
+#pragma unroll
+      for (int t = 0; t < NDW; ++t) {
+        w1[t] = FA[t];
+        w1[NDW + t] = __builtin_amdgcn_perm(0u, CA[NDW - 1 - t], 0x00010203u);
+      }
+    }
+
+#pragma unroll 1
+    for (int grp = 0; grp < GROUPS; ++grp) {
+      // the slice's code words: bases [12 grp, 12 grp + 32) are the low 64 bits of W and the top 64 bits of V
+      const uint64_t Gc = ~mk64(W[0], W[1]);  // complement codes; read LSB-first this IS the reverse strand
+      const uint64_t Gm = mk64(V[2], V[3]);
+      const uint32_t inv_g = (uint32_t)inv;
+      // (the reverse offsets 112 - K - J exceed the inline-constant range of v_cndmask: RBIAS of them sits in the pointer)
+      constexpr int RBIAS = 48;
+      using lds_u8p = __attribute__((address_space(3))) const uint8_t *;
+      using lds_u32p = __attribute__((address_space(3))) const uint32_t *;
+      const uint32_t my32 = (uint32_t)(uintptr_t)(lds_u8p)mywin;  // the lane's image as a 32-bit LDS address
+      const uint32_t winF = my32 + M * grp, winR = my32 + RBIAS - M * grp;
+
+      uint64_t wq[2][NW];
+      auto fetch_words = [&](auto jjc, uint64_t *w) __attribute__((always_inline)) {
+        constexpr int jj = decltype(jjc)::value;
+        // odd K: the compare is decided inside the 2K bits, the values only have to be TOP-aligned (kmer_sample_fast)
+        const uint64_t fv = Gm << (2 * jj);
+        const uint64_t rv = Gc << (2 * (32 - K - jj));
+        uint64_t lt;
+        uint32_t off;
+        uint32_t bsel;
+        asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(jj), "n"(2 * BW - K - jj - RBIAS), "s"(lt));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bsel) : "v"(winF), "v"(winR), "s"(lt));
+        constexpr int NDR = (K + 3 + 3) / 4;  // aligned dwords that cover any K bytes starting at shift 0..3
+        const lds_u32p src = (lds_u32p)(uintptr_t)(bsel + (off & ~3u));
+        uint32_t t[NDR + 1], d[2 * NW];
+#pragma unroll
+        for (int m = 0; m < NDR; ++m) t[m] = src[m];
+        t[NDR] = 0;
+#pragma unroll
+        for (int m = 0; m < 2 * NW; ++m) {
+          if (m < ND) d[m] = __builtin_amdgcn_alignbyte(t[m + 1 < NDR ? m + 1 : NDR], t[m], off);
+          else d[m] = 0;
+        }
+        if constexpr (NB < 4) d[ND - 1] &= (1u << (8 * (NB & 3))) - 1;
+#pragma unroll
+        for (int m = 0; m < NW; ++m) w[m] = mk64(d[2 * m], d[2 * m + 1]);
+      };
+      auto run_kmers = [&](auto checkc) __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(checkc)::value;
+        static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const bool valid = !CHECK || ((inv_g >> j) & MASKK) == 0;
+          if constexpr (j == 0) fetch_words(jc, wq[0]);
+          if constexpr (j + 1 < M) fetch_words(std::integral_constant<int, j + 1>{}, wq[(j + 1) & 1]);
+          const uint64_t h = t1ha2_fixed_w<K>(wq[j & 1], seed);
+          if (valid && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+        });
+      };
+      if (!wave_dirty) run_kmers(std::false_type{});
+      else run_kmers(std::true_type{});
+
+      // slide to the next slice: 12 bases = 24 bits of both streams, 12 bits of the validity mask
+      W[0] = __builtin_amdgcn_alignbit(W[1], W[0], 24), W[1] = __builtin_amdgcn_alignbit(W[2], W[1], 24);
+      W[2] = __builtin_amdgcn_alignbit(W[3], W[2], 24), W[3] >>= 24;
+      V[3] = __builtin_amdgcn_alignbit(V[3], V[2], 8), V[2] = __builtin_amdgcn_alignbit(V[2], V[1], 8);
+      V[1] = __builtin_amdgcn_alignbit(V[1], V[0], 8), V[0] <<= 24;
+      inv >>= M;
+    }
   }
   flush_hits(stage, gm, g, hits, cnt);
 }
@@ -817,6 +1026,13 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 #undef HG_V
   }
 #endif
+  if constexpr (Geo<K>::M == 12 && (K & 1) != 0) {  // k = 19, 21: three slices of 12 k-mers per window
+    if (canonical && HG_KMER_GROUPED) {
+      hipLaunchKernelGGL((kmer_sample_grouped<K>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, threshold,
+                         seed, u2t, d_hits, d_cnt);
+      return hipGetLastError();
+    }
+  }
   if (canonical)
     hipLaunchKernelGGL((kmer_sample_fast<K, true, HG_KMER_DEFAULT_VAR>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,
                        d_item_genome, threshold, seed, u2t, d_hits, d_cnt);
@@ -831,7 +1047,7 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 uint32_t hg_kmer_item_starts(uint32_t k) {
   if (fast64_k(k)) return (uint32_t)(WG * 32 * TILES_PER_ITEM64);
   if (!fast_k(k)) return GEN_ITEM;
-  return (uint32_t)(WG * ((33 - k) & ~3u) * TILES_PER_ITEM);
+  return (uint32_t)(WG * ((33 - k) & ~3u) * tiles_per_item((int)k));
 }
 
 hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
