@@ -530,6 +530,7 @@ struct GemmArgs {
   int symmetric;
   uint32_t ref_off, qry_off;  // global index of row 0 / column 0 (a block of a larger matrix): hits and the i < j test use them
   uint32_t tiles_m, tiles_n;  // tile grid
+  const uint8_t *bitsA, *bitsB;  // HAMB: blocked bit operands ([row block of 256][K-step][row][16 bytes])
   const uint32_t *tile_map;   // block -> tile id (tm * tiles_n + tn, ~0 = none), or NULL for the arithmetic walk below
   const uint32_t *verdict;    // speculative launch: runs only if v_lo <= verdict[0] <= v_hi (see decide_kernel);
   uint32_t v_lo, v_hi;        // with chunk_from_verdict the window length (K-steps) is verdict[1]
@@ -567,9 +568,13 @@ __device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...
 }
 // HAM (with I8): the operands are +-1 bytes expanded from bit-packed hypervectors, G = D - 2*hamming; the epilogue
 // keeps G >= ham_thr and reports {ref, qry, (D - G) / 2} -- the bit-packed search on the matrix pipe.
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool W4 = false>
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool W4 = false,
+          bool HAMB = false>
 __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT, W4>;
+  // HAMB: the Hamming operands arrive as BITS (block_bits_kernel's layout) by LDS-DMA, 16 bytes per row and K-step, and
+  // every thread expands its row's next K-step into the byte stage, one 16-byte chunk per MFMA phase
+  static_assert(!HAMB || (HAM && I8 && GLDS && BIG && NT == 4 && !W4), "bit-stream operands: 256 x 256 Hamming tiles only");
   static_assert(!W4 || (BIG && GLDS && I8 && (NT == 6 || NT == 8)), "the four-wave shape exists for the i8 LDS-DMA path");
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
@@ -756,6 +761,38 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   }
   // A fragments per phase: 2 (x NT B fragments = 8..10 MFMAs, another wave of the SIMD covers the fragment latency) or,
   // with one wave per SIMD (W4), 4 x 8 = 32 MFMAs = 512 cycles between a fragment's request and its first use
+  // HAMB: bit stages behind the two byte stages; K-step k's bits live in bit stage k & 1.  One 1 KiB instruction per
+  // wave: waves 0..3 fetch the A block's 256 rows, waves 4..7 the B block's; lane l of wave w fetches (and later reads
+  // back) the 16 bytes of tile row 64 (w & 3) + l.
+  uint8_t *const hb_stage = reinterpret_cast<uint8_t *>(sAB) + 2 * STAGE_ELEMS * sizeof(_Float16);
+  __amdgpu_buffer_rsrc_t rsBits;
+  uint32_t hb_swz = 0;
+  uint8_t *hb_row = nullptr;  // this thread's row inside a byte stage (stage 0)
+  if constexpr (!HAMB) rsBits = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A), 0, 0, 0);
+  if constexpr (HAMB) {
+    const uint32_t nst = g.Kp / BK;
+    const uint8_t *base = wave < 4 ? g.bitsA + (size_t)tm * nst * 4096 : g.bitsB + (size_t)tn * nst * 4096;
+    rsBits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 0x7fffffff, 0x00020000);
+    const uint32_t trow = tid & 255u;
+    hb_swz = (trow >> 1) & 7u;
+    hb_row = reinterpret_cast<uint8_t *>(sAB) + (wave < 4 ? 0u : TILE_ELEMS * (uint32_t)sizeof(_Float16)) + trow * (LROW * 2u);
+  }
+#define HG_BDMA(kstep)                                                                                                   \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBits, (lds_ptr_t)(hb_stage + ((kstep) & 1u) * 8192u + wave * 1024u), 16,  \
+                                           ((tid & 255u) * 16u), (kstep) * 4096u, 0, 0);
+  uint32_t hb_bits[4] = {0, 0, 0, 0};
+  // chunk `ch` of the K-step held in hb_bits -> byte stage `stage`
+#define HG_EXPAND(stage, ch)                                                                                             \
+  {                                                                                                                      \
+    const uint32_t b16_ = (hb_bits[(ch) >> 1] >> (16 * ((ch) & 1))) & 0xFFFFu;                                          \
+    uint32_t e_[4];                                                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                  \
+      const uint32_t m_ = (((b16_ >> (4 * q_)) & 0xFu) * 0x00204081u) & 0x01010101u;                                   \
+      e_[q_] = __builtin_amdgcn_perm(0u, 0x000001FFu, m_); /* selector byte 0 -> 0xFF (-1), 1 -> 0x01 (+1) */           \
+    }                                                                                                                    \
+    *reinterpret_cast<uint4 *>(hb_row + (stage) * (STAGE_ELEMS * 2u) + (((ch) ^ hb_swz) * 16u)) =                       \
+        make_uint4(e_[0], e_[1], e_[2], e_[3]);                                                                          \
+  }
   constexpr int AF = W4 ? 4 : 2;
   constexpr int MP = WTM / AF, PHASES = (BK / 32) * MP;
   half8 bfr[2][NT], afr[2][AF];
@@ -770,7 +807,18 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     _Pragma("unroll") for (int i_ = 0; i_ < AF; ++i_)                                                       \
         afr[buf][i_] = *reinterpret_cast<const half8 *>((pa) + (AF * (mp) + i_) * 16 * LROW + ko_);         \
   }
-  if (GLDS) {
+  if constexpr (HAMB) {
+    HG_BDMA(0u)
+    if (nsteps > 1) HG_BDMA(1u)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      const uint4 v_ = *reinterpret_cast<const uint4 *>(hb_stage + tid * 16u);
+      hb_bits[0] = v_.x, hb_bits[1] = v_.y, hb_bits[2] = v_.z, hb_bits[3] = v_.w;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) HG_EXPAND(0u, ch)
+  } else if (GLDS) {
     HG_DMA(0, 0)
   } else {
     HG_GLOAD(0)
@@ -780,7 +828,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     }
   }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
-  if (GLDS && nsteps > 1 && !HG_DMA_SPREAD) HG_DMA(1, BK)
+  if constexpr (HAMB) {
+    if (nsteps > 2) HG_BDMA(2u)  // into bit stage 0, whose K-step 0 has just been expanded
+  } else if (GLDS && nsteps > 1 && !HG_DMA_SPREAD) HG_DMA(1, BK)
   if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
@@ -792,6 +842,12 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
         HG_GLOAD(k2)
       }
     }
+    if constexpr (HAMB) {
+      if (ks + 1 < nsteps) {  // this thread's row of K-step ks + 1 (landed before the last barrier)
+        const uint4 v_ = *reinterpret_cast<const uint4 *>(hb_stage + ((ks + 1) & 1u) * 8192u + tid * 16u);
+        hb_bits[0] = v_.x, hb_bits[1] = v_.y, hb_bits[2] = v_.z, hb_bits[3] = v_.w;
+      }
+    }
     const _Float16 *fA = sAB + cur * STAGE_ELEMS + fa_off, *fB = sAB + cur * STAGE_ELEMS + fb_off;
     const _Float16 *nA = sAB + (cur ^ 1) * STAGE_ELEMS + fa_off, *nB = sAB + (cur ^ 1) * STAGE_ELEMS + fb_off;
 #pragma unroll
@@ -801,12 +857,20 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
         constexpr int PMAX_ = PA > PB ? PA : PB, Q4 = (PMAX_ + 3) / 4;
         HG_DMA_PART(cur ^ 1, (ks + 1) * BK, t * Q4, (t + 1) * Q4 < PMAX_ ? (t + 1) * Q4 : PMAX_)
       }
+      if constexpr (HAMB) {
+        static_assert(!HAMB || PHASES == 8, "one 16-byte chunk of the next K-step per phase");
+        if (ks + 1 < nsteps) HG_EXPAND(cur ^ 1u, t)
+      }
       if (t + 1 < PHASES) {
         if (!HG_EXP(2) && !(HG_EXP(32) && ks)) HG_FRAGS((t + 1) & 1, fA, fB, (t + 1) / MP, (t + 1) % MP)
       } else {
         // every fragment read of this stage must have returned before another wave may refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (HAMB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bits of K-step ks + 2 have landed
         if (!HG_EXP(16)) __syncthreads();
+        if constexpr (HAMB) {
+          if (ks + 3 < nsteps) HG_BDMA(ks + 3u)  // bit stage (ks + 1) & 1: its K-step was read at the top of this step
+        } else
         if (GLDS && ks + 2 < nsteps && !HG_EXP(1) && !HG_DMA_SPREAD) HG_DMA(cur, (ks + 2) * BK)
         if (ks + 1 < nsteps && !HG_EXP(2) && !HG_EXP(32)) HG_FRAGS(0, nA, nB, 0, 0)
       }
@@ -872,6 +936,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
 #undef HG_LSTORE
 #undef HG_DMA
 #undef HG_DMA_PART
+#undef HG_BDMA
+#undef HG_EXPAND
 #undef HG_FRAGS
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
@@ -1132,6 +1198,20 @@ __global__ __launch_bounds__(256) void expand_bits_kernel(const uint32_t *__rest
   }
 }
 
+// Bit-stream operands of the Hamming GEMM (HAMB): the bit-packed rows regrouped so that what a workgroup needs per
+// K-step -- 16 bytes of each of its 256 rows -- is 4 KiB contiguous: out[((block * nsteps + kstep) * 256 + row) * 16].
+// Rows past `rows` are filled with `pad` (A: zero bits, B: one bits -- padding against padding then scores -D and never
+// passes the threshold test).
+__global__ __launch_bounds__(256) void block_bits_kernel(const uint32_t *__restrict__ bits, uint32_t rows, uint32_t words,
+                                                         uint32_t pad, uint4 *__restrict__ out) {
+  const uint32_t nsteps = words / 4, block = blockIdx.y, row = block * 256 + threadIdx.x;
+  for (uint32_t ks = blockIdx.x; ks < nsteps; ks += gridDim.x) {
+    uint4 v = make_uint4(pad, pad, pad, pad);
+    if (row < rows) v = *reinterpret_cast<const uint4 *>(bits + (size_t)row * words + 4 * ks);
+    out[((size_t)block * nsteps + ks) * 256 + threadIdx.x] = v;
+  }
+}
+
 // Block -> tile table for the thresholded GEMMs.  Hits cluster where related genomes sit next to each other in both
 // sets -- a database against itself in file order: on the diagonal -- and a tile with ten thousand hits runs its
 // epilogue ~40 us longer than a tile without.  The arithmetic walk gives each XCD one contiguous run of tiles, so the
@@ -1185,6 +1265,48 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
                               uint32_t ref_off, uint32_t qry_off) {
   static_assert(sizeof(hg_ham_hit) == sizeof(hg_ani_hit), "the GEMM epilogue writes 12-byte records");
   const uint32_t words = hv_d / 32, ldk8 = hv_d + 128;  // hv_d is a multiple of 128 (checked by the caller)
+  // Bit-stream operands (dist_mfma_kernel<..., HAMB>): 1/8 of the operand bytes in HBM and through L2 -> LDS, expanded
+  // by the workgroup.  A/B at 50 000 x 10 000 x 16384: 6.87 ms against 6.56 ms with byte operands -- the LDS (192 KB of
+  // fragment reads + 64 KB of stage writes per K-step either way), not the L2 stream, is what co-limits with the matrix
+  // pipe -- so it is chosen only where the byte copies would not be reasonable to hold (> 16 GB), or by the test hook.
+  const bool bits_path = c->dbg_ham_path == "mfmab" ||
+                         (c->dbg_ham_path.empty() && ((uint64_t)R + Q) * (uint64_t)ldk8 > ((uint64_t)16 << 30));
+  if (bits_path) {
+    const uint32_t nsteps = hv_d / 128, rb = (R + 255) / 256, qb = (Q + 255) / 256;
+    hg_status s;
+    if ((s = hg_ensure(c, c->w_i8a, (size_t)rb * nsteps * 4096 + 64)) != HG_OK) return s;
+    if ((s = hg_ensure(c, c->w_i8b, (size_t)qb * nsteps * 4096 + 64)) != HG_OK) return s;
+    c->i8_sig_ref = c->i8_sig_qry = nullptr;  // the dist path's operand copies are gone
+    {
+      hg_timed tp(c, HG_T_DIST_PREP);
+      const unsigned gx = std::min<uint32_t>(nsteps, 64);
+      hipLaunchKernelGGL(block_bits_kernel, dim3(gx, rb), dim3(256), 0, c->stream, d_ref_bits, R, words, 0u,
+                         static_cast<uint4 *>(c->w_i8a.p));
+      HG_HIP(c, hipGetLastError());
+      hipLaunchKernelGGL(block_bits_kernel, dim3(gx, qb), dim3(256), 0, c->stream, d_qry_bits, Q, words, 0xFFFFFFFFu,
+                         static_cast<uint4 *>(c->w_i8b.p));
+      HG_HIP(c, hipGetLastError());
+    }
+    GemmArgs g{};
+    g.bitsA = static_cast<const uint8_t *>(c->w_i8a.p), g.bitsB = static_cast<const uint8_t *>(c->w_i8b.p);
+    g.R = R, g.Q = Q, g.Kp = hv_d / 2, g.ldk = ldk8 / 2, g.chunk_steps = ~0u;
+    g.hits = reinterpret_cast<hg_ani_hit *>(d_hits), g.hit_count = d_count, g.hit_cap = cap;
+    g.ref_off = ref_off, g.qry_off = qry_off, g.hv_d = hv_d;
+    g.ham_thr = max_dist >= hv_d ? -(int32_t)hv_d - 1 : (int32_t)hv_d - 2 * (int32_t)max_dist;
+    g.tiles_m = rb, g.tiles_n = qb;
+    const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+    const size_t lds = 2 * (256 + 256) * BK * sizeof(_Float16) + 2 * 8192;  // two byte stages + two bit stages
+    const void *fp = reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, true, false, true>);
+    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+      HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->lds_attr_done.push_back(fp);
+    }
+    hg_timed tg(c, HG_T_DIST);
+    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true, true, false, true>), dim3(n_tiles),
+                       dim3(TileCfg<true, 4>::THREADS), lds, c->stream, g);
+    HG_HIP(c, hipGetLastError());
+    return HG_OK;
+  }
   auto padded = [](uint32_t n) { return std::max({(n + 255) / 256 * 256, (n + 319) / 320 * 320, (n + 191) / 192 * 192}); };
   const uint32_t Rp = padded(R), Qp = padded(Q);
   hg_status s;

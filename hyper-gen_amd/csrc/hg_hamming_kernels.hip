@@ -208,7 +208,7 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   // ANI kernel's tiles and hit lists); small ones -- and everything when the hook says "popc" -- on the xor + popcount
   // kernel above.  Both give the same integers.
   const bool mfma = c->dbg_ham_path != "popc" && hv_d % 128 == 0 && hv_d <= 65536 && R < 0x7FFFFFFFull && Q < 0x7FFFFFFFull &&
-                    ((uint64_t)R * Q >= (uint64_t)1 << 24 || c->dbg_ham_path == "mfma" || c->dbg_ham_path == "mfma4");
+                    ((uint64_t)R * Q >= (uint64_t)1 << 24 || c->dbg_ham_path == "mfma" || c->dbg_ham_path == "mfma4" || c->dbg_ham_path == "mfmab");
   c->last_ham_path = mfma ? 1 : 0;
   if (mfma)
     s = hg_run_hamming_mfma(c, d_ref_bits, (uint32_t)R, d_qry_bits, (uint32_t)Q, hv_d, max_dist, d_out, d_count,

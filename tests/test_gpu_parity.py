@@ -359,7 +359,7 @@ def test_binarize_and_hamming(ctx, orc, R, Q, d):
     cap = R * Q
     hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
     exp = {(i, j, int(want[i, j])) for i, j in zip(*np.nonzero(want <= max_dist))}
-    for path in ("popc", "mfma", "mfma4"):  # xor + popcount kernel / +-1 byte GEMM on the matrix pipe (4- and 8-wave tiles): the same integers
+    for path in ("popc", "mfma", "mfma4", "mfmab"):  # xor + popcount kernel / +-1 byte GEMM on the matrix pipe (4- and 8-wave tiles): the same integers
         ctx.set_debug("ham_path", path)
         try:
             n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, max_dist, hits.data_ptr(), cap)
