@@ -551,8 +551,18 @@ def main():
             hroof = {"bound": "valu", "achieved": word_ops / (hms * 1e-3) / 1e12, "peak": pair_bound / 1e12,
                      "unit": "T lane-ops/s (xor + popcount)", "frac": word_ops / (hms * 1e-3) / pair_bound,
                      "kernel": "hamming_kernel", "launch_ms": hms, "algorithmic_lane_ops_per_launch": word_ops}
+        # HBM-side bytes per launch of the search kernel from the newest committed PMC pass of this command (only
+        # for the shape that pass was taken on: all 50 000 refs x 10 000 queries on one GPU)
+        ham_traffic = None
+        if hpath == 1 and world == 1 and a.hamming_refs == 50000 and HQ == 10000:
+            try:
+                d = json.load(open(newest_profile("_pmc.json")))
+                ham_traffic = max((v for k, v in d.items() if k.startswith("dist_mfma_kernel") and k.rstrip(">").split(",")[6].strip() == "true"),
+                                  key=lambda v: v.get("GRBM_GUI_ACTIVE", 0)).get("hbm_bytes_per_launch")
+            except Exception:
+                ham_traffic = None
         hroof.update(compulsory_bytes_per_launch=(refs + HQ) * words * 4,
-                     compulsory_gbs=(refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, traffic=None)
+                     compulsory_gbs=(refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, traffic=ham_traffic)
         out["hamming"] = {
             "metric": "M Hamming-pairs/sec (D=16384 bit-packed)", "value": a.hamming_refs * HQ * a.steps / hdt / 1e6,
             "unit": "M pairs/sec", "ms_per_step": hdt / a.steps * 1e3, "scaling": "strong",
