@@ -80,7 +80,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort,
                          &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
-                         &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc, &c->w_tilemap};
+                         &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto &t : c->t_pending) (void)hipEventDestroy(t.e0), (void)hipEventDestroy(t.e1);
@@ -126,7 +126,6 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   else if (k == "sort_test_buckets") c->dbg_sort_buckets = std::atoi(v.c_str());
   else if (k == "dist_path") c->dbg_dist_path = v;
   else if (k == "ham_path") c->dbg_ham_path = v;
-  else if (k == "dist_order") c->dbg_dist_order = v;
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;
 }

@@ -531,7 +531,6 @@ struct GemmArgs {
   uint32_t ref_off, qry_off;  // global index of row 0 / column 0 (a block of a larger matrix): hits and the i < j test use them
   uint32_t tiles_m, tiles_n;  // tile grid
   const uint8_t *bitsA, *bitsB;  // HAMB: blocked bit operands ([row block of 256][K-step][row][16 bytes])
-  const uint32_t *tile_map;   // block -> tile id (tm * tiles_n + tn, ~0 = none), or NULL for the arithmetic walk below
   const uint32_t *verdict;    // speculative launch: runs only if v_lo <= verdict[0] <= v_hi (see decide_kernel);
   uint32_t v_lo, v_hi;        // with chunk_from_verdict the window length (K-steps) is verdict[1]
   uint32_t chunk_from_verdict;
@@ -613,12 +612,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   // B blocks (measured: 7.0 GB of L2 misses per 10k x 10k launch with plain row-major order)
   const uint32_t sup_n = (g.tiles_n + ST - 1) / ST;
   const uint32_t sup = bid / (ST * ST), within = bid % (ST * ST);
-  uint32_t tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
-  if (g.tile_map) {  // host-built order (hg_tile_map): tiles on the diagonal first, dealt evenly to the XCDs
-    const uint32_t t = g.tile_map[blockIdx.x];
-    if (t == 0xFFFFFFFFu) return;
-    tm = t / g.tiles_n, tn = t % g.tiles_n;
-  }
+  const uint32_t tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
   if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // padding of the super-tile grid
   const uint32_t row0 = tm * BM, col0 = tn * BN;
   if (g.symmetric && row0 + g.ref_off >= col0 + g.qry_off + BN) return;  // tile entirely on/below the diagonal
@@ -1212,54 +1206,6 @@ __global__ __launch_bounds__(256) void block_bits_kernel(const uint32_t *__restr
   }
 }
 
-// Block -> tile table for the thresholded GEMMs.  Hits cluster where related genomes sit next to each other in both
-// sets -- a database against itself in file order: on the diagonal -- and a tile with ten thousand hits runs its
-// epilogue ~40 us longer than a tile without.  The arithmetic walk gives each XCD one contiguous run of tiles, so the
-// diagonal's tiles land on a few XCDs and late in their runs: the kernel then ends with a handful of CUs working off
-// heavy tiles (+0.06-0.08 ms of 0.44 at 10 000 x 10 000 with 1.3 M hits).  Here the tiles that touch the diagonal
-// come first and are dealt round-robin to the XCDs (block b runs on XCD b % 8); the others keep the super-tile walk,
-// one contiguous run per XCD, for the L2.  Cached per geometry.
-static hg_status hg_tile_map(hg_ctx *c, uint32_t tiles_m, uint32_t tiles_n, uint32_t bm, uint32_t bn, uint32_t R, uint32_t Q,
-                             const uint32_t **d_map, uint32_t *n_blocks) {
-  const std::vector<uint32_t> key{tiles_m, tiles_n, bm, bn, R, Q};
-  if (c->tmap_key != key) {
-    std::vector<uint32_t> heavy, light;
-    const uint32_t sup_m = (tiles_m + ST - 1) / ST, sup_n = (tiles_n + ST - 1) / ST;
-    for (uint32_t sm = 0; sm < sup_m; ++sm)
-      for (uint32_t sn = 0; sn < sup_n; ++sn)
-        for (uint32_t w = 0; w < ST * ST; ++w) {
-          const uint32_t tm = sm * ST + w / ST, tn = sn * ST + w % ST;
-          if (tm >= tiles_m || tn >= tiles_n) continue;
-          // the tile's row span and column span, both as fractions of their set: on the diagonal if they overlap
-          const double r0 = (double)tm * bm / R, r1 = std::min(1.0, (double)(tm + 1) * bm / R);
-          const double q0 = (double)tn * bn / Q, q1 = std::min(1.0, (double)(tn + 1) * bn / Q);
-          (r0 < q1 && q0 < r1 ? heavy : light).push_back(tm * tiles_n + tn);
-        }
-    std::vector<std::vector<uint32_t>> per(8);
-    for (size_t i = 0; i < heavy.size(); ++i) per[i % 8].push_back(heavy[i]);
-    // light tiles: contiguous runs that even out the list lengths
-    const size_t total = heavy.size() + light.size();
-    size_t pos = 0;
-    for (uint32_t x = 0; x < 8; ++x) {
-      const size_t want = total / 8 + (x < total % 8 ? 1 : 0);
-      while (per[x].size() < want && pos < light.size()) per[x].push_back(light[pos++]);
-    }
-    for (uint32_t x = 0; pos < light.size(); x = (x + 1) % 8) per[x].push_back(light[pos++]);
-    size_t longest = 0;
-    for (auto &v : per) longest = std::max(longest, v.size());
-    std::vector<uint32_t> map(longest * 8, 0xFFFFFFFFu);
-    for (uint32_t x = 0; x < 8; ++x)
-      for (size_t i = 0; i < per[x].size(); ++i) map[i * 8 + x] = per[x][i];
-    hg_status s = hg_ensure(c, c->w_tilemap, map.size() * sizeof(uint32_t) + 64);
-    if (s != HG_OK) return s;
-    HG_HIP(c, hipMemcpyAsync(c->w_tilemap.p, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HG_HIP(c, hipStreamSynchronize(c->stream));  // (the host vector goes away; once per geometry)
-    c->tmap_key = key, c->tmap_blocks = (uint32_t)map.size();
-  }
-  *d_map = static_cast<const uint32_t *>(c->w_tilemap.p), *n_blocks = c->tmap_blocks;
-  return HG_OK;
-}
-
 hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R, const uint32_t *d_qry_bits, uint32_t Q,
                               uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_hits, uint32_t *d_count, uint32_t cap,
                               uint32_t ref_off, uint32_t qry_off) {
@@ -1465,11 +1411,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
       else if (c->dbg_dist_tile == "wide") nt = 5;
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
-    uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
-    if (c->dbg_dist_order != "walk") {
-      hg_status ts = hg_tile_map(c, g.tiles_m, g.tiles_n, 256u, (uint32_t)nt * 64u, a.R, a.Q, &g.tile_map, &n_tiles);
-      if (ts != HG_OK) return ts;
-    }
+    const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
     const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
                                : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
     const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)

@@ -72,12 +72,9 @@ struct hg_ctx {
   // rows [pad_rows, padded rows) of the f16 operand copies are known to be zero (dist tiles hang over)
   const void *pad_a_ptr = nullptr, *pad_b_ptr = nullptr;
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
-  Buf w_tilemap;                         // block -> tile table of the thresholded GEMMs (hg_tile_map), cached per geometry
-  std::vector<uint32_t> tmap_key;
-  uint32_t tmap_blocks = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // development / test hooks (hg_ctx_set_debug); never read from the environment
-  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order;
+  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path;
   int dbg_sort_buckets = 0;
   // pinned host scratch
   void *h_pin = nullptr;

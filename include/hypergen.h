@@ -66,7 +66,6 @@ int hg_device_count(void);
 /* development / test hook (no reference counterpart): force an internal code path of THIS ctx.
  * keys: "dist_tile" = "" | "small" | "big" | "big_reg" | "wide" | "nt3"   (GEMM tile geometry)
  *       "dist_path" = "" | "f16" | "i8"                                    (operand format of the ANI GEMM)
- *       "dist_order" = "" | "walk"   (thresholded i8 GEMM: diagonal-first tile table / plain super-tile walk)
  *       "ham_path"  = "" | "popc" | "mfma" | "mfma4" | "mfmab"             (Hamming search: xor+popcount, +-1 byte GEMM, its 4-wave tile, bit-stream operands)
  *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
  * Nothing in the library reads environment variables. */
