@@ -45,7 +45,17 @@ constexpr uint64_t P6 = 0xCB5AF53AE3AAAC31ull;
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) {
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
-__device__ __forceinline__ uint64_t rot64(uint64_t v, unsigned s) {
+#ifndef HG_ROT_ALIGNBIT
+#define HG_ROT_ALIGNBIT 1  /* rot64 by a constant as two v_alignbit_b32 (0: the compiler's 64-bit shift + shift + or) */
+#endif
+__device__ __forceinline__ uint64_t rot64(uint64_t v, unsigned s) {  // rotate right
+#if HG_ROT_ALIGNBIT
+  if (__builtin_constant_p(s) && s > 0 && s < 64 && s != 32) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return s < 32 ? mk64(__builtin_amdgcn_alignbit(hi, lo, s), __builtin_amdgcn_alignbit(lo, hi, s))
+                  : mk64(__builtin_amdgcn_alignbit(lo, hi, s - 32), __builtin_amdgcn_alignbit(hi, lo, s - 32));
+  }
+#endif
   return (v >> s) | (v << (64 - s));
 }
 // lo64(x * P) returned, hi64(x * P) + addend stored in hi_plus.
@@ -98,11 +108,31 @@ __device__ __forceinline__ void mixup64(uint64_t &a, uint64_t &b, uint64_t v) {
     b += (uint64_t)(m >> 64);
   }
 }
+// lo64(x * P).  The compiler's form is one v_mad_u64_u32 + two v_mul_lo_u32 + v_add3 (four slow-class
+// instructions); here the two cross products are chained through one 64-bit accumulator -- three v_mad_u64_u32 and a
+// plain add (HG_LO64MUL_HAND=0: the compiler's form, A/B).
+#ifndef HG_LO64MUL_HAND
+#define HG_LO64MUL_HAND 1
+#endif
+template <uint64_t P>
+__device__ __forceinline__ uint64_t lo64mul(uint64_t x) {
+#if HG_LO64MUL_HAND
+  constexpr uint32_t p0 = (uint32_t)P, p1 = (uint32_t)(P >> 32);
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+  const uint64_t t = (uint64_t)x0 * p0;
+  uint64_t w1, w, junk;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(w1), "=s"(junk) : "v"(x0), "s"(p1));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(w), "=s"(junk) : "v"(x1), "s"(p0), "v"(w1));
+  return mk64((uint32_t)t, (uint32_t)(t >> 32) + (uint32_t)w);
+#else
+  return x * P;
+#endif
+}
 // src/cuda_kernel.cu:143-153
 template <bool HAND = true>
 __device__ __forceinline__ uint64_t final64(uint64_t a, uint64_t b) {
-  uint64_t x = (a + rot64(b, 41)) * P0;
-  uint64_t y = (rot64(a, 23) + b) * P6;
+  uint64_t x = HAND ? lo64mul<P0>(a + rot64(b, 41)) : (a + rot64(b, 41)) * P0;
+  uint64_t y = HAND ? lo64mul<P6>(rot64(a, 23) + b) : (rot64(a, 23) + b) * P6;
   if (HAND) {
     uint64_t hi;
     const uint64_t lo = mul128_lo_hiadd<P5, true>(x ^ y, 0, hi);
@@ -674,6 +704,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
           if constexpr (j == 0) fetch_words(jc, wq[0]);
           if constexpr (j + 1 < M) fetch_words(std::integral_constant<int, j + 1>{}, wq[(j + 1) & 1]);
           const uint64_t h = t1ha2_fixed_w<K>(wq[j & 1], seed);
+          // (a 32-bit pre-test of the high dword in front of this 64-bit compare measured +0.8 %)
           if (valid && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
         });
       };
