@@ -38,7 +38,7 @@ def test_g1_reference_fixture(ctx, orc):
         assert ["%016x" % int(x) for x in got] == g[key], key
 
 
-@pytest.mark.parametrize("k", [1, 4, 8, 9, 12, 15, 16, 17, 20, 21, 22, 24, 25, 28, 29, 30, 31, 32])
+@pytest.mark.parametrize("k", [1, 4, 8, 9, 12, 15, 16, 17, 18, 19, 20, 21, 22, 24, 25, 28, 29, 30, 31, 32])
 def test_hash_sets_all_k(ctx, orc, k):
     rng = np.random.default_rng(100 + k)
     s = rand_seq(rng, 20011)
@@ -63,14 +63,21 @@ def test_hash_sets_long_k(ctx, orc, k):
         assert want.size > 100 and got.size == want.size and (got == want).all(), (k, canonical)
 
 
-@pytest.mark.parametrize("n", [0, 1, 20, 21, 22, 31, 32, 33, 43, 44, 45, 3071, 3072, 3073, 3092, 3093,
-                               24575, 24576, 24577, 24596, 24597, 50000])
+@pytest.mark.parametrize("n", [0, 1, 20, 21, 22, 31, 32, 33, 43, 44, 45, 55, 56, 57, 76, 77, 3071, 3072, 3073, 3092, 3093,
+                               9215, 9216, 9217, 9236, 9237, 9271, 9272, 24575, 24576, 24577, 24596, 24597,
+                               27647, 27648, 27649, 27668, 27669, 27703, 27704, 50000])
 def test_hash_sets_ragged_lengths(ctx, orc, n):
+    """lengths around the tile / work-item / window edges of both k = 21 kernels (32-base windows: 3 072 and 24 576
+    starts; grouped 56-base windows: 9 216 and 27 648 starts), with and without a non-base near the end"""
     rng = np.random.default_rng(n)
     s = rand_seq(rng, n)
-    want = orc.kmer_hash_sample(s, 21, 3)
-    got = ctx.kmer_hash_sample(s, 21, 3)
-    assert got.size == want.size and (got == want).all()
+    for dirty in (False, True):
+        if dirty and n > 30:
+            s[n - 1 - int(rng.integers(0, min(n - 1, 60)))] = ord("N")
+        for k in (21, 19):
+            want = orc.kmer_hash_sample(s, k, 3)
+            got = ctx.kmer_hash_sample(s, k, 3)
+            assert got.size == want.size and (got == want).all(), (k, dirty)
 
 
 def test_hash_set_scaled1_every_kmer(ctx, orc):
