@@ -210,7 +210,7 @@ constexpr uint32_t FAST64_FROM = 22;
 #define HG_U2T_HOIST 1  /* the u/U -> T rewrite behind one branch per window (0: one branch per dword) */
 #endif
 #ifndef HG_KMER_GROUPED
-#define HG_KMER_GROUPED 1  /* canonical k = 19, 21: kmer_sample_grouped instead of kmer_sample_fast (A/B: -DHG_KMER_GROUPED=0) */
+#define HG_KMER_GROUPED 1  /* canonical k = 18..21: kmer_sample_grouped instead of kmer_sample_fast (A/B: -DHG_KMER_GROUPED=0) */
 #endif
 constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
     const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
     uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
   using G = Geo<K>;
-  static_assert(G::M == 12 && (K & 1), "written for 12 starts per slice and odd k (unmasked strand compare)");
+  static_assert(G::M == 12, "written for 12 starts per slice (k = 18..21)");
   constexpr int M = 12, GROUPS = 3, MB = M * GROUPS, BW = (GROUPS - 1) * M + 32, NDW = BW / 4;  // 36 starts, 56 bases, 14 dwords
   constexpr int ND = G::ND, NB = G::NB, NW = (K + 7) / 8;
   constexpr int PITCH = 2 * BW + 4;  // 116 bytes = 29 dwords: odd, the lanes' dword accesses spread over the banks
@@ -672,9 +672,16 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
       uint64_t wq[2][NW];
       auto fetch_words = [&](auto jjc, uint64_t *w) __attribute__((always_inline)) {
         constexpr int jj = decltype(jjc)::value;
-        // odd K: the compare is decided inside the 2K bits, the values only have to be TOP-aligned (kmer_sample_fast)
-        const uint64_t fv = Gm << (2 * jj);
-        const uint64_t rv = Gc << (2 * (32 - K - jj));
+        uint64_t fv, rv;
+        if constexpr ((K & 1) != 0) {
+          // odd K: the compare is decided inside the 2K bits, the values only have to be TOP-aligned (kmer_sample_fast)
+          fv = Gm << (2 * jj);
+          rv = Gc << (2 * (32 - K - jj));
+        } else {
+          constexpr uint64_t MASK2K = (1ull << (2 * K)) - 1;
+          fv = (Gm >> (2 * (32 - K - jj))) & MASK2K;
+          rv = (Gc >> (2 * jj)) & MASK2K;
+        }
         uint64_t lt;
         uint32_t off;
         uint32_t bsel;
@@ -1057,7 +1064,7 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 #undef HG_V
   }
 #endif
-  if constexpr (Geo<K>::M == 12 && (K & 1) != 0) {  // k = 19, 21: three slices of 12 k-mers per window
+  if constexpr (Geo<K>::M == 12) {  // k = 18..21: three slices of 12 k-mers per window
     if (canonical && HG_KMER_GROUPED) {
       hipLaunchKernelGGL((kmer_sample_grouped<K>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, threshold,
                          seed, u2t, d_hits, d_cnt);
