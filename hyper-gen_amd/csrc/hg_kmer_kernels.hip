@@ -662,12 +662,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
       const uint64_t Gc = ~mk64(W[0], W[1]);  // complement codes; read LSB-first this IS the reverse strand
       const uint64_t Gm = mk64(V[2], V[3]);
       const uint32_t inv_g = (uint32_t)inv;
-      // (the reverse offsets 112 - K - J exceed the inline-constant range of v_cndmask: RBIAS of them sits in the pointer)
-      constexpr int RBIAS = 48;
       using lds_u8p = __attribute__((address_space(3))) const uint8_t *;
       using lds_u32p = __attribute__((address_space(3))) const uint32_t *;
       const uint32_t my32 = (uint32_t)(uintptr_t)(lds_u8p)mywin;  // the lane's image as a 32-bit LDS address
-      const uint32_t winF = my32 + M * grp, winR = my32 + RBIAS - M * grp;
+      const uint32_t winF = my32 + M * grp, winR = my32 - M * grp;
 
       uint64_t wq[2][NW];
       auto fetch_words = [&](auto jjc, uint64_t *w) __attribute__((always_inline)) {
@@ -686,10 +684,16 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
         uint32_t off;
         uint32_t bsel;
         asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(jj), "n"(2 * BW - K - jj - RBIAS), "s"(lt));
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bsel) : "v"(winF), "v"(winR), "s"(lt));
+        // forward bytes at image offset jj, reverse bytes at OFFR.  Only the byte shifts (low two bits) go through the
+        // per-k-mer select; the aligned parts are compile-time: the forward one (CF) is the immediate offset of the
+        // reads for BOTH strands, the difference DR sits in the reverse base pointer (three to six distinct values of
+        // winR + DR per slice, computed once per slice and shared by the compiler) -- no v_and / v_add per k-mer
+        constexpr int OFFR = 2 * BW - K - jj, CF = jj & ~3, DR = (OFFR & ~3) - CF;
+        const uint32_t winRD = winR + (uint32_t)DR;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(jj & 3), "n"(OFFR & 3), "s"(lt));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bsel) : "v"(winF), "v"(winRD), "s"(lt));
         constexpr int NDR = (K + 3 + 3) / 4;  // aligned dwords that cover any K bytes starting at shift 0..3
-        const lds_u32p src = (lds_u32p)(uintptr_t)(bsel + (off & ~3u));
+        const lds_u32p src = (lds_u32p)(uintptr_t)bsel + CF / 4;
         uint32_t t[NDR + 1], d[2 * NW];
 #pragma unroll
         for (int m = 0; m < NDR; ++m) t[m] = src[m];
