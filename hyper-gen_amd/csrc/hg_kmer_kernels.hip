@@ -690,7 +690,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
         // winR + DR per slice, computed once per slice and shared by the compiler) -- no v_and / v_add per k-mer
         constexpr int OFFR = 2 * BW - K - jj, CF = jj & ~3, DR = (OFFR & ~3) - CF;
         const uint32_t winRD = winR + (uint32_t)DR;
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(jj & 3), "n"(OFFR & 3), "s"(lt));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "n"(8 * (jj & 3)), "n"(8 * (OFFR & 3)), "s"(lt));  // in bits
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(bsel) : "v"(winF), "v"(winRD), "s"(lt));
         constexpr int NDR = (K + 3 + 3) / 4;  // aligned dwords that cover any K bytes starting at shift 0..3
         const lds_u32p src = (lds_u32p)(uintptr_t)bsel + CF / 4;
@@ -700,10 +700,16 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
         t[NDR] = 0;
 #pragma unroll
         for (int m = 0; m < 2 * NW; ++m) {
-          if (m < ND) d[m] = __builtin_amdgcn_alignbyte(t[m + 1 < NDR ? m + 1 : NDR], t[m], off);
+          if (m < ND) d[m] = __builtin_amdgcn_alignbit(t[m + 1 < NDR ? m + 1 : NDR], t[m], off);
           else d[m] = 0;
         }
-        if constexpr (NB < 4) d[ND - 1] &= (1u << (8 * (NB & 3))) - 1;
+        if constexpr (NB == 1) {
+          // a k-mer's last byte lies inside its last aligned dword whatever the shift: one v_bfe_u32 instead of
+          // v_alignbit + v_and
+          d[ND - 1] = __builtin_amdgcn_ubfe(t[ND - 1], off, 8u);
+        } else if constexpr (NB < 4) {
+          d[ND - 1] &= (1u << (8 * (NB & 3))) - 1;
+        }
 #pragma unroll
         for (int m = 0; m < NW; ++m) w[m] = mk64(d[2 * m], d[2 * m + 1]);
       };
