@@ -200,6 +200,8 @@ constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 // starts (8 at k = 22..25, 4 at k = 26..29).  Measured A/B on one box: k = 22..25 4-6 % faster, k = 26..29
 // 16-17 % faster with the wide window; k <= 21 the two kernels tie.
 constexpr uint32_t FAST64_FROM = 22;
+constexpr int TILES_PER_ITEM64 = 4;  // work item of k = 22..32: 4 tiles x 256 lanes x 32 starts
+constexpr bool fast64_k(uint32_t k) { return k >= FAST64_FROM && k <= 32; }
 // canonical fast kernels: 4 = chosen strand fetched from an LDS image of the window (| 8: dword-aligned reads +
 // run-time v_alignbyte; without it byte-offset ds_reads; | 16: a second copy of the k-mer loop without the validity
 // test for waves that saw only bases), 0 = register extraction of both strands + mux
@@ -210,7 +212,7 @@ constexpr uint32_t FAST64_FROM = 22;
 #define HG_U2T_HOIST 1  /* the u/U -> T rewrite behind one branch per window (0: one branch per dword) */
 #endif
 #ifndef HG_KMER_GROUPED
-#define HG_KMER_GROUPED 1  /* canonical k = 18..21: kmer_sample_grouped instead of kmer_sample_fast (A/B: -DHG_KMER_GROUPED=0) */
+#define HG_KMER_GROUPED 1  /* canonical k = 18..25: kmer_sample_grouped instead of kmer_sample_fast / fast64 (A/B: -DHG_KMER_GROUPED=0) */
 #endif
 constexpr bool fast_k(uint32_t k) { return k >= 1 && k < FAST64_FROM; }
 
@@ -545,12 +547,16 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
     const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
     uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
   using G = Geo<K>;
-  static_assert(G::M == 12, "written for 12 starts per slice (k = 18..21)");
-  constexpr int M = 12, GROUPS = 3, MB = M * GROUPS, BW = (GROUPS - 1) * M + 32, NDW = BW / 4;  // 36 starts, 56 bases, 14 dwords
+  static_assert(G::M == 12 || G::M == 8, "12 starts per slice (k = 18..21) or 8 (k = 22..25)");
+  // 3 slices of 12 or 4 slices of 8 starts: 36 / 32 starts per lane and window; 56 bases = 14 dwords either way
+  constexpr int M = G::M, GROUPS = 24 / M + 1, MB = M * GROUPS, BW = (GROUPS - 1) * M + 32, NDW = BW / 4;
+  static_assert(BW == 56, "window of 56 bases");
   constexpr int ND = G::ND, NB = G::NB, NW = (K + 7) / 8;
   constexpr int PITCH = 2 * BW + 4;  // 116 bytes = 29 dwords: odd, the lanes' dword accesses spread over the banks
-  constexpr int TILE = WG * MB, TILES = G::ITEM / TILE;
-  static_assert(TILES * TILE == G::ITEM, "the work item is a whole number of grouped tiles");
+  // the work item is the one the host plans for this k (hg_kmer_item_starts): k >= 22 shares kmer_sample_fast64's
+  constexpr int ITEM = fast64_k(K) ? WG * 32 * TILES_PER_ITEM64 : G::ITEM;
+  constexpr int TILE = WG * MB, TILES = ITEM / TILE;
+  static_assert(TILES * TILE == ITEM, "the work item is a whole number of grouped tiles");
   constexpr uint32_t MASKK = (1u << K) - 1;
 
   const uint32_t item = blockIdx.x;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
   if (n_bps < (uint64_t)K) return;
   const uint64_t n_starts = n_bps - K + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
-  const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+  const uint64_t item_start = (uint64_t)(item - gm.item_first) * ITEM;
   __shared__ HitStage stage;
   __shared__ __attribute__((aligned(16))) uint8_t s_win[WG * PITCH + 16];
   uint8_t *const mywin = s_win + threadIdx.x * PITCH;
@@ -728,11 +734,12 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
       if (!wave_dirty) run_kmers(std::false_type{});
       else run_kmers(std::true_type{});
 
-      // slide to the next slice: 12 bases = 24 bits of both streams, 12 bits of the validity mask
-      W[0] = __builtin_amdgcn_alignbit(W[1], W[0], 24), W[1] = __builtin_amdgcn_alignbit(W[2], W[1], 24);
-      W[2] = __builtin_amdgcn_alignbit(W[3], W[2], 24), W[3] >>= 24;
-      V[3] = __builtin_amdgcn_alignbit(V[3], V[2], 8), V[2] = __builtin_amdgcn_alignbit(V[2], V[1], 8);
-      V[1] = __builtin_amdgcn_alignbit(V[1], V[0], 8), V[0] <<= 24;
+      // slide to the next slice: M bases = 2 M bits of both streams, M bits of the validity mask
+      constexpr int SB = 2 * M;
+      W[0] = __builtin_amdgcn_alignbit(W[1], W[0], SB), W[1] = __builtin_amdgcn_alignbit(W[2], W[1], SB);
+      W[2] = __builtin_amdgcn_alignbit(W[3], W[2], SB), W[3] >>= SB;
+      V[3] = __builtin_amdgcn_alignbit(V[3], V[2], 32 - SB), V[2] = __builtin_amdgcn_alignbit(V[2], V[1], 32 - SB);
+      V[1] = __builtin_amdgcn_alignbit(V[1], V[0], 32 - SB), V[0] <<= SB;
       inv >>= M;
     }
   }
@@ -744,7 +751,6 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
 // =========================================================================================
 // Same scheme as kmer_sample_fast with a 64-base register window per lane (16 dwords, 32 k-mer starts,
 // 32-byte lane stride); the 2-bit streams are 128 bits wide, k-mer values are still <= 64 bits.
-constexpr int TILES_PER_ITEM64 = 4;
 template <int K>
 struct Geo64 {
   static constexpr int M = 32;
@@ -753,7 +759,6 @@ struct Geo64 {
   static constexpr int TILE = WG * M;
   static constexpr int ITEM = TILE * TILES_PER_ITEM64;
 };
-constexpr bool fast64_k(uint32_t k) { return k >= FAST64_FROM && k <= 32; }
 
 template <int K, bool CANON>
 __global__ __launch_bounds__(WG) void kmer_sample_fast64(
@@ -1119,6 +1124,13 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
 #undef HG_FAST_CASE
 #define HG_FAST64_CASE(KK)                                                                              \
   case KK:                                                                                              \
+    if constexpr (Geo<KK>::M == 8) { /* k = 22..25: four slices of 8 k-mers per 56-base window */      \
+      if (canonical && HG_KMER_GROUPED) {                                                               \
+        hipLaunchKernelGGL((kmer_sample_grouped<KK>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,    \
+                           d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                         \
+        return hipGetLastError();                                                                       \
+      }                                                                                                 \
+    }                                                                                                   \
     if (canonical)                                                                                      \
       hipLaunchKernelGGL((kmer_sample_fast64<KK, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, \
                          d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                           \
