@@ -87,6 +87,41 @@ int main(int argc, char **argv) {
     hg_free(p); hg_free(pz);
   }
   hg_free(buf);
+  // block-wise reader (256 KiB blocks of whole lines), both read modes, 2-bit packing (also in place), long single line
+  {
+    std::string big = ">rec one\n";
+    unsigned x = 12345;
+    const char alpha[] = "ACGTacgtNnUu \t";
+    for (int line = 0; line < 9000; ++line) {
+      const int len = 1 + (int)(x % 97);
+      for (int i = 0; i < len; ++i) { x = x * 1664525u + 1013904223u; big += alpha[(x >> 24) % (line % 50 ? 8 : 14)]; }
+      big += (line % 7) ? "\n" : "\r\n";
+      if (line % 1500 == 1499) big += ">next record\n";
+    }
+    big += ">long\n";
+    for (int i = 0; i < 700000; ++i) { x = x * 1664525u + 1013904223u; big += alpha[(x >> 24) % 4]; }  // no trailing newline
+    FILE *o = fopen((T + "/big.fa").c_str(), "wb"); fwrite(big.data(), 1, big.size(), o); fclose(o);
+    for (uint32_t mode : {HG_READ_MERGE, HG_READ_NEEDLETAIL}) {
+      uint8_t *a = nullptr, *b = nullptr; size_t ca = 0, cb = 0, na = 0, nb = 0;
+      if (hg_read_fastx_into((T + "/big.fa").c_str(), mode, &a, &ca, &na) != HG_OK) return 12;
+      const uint32_t norm = mode == HG_READ_NEEDLETAIL ? HG_NORM_U2T : HG_NORM_ACGT;
+      const uint32_t flags = mode | HG_READ_PACK2 | (norm == HG_NORM_U2T ? HG_READ_PACK2_U2T : 0u);
+      if (hg_read_fastx_into((T + "/big.fa").c_str(), flags, &b, &cb, &nb) != HG_OK) return 13;
+      if (na != nb || na < 700000) return 14;
+      std::vector<uint8_t> blob(hg_pack2_size(na));
+      if (hg_pack2(a, na, norm, blob.data()) != HG_OK) return 15;
+      if (memcmp(blob.data(), b, blob.size())) return 16;
+      std::vector<uint8_t> inplace(std::max(na, hg_pack2_size(na)));
+      memcpy(inplace.data(), a, na);
+      if (hg_pack2(inplace.data(), na, norm, inplace.data()) != HG_OK) return 17;
+      if (memcmp(blob.data(), inplace.data(), blob.size())) return 18;
+      hg_free(a); hg_free(b);
+    }
+    for (size_t n : {(size_t)0, (size_t)1, (size_t)31, (size_t)32, (size_t)33, (size_t)4097}) {
+      std::vector<uint8_t> q(n ? n : 1, 'A'), out(hg_pack2_size(n) + 1, 0x5A);
+      if (hg_pack2(q.data(), n, HG_NORM_ACGT, out.data()) != HG_OK || out[hg_pack2_size(n)] != 0x5A) return 19;
+    }
+  }
   printf("asan driver ok\n");
   return 0;
 }
