@@ -104,6 +104,20 @@ def newest_profile(suffix):
     return c[-1] if c else None
 
 
+SETTLE = {"sketch": 25, "dist": 300, "hamming": 30}  # untimed repetitions in front of a leg's warmup steps
+
+
+def settle(fn, n):
+    """Untimed clock settle in front of a leg's W warmup steps: the GPU's DVFS takes a few tens of milliseconds of load
+    to reach the clock it then holds (three back-to-back 1 000-genome sketches on an idle MI355X: 12.9 / 11.3 /
+    10.8 ms), so with a small K the timed steps would otherwise measure the ramp.  The leg's own step is repeated a
+    FIXED number of times (about 0.2 s of work; the same count on every rank -- the steps of the dist and search legs
+    contain collectives); the counts are reported as `settle_steps` in the line."""
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+
+
 def valu_issue(n_genomes):
     """Secondary, informative roofline of the k-mer kernel: its VALU instruction rate against the issue rate the
     same instruction mix reaches in tools/gpu_microbench.hip.  Instruction count and kernel cycles: the newest
@@ -239,6 +253,7 @@ def main():
     def step():
         ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
 
+    settle(step, SETTLE["sketch"])
     for _ in range(a.warmup):
         step()
     ctx.enable_timing(True)
@@ -268,7 +283,7 @@ def main():
 
     out = {
         "metric": "genomes/sec sketch (k=21,s=1500,D=4096)", "value": value, "unit": "genomes/sec",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps": SETTLE, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": "%d synthetic 5 Mbp genomes per GPU (BASELINE configs[1]), sketch k=21 "
@@ -429,6 +444,7 @@ def main():
             found, _ = ctx.dist_dev(r.data_ptr(), rn.data_ptr(), nr, mine.data_ptr(), mine_n2.data_ptr(), rows,
                                     HV_D, KSIZE, False, 85.0, hits.data_ptr(), cap)
 
+        settle(dstep, SETTLE["dist"])
         for _ in range(max(a.warmup, 1)):
             dstep()
         ctx.enable_timing(True)
@@ -514,6 +530,7 @@ def main():
                 qb.copy_(hq)
                 merged = shard.gather_records(search_block(rb, lo, qb), world, cdev)
 
+        settle(hstep, SETTLE["hamming"])
         hstep()
         ctx.enable_timing(True)
         ctx.timings()
