@@ -336,10 +336,10 @@ __global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *_
 // Both sums are evaluated in the epilogue, only for the few candidates that survive the threshold pre-filter AND sit
 // in a row / column that has clamped entries (~4 % of the rows): a row's entries (dim, b) are consecutive in a sorted
 // list, c_j[d] and a_i[d] are read back from the original i16 matrices.  Rows of mixed
-// parity, residuals beyond a byte, more than I8_ENT_CAP outlier entries or a row with more than 255 of them veto
+// parity, residuals beyond a byte, a row with more than 255 clamped entries or an overflow of the entry list veto
 // the path on the device and the f16 kernels queued behind it run instead; the dot product is the same integer
 // either way.
-constexpr uint32_t I8_ENT_CAP = 1024;
+constexpr uint32_t I8_ROW_ENT_MAX = 256;  // clamped entries one row may have (the slot word counts to 255)
 struct I8Outlier {
   uint32_t row;
   uint16_t d;
@@ -351,10 +351,16 @@ struct I8Outlier {
 __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict__ hv, uint32_t rows, uint32_t hv_d,
                                                       uint32_t kp8, uint32_t ldk8, int8_t *__restrict__ out_a,
                                                       int32_t *__restrict__ rowinfo, int32_t *__restrict__ rowslot,
-                                                      I8Outlier *__restrict__ list, uint32_t *__restrict__ ctrl,
-                                                      uint32_t *__restrict__ maxs_slots, uint32_t side) {
-  const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                      uint32_t *__restrict__ rowfirst, I8Outlier *__restrict__ list,
+                                                      uint32_t list_cap, uint32_t *__restrict__ ctrl, uint32_t side) {
+  // the row's clamped entries are collected in LDS (one wave = one row) and go to the global list as ONE contiguous
+  // range reserved with a single atomic: no sort, no second kernel, and the list can be as long as memory allows
+  __shared__ uint32_t s_ent[4][I8_ROW_ENT_MAX];
+  __shared__ uint32_t s_n[4];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
   if (row >= rows) return;  // whole wave
+  if (lane == 0) s_n[wv] = 0;
+  __builtin_amdgcn_wave_barrier();
   const int16_t *__restrict__ src = hv + (size_t)row * hv_d;
   const int32_t x0 = src[0], e = x0 & 1;
   int32_t S = 0;
@@ -396,8 +402,8 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
         const int32_t a = cc > 127 ? 127 : (cc < -127 ? -127 : cc), b = cc - a;
         if (b != 0) {
           if (b > 127 || b < -127) bad |= 4u;
-          const uint32_t idx = atomicAdd(&ctrl[0], 1u);
-          if (idx < I8_ENT_CAP) list[idx] = I8Outlier{row, (uint16_t)(d0 + i), (int8_t)b, (uint8_t)side};
+          const uint32_t idx = atomicAdd(&s_n[wv], 1u);
+          if (idx < I8_ROW_ENT_MAX) s_ent[wv][idx] = (d0 + i) | ((uint32_t)(uint8_t)(int8_t)b << 16);
         }
         pk[i >> 2] |= (uint32_t)(uint8_t)(int8_t)a << (8 * (i & 3));
       }
@@ -406,86 +412,42 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
-  const bool anypar = __any(par != 0), anybad = __any(bad != 0);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const uint32_t n_raw = s_n[wv], n = n_raw < I8_ROW_ENT_MAX ? n_raw : I8_ROW_ENT_MAX;
+  uint32_t bs = 0;  // sum |b| over the row's entries (the epilogue's per-row slack)
+  for (uint32_t t = lane; t < n; t += 64) {
+    const int32_t bb = (int8_t)(uint8_t)(s_ent[wv][t] >> 16);
+    bs += (uint32_t)(bb < 0 ? -bb : bb);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bs += __shfl_xor(bs, o);
+  if (n_raw > 255u || bs >= (1u << 14)) bad |= 2u;  // more than the slot word can describe
+  uint32_t base = 0;
+  if (lane == 0 && n) base = atomicAdd(&ctrl[0], n);
+  base = __shfl(base, 0);
+  if (n && (uint64_t)base + n <= list_cap) {
+    for (uint32_t t = lane; t < n; t += 64) {
+      const uint32_t v = s_ent[wv][t];
+      list[base + t] = I8Outlier{row, (uint16_t)(v & 0xffffu), (int8_t)(uint8_t)(v >> 16), (uint8_t)side};
+    }
+  }
+  const bool anypar = __any(par != 0), anybad4 = __any((bad & 4u) != 0), anybad2 = __any((bad & 2u) != 0);
   if (lane == 0) {
     rowinfo[row] = 2 * S + e;
-    rowslot[row] = 0;  // "no outlier entries" until i8_entries_kernel says otherwise
-    const uint32_t fl = (anypar ? 1u : 0u) | (anybad ? 4u : 0u);
+    rowfirst[row] = base;
+    rowslot[row] = n ? (int32_t)(((n & 255u) << 14) | (bs & 0x3fffu)) : 0;  // entries (8 bits) | sum |b| (14 bits); 0 = none
+    const uint32_t fl = (anypar ? 1u : 0u) | (anybad2 ? 2u : 0u) | (anybad4 ? 4u : 0u);
     if (fl) atomicOr(&ctrl[1], fl);
-    // max |S| over the rows, in one of 1 024 slots (folded by i8_entries_kernel): a single counter would take one
-    // same-address atomic from every wave resident at the start (they all see the initial zero), ~12 ns each
-    const uint32_t as = (uint32_t)(S < 0 ? -S : S);
-    uint32_t *sl = &maxs_slots[blockIdx.x % PREP_SLOTS];
-    if (as > __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sl, as);
   }
 }
 
-// One workgroup: the outlier entries sorted by (side, row, dim) so that a row's entries are consecutive; per row
-// (first entry | count | sum |b|) into rowslot; the verdict into ctrl.
-__global__ __launch_bounds__(1024) void i8_entries_kernel(const I8Outlier *__restrict__ list, I8Outlier *__restrict__ sorted,
-                                                          uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ maxs_slots,
-                                                          int32_t *__restrict__ slot_r, int32_t *__restrict__ slot_q,
-                                                          uint32_t kp8, uint32_t hv_d) {
-  __shared__ unsigned long long s_key[I8_ENT_CAP];
-  __shared__ uint32_t s_mx, s_bsum, s_bad, s_n0;
-  const uint32_t tid = threadIdx.x;
-  if (tid == 0) s_mx = 0, s_bsum = 0, s_bad = 0, s_n0 = 0;
-  __syncthreads();
-  {
-    const uint32_t v = maxs_slots[tid];  // PREP_SLOTS == blockDim.x
-    if (v) atomicMax(&s_mx, v);
-  }
-  const uint32_t n_raw = ctrl[0];
-  const uint32_t n = n_raw < I8_ENT_CAP ? n_raw : I8_ENT_CAP;
-  bool bad = ctrl[1] != 0 || n_raw > I8_ENT_CAP || kp8 > 65535;
-  // key: side | row | dim | residual byte  (ascending = grouped by side, then row)
-  unsigned long long key = ~0ull;
-  if (tid < n) {
-    const I8Outlier o = list[tid];
-    key = ((unsigned long long)(o.side & 1) << 63) | ((unsigned long long)(o.row & 0x7fffffffu) << 24) |
-          ((unsigned long long)o.d << 8) | (uint8_t)o.b;
-    if (o.side == 0) atomicAdd(&s_n0, 1u);
-  }
-  s_key[tid] = key;
-  __syncthreads();
-  for (uint32_t k = 2; k <= I8_ENT_CAP; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t ixj = tid ^ j;
-      if (ixj > tid) {
-        const unsigned long long x = s_key[tid], y = s_key[ixj];
-        const bool up = (tid & k) == 0;
-        if ((x > y) == up) s_key[tid] = y, s_key[ixj] = x;
-      }
-      __syncthreads();
-    }
-  const uint32_t n0 = s_n0;
-  if (tid < n) {
-    const unsigned long long kk = s_key[tid];
-    const uint32_t side = (uint32_t)(kk >> 63), row = (uint32_t)(kk >> 24) & 0x7fffffffu;
-    sorted[tid] = I8Outlier{row, (uint16_t)(kk >> 8), (int8_t)(uint8_t)kk, (uint8_t)side};
-    const bool first = tid == 0 || (s_key[tid - 1] >> 24) != (kk >> 24);
-    if (first) {  // run length and sum |b| of this row's entries
-      uint32_t cnt = 0, bs = 0;
-      for (uint32_t t = tid; t < n && (s_key[t] >> 24) == (kk >> 24); ++t) {
-        const int32_t bb = (int8_t)(uint8_t)s_key[t];
-        ++cnt, bs += (uint32_t)(bb < 0 ? -bb : bb);
-      }
-      if (cnt > 255 || bs >= (1u << 14)) atomicOr(&s_bad, 1u);
-      atomicMax(&s_bsum, bs);
-      const uint32_t first_idx = side ? tid - n0 : tid;  // index inside this side's correction table
-      // slot word: first entry (10 bits) | entries (8 bits) | sum |b| of the row (14 bits: the epilogue's per-row slack)
-      (side ? slot_q : slot_r)[row] = (int32_t)((first_idx << 22) | ((cnt & 255u) << 14) | (bs & 0x3fffu));
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    bad = bad || s_bad != 0;
-    ctrl[2] = 4u * s_mx + hv_d + 64u + 8u * s_bsum * 254u;  // (global form of the epilogue's slack; informational)
-    ctrl[3] = n0;
-    ctrl[4] = bad ? 0u : 1u;
-    ctrl[5] = kp8 / 128;
-  }
+// The i8 attempt is valid iff no row broke the scheme (ctrl[1]: parity / residual / per-row limits) and the entry list
+// did not overflow (ctrl[0] counts every reserved entry).  Every workgroup of the GEMM evaluates this by itself.
+__device__ __forceinline__ bool i8_attempt_valid(const uint32_t *ctrl, uint32_t list_cap) {
+  return ctrl[1] == 0u && ctrl[0] <= list_cap;
 }
+
 
 // ---- MFMA GEMM + ANI ------------------------------------------------------------------------------
 constexpr int BK = 64;
@@ -537,10 +499,14 @@ struct GemmArgs {
   const uint32_t *veto;       // f16 kernels queued behind an i8 attempt: return at once if *veto == 1 (i8 path valid)
   // i8 operand path (I8 instantiations): row / column info words 2*S + e, control words of the i8 prepass
   const int32_t *info_r, *info_q;
-  const int32_t *slot_r, *slot_q;  // first entry (10 bits) | entries (8) | sum |b| (14) per row / column, 0 = none
+  const int32_t *slot_r, *slot_q;  // entries (8 bits) | sum |b| (14) per row / column, 0 = none
+  const uint32_t *first_r, *first_q;  // ... and where the row's / column's entries start in `ents`
+  uint32_t ent_cap;                // capacity of `ents`
+  uint32_t *i8verdict;             // [0] <- 1 when the i8 attempt is valid, [1] <- K-steps (written by workgroup 0: the
+                                   // host's read-back and the veto word of the f16 kernels queued behind)
   const I8Outlier *ents;           // clamped entries sorted by (side, row, dim)
   const int16_t *raw_r, *raw_q;    // the original i16 matrices (rows of hv_d)
-  const uint32_t *i8ctrl;          // [3] entries of side 0, [4] verdict, [5] K-steps
+  const uint32_t *i8ctrl;          // [0] entries reserved, [1] flags of the prepass
   uint32_t hv_d, same_set;
   int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
 };
@@ -579,8 +545,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
   if (I8 && !HAM) {
-    if (g.i8ctrl[4] != 1u) return;
-    g.Kp = g.i8ctrl[5] * BK;  // K-steps of 128 bytes = BK two-byte units, extra columns included
+    const bool ok = i8_attempt_valid(g.i8ctrl, g.ent_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) g.i8verdict[0] = ok ? 1u : 0u, g.i8verdict[1] = g.Kp / BK;
+    if (!ok) return;
   }
   if (g.verdict) {  // uniform
     const uint32_t code = g.verdict[0];
@@ -913,7 +880,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   int32_t *s_nr = reinterpret_cast<int32_t *>(reinterpret_cast<uint2 *>(sAB) + (THREADS / 64) * CAND_CAP), *s_nq = s_nr + BM;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_nq + BN);  // per-wave hit counts + the workgroup's base
   int32_t *s_ir = reinterpret_cast<int32_t *>(s_cnt + THREADS / 64 + 1), *s_iq = s_ir + BM;  // i8 path: 2*S + e per row / column
-  int32_t *s_sr = s_iq + BN, *s_sq = s_sr + BM;                                             // ... and the outlier-entry slots
+  int32_t *s_sr = s_iq + BN, *s_sq = s_sr + BM;                                             // ... the outlier-entry slots
+  uint32_t *s_fr = reinterpret_cast<uint32_t *>(s_sq + BN), *s_fq = s_fr + BM;              // ... and their first entries
   for (uint32_t t = tid; t < (uint32_t)(BM + BN); t += THREADS) {
     const bool is_r = t < (uint32_t)BM;
     const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
@@ -922,9 +890,10 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     if (I8 && !HAM) {
       s_ir[t] = in ? (is_r ? g.info_r[idx] : g.info_q[idx]) : 0;
       s_sr[t] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
+      s_fr[t] = in ? (is_r ? g.first_r[idx] : g.first_q[idx]) : 0u;
     }
   }
-  if (tid == 0) reinterpret_cast<uint32_t *>(s_sq + BN)[THREADS / 64] = 0u;  // "some candidate list is nearly full"
+  if (tid == 0) (s_fq + BN)[THREADS / 64] = 0u;  // "some candidate list is nearly full"
   __syncthreads();
 #undef HG_GLOAD
 #undef HG_LSTORE
@@ -960,17 +929,16 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   // (info word = 2*S + e).  Runs per candidate in phase 2, outside the unrolled accumulator sweep.
   auto i8_exact_dot = [&](int32_t G, uint32_t li, uint32_t lj, uint32_t gi, uint32_t gj) __attribute__((always_inline)) -> int32_t {
     const int32_t sr = s_sr[li], sq = s_sq[lj];
-    const uint32_t ur_ = (uint32_t)sr, uq_ = (uint32_t)sq;  // first (10) | count (8) | sum |b| (14)
+    const uint32_t ur_ = (uint32_t)sr, uq_ = (uint32_t)sq;  // count (8) | sum |b| (14)
     const int32_t ir = s_ir[li], iq = s_iq[lj];
     const int32_t er = ir & 1, eq = iq & 1;
     for (uint32_t t = 0; t < ((ur_ >> 14) & 255u); ++t) {  // b_i[d] * c_j[d], c = the true centred count of column j
-      const I8Outlier o = g.ents[(ur_ >> 22) + t];
+      const I8Outlier o = g.ents[s_fr[li] + t];
       G += (int32_t)o.b * (((int32_t)g.raw_q[(size_t)gj * g.hv_d + o.d] + eq) >> 1);
     }
-    if ((uq_ >> 14) & 255u) {
-      const uint32_t qbase = g.same_set ? 0u : g.i8ctrl[3];
+    {
       for (uint32_t t = 0; t < ((uq_ >> 14) & 255u); ++t) {  // a_i[d] * b_j[d], a = the clamped byte of row i
-        const I8Outlier o = g.ents[qbase + (uq_ >> 22) + t];
+        const I8Outlier o = g.ents[s_fq[lj] + t];
         const int32_t cc = ((int32_t)g.raw_r[(size_t)gi * g.hv_d + o.d] + er) >> 1;
         G += (int32_t)o.b * (cc > 127 ? 127 : (cc < -127 ? -127 : cc));
       }
@@ -1021,7 +989,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   // hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round, and one atomic per
   // wave kept every CU waiting ~25 us per round), and the batches of all lists dealt round-robin to the waves.
   constexpr uint32_t NW_ = THREADS / 64;
-  uint32_t *s_len = reinterpret_cast<uint32_t *>(s_sq + BN);  // the list lengths + the "some list is nearly full" flag
+  uint32_t *s_len = s_fq + BN;  // the list lengths + the "some list is nearly full" flag
   auto flush_all = [&]() __attribute__((always_inline)) {
     if (lane == 0) s_len[wave] = staged;
     __syncthreads();
@@ -1359,35 +1327,34 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
     if (!same && (s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldk8)) != HG_OK) return s;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    // misc block: info_r, info_q, slot_r, slot_q, raw + sorted entry lists, max |S| slots
+    // misc block: info, slot and first-entry words per row / column, the list of clamped entries
+    // capacity = 2 entries per row on average: beyond that (sketches of more than ~5 500 hashes at D = 4096) the
+    // per-candidate corrections and the wider pre-filter slack cost more than the i8 GEMM saves (10 000 x 10 000,
+    // 1.29 M hits: 4 500 hashes 0.62 ms vs 0.89 ms f16, 5 500: 0.84 vs 0.89, 6 666: 1.17 vs 0.87) -- the overflow vetoes
+    const uint64_t cap64 = std::min<uint64_t>(((uint64_t)a.R + a.Q) * 2 + 1024, (uint64_t)1 << 26);
+    const uint32_t ent_cap = (uint32_t)cap64;
     const size_t o_iq = al((size_t)a.R * 4), o_sr = o_iq + al((size_t)a.Q * 4), o_sq = o_sr + al((size_t)a.R * 4);
-    const size_t o_list = o_sq + al((size_t)a.Q * 4), o_sorted = o_list + al(I8_ENT_CAP * sizeof(I8Outlier));
-    const size_t o_slots = o_sorted + al(I8_ENT_CAP * sizeof(I8Outlier));
-    if ((s = hg_ensure(c, c->w_i8misc, o_slots + al(PREP_SLOTS * 4) + 256)) != HG_OK) return s;
+    const size_t o_fr = o_sq + al((size_t)a.Q * 4), o_fq = o_fr + al((size_t)a.R * 4), o_list = o_fq + al((size_t)a.Q * 4);
+    if ((s = hg_ensure(c, c->w_i8misc, o_list + al((size_t)ent_cap * sizeof(I8Outlier)) + 256)) != HG_OK) return s;
     auto *a8 = static_cast<int8_t *>(c->w_i8a.p), *b8 = same ? a8 : static_cast<int8_t *>(c->w_i8b.p);
     auto *mb = static_cast<uint8_t *>(c->w_i8misc.p);
     auto *info_r = reinterpret_cast<int32_t *>(mb), *info_q = same ? info_r : reinterpret_cast<int32_t *>(mb + o_iq);
     auto *slot_r = reinterpret_cast<int32_t *>(mb + o_sr), *slot_q = same ? slot_r : reinterpret_cast<int32_t *>(mb + o_sq);
-    auto *list = reinterpret_cast<I8Outlier *>(mb + o_list), *sorted = reinterpret_cast<I8Outlier *>(mb + o_sorted);
-    auto *maxs = reinterpret_cast<uint32_t *>(mb + o_slots);
-    HG_HIP(c, hipMemsetAsync(maxs, 0, PREP_SLOTS * 4, c->stream));
+    auto *first_r = reinterpret_cast<uint32_t *>(mb + o_fr), *first_q = same ? first_r : reinterpret_cast<uint32_t *>(mb + o_fq);
+    auto *list = reinterpret_cast<I8Outlier *>(mb + o_list);
     uint32_t *ctrl = d_verdict + 3;  // words 4.. of the caller's result block (zeroed by the caller, read back with the hit count)
     if (Rp > a.R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)a.R * ldk8, 0, (size_t)(Rp - a.R) * ldk8, c->stream));
     if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)a.Q * ldk8, 0, (size_t)(Qp - a.Q) * ldk8, c->stream));
     {
       hg_timed tmp(c, HG_T_DIST_PREP);
-      static_assert(PREP_SLOTS == 1024, "i8_entries_kernel folds one slot per thread");
       hipLaunchKernelGGL(prep_i8_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, kp8, ldk8, a8,
-                         info_r, slot_r, list, ctrl, maxs, 0u);
+                         info_r, slot_r, first_r, list, ent_cap, ctrl, 0u);
       HG_HIP(c, hipGetLastError());
       if (!same) {
         hipLaunchKernelGGL(prep_i8_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, kp8, ldk8, b8,
-                           info_q, slot_q, list, ctrl, maxs, 1u);
+                           info_q, slot_q, first_q, list, ent_cap, ctrl, 1u);
         HG_HIP(c, hipGetLastError());
       }
-      hipLaunchKernelGGL(i8_entries_kernel, dim3(1), dim3(1024), 0, c->stream, list, sorted, ctrl, maxs, slot_r, slot_q, kp8,
-                         a.hv_d);
-      HG_HIP(c, hipGetLastError());
     }
     GemmArgs g{};
     g.A = reinterpret_cast<const _Float16 *>(a8), g.B = reinterpret_cast<const _Float16 *>(b8);
@@ -1400,7 +1367,8 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     if (g.j_lo == -INFINITY) g.pre_c = 0.f, g.pre_b = -INFINITY;
     else if (g.j_lo == INFINITY) g.pre_c = 0.f, g.pre_b = INFINITY;
     else g.pre_c = (float)((double)g.j_lo / (1.0 + (double)g.j_lo) * (1.0 - 1e-5)), g.pre_b = 0.f;
-    g.info_r = info_r, g.info_q = info_q, g.slot_r = slot_r, g.slot_q = slot_q, g.ents = sorted;
+    g.info_r = info_r, g.info_q = info_q, g.slot_r = slot_r, g.slot_q = slot_q, g.ents = list;
+    g.first_r = first_r, g.first_q = first_q, g.ent_cap = ent_cap, g.i8verdict = ctrl + 4;
     g.raw_r = a.ref_hv, g.raw_q = a.qry_hv, g.i8ctrl = ctrl, g.hv_d = a.hv_d, g.same_set = same ? 1u : 0u;
     int nt = 4;
     {

@@ -581,6 +581,37 @@ def test_dist_i8_operand_path_equals_f16_and_oracle(ctx, orc, same):
         ctx.set_debug("dist_path", "")
 
 
+@pytest.mark.parametrize("n,expect_i8", [(4400, True), (5200, True), (9000, False)])
+def test_dist_i8_reach_mid_size_sketches(ctx, orc, n, expect_i8):
+    """Sketches of 4 000-5 500 hashes have a few clamped entries in most rows (|count - n/2| > 127 at ~3.5 sigma): every
+    row's entries are one contiguous range of the entry list, both operands' entries meet in the same dimension now and
+    then -- the i8 path must take them (automatically) and give the f16 path's hits bit for bit; at 9 000 hashes the
+    list overflows its two-entries-per-row capacity and the call falls back to f16 by itself."""
+    rng = np.random.default_rng(n)
+    D, R, Q = 4096, 640, 500
+    base = rng.binomial(int(n * 0.6), 0.5, (5, D))
+    r, q = _sketch_like(rng, R, D, n, base), _sketch_like(rng, Q, D, n, base)
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+    clamped = int((np.abs((r.astype(np.int32) + (r[:, :1] & 1)) >> 1) > 127).sum())
+    assert (clamped > 200) if expect_i8 else (clamped > 2 * (R + Q) + 1024)
+    key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    try:
+        ctx.set_debug("dist_path", "i8")  # (small problem: the automatic choice starts at 256^3 pairs x dims)
+        h8 = key(ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=60.0))
+        assert ctx.last_dist_path() == (1 if expect_i8 else 0)
+        ctx.set_debug("dist_path", "f16")
+        h16 = key(ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=60.0))
+    finally:
+        ctx.set_debug("dist_path", "")
+    assert h8.size == h16.size > 1000 and np.array_equal(h8, h16)
+    got = np.zeros_like(want)
+    got[h8["ref_idx"], h8["qry_idx"]] = h8["ani"]
+    sel = want >= 60.0 + 1e-4
+    assert (got[sel] > 0).all() and np.abs(got[sel] - want[sel]).max() <= 1e-4
+
+
 def test_dist_i8_vetoed_inputs_fall_back_to_f16(ctx, orc):
     """Inputs the i8 path must refuse on the device -- a row of mixed parity, a residual beyond a byte, more outlier
     dims than extra columns -- still give the f16 result (the f16 kernels queued behind the attempt run)."""
