@@ -20,12 +20,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import hypergen_amd as hg  # noqa: E402
+# numpy / torch / hypergen_amd are imported by main() AFTER the self-launch decision: the parent of an N > 1 run
+# must not load the HIP runtime (its children are fresh processes, never a re-exec of one that touched the GPU)
+np = torch = hg = None
 
 L_GENOME = 5_000_000
 HV_D = 4096
@@ -51,19 +50,22 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank logic on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses device 0")
+    ap.add_argument("--collectives", action="store_true",
+                    help="initialise the process group and run the all-gather / broadcast steps even with ONE rank "
+                         "(a one-GPU box then executes the RCCL code path of the N > 1 run)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 def barrier_sync(world):
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(x, world, dev):
-    if world == 1:
+    if world == 1 and not torch.distributed.is_initialized():
         return x
     if torch.distributed.get_backend() != "nccl":
         dev = torch.device("cpu")
@@ -76,6 +78,7 @@ def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100):
     """Synthetic i16 HVs with the statistics of real sketches: hv = 2*count - n where count is
     Binomial(n, 1/2); members of a cluster share the counts of shared_frac*n hashes, so
     within-cluster ANI is ~96-97 % and cross-cluster ANI ~0 (about 1 % of pairs pass ani_th=85)."""
+    import torch  # (tests import this helper without going through main())
     ns = int(n * shared_frac)
     ids = torch.arange(first_row, first_row + rows, device=dev)
     cl = ids // cluster
@@ -211,21 +214,52 @@ def cpu_baseline_dist(hv, n2, seconds, log):
                       "i16 dot per pair), OpenMP over rows on %d threads, %.2f s" % (rows, q_rows, cores, dt)}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks as CHILD
+    processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1), let rank 0's JSON line through on the
+    inherited stdout and exit with the children's status.  Nothing in this parent has imported torch or the HIP
+    library at this point."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
+    global np, torch, hg
+    import numpy as np
+    import torch
+    import torch.distributed  # noqa: F401
+    import hypergen_amd as hg
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.share_gpu:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # tensors handed to collectives live on the GPU for RCCL; gloo (testing aid) gets host copies
     cdev = dev if a.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    coll = world > 1 or a.collectives  # run the exchange steps (always at N > 1; at N = 1 only on request)
+    if coll:
+        if "WORLD_SIZE" not in os.environ:  # bare one-rank run with --collectives: a private rendezvous
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+            s.close()
         if a.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
@@ -420,14 +454,14 @@ def main():
         mine_n2 = (mine.int() ** 2).sum(1).int()
         cap = max(1 << 20, rows * R // 20)
         hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)  # hg_ani_hit = 12 bytes
-        if world > 1:
+        if coll:
             ref_all = torch.empty((R // world * world, HV_D), dtype=torch.int16, device=dev)
             ref_n2 = torch.empty(R // world * world, dtype=torch.int32, device=dev)
         found = 0
 
         def dstep():
             nonlocal found
-            if world > 1:  # the path's one exchange step: all-gather the reference HV matrix (RCCL/xGMI)
+            if coll:  # the path's one exchange step: all-gather the reference HV matrix (RCCL/xGMI)
                 # as raw bytes: RCCL has no int16 datatype and the payload is opaque to the collective
                 if a.backend == "nccl":
                     torch.distributed.all_gather_into_tensor(ref_all.view(torch.uint8).view(-1),
@@ -520,15 +554,15 @@ def main():
 
         def hstep():
             nonlocal merged
-            if world > 1 and rank == 0:
+            if coll and rank == 0:
                 qb.copy_(qsrc)  # (the broadcast is in place; rank 0 re-publishes its query set every step)
-            if a.backend == "nccl" or world == 1:
-                merged = shard.sharded_search(search_block, rb, lo, qb, world, dev)
+            if a.backend == "nccl" or not coll:
+                merged = shard.sharded_search(search_block, rb, lo, qb, world, dev, force=coll)
             else:  # gloo (testing aid): broadcast / gather on host copies
                 hq = qb.cpu()
-                shard.broadcast_rows(hq, world, 0)
+                shard.broadcast_rows(hq, world, 0, force=coll)
                 qb.copy_(hq)
-                merged = shard.gather_records(search_block(rb, lo, qb), world, cdev)
+                merged = shard.gather_records(search_block(rb, lo, qb), world, cdev, force=coll)
 
         settle(hstep, SETTLE["hamming"])
         hstep()
@@ -635,7 +669,10 @@ def main():
         out["parity_gate"] = dict(gate, status="passed")
     elif rank == 0:
         out["parity_gate"] = {"status": "skipped (no CPU leg: N > 1 or --no-cpu-baseline); hamming / 10k / host-fed self-checks ran"}
-    if world > 1:
+    if coll:
+        out["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
+                              "steps": "all-gather of the reference HV matrix + norms (dist), query broadcast + hit "
+                                       "gather (hamming), barrier / max-reduce around every timed region"}
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("HYPERGEN_LIB") or os.path.join(_HERE, "libhypergen_hi
 CLI_PATH = os.path.join(_HERE, "hyper-gen")
 
 LAYOUT_SCALAR, LAYOUT_AVX2 = 0, 1
+GATHER_PEER, GATHER_RCCL = 0, 1
 NORM_ACGT, NORM_U2T = 0, 1
 (OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_IO,
  ERR_INEXACT) = range(9)
@@ -70,12 +71,14 @@ EXPORTS = [
     "hg_hv_binarize_dev", "hg_hamming_full_dev", "hg_hamming_search_dev",
     "hg_ctx_set_debug", "hg_read_fastx_into", "hg_dist_block_dev", "hg_hamming_search_block_dev",
     "hg_multi_create", "hg_multi_destroy", "hg_multi_size", "hg_multi_ctx", "hg_multi_last_error", "hg_shard_range",
+    "hg_multi_peer_report", "hg_multi_set_gather", "hg_multi_gather_mode", "hg_multi_gather_report",
     "hg_sketch_batch_multi", "hg_dist_multi", "hg_dist_multi_dev", "hg_hamming_search_multi",
     "hg_sort_ani_hits_dev", "hg_sort_ani_hits_staged", "hg_topk_per_query_dev", "hg_ctx_last_dist_path",
     "hg_ctx_last_hamming_path", "hg_read_fastx_pinned", "hg_pinned_free",
     "hg_sketch_stream_open", "hg_sketch_stream_push", "hg_sketch_stream_pop", "hg_sketch_stream_finish",
     "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node",
     "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
+    "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
 ]
 
 
@@ -149,6 +152,8 @@ def lib():
         "hg_sketch_stream_pop": (C.c_int, [vp, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_int)]),
         "hg_sketch_stream_push_packed": (C.c_int, [vp, vp, sz, C.c_uint64]),
+        "hg_sketch_stream_try_push": (C.c_int, [vp, vp, sz, C.c_uint64, C.c_int]),
+        "hg_sketch_stream_max_pending": (sz, [vp]),
         "hg_pack2_size": (sz, [sz]),
         "hg_pack2": (C.c_int, [vp, sz, C.c_uint32, vp]),
         "hg_unpack2_dev": (C.c_int, [vp, vp, sz, vp]),
@@ -170,6 +175,10 @@ def lib():
         "hg_multi_size": (C.c_int, [vp]),
         "hg_multi_ctx": (vp, [vp, C.c_int]),
         "hg_multi_last_error": (C.c_char_p, [vp]),
+        "hg_multi_peer_report": (C.c_char_p, [vp]),
+        "hg_multi_gather_report": (C.c_char_p, [vp]),
+        "hg_multi_set_gather": (C.c_int, [vp, C.c_int]),
+        "hg_multi_gather_mode": (C.c_int, [vp]),
         "hg_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
         "hg_sketch_batch_multi": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(SketchParams),
                                             vp, vp, vp]),
@@ -445,6 +454,19 @@ class Multi:
     def ctx_handle(self, shard):
         return lib().hg_multi_ctx(self._h, shard)
 
+    def peer_report(self):
+        return lib().hg_multi_peer_report(self._h).decode()
+
+    def set_gather(self, mode):
+        """GATHER_PEER (direct hipMemcpyPeerAsync pulls) or GATHER_RCCL (ncclAllGather / grouped ncclBroadcast)."""
+        self._ck(lib().hg_multi_set_gather(self._h, mode))
+
+    def gather_mode(self):
+        return lib().hg_multi_gather_mode(self._h)
+
+    def gather_report(self):
+        return lib().hg_multi_gather_report(self._h).decode()
+
     def sketch_batch(self, seqs, params=None):
         p = params or default_params()
         arrs = [np.ascontiguousarray(s, dtype=np.uint8) if isinstance(s, np.ndarray)
@@ -617,39 +639,65 @@ class SketchStream:
         st = lib().hg_sketch_stream_open(ids, len(device_ids), C.byref(self.params), C.byref(self._h))
         if st != OK:
             raise HgError(st, "hg_sketch_stream_open: " + lib().hg_last_error(None).decode())
-        self._keep = {}
+        self._keep = {}      # internal id -> (user tag, the array the device may still read)
+        self._next = 0
+        self._ready = []     # results popped on the pusher's behalf while the stream was full
         self._lock = threading.Lock()
 
     def _check(self, st, what):
         if st != OK:
             raise HgError(st, what + ": " + lib().hg_sketch_stream_last_error(self._h).decode())
 
+    def _push(self, a, n_bps, tag, packed):
+        # The C push blocks once max_pending results are outstanding; a caller that pushes everything before it pops
+        # (the natural single-threaded use) would wait for ever.  So: never block here -- when the stream is full, take
+        # one finished result out and hand it over on a later pop().  Arrays are kept by an internal id, not by the
+        # user's tag (a reused tag must not drop the keep-alive of an array the device may still read).
+        with self._lock:
+            iid = self._next
+            self._next += 1
+            self._keep[iid] = (tag, a)
+        while True:
+            st = lib().hg_sketch_stream_try_push(self._h, _ptr(a), n_bps, iid, int(packed))
+            if st != ERR_CAPACITY:
+                break
+            r = self._pop_c()
+            if r is not None:
+                with self._lock:
+                    self._ready.append(r)
+        if st != OK:
+            with self._lock:
+                self._keep.pop(iid, None)
+        self._check(st, "hg_sketch_stream_try_push")
+
     def push(self, seq, tag):
         a = np.ascontiguousarray(seq, np.uint8)
-        with self._lock:
-            self._keep[tag] = a
-        self._check(lib().hg_sketch_stream_push(self._h, _ptr(a), a.size, tag), "hg_sketch_stream_push")
+        self._push(a, a.size, tag, False)
 
     def push_packed(self, blob, n_bps, tag):
         a = np.ascontiguousarray(blob, np.uint8)
         assert a.size >= lib().hg_pack2_size(n_bps)
-        with self._lock:
-            self._keep[tag] = a
-        self._check(lib().hg_sketch_stream_push_packed(self._h, _ptr(a), n_bps, tag), "hg_sketch_stream_push_packed")
+        self._push(a, n_bps, tag, True)
 
     def finish(self):
         self._check(lib().hg_sketch_stream_finish(self._h), "hg_sketch_stream_finish")
 
-    def pop(self):
-        tag, n2, nh, got = C.c_uint64(), C.c_int32(), C.c_uint32(), C.c_int()
+    def _pop_c(self):
+        iid, n2, nh, got = C.c_uint64(), C.c_int32(), C.c_uint32(), C.c_int()
         hv = np.empty(self.params.hv_d, np.int16)
-        self._check(lib().hg_sketch_stream_pop(self._h, C.byref(tag), _ptr(hv), C.byref(n2), C.byref(nh), C.byref(got)),
+        self._check(lib().hg_sketch_stream_pop(self._h, C.byref(iid), _ptr(hv), C.byref(n2), C.byref(nh), C.byref(got)),
                     "hg_sketch_stream_pop")
         if not got.value:
             return None
         with self._lock:
-            self._keep.pop(tag.value, None)
-        return tag.value, hv, n2.value, nh.value
+            tag, _ = self._keep.pop(iid.value)
+        return tag, hv, n2.value, nh.value
+
+    def pop(self):
+        with self._lock:
+            if self._ready:
+                return self._ready.pop(0)
+        return self._pop_c()
 
     def stats(self, engine=0):
         out = (C.c_double * 6)()

@@ -893,7 +893,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
       s_fr[t] = in ? (is_r ? g.first_r[idx] : g.first_q[idx]) : 0u;
     }
   }
-  if (tid == 0) (s_fq + BN)[THREADS / 64] = 0u;  // "some candidate list is nearly full"
+  if (tid < 3) (s_fq + BN)[THREADS / 64 + tid] = 0u;  // "some candidate list is nearly full": three slots in rotation
   __syncthreads();
 #undef HG_GLOAD
 #undef HG_LSTORE
@@ -989,7 +989,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   // hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round, and one atomic per
   // wave kept every CU waiting ~25 us per round), and the batches of all lists dealt round-robin to the waves.
   constexpr uint32_t NW_ = THREADS / 64;
-  uint32_t *s_len = s_fq + BN;  // the list lengths + the "some list is nearly full" flag
+  uint32_t *s_len = s_fq + BN;  // the list lengths + three "some list is nearly full" flags (slot m % 3)
   auto flush_all = [&]() __attribute__((always_inline)) {
     if (lane == 0) s_len[wave] = staged;
     __syncthreads();
@@ -1009,7 +1009,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
 #pragma unroll
       for (uint32_t w = 0; w < NW_; ++w) total += s_cnt[w];
       s_cnt[NW_] = total ? atomicAdd(g.hit_count, total) : 0u;
-      s_len[NW_] = 0u;
     }
     __syncthreads();
     uint32_t off = s_cnt[NW_];
@@ -1093,9 +1092,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     // At most 4 * NT * 64 candidates per m and wave.  A list that might overflow in the next m (dense blocks of hits
     // only) is emptied by the WHOLE workgroup: the decision is made uniform through LDS, one barrier per m.
     if constexpr (m + 1 < WTM) {
-      if (lane == 0 && staged > CAND_CAP - 4 * NT * 64) s_len[NW_] = 1u;
+      // Three flag slots in rotation: slot m % 3 is raised before this m's barrier and read after it; the slot of
+      // m + 2 is cleared here, between barrier m and barrier m + 1 -- every wave read it (as slot m - 1) before it
+      // arrived at barrier m, and nobody raises it before barrier m + 1.  (With ONE slot a fast wave could raise the
+      // flag for m + 1 before a slow one had read it for m: the two would then disagree about the flush.)
+      if (lane == 0 && staged > CAND_CAP - 4 * NT * 64) s_len[NW_ + m % 3] = 1u;
       __syncthreads();
-      const bool any_full = s_len[NW_] != 0u;
+      const bool any_full = s_len[NW_ + m % 3] != 0u;
+      if (wave == 0 && lane == 0) s_len[NW_ + (m + 2) % 3] = 0u;
       if (any_full) flush_all();
     }
   });

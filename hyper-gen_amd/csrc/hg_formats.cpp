@@ -442,11 +442,32 @@ hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, si
   }
   if (st == HG_OK && !grow(buf, cap, fsize + 64, 0, user)) st = HG_ERR_OOM;
   if (st == HG_OK && pack && !(mask = thread_mask(al16((fsize + 7) / 8) + 64))) st = HG_ERR_OOM;
+  // The buffers were sized from fstat(), but the file may hold more than st_size by the time it is read (a file
+  // that is still being appended to, procfs-style files that report size 0): every block checks the room it needs
+  // first and grows the result -- and, when packing, the mask -- keeping what was produced so far.
+  size_t mask_cap = al16((fsize + 7) / 8) + 64;
   auto emit = [&](size_t n_lines_bytes) {  // blk[0, n) holds whole lines (or the file's last, open one)
+    // a merged block is never longer than its text: every 'N' replaces a header line of at least one byte
     if (!pack) {
+      if (w + n_lines_bytes + 64 > cap && !grow(buf, cap, 2 * (w + n_lines_bytes) + 64, w, user)) {
+        st = HG_ERR_OOM;
+        return;
+      }
       w += base_mode == HG_READ_NEEDLETAIL ? merge_lines_needletail(blk.data(), n_lines_bytes, buf + w, nst)
                                            : merge_lines(blk.data(), n_lines_bytes, buf + w);
       return;
+    }
+    const size_t bases_max = w + have + n_lines_bytes;  // bases after this block, at most
+    if (hg_pack2_size(bases_max) + 64 > cap && !grow(buf, cap, 2 * hg_pack2_size(bases_max) + 64, std::min(cap, (w >> 2) + 16), user)) {
+      st = HG_ERR_OOM;
+      return;
+    }
+    if (al16((bases_max + 7) / 8) + 64 > mask_cap) {
+      mask_cap = 2 * al16((bases_max + 7) / 8) + 64;
+      if (!(mask = thread_mask(mask_cap))) {  // (a resize: the bits collected so far stay)
+        st = HG_ERR_OOM;
+        return;
+      }
     }
     const size_t m = base_mode == HG_READ_NEEDLETAIL ? merge_lines_needletail(blk.data(), n_lines_bytes, mst.data() + have, nst)
                                                      : merge_lines(blk.data(), n_lines_bytes, mst.data() + have);
@@ -518,7 +539,7 @@ hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, si
   if (pack) {
     pack2_span(mst.data(), have, u2t, buf + (w >> 2), mask + (w >> 3));
     w += have;
-    pack2_finish(buf, w, mask);  // hg_pack2_size(w) <= 0.375 w + 32 <= file size + 64
+    pack2_finish(buf, w, mask);  // hg_pack2_size(w) + 64 <= cap: emit() made the room
   } else {
     std::memset(buf + w, 0, 64);
   }

@@ -8,13 +8,69 @@
 // hipMemcpyPeerAsync -- 7 concurrent transfers per GPU, one per link, each block crossing exactly one link.
 // (A ring all-gather would push every block over n - 1 hops of a per-link-bound ring.)  Ordering is by events:
 // a block is published by an event on its owner's stream, the puller's stream waits for that event.
+//
+// The same exchange through RCCL (hg_multi_set_gather(m, HG_GATHER_RCCL); SURVEY.md 8(e): "one ncclAllGather of
+// the R x D i16 ref matrix + R i32 norms"): one communicator per shard from ncclCommInitAll, the collective queued
+// on every shard's stream inside one ncclGroupStart/End -- ncclAllGather when the row blocks have equal sizes,
+// one ncclBroadcast per owner otherwise (the all-gather-v idiom).  librccl is opened with dlopen the first time
+// the mode is selected, so the library carries no link-time dependency on it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "hg_internal.h"
+
+namespace {
+struct RcclApi {
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  std::string why;  // why it is unusable, if it is
+  bool ok = false;
+};
+const RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void *h = nullptr;
+    // a copy that is already in the process (PyTorch ships its own) is reused through the soname lookup
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+      const char *e = dlerror();
+      api.why = std::string("librccl not loadable: ") + (e ? e : "?");
+      return;
+    }
+    bool all = true;
+    auto sym = [&](const char *n) {
+      void *p = dlsym(h, n);
+      if (!p) all = false, api.why = std::string("librccl lacks ") + n;
+      return p;
+    };
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
+    api.ok = all;
+  });
+  return api;
+}
+}  // namespace
 
 struct hg_multi {
   std::vector<hg_ctx *> ctx;
@@ -28,6 +84,10 @@ struct hg_multi {
     hipEvent_t ready = nullptr;   // "this shard's published rows are complete"
   };
   std::vector<Shard> sh;
+  int gather = HG_GATHER_PEER;
+  std::vector<ncclComm_t> comm;  // one per shard once HG_GATHER_RCCL was selected
+  std::string peer_report;       // what hipDeviceEnablePeerAccess said at creation
+  std::string gather_report;     // how the last exchange step ran
 };
 
 namespace {
@@ -99,18 +159,67 @@ extern "C" hg_status hg_multi_create(const int *device_ids, int n, hg_multi **ou
       return hg_fail(nullptr, HG_ERR_HIP, "hg_multi: event creation failed");
     }
   }
-  // direct xGMI access between distinct devices (hipMemcpyPeerAsync stages through the host without it)
+  // direct xGMI access between distinct devices (hipMemcpyPeerAsync stages through the host without it).  The
+  // outcome is kept for the caller (hg_multi_peer_report): a pair without peer access still works, at PCIe speed.
+  int pairs = 0, enabled = 0;
+  std::string failed;
   for (int a = 0; a < n; ++a)
     for (int b = 0; b < n; ++b) {
       if (m->dev[a] == m->dev[b]) continue;
+      bool seen = false;  // repeated ids: report every ordered device pair once
+      for (int a2 = 0; a2 <= a && !seen; ++a2)
+        for (int b2 = 0; b2 < (a2 == a ? b : n) && !seen; ++b2)
+          seen = m->dev[a2] == m->dev[a] && m->dev[b2] == m->dev[b];
+      if (seen) continue;
+      ++pairs;
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, m->dev[a], m->dev[b]) == hipSuccess && can) {
+      hipError_t e = hipDeviceCanAccessPeer(&can, m->dev[a], m->dev[b]);
+      if (e == hipSuccess && can) {
         (void)hipSetDevice(m->dev[a]);
-        const hipError_t e = hipDeviceEnablePeerAccess(m->dev[b], 0);
-        if (e != hipSuccess) (void)hipGetLastError();  // already enabled is fine
+        e = hipDeviceEnablePeerAccess(m->dev[b], 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess, (void)hipGetLastError();
+      } else if (e == hipSuccess) {
+        e = hipErrorPeerAccessUnsupported;
+      }
+      if (e == hipSuccess) {
+        ++enabled;
+      } else {
+        (void)hipGetLastError();
+        failed += " " + std::to_string(m->dev[a]) + "->" + std::to_string(m->dev[b]) + " (" + hipGetErrorName(e) + ")";
       }
     }
+  m->peer_report = "peer access enabled for " + std::to_string(enabled) + " of " + std::to_string(pairs) +
+                   " ordered device pairs" + (failed.empty() ? std::string() : "; host-staged copies for:" + failed);
   *out = m;
+  return HG_OK;
+}
+
+extern "C" const char *hg_multi_peer_report(const hg_multi *m) { return m ? m->peer_report.c_str() : ""; }
+extern "C" const char *hg_multi_gather_report(const hg_multi *m) { return m ? m->gather_report.c_str() : ""; }
+extern "C" int hg_multi_gather_mode(const hg_multi *m) { return m ? m->gather : -1; }
+
+extern "C" hg_status hg_multi_set_gather(hg_multi *m, int mode) {
+  if (!m) return HG_ERR_INVALID;
+  if (mode == HG_GATHER_PEER) {
+    m->gather = mode;
+    return HG_OK;
+  }
+  if (mode != HG_GATHER_RCCL) return mfail(m, HG_ERR_INVALID, "gather mode: HG_GATHER_PEER or HG_GATHER_RCCL");
+  const int n = (int)m->ctx.size();
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (m->dev[a] == m->dev[b])
+        return mfail(m, HG_ERR_UNSUPPORTED, "HG_GATHER_RCCL needs distinct devices (one communicator rank per GPU)");
+  const RcclApi &r = rccl();
+  if (!r.ok) return mfail(m, HG_ERR_UNSUPPORTED, r.why);
+  if (m->comm.empty()) {
+    for (int s = 0; s < n; ++s) (void)hipSetDevice(m->dev[s]), (void)hipStreamSynchronize(m->ctx[s]->stream);
+    std::vector<ncclComm_t> comm(n, nullptr);
+    const ncclResult_t e = r.CommInitAll(comm.data(), n, m->dev.data());
+    if (e != ncclSuccess) return mfail(m, HG_ERR_HIP, std::string("ncclCommInitAll: ") + r.GetErrorString(e));
+    m->comm = comm;
+  }
+  m->gather = mode;
   return HG_OK;
 }
 
@@ -119,6 +228,11 @@ extern "C" void hg_multi_destroy(hg_multi *m) {
   for (size_t s = 0; s < m->ctx.size(); ++s) {
     (void)hipSetDevice(m->dev[s]);
     (void)hipStreamSynchronize(m->ctx[s]->stream);
+  }
+  for (ncclComm_t c : m->comm)
+    if (c) (void)rccl().CommDestroy(c);
+  for (size_t s = 0; s < m->ctx.size(); ++s) {
+    (void)hipSetDevice(m->dev[s]);
     hg_multi::Shard &x = m->sh[s];
     for (hg_ctx::Buf *b : {&x.ref_all, &x.n2_all, &x.mine, &x.mine_n2, &x.qry, &x.qry_n2, &x.hits})
       if (b->p) (void)hipFree(b->p);
@@ -162,46 +276,120 @@ struct DistPlan {
   size_t R = 0, Q = 0;
 };
 
+// every shard's stream idle: no copy queued by a call may outlive it (a peer pull still reading another shard's
+// `mine` buffer while the caller's retry re-uploads into it)
+void drain(hg_multi *m) {
+  for (size_t s = 0; s < m->ctx.size(); ++s)
+    if (hipSetDevice(m->dev[s]) == hipSuccess) (void)hipStreamSynchronize(m->ctx[s]->stream);
+}
+struct DrainOnExit {
+  hg_multi *m;
+  ~DrainOnExit() { drain(m); }
+};
+
+// the exchange step: every shard's gathered matrix g_hv[s] / g_n2[s] receives all owners' row blocks
+hg_status gather_refs(hg_multi *m, const int16_t *const *d_ref, const int32_t *const *d_rn, const DistPlan &pl,
+                      uint32_t hv_d, const std::vector<int16_t *> &g_hv, const std::vector<int32_t *> &g_n2) {
+  const int ns = (int)m->ctx.size();
+  const size_t row_bytes = (size_t)hv_d * sizeof(int16_t);
+  if (m->gather == HG_GATHER_RCCL && !m->comm.empty()) {
+    const RcclApi &r = rccl();
+    bool equal = true;
+    for (int t = 1; t < ns; ++t) equal = equal && (pl.rhi[t] - pl.rlo[t]) == (pl.rhi[0] - pl.rlo[0]);
+    ncclResult_t e = r.GroupStart();
+    for (int s = 0; s < ns && e == ncclSuccess; ++s) {
+      if (!g_hv[s]) continue;  // (a shard without query rows still has to take part: see the caller)
+      if (hipSetDevice(m->dev[s]) != hipSuccess) return mfail(m, HG_ERR_HIP, "hipSetDevice failed");
+      hipStream_t st = m->ctx[s]->stream;
+      if (equal) {
+        const size_t rows = pl.rhi[s] - pl.rlo[s];
+        e = r.AllGather(d_ref[s], g_hv[s], rows * row_bytes, ncclUint8, m->comm[s], st);
+        if (e == ncclSuccess) e = r.AllGather(d_rn[s], g_n2[s], rows * sizeof(int32_t), ncclUint8, m->comm[s], st);
+      } else {
+        for (int t = 0; t < ns && e == ncclSuccess; ++t) {
+          const size_t rows = pl.rhi[t] - pl.rlo[t];
+          if (!rows) continue;
+          e = r.Broadcast(d_ref[s], g_hv[s] + pl.rlo[t] * (size_t)hv_d, rows * row_bytes, ncclUint8, t, m->comm[s], st);
+          if (e == ncclSuccess)
+            e = r.Broadcast(d_rn[s], g_n2[s] + pl.rlo[t], rows * sizeof(int32_t), ncclUint8, t, m->comm[s], st);
+        }
+      }
+    }
+    const ncclResult_t e2 = r.GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return mfail(m, HG_ERR_HIP, std::string("RCCL all-gather: ") + r.GetErrorString(e));
+    int ver = 0;
+    (void)r.GetVersion(&ver);
+    m->gather_report = std::string("rccl ") + (equal ? "ncclAllGather" : "grouped ncclBroadcast") + " over " +
+                       std::to_string(ns) + " ranks, " + std::to_string(pl.R * row_bytes) + " B, version " + std::to_string(ver);
+    return HG_OK;
+  }
+  // direct pulls: one copy per peer block, all queued at once on the puller's stream
+  for (int s = 0; s < ns; ++s) {
+    if (hipSetDevice(m->dev[s]) != hipSuccess || hipEventRecord(m->sh[s].ready, m->ctx[s]->stream) != hipSuccess)
+      return mfail(m, HG_ERR_HIP, "hg_dist_multi: event record failed");
+  }
+  size_t peer_bytes = 0;
+  for (int s = 0; s < ns; ++s) {
+    if (!g_hv[s]) continue;
+    hg_ctx *c = m->ctx[s];
+    HG_HIP(c, hipSetDevice(m->dev[s]));
+    for (int t = 0; t < ns; ++t) {
+      const size_t rows = pl.rhi[t] - pl.rlo[t];
+      if (!rows) continue;
+      if (t != s) HG_HIP(c, hipStreamWaitEvent(c->stream, m->sh[t].ready, 0));
+      HG_HIP(c, peer_copy(m, s, g_hv[s] + pl.rlo[t] * (size_t)hv_d, t, d_ref[t], rows * row_bytes));
+      HG_HIP(c, peer_copy(m, s, g_n2[s] + pl.rlo[t], t, d_rn[t], rows * sizeof(int32_t)));
+      if (m->dev[s] != m->dev[t]) peer_bytes += rows * row_bytes;
+    }
+  }
+  m->gather_report = "peer pulls (hipMemcpyPeerAsync), " + std::to_string(peer_bytes) + " B between distinct devices; " +
+                     m->peer_report;
+  return HG_OK;
+}
+
 // d_ref / d_rn: shard s's reference rows on its device.  d_qry == nullptr: all-vs-all on the gathered matrix.
 hg_status dist_core(hg_multi *m, const int16_t *const *d_ref, const int32_t *const *d_rn, const int16_t *const *d_qry,
                     const int32_t *const *d_qn, const DistPlan &pl, uint32_t hv_d, uint32_t ksize, int symmetric,
                     float ani_th, hg_ani_hit *out, size_t cap, size_t *n_out) {
   const int ns = (int)m->ctx.size();
   const size_t row_bytes = (size_t)hv_d * sizeof(int16_t);
-  // publish: "my reference rows are complete" on every owner's stream
-  for (int s = 0; s < ns; ++s) {
-    if (hipSetDevice(m->dev[s]) != hipSuccess || hipEventRecord(m->sh[s].ready, m->ctx[s]->stream) != hipSuccess)
-      return mfail(m, HG_ERR_HIP, "hg_dist_multi: event record failed");
-  }
+  DrainOnExit drain_guard{m};  // every return below leaves all shard streams idle
   std::vector<size_t> found(ns, 0), caps(ns, 0);
+  std::vector<int16_t *> g_hv(ns, nullptr);
+  std::vector<int32_t *> g_n2(ns, nullptr);
+  const bool rccl_mode = m->gather == HG_GATHER_RCCL && !m->comm.empty();
+  // phase 1 (one thread per shard): workspaces.  Under RCCL every rank takes part in the collective, so every
+  // shard gets a gathered matrix; the peer pulls skip shards that have no query rows.
   hg_status st = for_each_shard(m, [&](int s) -> hg_status {
     hg_ctx *c = m->ctx[s];
     hg_multi::Shard &x = m->sh[s];
     const size_t qn_rows = pl.chi[s] - pl.clo[s];
-    if (qn_rows == 0) return HG_OK;
+    if (qn_rows == 0 && !rccl_mode) return HG_OK;
     HG_HIP(c, hipSetDevice(m->dev[s]));
     hg_status e;
     if ((e = hg_ensure(c, x.ref_all, pl.R * row_bytes + 64)) != HG_OK) return e;
     if ((e = hg_ensure(c, x.n2_all, pl.R * sizeof(int32_t) + 64)) != HG_OK) return e;
-    auto *g_hv = static_cast<int16_t *>(x.ref_all.p);
-    auto *g_n2 = static_cast<int32_t *>(x.n2_all.p);
-    // all-gather by direct pulls: one copy per peer block, all queued at once on this shard's stream
-    for (int t = 0; t < ns; ++t) {
-      const size_t rows = pl.rhi[t] - pl.rlo[t];
-      if (!rows) continue;
-      if (t != s) HG_HIP(c, hipStreamWaitEvent(c->stream, m->sh[t].ready, 0));
-      HG_HIP(c, peer_copy(m, s, g_hv + pl.rlo[t] * (size_t)hv_d, t, d_ref[t], rows * row_bytes));
-      HG_HIP(c, peer_copy(m, s, g_n2 + pl.rlo[t], t, d_rn[t], rows * sizeof(int32_t)));
-    }
-    const int16_t *q_hv = d_qry ? d_qry[s] : g_hv + pl.clo[s] * (size_t)hv_d;
-    const int32_t *q_n2 = d_qry ? d_qn[s] : g_n2 + pl.clo[s];
+    g_hv[s] = static_cast<int16_t *>(x.ref_all.p), g_n2[s] = static_cast<int32_t *>(x.n2_all.p);
     // capacity of this shard's list: its share of the caller's capacity can be exceeded by a skewed hit
     // distribution, so it gets the whole `cap`, bounded by its pair count
     const unsigned __int128 pairs = (unsigned __int128)pl.R * qn_rows;
     caps[s] = (size_t)std::min<unsigned __int128>(pairs, cap);
-    if ((e = hg_ensure(c, x.hits, caps[s] * sizeof(hg_ani_hit) + 64)) != HG_OK) return e;
-    return hg_dist_block_dev(c, g_hv, g_n2, pl.R, 0, q_hv, q_n2, qn_rows, pl.clo[s], hv_d, ksize, symmetric, ani_th,
-                             static_cast<hg_ani_hit *>(x.hits.p), caps[s], &found[s]);
+    return hg_ensure(c, x.hits, caps[s] * sizeof(hg_ani_hit) + 64);
+  });
+  if (st != HG_OK) return st;
+  // phase 2 (this thread): the exchange step, queued on the shards' streams
+  if ((st = gather_refs(m, d_ref, d_rn, pl, hv_d, g_hv, g_n2)) != HG_OK) return st;
+  // phase 3 (one thread per shard): (all refs) x (this shard's query rows)
+  st = for_each_shard(m, [&](int s) -> hg_status {
+    hg_ctx *c = m->ctx[s];
+    const size_t qn_rows = pl.chi[s] - pl.clo[s];
+    if (qn_rows == 0) return HG_OK;
+    HG_HIP(c, hipSetDevice(m->dev[s]));
+    const int16_t *q_hv = d_qry ? d_qry[s] : g_hv[s] + pl.clo[s] * (size_t)hv_d;
+    const int32_t *q_n2 = d_qry ? d_qn[s] : g_n2[s] + pl.clo[s];
+    return hg_dist_block_dev(c, g_hv[s], g_n2[s], pl.R, 0, q_hv, q_n2, qn_rows, pl.clo[s], hv_d, ksize, symmetric, ani_th,
+                             static_cast<hg_ani_hit *>(m->sh[s].hits.p), caps[s], &found[s]);
   });
   size_t total = 0;
   for (int s = 0; s < ns; ++s) total += found[s];
@@ -338,6 +526,7 @@ extern "C" hg_status hg_hamming_search_multi(hg_multi *m, const uint32_t *ref_bi
   const int ns = (int)m->ctx.size();
   const size_t words = (hv_d + 31) / 32, row_bytes = words * sizeof(uint32_t);
   std::vector<size_t> found(ns, 0), caps(ns, 0);
+  DrainOnExit drain_guard{m};  // every return below leaves all shard streams idle
   hg_status st = for_each_shard(m, [&](int s) -> hg_status {
     size_t lo, hi;
     hg_shard_range(R, s, ns, &lo, &hi);

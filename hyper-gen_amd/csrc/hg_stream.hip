@@ -452,20 +452,27 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
   return HG_OK;
 }
 
-static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed);
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed, bool wait);
 
 extern "C" hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag) {
-  return push_item(s, seq, len, tag, false);
+  return push_item(s, seq, len, tag, false, true);
 }
 
 extern "C" hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag) {
-  return push_item(s, blob, n_bps, tag, true);
+  return push_item(s, blob, n_bps, tag, true, true);
 }
 
-static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed) {
+extern "C" hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_t *data, size_t n_bps, uint64_t tag, int packed) {
+  return push_item(s, data, n_bps, tag, packed != 0, false);
+}
+
+extern "C" size_t hg_sketch_stream_max_pending(const hg_sketch_stream *s) { return s ? s->max_pending : 0; }
+
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed, bool wait) {
   if (!s || (len && !seq)) return HG_ERR_INVALID;
   std::unique_lock<std::mutex> lk(s->mu);
   if (s->finishing) return HG_ERR_INVALID;
+  if (!wait && s->err == HG_OK && s->pushed - s->popped >= s->max_pending) return HG_ERR_CAPACITY;  // would block
   s->cv_room.wait(lk, [&] { return s->pushed - s->popped < s->max_pending || s->err != HG_OK; });
   if (s->err != HG_OK) return s->err;
   Engine *best = s->eng[0];

@@ -47,18 +47,19 @@ def allgather_rows(local, world, group=None):
     return torch.cat([o.view(local.dtype).reshape(pad.shape)[:s] for o, s in zip(out, sizes)])
 
 
-def broadcast_rows(t, world, src=0, group=None):
-    """Broadcast a tensor of any dtype from `src` as raw bytes (in place; returns t)."""
-    if world > 1:
+def broadcast_rows(t, world, src=0, group=None, force=False):
+    """Broadcast a tensor of any dtype from `src` as raw bytes (in place; returns t).  `force` runs the
+    collective with one rank too (a one-GPU box then executes the RCCL code path)."""
+    if world > 1 or force:
         dist.broadcast(t.view(torch.uint8).view(-1), src=src, group=group)
     return t
 
 
-def gather_records(local, world, device=None, group=None):
+def gather_records(local, world, device=None, group=None, force=False):
     """Concatenate variable-length numpy record arrays (hit lists) of all ranks, in rank order.
     Every rank gets the result (an all-gather of padded byte blocks -- hit lists are small next to
     the operands); `device` is where the collective's tensors live (cuda for nccl, cpu for gloo)."""
-    if world == 1:
+    if world == 1 and not force:
         return local
     device = device or torch.device("cpu")
     raw = torch.from_numpy(np.ascontiguousarray(local).view(np.uint8).copy()).to(device)
@@ -72,7 +73,7 @@ def gather_records(local, world, device=None, group=None):
     return np.concatenate(parts) if parts else local
 
 
-def sharded_search(search_block, ref_local, ref_lo, queries, world, device=None, group=None):
+def sharded_search(search_block, ref_local, ref_lo, queries, world, device=None, group=None, force=False):
     """Database search over a row-sharded reference set.
 
     ref_local : this rank's reference rows, global rows [ref_lo, ref_lo + len)
@@ -80,6 +81,6 @@ def sharded_search(search_block, ref_local, ref_lo, queries, world, device=None,
     search_block(ref_local, ref_lo, queries) -> numpy record array of hits with GLOBAL ref_idx
     Returns the merged hit list (all ranks), in rank order.
     """
-    broadcast_rows(queries, world, 0, group)
+    broadcast_rows(queries, world, 0, group, force)
     hits = search_block(ref_local, ref_lo, queries)
-    return gather_records(hits, world, device, group)
+    return gather_records(hits, world, device, group, force)

@@ -253,7 +253,9 @@ void hg_sketch_file_free(hg_sketch_file *f);
  *   open    one engine per entry of device_ids (an id may repeat); params are fixed for the stream's lifetime
  *   push    any thread; `seq` must stay valid and unchanged until the genome's result has been popped; page-locked
  *           memory (hg_read_fastx_pinned) is fetched by DMA at the link rate, other memory is staged by the runtime;
- *           blocks while 4096 results are outstanding
+ *           BLOCKS while hg_sketch_stream_max_pending (4096) results are outstanding -- back-pressure for reader
+ *           threads; a caller that pushes and pops on ONE thread must use hg_sketch_stream_try_push instead, which
+ *           returns HG_ERR_CAPACITY ("would block": pop some results first) and never waits
  *   pop     any thread; blocks until a result is ready (completion order, identified by `tag`); *got = 0 with
  *           HG_OK once hg_sketch_stream_finish was called and every pushed genome has been popped; hv_out holds
  *           hv_d int16, any output pointer may be NULL
@@ -267,6 +269,9 @@ hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t 
  * ASCII the kernels would have classified the same way: results are bit-identical).  The blob must have been
  * packed with the stream's norm_mode. */
 hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
+/* non-blocking push of either form (packed != 0: `data` is a hg_pack2 blob); HG_ERR_CAPACITY = would block */
+hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_t *data, size_t n_bps, uint64_t tag, int packed);
+size_t hg_sketch_stream_max_pending(const hg_sketch_stream *s);
 hg_status hg_sketch_stream_pop(hg_sketch_stream *s, uint64_t *tag, int16_t *hv_out, int32_t *norm2_out,
                                uint32_t *nhash_out, int *got);
 hg_status hg_sketch_stream_finish(hg_sketch_stream *s);
@@ -362,6 +367,19 @@ void hg_multi_destroy(hg_multi *m);
 int hg_multi_size(const hg_multi *m);
 hg_ctx *hg_multi_ctx(hg_multi *m, int shard); /* borrowed: valid until hg_multi_destroy */
 const char *hg_multi_last_error(const hg_multi *m);
+/* what hipDeviceEnablePeerAccess said when the shards were opened ("peer access enabled for 56 of 56 ordered device
+ * pairs", or the pairs that fall back to host-staged copies and why) */
+const char *hg_multi_peer_report(const hg_multi *m);
+/* The exchange step of dist (the reference has none: src/dist.rs:231-294 runs on one host).
+ *   HG_GATHER_PEER (default): direct hipMemcpyPeerAsync pulls, one per peer block;
+ *   HG_GATHER_RCCL          : ncclAllGather (equal row blocks) / grouped ncclBroadcast per owner over one RCCL
+ *                             communicator per shard (ncclCommInitAll).  Needs distinct device ids; librccl is opened
+ *                             with dlopen at this call (HG_ERR_UNSUPPORTED if it is absent).
+ * Both give the same gathered matrix, hence the same hits.  hg_multi_gather_report: how the last exchange ran. */
+enum { HG_GATHER_PEER = 0, HG_GATHER_RCCL = 1 };
+hg_status hg_multi_set_gather(hg_multi *m, int mode);
+int hg_multi_gather_mode(const hg_multi *m);
+const char *hg_multi_gather_report(const hg_multi *m);
 /* contiguous block [*lo, *hi) of n units owned by `shard` of n_shards; sizes differ by at most one */
 void hg_shard_range(size_t n, int shard, int n_shards, size_t *lo, size_t *hi);
 

@@ -32,27 +32,63 @@ def test_bench_json_contract():
     assert j["hamming"]["value"] > 0
 
 
+TWO_RANK_ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--genomes", "24", "--genomes-10k", "50", "--dist-n", "2048",
+                 "--hamming-refs", "6001", "--hamming-queries", "300", "--backend", "gloo", "--share-gpu"]
+
+
+def _two_ranks(launcher):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    r = subprocess.run(cmd + [os.path.join(ROOT, "bench.py")] + TWO_RANK_ARGS, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    return json.loads(lines[0])
+
+
 def test_bench_two_ranks_share_one_gpu():
     """bench.py's N > 1 logic on a one-GPU box: two ranks (torch.distributed.run, gloo, both on device 0) run the real
     kernels through the sharded code paths -- weak-scaled sketch, the 10k-style strong-scaled leg, the all-gathered
     reference matrix of dist, the sharded Hamming search with ONE broadcast query set and merged hits (rank 0 verifies
     that every query finds its source row by global index).  RCCL itself is what the driver's 8-GPU run exercises."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--genomes", "24", "--genomes-10k", "50", "--dist-n", "2048", "--hamming-refs", "6001",
-                        "--hamming-queries", "300", "--backend", "gloo", "--share-gpu"],
-                       capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1  # rank 0 only
-    j = json.loads(lines[0])
+    j = _two_ranks(launcher=True)
     assert j["n_gpus"] == 2 and j["value"] > 0 and "cpu_baseline" not in j
     assert j["sketch_10k"]["config"]["genomes_per_gpu"] == 25 and j["sketch_10k"]["scaling"] == "strong"
     assert j["dist"]["value"] > 0 and j["dist"]["config"]["hits_per_rank"] > 0
     assert j["hamming"]["config"]["hits_merged"] == 300 and j["hamming"]["config"]["refs_per_rank"] == 3001
+
+
+def test_bench_bare_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` without torch.distributed.run in front (the form the driver uses at N = 1): the
+    parent starts the two ranks as child processes and relays rank 0's line and the exit status."""
+    j = _two_ranks(launcher=False)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["collectives"]["backend"] == "gloo" and j["collectives"]["world"] == 2
+    assert j["dist"]["config"]["hits_per_rank"] > 0 and j["hamming"]["config"]["hits_merged"] == 300
+
+
+def test_bench_rccl_one_rank():
+    """RCCL's code path on the one-GPU box: `--backend nccl --collectives` initialises the process group through RCCL
+    with ONE rank and runs the byte all-gather of the reference HV matrix, the query broadcast, the hit gather and the
+    barrier / max-reduce brackets -- the same calls the 8-GPU run makes."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--genomes", "16", "--genomes-10k", "40", "--hostfed-genomes", "0", "--dist-n", "2048",
+                        "--hamming-refs", "4096", "--hamming-queries", "300", "--backend", "nccl", "--collectives",
+                        "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["collectives"] == dict(j["collectives"], backend="nccl", world=1)
+    assert j["dist"]["config"]["hits_per_rank"] > 0 and j["hamming"]["config"]["hits_merged"] == 300
+    assert j["parity_gate"]["status"] == "passed"  # the all-gathered matrix gave the same ANI block as the CPU

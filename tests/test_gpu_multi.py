@@ -137,3 +137,32 @@ def test_hg_multi_hamming_search_sharded_refs(hg, orc):
         with hg.Multi(list(ids)) as m:
             h = m.hamming_search(refs, q, HD, 60, cap=16)
             assert sorted(zip(h["ref_idx"].tolist(), h["qry_idx"].tolist(), h["dist"].tolist())) == want, ids
+
+
+def test_hg_multi_rccl_gather_one_rank_and_reports(hg, genomes):
+    """The exchange step of dist through RCCL behind the C ABI (hg_multi_set_gather(HG_GATHER_RCCL)): on this one-GPU box a
+    one-rank communicator (ncclCommInitAll + ncclAllGather / grouped ncclBroadcast really execute); repeated device ids
+    are refused (one communicator rank per GPU); both gathers give the same hits."""
+    p = hg.default_params(scaled=100)
+    with hg.Context(0) as one:
+        hv1, n21, _ = one.sketch_batch(genomes, p)
+        want = one.dist(hv1, n21, hv1, n21, 21, symmetric=True, ani_th=80.0)
+        want2 = one.dist(hv1[:7], n21[:7], hv1[3:], n21[3:], 21, symmetric=False, ani_th=80.0)
+    with hg.Multi([0]) as m:
+        assert m.gather_mode() == hg.GATHER_PEER and "0 of 0 ordered device pairs" in m.peer_report()
+        got = m.dist(hv1, n21, None, None, 21, symmetric=True, ani_th=80.0)
+        assert "peer pulls" in m.gather_report()
+        m.set_gather(hg.GATHER_RCCL)
+        assert m.gather_mode() == hg.GATHER_RCCL
+        got_r = m.dist(hv1, n21, None, None, 21, symmetric=True, ani_th=80.0)
+        assert m.gather_report().startswith("rccl ncclAllGather over 1 ranks"), m.gather_report()
+        got_r2 = m.dist(hv1[:7], n21[:7], hv1[3:], n21[3:], 21, symmetric=False, ani_th=80.0)
+        assert np.array_equal(_key(got), _key(want)) and np.array_equal(_key(got_r), _key(want))
+        assert np.array_equal(_key(got_r2), _key(want2))
+        m.set_gather(hg.GATHER_PEER)
+        assert np.array_equal(_key(m.dist(hv1, n21, None, None, 21, symmetric=True, ani_th=80.0)), _key(want))
+    with hg.Multi([0, 0]) as m2:
+        with pytest.raises(hg.HgError) as e:
+            m2.set_gather(hg.GATHER_RCCL)
+        assert e.value.status == hg.ERR_UNSUPPORTED and m2.gather_mode() == hg.GATHER_PEER
+        assert "0 of 0" in m2.peer_report()  # the two shards share one device: no peer pair to enable

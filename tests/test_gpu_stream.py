@@ -216,3 +216,52 @@ def test_stream_concurrent_push_pop_and_early_close(hg, orc):
         st.push(genomes[i], i)
     st.pop()
     st.close()  # 199 results dropped
+
+
+def test_single_thread_push_everything_then_pop_and_reused_tags(hg, orc):
+    """One thread pushes more genomes than the stream keeps outstanding (4096) before it pops anything -- the blocking C
+    push would wait for ever there; hg_sketch_stream_try_push reports "would block" and the wrapper drains.  Tags are the
+    caller's business: the same tag for every genome must neither lose results nor drop an array that is still read."""
+    n = 4500
+    base = orc.synth_genome(3, 40_000)[1:]
+    genomes = [base[i: i + 3_000 + (i % 7)].copy() for i in range(n)]
+    p = hg.default_params(scaled=50)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch(genomes, p)
+    lib = hg.lib()
+    with hg.SketchStream((0,), p) as st:
+        assert lib.hg_sketch_stream_max_pending(st._h) == 4096
+        for i in range(n):
+            st.push(genomes[i], i)  # would dead-lock at i = 4096 with the blocking entry point
+        st.finish()
+        out = _drain(st, n)
+    for i in range(0, n, 97):
+        assert out[i][2] == nh[i] and out[i][1] == n2[i] and np.array_equal(out[i][0], hv[i]), i
+    # the raw entry point: fill the stream, then one more push must say HG_ERR_CAPACITY at once
+    with hg.SketchStream((0,), p) as st:
+        big = [orc.synth_genome(g, 6_000_000)[1:] for g in range(2)]
+        pending = 0
+        import ctypes as C
+        st_code = hg.OK
+        tiny = np.zeros(4, np.uint8)
+        while st_code == hg.OK and pending < 5000:
+            a = big[pending % 2] if pending < 2 else tiny
+            st_code = lib.hg_sketch_stream_try_push(st._h, C.c_void_p(a.ctypes.data), a.size, pending, 0)
+            pending += st_code == hg.OK
+        assert st_code == hg.ERR_CAPACITY and pending == 4096
+        got = C.c_int()
+        for _ in range(pending):
+            assert lib.hg_sketch_stream_pop(st._h, None, None, None, None, C.byref(got)) == hg.OK and got.value == 1
+    # one tag for everything
+    with hg.SketchStream((0,), p) as st:
+        for i in range(300):
+            st.push(genomes[i].copy(), 7)  # temporaries: only the wrapper keeps them alive
+        st.finish()
+        res = []
+        while True:
+            r = st.pop()
+            if r is None:
+                break
+            res.append(r)
+        assert len(res) == 300 and all(r[0] == 7 for r in res)
+        assert sorted(int(r[3]) for r in res) == sorted(int(x) for x in nh[:300])

@@ -134,3 +134,40 @@ def test_two_rank_sketch_and_dist_decomposition(tmp_path, orc):
     full = orc.ani_matrix(hv, n2, hv, n2, 21)
     got = np.concatenate([np.load(tmp_path / ("block%d.npy" % r)) for r in range(world)], axis=1)
     assert got.shape == full.shape and (got == full).all()
+
+
+def test_bench_self_launch_parent_stays_off_the_gpu():
+    """`python bench.py --gpus N` (N > 1, no torch.distributed environment) must start its ranks as CHILD processes
+    before torch or the HIP library is loaded, pass its own arguments on and exit with the children's status."""
+    code = r"""
+import os, subprocess, sys
+for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    os.environ.pop(k, None)
+sys.path.insert(0, %r)
+import bench
+calls = []
+class R:
+    returncode = 7
+def fake_run(cmd, **kw):
+    calls.append((cmd, kw))
+    return R()
+subprocess.run = fake_run
+sys.argv = ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "2"]
+try:
+    bench.main()
+    code = None
+except SystemExit as e:
+    code = e.code
+assert code == 7, code
+assert "torch" not in sys.modules and "hypergen_amd" not in sys.modules and "numpy" not in sys.modules
+(cmd, kw), = calls
+i = cmd.index("--nproc-per-node")
+assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[i + 1] == "4" and "127.0.0.1" in cmd
+assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+assert kw["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+print("ok")
+""" % ROOT
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
