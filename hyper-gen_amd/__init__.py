@@ -64,7 +64,7 @@ EXPORTS = [
     "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
     "hg_copy_h2d", "hg_copy_d2h", "hg_sketch_params_default", "hg_kmer_hash_sample",
     "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
-    "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack",
+    "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack", "hg_hv_packed_bytes",
     "hg_hv_unpack", "hg_sketch_file_write", "hg_sketch_file_read", "hg_sketch_file_count",
     "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_read_merge_seq_into", "hg_free",
     "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
@@ -133,6 +133,7 @@ def lib():
         "hg_sort_ani_hits": (None, [vp, sz, sz, C.c_int]),
         "hg_hv_quant_bits": (C.c_uint32, [vp, C.c_uint32]),
         "hg_hv_pack": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "hg_hv_packed_bytes": (sz, [C.c_uint32, C.c_uint32]),
         "hg_hv_unpack": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
         "hg_sketch_file_write": (C.c_int, [C.c_char_p, C.POINTER(FileSketch), sz]),
         "hg_sketch_file_read": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
@@ -541,7 +542,7 @@ def hv_quant_bits(hv):
 def hv_pack(hv, q=None):
     hv = np.ascontiguousarray(hv, np.int16)
     q = hv_quant_bits(hv) if q is None else q
-    out = np.zeros(q * hv.size // 8, np.uint8)
+    out = np.zeros(lib().hg_hv_packed_bytes(hv.size, q), np.uint8)
     st = lib().hg_hv_pack(_ptr(hv), hv.size, q, _ptr(out))
     if st != OK:
         raise HgError(st, "hg_hv_pack")

@@ -215,7 +215,9 @@ int run_sketch(const Cli &c) {
   logline("INFO", "Start sketching...");
   const auto t0 = std::chrono::steady_clock::now();
   if (c.scaled == 0) die("scaled must be >= 1");
-  if (c.hv_d % 256) die("hv_d must be a multiple of 256 (bit-packed sketch blocks, src/hd.rs:143-153)");
+  if (c.hv_d == 0 || c.hv_d > 32768) die("hv_d must be in 1..32768");
+  if (c.hv_d % 256)  // the reference packs whole 256-blocks only (src/hd.rs:147) and says nothing; same bytes here
+    logline("WARN", "hv_d is not a multiple of 256: the dimensions behind the last whole block are lost in the .sketch file (as in the reference)");
   hg_sketch_params p;
   hg_sketch_params_default(&p);
   const bool gpu_mode = c.device == "gpu";
@@ -321,14 +323,14 @@ int run_sketch(const Cli &c) {
     cv_space.notify_all();
     const double ts1 = now_s();
     const uint32_t q = hg_hv_quant_bits(hv.data(), (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
-    payload[f].resize((size_t)q * c.hv_d / 16);
+    payload[f].resize((hg_hv_packed_bytes((uint32_t)c.hv_d, q) + 1) / 2);  // (the i16 view of the bytes, src/hd.rs:155-157)
     if (hg_hv_pack(hv.data(), (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[f].data())) != HG_OK) die("pack");
     hg_file_sketch &r = recs[f];
     std::memset(&r, 0, sizeof r);
     r.ksize = (uint8_t)c.ksize, r.canonical = c.canonical, r.hv_quant_bits = (uint8_t)q, r.hv_norm_2 = n2;
     r.scaled = c.scaled, r.seed = c.seed, r.hv_d = c.hv_d;
     r.file_str = files[f].c_str();
-    r.hv = payload[f].data(), r.hv_len = payload[f].size();
+    r.hv = payload[f].data(), r.hv_len = hg_hv_packed_bytes((uint32_t)c.hv_d, q) / 2;  // align_to::<i16>().1: whole i16s
     t_wait += ts1 - tw0, t_pack += now_s() - ts1;
   }
   for (auto &t : readers) t.join();
@@ -374,7 +376,7 @@ void load(const std::string &path, Loaded &L, unsigned threads) {
   const hg_file_sketch *r0 = hg_sketch_file_get(L.f, 0);
   L.hv_d = r0->hv_d, L.ksize = r0->ksize;
   // validate before sizing anything from the file's own numbers
-  if (L.hv_d == 0 || L.hv_d % 256 || L.hv_d > 65536) die("unsupported HV dimension in " + path);
+  if (L.hv_d == 0 || L.hv_d > 65536) die("unsupported HV dimension in " + path);
   for (size_t i = 0; i < L.n; ++i) {
     const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
     if (r->hv_quant_bits < 1 || r->hv_quant_bits > 16) die("corrupt sketch record (quantisation bits) in " + path);
@@ -389,7 +391,7 @@ void load(const std::string &path, Loaded &L, unsigned threads) {
     for (size_t i; (i = next.fetch_add(1)) < L.n;) {
       const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
       if (r->hv_d != L.hv_d) die("sketches of one file use different HV dimensions");
-      if (r->hv_len * 16 != (uint64_t)r->hv_quant_bits * L.hv_d) die("corrupt sketch payload in " + path);
+      if (r->hv_len != hg_hv_packed_bytes((uint32_t)L.hv_d, r->hv_quant_bits) / 2) die("corrupt sketch payload in " + path);
       if (hg_hv_unpack(reinterpret_cast<const uint8_t *>(r->hv), (uint32_t)L.hv_d, r->hv_quant_bits,
                        L.hv.data() + i * L.hv_d) != HG_OK)
         die("unpack failed");

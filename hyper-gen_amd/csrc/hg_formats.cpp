@@ -72,10 +72,16 @@ void unpack_block(const uint32_t *in, uint32_t q, uint32_t *out) {
 }
 }  // namespace
 
+extern "C" size_t hg_hv_packed_bytes(uint32_t hv_d, uint32_t q) { return (size_t)q * (hv_d >> 3); }  // src/hd.rs:146
+
 extern "C" hg_status hg_hv_pack(const int16_t *hv, uint32_t hv_d, uint32_t q, uint8_t *packed) {
-  if (!hv || !packed || q < 1 || q > 16 || hv_d % 256) return HG_ERR_INVALID;
+  if (!hv || !packed || q < 1 || q > 16) return HG_ERR_INVALID;
   const int16_t offset = (int16_t)(1 << (q - 1));  // i16 arithmetic, src/hd.rs:140-141
   uint32_t blk[256], out[8 * 16];
+  // Only whole 256-blocks are packed (src/hd.rs:147 `hv_d / BLOCK_LEN`); the reference leaves the rest of its
+  // zero-initialised `quant_bit * (hv_d >> 3)` bytes untouched, so the dimensions behind the last block are LOST
+  const size_t tail0 = (size_t)32 * q * (hv_d / 256), total = hg_hv_packed_bytes(hv_d, q);
+  if (total > tail0) std::memset(packed + tail0, 0, total - tail0);
   for (uint32_t b = 0; b < hv_d / 256; ++b) {
     for (uint32_t i = 0; i < 256; ++i) blk[i] = (uint32_t)(int32_t)(int16_t)(hv[b * 256 + i] + offset);
     pack_block(blk, q, out);
@@ -85,7 +91,10 @@ extern "C" hg_status hg_hv_pack(const int16_t *hv, uint32_t hv_d, uint32_t q, ui
 }
 
 extern "C" hg_status hg_hv_unpack(const uint8_t *packed, uint32_t hv_d, uint32_t q, int16_t *hv) {
-  if (!hv || !packed || q < 1 || q > 16 || hv_d % 256) return HG_ERR_INVALID;
+  if (!hv || !packed || q < 1 || q > 16) return HG_ERR_INVALID;
+  // dimensions behind the last whole block decode from the reference's zero-initialised u32 vector
+  // (src/hd.rs:194,206-212): 0 as i16 - offset
+  for (uint32_t d = hv_d / 256 * 256; d < hv_d; ++d) hv[d] = (int16_t)(0 - (int16_t)(1 << (q - 1)));
   const int16_t offset = (int16_t)(1 << (q - 1));
   uint32_t blk[256], in[8 * 16];
   for (uint32_t b = 0; b < hv_d / 256; ++b) {

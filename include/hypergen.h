@@ -219,7 +219,12 @@ hg_status hg_topk_per_query_dev(hg_ctx *ctx, const hg_ani_hit *d_hits, size_t n,
 
 /* ---- sketch compression (host side; src/hd.rs:114-232) -------------------------------- */
 uint32_t hg_hv_quant_bits(const int16_t *hv, uint32_t hv_d);
-/* packed must hold quant_bits * hv_d / 8 bytes; hv_d must be a multiple of 256 */
+/* packed holds hg_hv_packed_bytes(hv_d, quant_bits) = quant_bits * (hv_d >> 3) bytes (src/hd.rs:146).  Like the
+ * reference, only whole blocks of 256 dimensions are packed (src/hd.rs:147): for hv_d % 256 != 0 the bytes behind
+ * them are zero and hg_hv_unpack gives every dimension behind the last whole block the value -2^(quant_bits-1)
+ * (src/hd.rs:194,206-212) -- the round trip is lossless only for multiples of 256.  quant_bits = 16 reproduces the
+ * reference's sign-extension spill (src/hd.rs:140-141) bit for bit. */
+size_t hg_hv_packed_bytes(uint32_t hv_d, uint32_t quant_bits);
 hg_status hg_hv_pack(const int16_t *hv, uint32_t hv_d, uint32_t quant_bits, uint8_t *packed);
 hg_status hg_hv_unpack(const uint8_t *packed, uint32_t hv_d, uint32_t quant_bits, int16_t *hv);
 

@@ -354,59 +354,63 @@ unsigned orc_quant_bits(const int16_t *hv, size_t hv_d) {
   return q;
 }
 
-/* BitPacker8x (crate bitpacking 0.9.2): a 256-block is 32 rows of 8 u32 lanes;
- * lane l packs its 32 values LSB-first into q u32 words; word w of lane l is
- * output u32 #(8w + l).  Values are OR-ed in unmasked. */
-static void bp8x_pack_block(const uint32_t *in, unsigned q, uint32_t *out) {
-  for (unsigned l = 0; l < 8; l++) {
-    uint32_t acc = 0;
-    unsigned w = 0;
-    for (unsigned r = 0; r < 32; r++) {
-      uint32_t v = in[8 * r + l];
-      unsigned cur = (r * q) & 31;
-      acc = cur ? (acc | (v << cur)) : v;
-      unsigned remaining = 32 - cur;
-      if (remaining <= q) {
-        out[8 * w + l] = acc;
-        w++;
-        acc = (remaining < q) ? (v >> remaining) : 0;
-      }
-    }
+/* BitPacker8x (crate bitpacking 0.9.2, `pack_unpack_with_bits!` over 8 x u32 lanes), restated from the
+ * crate's DEFINITION of the format rather than from its accumulator loop (the product's hg_formats.cpp follows the
+ * loop; two restatements of one reading would share a misreading):
+ *   - a block is 256 values; value i belongs to lane l = i % 8 and is that lane's element r = i / 8;
+ *   - lane l owns a bit stream of 32*q bits; element r starts at stream bit p = r*q (LSB first);
+ *   - stream word w (32 bits) of lane l is the block's output u32 number 8*w + l, little endian.
+ * The packer does not mask its input: an element wider than q bits spills into what follows it -- inside its first
+ * word (a 32-bit left shift drops what passes bit 31) and, only if the element straddles a word boundary, as
+ * `v >> (32 - p % 32)` into the next word.  That is what makes the reference's q = 16 path lossy (src/hd.rs:140-141:
+ * `1 << 15` as i16 is -32768, `(i + offset) as u32` sign-extends). */
+static void bp8x_scatter_block(const uint32_t *in, unsigned q, uint32_t *out) {
+  memset(out, 0, (size_t)32 * q);
+  for (unsigned i = 0; i < 256; i++) {
+    const unsigned lane = i & 7, p = (i >> 3) * q, w0 = p >> 5, c = p & 31;
+    out[8 * w0 + lane] |= in[i] << c;
+    if (c + q > 32) out[8 * (w0 + 1) + lane] |= in[i] >> (32 - c); /* straddles: c > 0 here */
   }
 }
 
-static void bp8x_unpack_block(const uint32_t *in, unsigned q, uint32_t *out) {
-  uint32_t mask = (q == 32) ? 0xffffffffu : ((1u << q) - 1);
-  for (unsigned l = 0; l < 8; l++) {
-    for (unsigned r = 0; r < 32; r++) {
-      unsigned bit = r * q, w = bit >> 5, cur = bit & 31;
-      uint32_t v = in[8 * w + l] >> cur;
-      if (cur + q > 32) v |= in[8 * (w + 1) + l] << (32 - cur);
-      out[8 * r + l] = v & mask;
-    }
+/* element r of lane l = bits [r*q, r*q + q) of the lane's stream, read through a 64-bit window */
+static void bp8x_gather_block(const uint32_t *in, unsigned q, uint32_t *out) {
+  for (unsigned i = 0; i < 256; i++) {
+    const unsigned lane = i & 7, p = (i >> 3) * q, w0 = p >> 5, c = p & 31;
+    uint64_t win = in[8 * w0 + lane];
+    if (w0 + 1 < q) win |= (uint64_t)in[8 * (w0 + 1) + lane] << 32;
+    out[i] = (uint32_t)((win >> c) & ((1ull << q) - 1));
   }
 }
 
+/* bytes of a packed sketch: src/hd.rs:146 `vec![0u8; quant_bit * (hv_d >> 3)]` */
+size_t orc_packed_bytes(size_t hv_d, unsigned q) { return (size_t)q * (hv_d >> 3); }
+
+/* src/hd.rs:138-157.  Only whole 256-blocks are packed (:147 `hv_d / BLOCK_LEN`): the bytes behind them stay 0. */
 void orc_pack_hv(const int16_t *hv, size_t hv_d, unsigned q, uint8_t *out) {
-  int16_t offset = (int16_t)(1 << (q - 1)); /* src/hd.rs:140: i16, wraps at q=16 */
+  const int16_t offset = (int16_t)(1u << (q - 1)); /* :140, i16: -32768 at q = 16 */
   uint32_t blk[256], packed[8 * 16];
+  memset(out, 0, orc_packed_bytes(hv_d, q));
   for (size_t b = 0; b < hv_d / 256; b++) {
     for (unsigned i = 0; i < 256; i++)
-      blk[i] = (uint32_t)(int32_t)(int16_t)(hv[b * 256 + i] + offset); /* :141 */
-    bp8x_pack_block(blk, q, packed);
+      blk[i] = (uint32_t)(int32_t)(int16_t)((uint16_t)hv[b * 256 + i] + (uint16_t)offset); /* :141 wrapping i16, then `as u32` */
+    bp8x_scatter_block(blk, q, packed);
     memcpy(out + (size_t)32 * q * b, packed, (size_t)32 * q);
   }
 }
 
+/* src/hd.rs:186-213.  Elements behind the last whole block decode from the zero-initialised u32 vector (:194):
+ * `0 as i16 - offset`. */
 void orc_unpack_hv(const uint8_t *packed, size_t hv_d, unsigned q, int16_t *hv) {
-  int16_t offset = (int16_t)(1 << (q - 1));
+  const int16_t offset = (int16_t)(1u << (q - 1));
   uint32_t blk[256], in[8 * 16];
   for (size_t b = 0; b < hv_d / 256; b++) {
     memcpy(in, packed + (size_t)32 * q * b, (size_t)32 * q);
-    bp8x_unpack_block(in, q, blk);
+    bp8x_gather_block(in, q, blk);
     for (unsigned i = 0; i < 256; i++)
-      hv[b * 256 + i] = (int16_t)((int16_t)blk[i] - offset); /* src/hd.rs:206-212 */
+      hv[b * 256 + i] = (int16_t)((uint16_t)blk[i] - (uint16_t)offset); /* :206-212 */
   }
+  for (size_t d = hv_d / 256 * 256; d < hv_d; d++) hv[d] = (int16_t)(0u - (uint16_t)offset);
 }
 
 /* ------------------------------------------------------------------------- */

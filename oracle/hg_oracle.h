@@ -77,6 +77,7 @@ unsigned orc_quant_bits(const int16_t *hv, size_t hv_d);
 
 /* compress_hd_sketch AVX2 branch (src/hd.rs:138-157): BitPacker8x blocks of 256.
  * out must hold quant_bits*hv_d/8 bytes.  hv_d must be a multiple of 256. */
+size_t orc_packed_bytes(size_t hv_d, unsigned quant_bits); /* q * (hv_d >> 3), src/hd.rs:146 */
 void orc_pack_hv(const int16_t *hv, size_t hv_d, unsigned quant_bits,
                  uint8_t *out);
 /* decompress_hd_sketch AVX2 branch (src/hd.rs:188-212). */

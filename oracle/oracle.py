@@ -213,7 +213,7 @@ def quant_bits(hv):
 def pack_hv(hv, q=None):
     hv = np.ascontiguousarray(hv, dtype=np.int16)
     q = quant_bits(hv) if q is None else q
-    out = np.zeros(q * hv.size // 8, np.uint8)
+    out = np.zeros(q * (hv.size >> 3), np.uint8)  # src/hd.rs:146
     lib().orc_pack_hv(_p(hv, C.c_int16), hv.size, q, _p(out, C.c_uint8))
     return q, out
 

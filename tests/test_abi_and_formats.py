@@ -65,8 +65,19 @@ def test_pack_matches_oracle(hg, orc):
             assert (hg.hv_unpack(packed, d, q) == hv).all()
         else:
             assert (hg.hv_unpack(packed, d, q) == orc.unpack_hv(opacked, d, q)).all()
-    with pytest.raises(hg.HgError):
-        hg.hv_pack(np.zeros(100, np.int16), 6)  # not a multiple of 256
+    # every width incl. the reference's lossy q = 16 (src/hd.rs:140-141), and dimensions that are not whole
+    # 256-blocks (the reference packs hv_d / 256 blocks into q * (hv_d >> 3) bytes and loses the rest, src/hd.rs:143-147).
+    # The oracle is written from the crate's format definition (scatter by element), the product follows the crate's
+    # accumulator loop; tests/test_oracle.py checks the oracle against a third, bit-level model.
+    for q in range(6, 17):
+        for d in (256, 100, 264, 1000, 4104):
+            amp = (1 << (q - 1)) - 1
+            hv = rng.integers(-amp - 1, amp + 1, d).astype(np.int16)
+            _, packed = hg.hv_pack(hv, q)
+            _, opacked = orc.pack_hv(hv, q)
+            assert packed.size == opacked.size == q * (d >> 3) == hg.lib().hg_hv_packed_bytes(d, q)
+            assert (packed == opacked).all(), (q, d)
+            assert (hg.hv_unpack(packed, d, q) == orc.unpack_hv(opacked, d, q)).all(), (q, d)
 
 
 def test_sketch_file_layout_and_roundtrip(hg, tmp_path):

@@ -161,3 +161,39 @@ def test_cli_search_topn_and_cpu_mode_reader(tmp_path, orc):
     assert x["hv_norm_2"] == w_n2 and (hg.hv_unpack(x["hv"].view(np.uint8), 4096, x["hv_quant_bits"]) == w_hv).all()
     # without -r / -q / -o `search` stays the reference's no-op
     assert subprocess.run([hg.CLI_PATH, "search"], capture_output=True).returncode == 0
+
+
+def test_cli_hv_d_not_a_multiple_of_256_follows_the_reference(tmp_path, orc):
+    """`-d 1000`: the reference packs hv_d / 256 whole blocks into q * (hv_d >> 3) bytes and never says that the last
+    232 dimensions are lost (src/hd.rs:143-153); `dist` then sees -2^(q-1) there (src/hd.rs:194,206-212) while the
+    stored norm is that of the full vector.  Same bytes, same ANI here (the oracle restates both)."""
+    import hypergen_amd as hg
+    d = tmp_path / "fa"
+    d.mkdir()
+    gen = {"a.fna": 0, "b.fna": 10, "c.fna": 101}
+    for name, g in gen.items():
+        write_fasta(str(d / name), orc.synth_genome(g, 200_000)[1:], name)
+    files = sorted(str(d / n) for n in gen)
+    out = str(tmp_path / "d1000.sketch")
+    r = subprocess.run([hg.CLI_PATH, "sketch", "-p", str(d), "-o", out, "-s", "100", "-d", "1000"], capture_output=True, text=True)
+    assert r.returncode == 0 and "not a multiple of 256" in (r.stdout + r.stderr), r.stderr
+    recs = hg.read_sketch_file(out)
+    hvs, n2s = [], []
+    for x, f in zip(recs, files):
+        hv, n2, _ = orc.sketch_genome(hg.read_merge_seq(f), scaled=100, hv_d=1000, norm=orc.NORM_U2T)
+        q, packed = orc.pack_hv(hv)
+        assert x["hv_d"] == 1000 and x["hv_quant_bits"] == q and x["hv_norm_2"] == n2
+        assert packed.size == q * 125 and x["hv"].size == packed.size // 2
+        assert (x["hv"].view(np.uint8) == packed[: 2 * x["hv"].size]).all()
+        hvs.append(orc.unpack_hv(packed, 1000, q))  # what the reference's dist works on
+        n2s.append(n2)
+        assert (hvs[-1][768:] == -(1 << (q - 1))).all() and (hvs[-1][:768] == hv[:768]).all()
+    tsv = str(tmp_path / "ani.tsv")
+    r = subprocess.run([hg.CLI_PATH, "dist", "-r", out, "-q", out, "-o", tsv, "-a", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = orc.ani_matrix(np.stack(hvs), np.array(n2s, np.int32), np.stack(hvs), np.array(n2s, np.int32), 21)
+    got = {(a, b): float(v) for a, b, v in (l.split("\t") for l in open(tsv).read().splitlines())}
+    assert len(got) == 3
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert abs(got[(files[i], files[j])] - want[i, j]) <= 1e-3 + 1e-4

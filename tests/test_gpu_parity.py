@@ -642,3 +642,74 @@ def test_dist_i8_vetoed_inputs_fall_back_to_f16(ctx, orc):
         sel = np.triu(want >= 70.0 + 1e-4, 1)
         assert h.size >= int(sel.sum()) > 100 and np.abs(got[sel] - want[sel]).max() <= 1e-4, kind
         assert ctx.last_dist_path() == (1 if kind == "clean" else 0), kind
+
+
+# ---- independent golden vectors straight through the kernels ---------------------------------------
+def test_wyrng_golden_streams_through_the_encode_kernel(hg, ctx):
+    """tests/golden/kat_wyrng.json (tools/gen_golden_wyrng.py: the published wyrng definition in Python integers) against
+    the DEVICE's WyRng: the scalar-layout HV of a one-hash set is hv[64 i + j] = -1 + 2 * bit j of word i
+    (src/hd.rs:100-107), so the encode kernels hand back the generator's words bit for bit."""
+    g = golden("kat_wyrng.json")
+    for st in g["streams"]:
+        want = [int(x, 16) for x in st["next_u64"]]
+        hv, n2 = ctx.hv_encode(np.array([int(st["seed"], 16)], np.uint64), 64 * len(want), hg.LAYOUT_SCALAR)
+        assert set(np.unique(hv).tolist()) <= {-1, 1} and n2 == hv.size
+        bits = ((hv.astype(np.int32) + 1) >> 1).reshape(len(want), 64)
+        got = [sum(int(b) << j for j, b in enumerate(row)) for row in bits]
+        assert got == want, st["seed"]
+        # the AVX2 order of the same words: hv[64 i + 4 (j & 15) + (j >> 4)] (src/hd.rs:84-87)
+        hv2, _ = ctx.hv_encode(np.array([int(st["seed"], 16)], np.uint64), 64 * len(want), hg.LAYOUT_AVX2)
+        j = np.arange(64)
+        assert np.array_equal(hv2.reshape(-1, 64)[:, 4 * (j & 15) + (j >> 4)], hv.reshape(-1, 64))
+    # two hashes in one set: counts add (word-wise popcount of the two streams)
+    a, b = g["streams"][0], g["streams"][3]
+    hv, _ = ctx.hv_encode(np.array(sorted([int(a["seed"], 16), int(b["seed"], 16)]), np.uint64), 1024, hg.LAYOUT_SCALAR)
+    wa, wb = [int(x, 16) for x in a["next_u64"]], [int(x, 16) for x in b["next_u64"]]
+    want = np.array([[-2 + 2 * (((x >> j) & 1) + ((y >> j) & 1)) for j in range(64)] for x, y in zip(wa, wb)]).ravel()
+    assert np.array_equal(hv, want)
+
+
+def _vectors_with_dot(dot, d=64):
+    """two i16 vectors of dimension d whose i32 dot product is exactly `dot` (|dot| <= 2^31)"""
+    s, m = (-1 if dot < 0 else 1), abs(dot)
+    big = 32767 * 32767
+    c, rem = divmod(m, big)
+    a, b = divmod(rem, 32767)
+    r, q = np.zeros(d, np.int64), np.zeros(d, np.int64)
+    for i in range(c):
+        r[i], q[i] = 32767, 32767
+    r[c], q[c] = a, 32767
+    r[c + 1], q[c + 1] = b, 1
+    assert int(r @ q) == m and c + 2 <= d
+    return (s * r).astype(np.int16), q.astype(np.int16)
+
+
+def test_ani_golden_through_the_dist_kernels(hg, ctx, orc):
+    """tests/golden/g4_ani.json (tools/gen_golden_cpu.py: src/dist.rs:153-160 in numpy float32 with the i32-wrapping
+    denominator; not the oracle) through hg_dist_full and hg_dist: row i / column i carry vectors whose dot product is
+    case i's `dot` and the case's norms -- dot = nr = nq, den = 0, negative dots, wrapped denominators, wrapped norms."""
+    cases = golden("g4_ani.json")
+    n = len(cases)
+    r = np.zeros((n, 64), np.int16)
+    q = np.zeros((n, 64), np.int16)
+    for i, c in enumerate(cases):
+        r[i], q[i] = _vectors_with_dot(c["dot"])
+    rn = np.array([c["nr"] for c in cases], np.int64).astype(np.int32)
+    qn = np.array([c["nq"] for c in cases], np.int64).astype(np.int32)
+    for k in sorted({c["k"] for c in cases}):
+        sel = [i for i, c in enumerate(cases) if c["k"] == k]
+        full = ctx.dist_full(r, rn, q, qn, k)
+        for i in sel:
+            assert abs(float(full[i, i]) - cases[i]["ani"]) <= 1e-4, cases[i]
+        want = orc.ani_matrix(r, rn, q, qn, k)  # off-diagonal pairs: the oracle
+        assert float(np.abs(full - want).max()) <= 1e-4
+        for th in (0.0, 50.0, 96.0):
+            hits = ctx.dist(r, rn, q, qn, k, symmetric=False, ani_th=th)
+            got = {(int(h["ref_idx"]), int(h["qry_idx"])): float(h["ani"]) for h in hits}
+            sure = {(i, j) for i in range(n) for j in range(n) if want[i, j] >= th + 1e-4}
+            maybe = {(i, j) for i in range(n) for j in range(n) if want[i, j] >= th - 1e-4}
+            assert sure <= set(got) <= maybe, (k, th)
+            assert all(abs(v - want[i, j]) <= 1e-4 for (i, j), v in got.items())
+            for i in sel:
+                if cases[i]["ani"] >= th + 1e-4:
+                    assert abs(got[(i, i)] - cases[i]["ani"]) <= 1e-4

@@ -14,7 +14,13 @@ def test_t1ha2_upstream_selfcheck(orc):
 
 def test_wyrng_upstream_kat(orc):
     g = golden("kat_wyrng.json")
-    assert orc.wyrng_stream(g["seed"], 1)[0] == int(g["first"], 16)
+    assert orc.wyrng_stream(g["seed"], 1)[0] == int(g["first"], 16) == 0x3E99A772750DCBE  # wyhash crate README
+    # 16 consecutive outputs for 8 seeds from tools/gen_golden_wyrng.py (the published definition in Python integers,
+    # written independently of hg_oracle.c)
+    assert len(g["streams"]) >= 4
+    for st in g["streams"]:
+        want = [int(x, 16) for x in st["next_u64"]]
+        assert len(want) >= 16 and orc.wyrng_stream(int(st["seed"], 16), len(want)) == want, st["seed"]
     # seed_from_u64 is the identity on the state: successive states differ by the increment
     a = orc.wyrng_stream(5, 3)
     assert a[1:] == orc.wyrng_stream((5 + 0xA0761D6478BD642F) % 2**64, 2)
@@ -145,6 +151,46 @@ def test_pack_roundtrip_and_width(orc):
     words = np.frombuffer(packed.tobytes(), "<u4").reshape(9, 8)
     stream = sum(int(words[w, 3]) << (32 * w) for w in range(9))
     assert (stream >> (5 * 9)) & 0x1FF == 7 + 256
+
+
+def _bp8x_model(values, q):
+    """BitPacker8x block from the crate's definition, bit by bit in Python integers (a third formulation, shared with
+    neither oracle/hg_oracle.c nor hg_formats.cpp): lane l = i % 8 owns a stream of 32*q bits, element r = i // 8
+    starts at bit r*q; an unmasked element spills up to bit 31 of its first word and, if it straddles a word
+    boundary, its bits from (32 - c) upwards continue at bit 0 of the next word; word w of lane l = output u32 8w + l."""
+    words = [[0] * 8 for _ in range(q)]
+    for i, v in enumerate(values):
+        lane, p = i % 8, (i // 8) * q
+        w0, c = divmod(p, 32)
+        words[w0][lane] |= (v << c) & 0xFFFFFFFF
+        if c + q > 32:
+            words[w0 + 1][lane] |= v >> (32 - c)
+    return np.array(words, dtype="<u4").tobytes()
+
+
+def test_pack_follows_the_crate_definition_incl_q16_and_partial_blocks(orc):
+    rng = np.random.default_rng(11)
+    for q in range(6, 17):
+        for d in (256, 1024, 100, 264, 1000, 4096 + 8):
+            amp = (1 << (q - 1)) - 1
+            hv = rng.integers(-amp - 1, amp + 1, d).astype(np.int16)
+            _, packed = orc.pack_hv(hv, q)
+            assert packed.size == q * (d >> 3)  # src/hd.rs:146
+            off = -32768 if q == 16 else 1 << (q - 1)  # src/hd.rs:140: i16
+            want = b""
+            for b in range(d // 256):
+                # (i + offset) as u32: wrapping i16 sum, sign-extended
+                blk = [(((int(x) + off + 32768) % 65536) - 32768) & 0xFFFFFFFF for x in hv[256 * b: 256 * b + 256]]
+                want += _bp8x_model(blk, q)
+            want += bytes(packed.size - len(want))  # the bytes behind the last whole block stay zero
+            assert packed.tobytes() == want, (q, d)
+            back = orc.unpack_hv(packed, d, q)
+            whole = d // 256 * 256
+            if q < 16:
+                assert (back[:whole] == hv[:whole]).all()
+            elif whole:  # every even-indexed element of a lane that was >= 0 spills 0xFFFF into its odd neighbour
+                assert (back[:whole] != hv[:whole]).any()
+            assert (back[whole:] == np.int16(-off if q < 16 else -32768)).all()  # 0 as i16 - offset (src/hd.rs:206-212)
 
 
 def test_ani_golden(orc):

@@ -5,10 +5,11 @@ Sources of the numbers (none is produced by the code under test):
   * kat_t1ha2.json  -- upstream t1ha self-check table for t1ha2_atonce (test pattern,
     seed = 1 << (len-1)), lengths 0..18 and the 64-byte/seed-0 entry.  The values are
     typed in here; the oracle merely has to reproduce them.
-  * kat_wyrng.json  -- wyhash crate README: WyRng::seed_from_u64(3).next_u64().
+  * kat_wyrng.json  -- NOT written here: tools/gen_golden_wyrng.py (the published wyrng definition in Python integers).
   * g1_test_fna.json -- SURVEY.md 8c "G1": the reference's own kernel source
     (src/cuda_kernel.cu) executed on the reference fixture test/test.fna.
-  * g4_ani.json     -- src/dist.rs:153-160 evaluated with numpy float32 scalars.
+  * g4_ani.json     -- src/dist.rs:153-160 evaluated with numpy float32 scalars (the i32 denominator wraps like the
+    reference's release build, Cargo.toml:63-65); this script is not the oracle and shares no code with it.
 """
 import json
 import os
@@ -44,7 +45,8 @@ a66dcaadba250048 e02a59e9b5121e75 ec4ebc51bcb9a28f edb41fdf139cc8f5 ff1b1c5541e2
 def ani_f32(dot, nr, nq, k):
     f = np.float32
     with np.errstate(all="ignore"):
-        den = np.int32(np.int64(nr) + np.int64(nq) - np.int64(dot))  # no wrap in these cases
+        den = (int(nr) + int(nq) - int(dot) + 2**31) % 2**32 - 2**31  # i32 wrapping sum (release build: no overflow check)
+        den = np.int32(den)
         j = f(dot) / f(den)
         ani = f(1.0) + np.log(f(2.0) / (f(1.0) / j + f(1.0)), dtype=np.float32) / f(k)
     if np.isnan(ani):
@@ -57,8 +59,6 @@ def main():
     json.dump({"pattern": PATTERN,
                "cases": [{"len": l, "seed": str(s), "hash": "%016x" % v} for l, s, v in T1HA2]},
               open(os.path.join(OUT, "kat_t1ha2.json"), "w"), indent=1)
-    json.dump({"seed": 3, "first": "%016x" % 0x3E99A772750DCBE},
-              open(os.path.join(OUT, "kat_wyrng.json"), "w"), indent=1)
     json.dump({"fasta": G1_FASTA, "seed": 123, "canonical": True,
                "k21_scaled1": G1_K21_S1, "k5_scaled1": G1_K5_S1, "k21_scaled1500": []},
               open(os.path.join(OUT, "g1_test_fna.json"), "w"), indent=1)
@@ -66,7 +66,19 @@ def main():
     rng = np.random.default_rng(7)
     tuples = [(13650000, 13650000, 13650000, 21), (0, 100, 100, 21), (-5, 100, 100, 21),
               (50, 100, 100, 21), (1, 1, 1, 31), (9000000, 13000000, 14000000, 21),
-              (100, 0, 0, 21), (0, 0, 0, 21), (12000000, 13650000, 13700000, 16)]
+              (100, 0, 0, 21), (0, 0, 0, 21), (12000000, 13650000, 13700000, 16),
+              # dot = nr = nq (J = 1) at both ends of the range; den = 0 with dot != 0 (+-inf) and dot = 0 (NaN -> 0)
+              (1, 1, 1, 21), (2**31 - 1, 2**31 - 1, 2**31 - 1, 21), (7, 7, 7, 1), (5, 2, 3, 21), (-5, -2, -3, 21),
+              (0, 5, -5, 21),
+              # negative dot products: J < 0 -> ln of a negative number or of a value < e^-k
+              (-1, 100, 100, 21), (-13650000, 13650000, 13650000, 21), (-2**31, 1, 1, 21), (-90, 100, 100, 21),
+              # J in (0, tiny]: the clamp at 0
+              (1, 2**30, 2**30, 21), (1000, 2**30, 2**30, 5),
+              # i32-wrapping denominators (nr + nq - dot leaves the i32 range: the reference wraps silently)
+              (5, 2**31 - 1, 2**31 - 1, 21), (-10, 2**31 - 1, 5, 21), (2**30, 2**31 - 1, 2**31 - 1, 21),
+              (-2**31, 2**31 - 1, 2**31 - 1, 21), (100, -2**31, -2**31, 21), (2**31 - 1, -2**31, 0, 21),
+              # norms that wrapped negative in compute_hv_l2_norm (src/dist.rs:132-137) with an ordinary dot
+              (12000000, -2000000000, 13650000, 21), (12000000, -2000000000, -2000000000, 21)]
     for _ in range(40):
         nr, nq = (int(x) for x in rng.integers(1_000_000, 30_000_000, 2))
         dot = int(rng.integers(-200_000, min(nr, nq)))
