@@ -444,6 +444,65 @@ def main():
                                    "passes; packing time not included" % (HF, reps)}}
         log("host-fed, 2-bit packed stream: %.0f genomes/s (%.1f GB/s over PCIe, host packing %.2f ms per genome and thread)" % (
             HF / best, pk_bytes / best / 1e9, pack_ms))
+        # ---- per_call: the literal drop-in of the reference's inner seam (src/sketch_cuda.rs:79-96,120-166) ------
+        # T host threads (the reference's rayon workers), each with its OWN hg_ctx on this GPU, one synchronous
+        # hg_kmer_hash_sample call per genome from pinned memory, the sampled hash list back on the host -- what a
+        # Rust caller sees that only swaps `extract_kmer_t1ha2_cuda` for the C ABI (HV encode left where the
+        # reference has it).  `sketch_one` is the same pattern through hg_sketch_batch with n = 1 (HV on the device).
+        PT = min(16, len(os.sched_getaffinity(0)), HF)
+        pc_ctx = [hg.Context(local) for _ in range(PT)]
+        thr = (2**64 - 1) // SCALED
+        want_nh = nh[:HF].cpu().numpy()
+
+        def run_threads(fn):
+            bad = []
+
+            def w(t):
+                try:
+                    for g in range(t, HF, PT):
+                        fn(pc_ctx[t], g)
+                except Exception as e:  # pragma: no cover
+                    bad.append(repr(e))
+            ths = [threading.Thread(target=w, args=(t,)) for t in range(PT)]
+            t0 = time.perf_counter()
+            for x in ths:
+                x.start()
+            for x in ths:
+                x.join()
+            if bad:
+                raise SystemExit("per_call leg failed: " + bad[0])
+            return time.perf_counter() - t0
+
+        got_n = np.zeros(HF, np.int64)
+        outs = [np.zeros(8192, np.uint64) for _ in range(PT)]
+
+        def call_sample(c, g):
+            n = hg.C.c_size_t(0)
+            c._ck(hg.lib().hg_kmer_hash_sample(c._h, hg._ptr(host_rows[g]), host_rows[g].size, KSIZE, hg.C.c_uint64(thr),
+                                               hg.C.c_uint64(p.seed), 1, 0, hg._ptr(outs[g % PT]), 8192, hg.C.byref(n)))
+            got_n[g] = n.value
+
+        def call_sketch(c, g):
+            c.sketch_batch([host_rows[g]], p)
+
+        run_threads(call_sample)  # warm-up (workspaces, plan caches)
+        if not np.array_equal(got_n, want_nh):
+            raise SystemExit("PARITY GATE FAILED: per-call hash counts differ from the batch's")
+        dt_s = min(run_threads(call_sample) for _ in range(2))
+        run_threads(call_sketch)
+        dt_k = min(run_threads(call_sketch) for _ in range(2))
+        for c in pc_ctx:
+            c.close()
+        out["per_call"] = {"value": HF / dt_s, "unit": "genomes/sec", "threads": PT,
+                           "pcie_gbs": HF * (L_GENOME + 1) / dt_s / 1e9,
+                           "sketch_one": {"value": HF / dt_k, "unit": "genomes/sec"},
+                           "config": {"workload": "%d of the step's genomes from pinned host memory, ONE synchronous "
+                                                  "hg_kmer_hash_sample call per genome (hash list back on the host) "
+                                                  "from %d host threads with one hg_ctx each on this GPU -- the "
+                                                  "reference's rayon pattern, src/sketch_cuda.rs:79-96; sketch_one = "
+                                                  "hg_sketch_batch with n = 1 in the same pattern; rank 0 only" % (HF, PT)}}
+        log("per_call: %.0f genomes/s through hg_kmer_hash_sample on %d threads (%.1f GB/s), %.0f through hg_sketch_batch(n=1)" % (
+            HF / dt_s, PT, out["per_call"]["pcie_gbs"], HF / dt_k))
         del host, blobs
 
     # ---------------- dist: R x Q ANI matrix, thresholded ------------------------------------------
@@ -582,19 +641,25 @@ def main():
                 np.array_equal(merged["ref_idx"][order], src_rows.cpu().numpy() + lo) and bool((merged["dist"] == words).all())
             if not ok:
                 raise SystemExit("PARITY GATE FAILED: merged Hamming hits != the queries' source rows")
-        # roofline of the search.  The library runs large searches as an exact +-1 byte GEMM on the matrix pipe
-        # (G = D - 2*distance, v_mfma_i32_16x16x64_i8): algorithmic flops = 2 * D per pair against the dense i8 MFMA
-        # peak (2x the f16 peak, MI355X_MICROARCH.md).  The xor + popcount kernel (small searches) is priced in lane-ops:
-        # one v_xor_b32 + one v_bcnt_u32_b32 per 32 dims and pair against the issue rate of that pair
-        # (3.1 ns per wave-instruction pair and SIMD, tools/gpu_microbench.hip).  Compulsory bytes: every packed row once.
+        # roofline of the search.  The library runs large searches as an exact +-1 GEMM on the matrix pipe (G = D -
+        # 2*distance): on e2m1 operands (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales; path 2) against the dense
+        # FP4 MFMA peak, or on byte operands (v_mfma_i32_16x16x64_i8; path 1, test hook only) against the dense i8 peak
+        # (MI355X_MICROARCH.md: ~10 / ~5 PFLOP/s); algorithmic flops = 2 * D per pair either way.  The xor + popcount
+        # kernel (small searches) is priced in lane-ops: one v_xor_b32 + one v_bcnt_u32_b32 per 32 dims and pair against
+        # the issue rate of that pair (3.1 ns per wave-instruction pair and SIMD, tools/gpu_microbench.hip).
+        # Compulsory bytes: every packed row once.
         hpath = ctx.last_hamming_path()
         prep_ms = htm["dist_prep"][0] / max(a.steps, 1)
         hms = htm["dist"][0] / max(a.steps, 1)
-        if hpath == 1:
+        if hpath in (1, 2):
             flops = 2.0 * HD * refs * HQ
-            hroof = {"bound": "mfma", "achieved": flops / (hms * 1e-3) / 1e12, "peak": 2 * MFMA_F16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": flops / (hms * 1e-3) / 1e12 / (2 * MFMA_F16_PEAK_TFLOPS),
-                     "peak_dtype": "i8 dense MFMA", "kernel": "dist_mfma_kernel (+-1 byte operands, Hamming epilogue)",
+            hpeak = MFMA_F16_PEAK_TFLOPS * (4.0 if hpath == 2 else 2.0)
+            hroof = {"bound": "mfma", "achieved": flops / (hms * 1e-3) / 1e12, "peak": hpeak,
+                     "unit": "TFLOP/s", "frac": flops / (hms * 1e-3) / 1e12 / hpeak,
+                     "peak_dtype": "FP4 dense MFMA" if hpath == 2 else "i8 dense MFMA",
+                     "frac_of_i8_peak": flops / (hms * 1e-3) / 1e12 / (2 * MFMA_F16_PEAK_TFLOPS),
+                     "kernel": "dist_mfma_kernel (+-1.0 e2m1 operands, Hamming epilogue)" if hpath == 2 else
+                               "dist_mfma_kernel (+-1 byte operands, Hamming epilogue)",
                      "launch_ms": hms, "expand_ms": prep_ms, "algorithmic_flops_per_launch": flops}
         else:
             word_ops = 2.0 * refs * HQ * words
@@ -605,7 +670,7 @@ def main():
         # HBM-side bytes per launch of the search kernel from the newest committed PMC pass of this command (only
         # for the shape that pass was taken on: all 50 000 refs x 10 000 queries on one GPU)
         ham_traffic = None
-        if hpath == 1 and world == 1 and a.hamming_refs == 50000 and HQ == 10000:
+        if hpath in (1, 2) and world == 1 and a.hamming_refs == 50000 and HQ == 10000:
             try:
                 d = json.load(open(newest_profile("_pmc.json")))
                 ham_traffic = max((v for k, v in d.items() if k.startswith("dist_mfma_kernel") and k.rstrip(">").split(",")[6].strip() == "true"),
@@ -624,7 +689,7 @@ def main():
             "roofline": hroof, "kernel_ms": hms,
         }
         log("hamming: %.0f M pairs/s, kernel %.3f ms (%s, %.0f %% of its bound), merged hits %d" % (
-            out["hamming"]["value"], hms, "matrix pipe" if hpath == 1 else "xor+popcount",
+            out["hamming"]["value"], hms, {1: "matrix pipe, i8", 2: "matrix pipe, FP4"}.get(hpath, "xor+popcount"),
             100 * out["hamming"]["roofline"]["frac"], merged.size))
         del rb, qb, hh
 

@@ -458,16 +458,13 @@ constexpr uint32_t ST = 8;       // super-tile edge, in tiles
 //   big  : 256 x 256, 8 waves, 144 KiB LDS, 1 workgroup / CU  -- half the LDS and L2 bytes per flop
 //   wide : 256 x 320 (NT = 5, LDS-DMA only): chosen when it divides the tile grid into fewer rounds over the
 //          CUs (10 000 x 10 000: 1 280 tiles = 5.0 rounds of 256 instead of 1 600 = 6.25 -> 7)
-//   w4   : 256 x 256 on FOUR waves of 128 x 128 (NT = 8, 256 accumulators per lane pinned to AGPRs, one wave per SIMD):
-//          a wave reads (128 + 128) x 128 B of fragments per K-step for 128 MFMAs where the 8-wave shape reads
-//          (128 + 64) x 128 B for 64 -- at K = 16384 the 8-wave shape sits at the LDS read rate (126 B/clk/CU, 67 %
-//          matrix-pipe busy).  NEGATIVE so far: 8.2 ms against 6.5 ms on the Hamming search (256 x 192: 8.5 ms); with
-//          a single wave per SIMD nothing covers the per-step barrier and the fragment latency.  Kept behind the
-//          Hamming test hook "mfma4".
-template <bool BIG, int NT = 4, bool W4 = false>
+// (Measured and removed again, see DESIGN.md 4.3 / 4.4 and the history of this file: a four-wave 128 x 128 per-wave shape
+// with AGPR-pinned accumulators, bit-stream operands expanded by the workgroup, a register-staged 256 x 256 variant,
+// the DMA burst spread over all waves, raised priority for the loader waves.)
+template <bool BIG, int NT = 4>
 struct TileCfg {
   static constexpr int WTM = BIG ? 8 : 4;   // 16-row MFMA tiles per wave in M
-  static constexpr int NWN = W4 ? 2 : (BIG ? 4 : 2);   // waves in N
+  static constexpr int NWN = BIG ? 4 : 2;   // waves in N
   static constexpr int BM = 2 * WTM * 16, BN = NWN * NT * 16;  // NT = 16-column MFMA tiles per wave in N
   static constexpr int THREADS = 2 * NWN * 64;
   static constexpr int LOADS = BM * BK * 2 / 16 / THREADS;    // 16-byte pieces per thread, A operand
@@ -492,7 +489,6 @@ struct GemmArgs {
   int symmetric;
   uint32_t ref_off, qry_off;  // global index of row 0 / column 0 (a block of a larger matrix): hits and the i < j test use them
   uint32_t tiles_m, tiles_n;  // tile grid
-  const uint8_t *bitsA, *bitsB;  // HAMB: blocked bit operands ([row block of 256][K-step][row][16 bytes])
   const uint32_t *verdict;    // speculative launch: runs only if v_lo <= verdict[0] <= v_hi (see decide_kernel);
   uint32_t v_lo, v_hi;        // with chunk_from_verdict the window length (K-steps) is verdict[1]
   uint32_t chunk_from_verdict;
@@ -527,22 +523,25 @@ struct GemmArgs {
 // chunk index with (row >> 1) & 7 -- applied to the per-lane SOURCE address when loading and to the
 // fragment address when reading (same involution on both sides).
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int8v __attribute__((ext_vector_type(8)));
 template <int... Js, class F>
 __device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...>, F &&f) {
   (f(std::integral_constant<int, Js>{}), ...);
 }
-// HAM (with I8): the operands are +-1 bytes expanded from bit-packed hypervectors, G = D - 2*hamming; the epilogue
-// keeps G >= ham_thr and reports {ref, qry, (D - G) / 2} -- the bit-packed search on the matrix pipe.
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool W4 = false,
-          bool HAMB = false>
-__global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kernel(GemmArgs g) {
-  using TC = TileCfg<BIG, NT, W4>;
-  // HAMB: the Hamming operands arrive as BITS (block_bits_kernel's layout) by LDS-DMA, 16 bytes per row and K-step, and
-  // every thread expands its row's next K-step into the byte stage, one 16-byte chunk per MFMA phase
-  static_assert(!HAMB || (HAM && I8 && GLDS && BIG && NT == 4 && !W4), "bit-stream operands: 256 x 256 Hamming tiles only");
-  static_assert(!W4 || (BIG && GLDS && I8 && (NT == 6 || NT == 8)), "the four-wave shape exists for the i8 LDS-DMA path");
+// HAM (with I8): the operands are +-1 expanded from bit-packed hypervectors, G = D - 2*hamming; the epilogue keeps
+// G >= ham_thr and reports {ref, qry, (D - G) / 2} -- the bit-packed search on the matrix pipe.  Two operand formats:
+//   bytes   (+-1 as i8, v_mfma_i32_16x16x64_i8: K = 64 dims per instruction), or
+//   FP4     (+-1.0 as e2m1 nibbles 0x2 / 0xA, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: K = 128 dims
+//           per instruction at the same cycles, exact in the f32 accumulator while D <= 2^24).  Either way a lane's
+//           fragment is 16 bytes and a K-step is 128 bytes per row, so staging, swizzle and fragment addressing are
+//           shared; the order of the dims inside a fragment is irrelevant as long as both operands use the same one
+//           (every product is +-1 and they are all summed).
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false>
+__global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(GemmArgs g) {
+  using TC = TileCfg<BIG, NT>;
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
+  static_assert(!FP4 || HAM, "e2m1 operands exist for the Hamming search only");
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
   if (I8 && !HAM) {
     const bool ok = i8_attempt_valid(g.i8ctrl, g.ent_cap);
@@ -588,7 +587,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   const uint32_t wm = wave / NWN, wn = wave % NWN;  // 2 x NWN waves, (WTM*16) x 64 each
   const uint32_t fr = lane & 15, fq = lane >> 4;
 
-  typedef typename std::conditional<I8, int4v, float4v>::type acc_t;  // i8 operands accumulate in exact i32
+  typedef typename std::conditional<I8 && !FP4, int4v, float4v>::type acc_t;  // i8 operands accumulate in exact i32
   acc_t acc[WTM][NT];
   int32_t iacc[CHUNKED ? WTM : 1][CHUNKED ? NT : 1][4];
 #pragma unroll
@@ -662,14 +661,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
   // up behind the workgroup's burst cannot issue MFMAs meanwhile, and with every wave loading right after the
   // barrier both waves of a SIMD sit in that queue together while the matrix pipe idles.  With one loader
   // per SIMD its partner keeps the pipe busy and the loader catches up while the partner waits at the barrier.
-  // HG_DMA_SPREAD (A/B switch): instead of one burst by four loader waves right after the barrier, ALL waves issue
-  // the pieces of tile k+1 spread over the first four phases of step k, a couple per phase between MFMA groups.
-#ifndef HG_DMA_SPREAD
-#define HG_DMA_SPREAD 0
-#endif
-#ifndef HG_DMA_LOADER_WAVES
-#define HG_DMA_LOADER_WAVES (HG_DMA_SPREAD ? 8 : 4)
-#endif
+  constexpr int HG_DMA_LOADER_WAVES = 4;
   constexpr int LW = HG_DMA_LOADER_WAVES < THREADS / 64 ? HG_DMA_LOADER_WAVES : THREADS / 64, LT = LW * 64;  // loader waves / threads
   constexpr int PA = BM * 8 / LT, PB = BN * 8 / LT;      // 16-byte pieces per loader thread, A / B tile
   // byte offsets of this thread's pieces inside the A / B row block (fixed-size arrays: a template-sized
@@ -690,13 +682,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
   }
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
-#ifndef HG_DMA_PRIO
-#define HG_DMA_PRIO 0  /* A/B switch: 1 = the loader waves issue their burst at raised priority */
-#endif
 #define HG_DMA(stage, k0)                                                                                   \
   {                                                                                                         \
   if (wave < (uint32_t)LW) {                                                                                \
-    if (HG_DMA_PRIO == 1) __builtin_amdgcn_s_setprio(3);                                                    \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
     _Pragma("unroll") for (int i = 0; i < (PA > PB ? PA : PB); ++i) {                                       \
       if (i < PA)                                                                                           \
@@ -704,57 +692,11 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
       if (i < PB)                                                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
     }                                                                                                       \
-    if (HG_DMA_PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                    \
-  } else if (HG_DMA_PRIO == 2) {                                                                            \
-    __builtin_amdgcn_s_setprio(1); /* 2 = static priority for the non-loading half */                       \
   }                                                                                                         \
   }
-  // pieces [lo, hi) of the same transfer (spread schedule)
-#define HG_DMA_PART(stage, k0, lo, hi)                                                                      \
-  if (wave < (uint32_t)LW) {                                                                                \
-    _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8;                                          \
-    _Pragma("unroll") for (int i = (lo); i < (hi); ++i) {                                                   \
-      if (i < PA)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
-      if (i < PB)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
-    }                                                                                                       \
-  }
-  // A fragments per phase: 2 (x NT B fragments = 8..10 MFMAs, another wave of the SIMD covers the fragment latency) or,
-  // with one wave per SIMD (W4), 4 x 8 = 32 MFMAs = 512 cycles between a fragment's request and its first use
-  // HAMB: bit stages behind the two byte stages; K-step k's bits live in bit stage k & 1.  One 1 KiB instruction per
-  // wave: waves 0..3 fetch the A block's 256 rows, waves 4..7 the B block's; lane l of wave w fetches (and later reads
-  // back) the 16 bytes of tile row 64 (w & 3) + l.
-  uint8_t *const hb_stage = reinterpret_cast<uint8_t *>(sAB) + 2 * STAGE_ELEMS * sizeof(_Float16);
-  __amdgpu_buffer_rsrc_t rsBits;
-  uint32_t hb_swz = 0;
-  uint8_t *hb_row = nullptr;  // this thread's row inside a byte stage (stage 0)
-  if constexpr (!HAMB) rsBits = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A), 0, 0, 0);
-  if constexpr (HAMB) {
-    const uint32_t nst = g.Kp / BK;
-    const uint8_t *base = wave < 4 ? g.bitsA + (size_t)tm * nst * 4096 : g.bitsB + (size_t)tn * nst * 4096;
-    rsBits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 0x7fffffff, 0x00020000);
-    const uint32_t trow = tid & 255u;
-    hb_swz = (trow >> 1) & 7u;
-    hb_row = reinterpret_cast<uint8_t *>(sAB) + (wave < 4 ? 0u : TILE_ELEMS * (uint32_t)sizeof(_Float16)) + trow * (LROW * 2u);
-  }
-#define HG_BDMA(kstep)                                                                                                   \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBits, (lds_ptr_t)(hb_stage + ((kstep) & 1u) * 8192u + wave * 1024u), 16,  \
-                                           ((tid & 255u) * 16u), (kstep) * 4096u, 0, 0);
-  uint32_t hb_bits[4] = {0, 0, 0, 0};
-  // chunk `ch` of the K-step held in hb_bits -> byte stage `stage`
-#define HG_EXPAND(stage, ch)                                                                                             \
-  {                                                                                                                      \
-    const uint32_t b16_ = (hb_bits[(ch) >> 1] >> (16 * ((ch) & 1))) & 0xFFFFu;                                          \
-    uint32_t e_[4];                                                                                                      \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                  \
-      const uint32_t m_ = (((b16_ >> (4 * q_)) & 0xFu) * 0x00204081u) & 0x01010101u;                                   \
-      e_[q_] = __builtin_amdgcn_perm(0u, 0x000001FFu, m_); /* selector byte 0 -> 0xFF (-1), 1 -> 0x01 (+1) */           \
-    }                                                                                                                    \
-    *reinterpret_cast<uint4 *>(hb_row + (stage) * (STAGE_ELEMS * 2u) + (((ch) ^ hb_swz) * 16u)) =                       \
-        make_uint4(e_[0], e_[1], e_[2], e_[3]);                                                                          \
-  }
-  constexpr int AF = W4 ? 4 : 2;
+  // A fragments per phase: 2 (x NT B fragments = 8..10 MFMAs, the other wave of the SIMD covers the fragment latency)
+  constexpr int AF = 2;
+  const int32_t fp4_unit_scale = 0x7f7f7f7f;  // FP4: E8M0 block scales of 2^0 for every 32-element block
   constexpr int MP = WTM / AF, PHASES = (BK / 32) * MP;
   half8 bfr[2][NT], afr[2][AF];
   // fragments of phase (kk, mp) of the stage whose fragment bases are pa / pb, into buffer set `buf`
@@ -768,18 +710,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     _Pragma("unroll") for (int i_ = 0; i_ < AF; ++i_)                                                       \
         afr[buf][i_] = *reinterpret_cast<const half8 *>((pa) + (AF * (mp) + i_) * 16 * LROW + ko_);         \
   }
-  if constexpr (HAMB) {
-    HG_BDMA(0u)
-    if (nsteps > 1) HG_BDMA(1u)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-      const uint4 v_ = *reinterpret_cast<const uint4 *>(hb_stage + tid * 16u);
-      hb_bits[0] = v_.x, hb_bits[1] = v_.y, hb_bits[2] = v_.z, hb_bits[3] = v_.w;
-    }
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) HG_EXPAND(0u, ch)
-  } else if (GLDS) {
+  if (GLDS) {
     HG_DMA(0, 0)
   } else {
     HG_GLOAD(0)
@@ -789,9 +720,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
     }
   }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
-  if constexpr (HAMB) {
-    if (nsteps > 2) HG_BDMA(2u)  // into bit stage 0, whose K-step 0 has just been expanded
-  } else if (GLDS && nsteps > 1 && !HG_DMA_SPREAD) HG_DMA(1, BK)
+  if (GLDS && nsteps > 1) HG_DMA(1, BK)
   if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
@@ -803,36 +732,18 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
         HG_GLOAD(k2)
       }
     }
-    if constexpr (HAMB) {
-      if (ks + 1 < nsteps) {  // this thread's row of K-step ks + 1 (landed before the last barrier)
-        const uint4 v_ = *reinterpret_cast<const uint4 *>(hb_stage + ((ks + 1) & 1u) * 8192u + tid * 16u);
-        hb_bits[0] = v_.x, hb_bits[1] = v_.y, hb_bits[2] = v_.z, hb_bits[3] = v_.w;
-      }
-    }
     const _Float16 *fA = sAB + cur * STAGE_ELEMS + fa_off, *fB = sAB + cur * STAGE_ELEMS + fb_off;
     const _Float16 *nA = sAB + (cur ^ 1) * STAGE_ELEMS + fa_off, *nB = sAB + (cur ^ 1) * STAGE_ELEMS + fb_off;
 #pragma unroll
     for (int t = 0; t < PHASES; ++t) {
       const int kk = t / MP, mp = t % MP;
-      if (GLDS && HG_DMA_SPREAD && t < 4 && ks + 1 < nsteps) {  // tile ks+1 -> the stage freed by the last barrier
-        constexpr int PMAX_ = PA > PB ? PA : PB, Q4 = (PMAX_ + 3) / 4;
-        HG_DMA_PART(cur ^ 1, (ks + 1) * BK, t * Q4, (t + 1) * Q4 < PMAX_ ? (t + 1) * Q4 : PMAX_)
-      }
-      if constexpr (HAMB) {
-        static_assert(!HAMB || PHASES == 8, "one 16-byte chunk of the next K-step per phase");
-        if (ks + 1 < nsteps) HG_EXPAND(cur ^ 1u, t)
-      }
       if (t + 1 < PHASES) {
         if (!HG_EXP(2) && !(HG_EXP(32) && ks)) HG_FRAGS((t + 1) & 1, fA, fB, (t + 1) / MP, (t + 1) % MP)
       } else {
         // every fragment read of this stage must have returned before another wave may refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (HAMB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bits of K-step ks + 2 have landed
         if (!HG_EXP(16)) __syncthreads();
-        if constexpr (HAMB) {
-          if (ks + 3 < nsteps) HG_BDMA(ks + 3u)  // bit stage (ks + 1) & 1: its K-step was read at the top of this step
-        } else
-        if (GLDS && ks + 2 < nsteps && !HG_EXP(1) && !HG_DMA_SPREAD) HG_DMA(cur, (ks + 2) * BK)
+        if (GLDS && ks + 2 < nsteps && !HG_EXP(1)) HG_DMA(cur, (ks + 2) * BK)
         if (ks + 1 < nsteps && !HG_EXP(2) && !HG_EXP(32)) HG_FRAGS(0, nA, nB, 0, 0)
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -846,12 +757,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
         for (int i = 0; i < AF; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            if constexpr (W4)  // > 256 live registers: pin the accumulators to AGPRs (the register allocator otherwise
-              // shuttles them between the two files inside the loop: 280 v_accvgpr moves per 96 MFMAs)
-              asm("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0"
-                           : "+a"(acc[AF * mp + i][n])
-                           : "v"(__builtin_bit_cast(int4v, afr[t & 1][i])), "v"(__builtin_bit_cast(int4v, bfr[kk & 1][n])));
-            else if constexpr (I8)  // the same 16-byte fragments hold 16 k-consecutive bytes per lane: one instruction covers K = 64
+            if constexpr (FP4) {  // 32 e2m1 values per lane in the fragment's 16 bytes; block scales 2^0 (E8M0 127).
+              // Written as asm: the builtin takes 8-register operand vectors (the e4m3 width); padding the 16-byte
+              // fragments to that width costs a copy of every fragment per K-step and 60 VGPRs (spills at 256).
+              asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                           : "+v"(acc[AF * mp + i][n])
+                           : "v"(__builtin_bit_cast(int4v, afr[t & 1][i])), "v"(__builtin_bit_cast(int4v, bfr[kk & 1][n])),
+                             "v"(fp4_unit_scale));
+            } else if constexpr (I8)  // the same 16-byte fragments hold 16 k-consecutive bytes per lane: one instruction covers K = 64
               acc[AF * mp + i][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(int4v, afr[t & 1][i]),
                                                                           __builtin_bit_cast(int4v, bfr[kk & 1][n]),
                                                                           acc[AF * mp + i][n], 0, 0, 0);
@@ -873,6 +786,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
         }
     }
   }
+  if constexpr (FP4)  // asm MFMAs: the hazard recogniser does not know that the accumulators come from the matrix pipe
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
   // The epilogue reuses the operand stages (every fragment read was retired by the last in-loop barrier):
   // per-wave candidate lists, then the tile's BM + BN norms -- phase 2 gathers them by candidate, and from
   // global memory each 64-candidate batch paid a full dependent-load latency (0.12 ms per launch at 1.3 M hits).
@@ -898,9 +813,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4, W4>::THREADS)) void dist_mfma_kern
 #undef HG_GLOAD
 #undef HG_LSTORE
 #undef HG_DMA
-#undef HG_DMA_PART
-#undef HG_BDMA
-#undef HG_EXPAND
 #undef HG_FRAGS
 
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
@@ -1164,135 +1076,110 @@ __global__ __launch_bounds__(256) void expand_bits_kernel(const uint32_t *__rest
   }
 }
 
-// Bit-stream operands of the Hamming GEMM (HAMB): the bit-packed rows regrouped so that what a workgroup needs per
-// K-step -- 16 bytes of each of its 256 rows -- is 4 KiB contiguous: out[((block * nsteps + kstep) * 256 + row) * 16].
-// Rows past `rows` are filled with `pad` (A: zero bits, B: one bits -- padding against padding then scores -D and never
-// passes the threshold test).
-__global__ __launch_bounds__(256) void block_bits_kernel(const uint32_t *__restrict__ bits, uint32_t rows, uint32_t words,
-                                                         uint32_t pad, uint4 *__restrict__ out) {
-  const uint32_t nsteps = words / 4, block = blockIdx.y, row = block * 256 + threadIdx.x;
-  for (uint32_t ks = blockIdx.x; ks < nsteps; ks += gridDim.x) {
-    uint4 v = make_uint4(pad, pad, pad, pad);
-    if (row < rows) v = *reinterpret_cast<const uint4 *>(bits + (size_t)row * words + 4 * ks);
-    out[((size_t)block * nsteps + ks) * 256 + threadIdx.x] = v;
+// bits -> e2m1 nibbles (bit 1 -> +1.0 = 0x2, bit 0 -> -1.0 = 0xA), one lane per 32-bit word = 16 bytes of output.  The
+// eight bits of a byte are spread to bit 0 of eight nibbles by three shift-or-mask steps; the code is
+// 0x2 | (!bit << 3).  Words past the row's end (K is padded to whole 128-byte K-steps) become zero nibbles: +0.0
+// contributes nothing to G.  Which dim lands in which nibble does not matter as long as both operands are expanded by
+// this kernel (see dist_mfma_kernel).
+__global__ __launch_bounds__(256) void expand_bits_fp4_kernel(const uint32_t *__restrict__ bits, uint32_t rows, uint32_t words,
+                                                              uint32_t groups, uint32_t ldk4, uint8_t *__restrict__ out) {
+  const uint32_t row = blockIdx.y;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < groups; w += gridDim.x * blockDim.x) {
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    if (w < words) {
+      const uint32_t v = ~bits[(size_t)row * words + w];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t y = (v >> (8 * i)) & 0xFFu;
+        y = (y | (y << 12)) & 0x000F000Fu;
+        y = (y | (y << 6)) & 0x03030303u;
+        y = (y | (y << 3)) & 0x11111111u;
+        d[i] = (y << 3) | 0x22222222u;
+      }
+    }
+    *reinterpret_cast<uint4 *>(out + (size_t)row * ldk4 + (size_t)w * 16) = make_uint4(d[0], d[1], d[2], d[3]);
   }
 }
 
+// path: 1 = +-1 byte operands on v_mfma_i32_16x16x64_i8 (hv_d a multiple of 128), 2 = e2m1 operands on
+// v_mfma_scale_f32_16x16x128_f8f6f4 (any hv_d: rows are whole 32-bit words; pad bits count like in the popcount kernel)
 hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R, const uint32_t *d_qry_bits, uint32_t Q,
                               uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_hits, uint32_t *d_count, uint32_t cap,
-                              uint32_t ref_off, uint32_t qry_off) {
+                              uint32_t ref_off, uint32_t qry_off, int path) {
   static_assert(sizeof(hg_ham_hit) == sizeof(hg_ani_hit), "the GEMM epilogue writes 12-byte records");
-  const uint32_t words = hv_d / 32, ldk8 = hv_d + 128;  // hv_d is a multiple of 128 (checked by the caller)
-  // Bit-stream operands (dist_mfma_kernel<..., HAMB>): 1/8 of the operand bytes in HBM and through L2 -> LDS, expanded
-  // by the workgroup.  A/B at 50 000 x 10 000 x 16384: 6.87 ms against 6.56 ms with byte operands -- the LDS (192 KB of
-  // fragment reads + 64 KB of stage writes per K-step either way), not the L2 stream, is what co-limits with the matrix
-  // pipe -- so it is chosen only where the byte copies would not be reasonable to hold (> 16 GB), or by the test hook.
-  const bool bits_path = c->dbg_ham_path == "mfmab" ||
-                         (c->dbg_ham_path.empty() && ((uint64_t)R + Q) * (uint64_t)ldk8 > ((uint64_t)16 << 30));
-  if (bits_path) {
-    const uint32_t nsteps = hv_d / 128, rb = (R + 255) / 256, qb = (Q + 255) / 256;
-    hg_status s;
-    if ((s = hg_ensure(c, c->w_i8a, (size_t)rb * nsteps * 4096 + 64)) != HG_OK) return s;
-    if ((s = hg_ensure(c, c->w_i8b, (size_t)qb * nsteps * 4096 + 64)) != HG_OK) return s;
-    c->i8_sig_ref = c->i8_sig_qry = nullptr;  // the dist path's operand copies are gone
-    {
-      hg_timed tp(c, HG_T_DIST_PREP);
-      const unsigned gx = std::min<uint32_t>(nsteps, 64);
-      hipLaunchKernelGGL(block_bits_kernel, dim3(gx, rb), dim3(256), 0, c->stream, d_ref_bits, R, words, 0u,
-                         static_cast<uint4 *>(c->w_i8a.p));
-      HG_HIP(c, hipGetLastError());
-      hipLaunchKernelGGL(block_bits_kernel, dim3(gx, qb), dim3(256), 0, c->stream, d_qry_bits, Q, words, 0xFFFFFFFFu,
-                         static_cast<uint4 *>(c->w_i8b.p));
-      HG_HIP(c, hipGetLastError());
-    }
-    GemmArgs g{};
-    g.bitsA = static_cast<const uint8_t *>(c->w_i8a.p), g.bitsB = static_cast<const uint8_t *>(c->w_i8b.p);
-    g.R = R, g.Q = Q, g.Kp = hv_d / 2, g.ldk = ldk8 / 2, g.chunk_steps = ~0u;
-    g.hits = reinterpret_cast<hg_ani_hit *>(d_hits), g.hit_count = d_count, g.hit_cap = cap;
-    g.ref_off = ref_off, g.qry_off = qry_off, g.hv_d = hv_d;
-    g.ham_thr = max_dist >= hv_d ? -(int32_t)hv_d - 1 : (int32_t)hv_d - 2 * (int32_t)max_dist;
-    g.tiles_m = rb, g.tiles_n = qb;
-    const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
-    const size_t lds = 2 * (256 + 256) * BK * sizeof(_Float16) + 2 * 8192;  // two byte stages + two bit stages
-    const void *fp = reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, true, false, true>);
-    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
-      HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      c->lds_attr_done.push_back(fp);
-    }
-    hg_timed tg(c, HG_T_DIST);
-    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true, true, false, true>), dim3(n_tiles),
-                       dim3(TileCfg<true, 4>::THREADS), lds, c->stream, g);
-    HG_HIP(c, hipGetLastError());
-    return HG_OK;
-  }
+  const bool fp4 = path == 2;
+  const uint32_t words = (hv_d + 31) / 32, dims = words * 32;  // G = dims - 2 * popcount(xor of whole words)
+  if (!fp4 && hv_d % 128) return hg_fail(c, HG_ERR_INVALID, "byte operands need hv_d % 128 == 0");
+  // row bytes: one per dim (bytes) or half of one (e2m1), padded to whole 128-byte K-steps, pitch + 128 B (see hg_run_dist)
+  const uint32_t kbytes = fp4 ? (dims / 2 + 127) / 128 * 128 : hv_d, ldkb = kbytes + 128;
   auto padded = [](uint32_t n) { return std::max({(n + 255) / 256 * 256, (n + 319) / 320 * 320, (n + 191) / 192 * 192}); };
   const uint32_t Rp = padded(R), Qp = padded(Q);
   hg_status s;
-  if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
-  if ((s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldk8)) != HG_OK) return s;
-  auto *a8 = static_cast<int8_t *>(c->w_i8a.p), *b8 = static_cast<int8_t *>(c->w_i8b.p);
+  if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldkb)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldkb)) != HG_OK) return s;
+  auto *a8 = static_cast<uint8_t *>(c->w_i8a.p), *b8 = static_cast<uint8_t *>(c->w_i8b.p);
   c->i8_sig_ref = c->i8_sig_qry = nullptr;  // the dist path's operand copies are gone
-  if (Rp > R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)R * ldk8, 0, (size_t)(Rp - R) * ldk8, c->stream));
-  if (Qp > Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)Q * ldk8, 0, (size_t)(Qp - Q) * ldk8, c->stream));
+  if (Rp > R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)R * ldkb, 0, (size_t)(Rp - R) * ldkb, c->stream));
+  if (Qp > Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)Q * ldkb, 0, (size_t)(Qp - Q) * ldkb, c->stream));
   {
     hg_timed tp(c, HG_T_DIST_PREP);
-    const unsigned gx = (words + 255) / 256;
-    for (uint32_t r0 = 0; r0 < R; r0 += 65535) {
-      const uint32_t m = std::min<uint32_t>(65535, R - r0);
-      hipLaunchKernelGGL(expand_bits_kernel, dim3(gx, m), dim3(256), 0, c->stream, d_ref_bits + (size_t)r0 * words, m, words, ldk8,
-                         a8 + (size_t)r0 * ldk8);
-      HG_HIP(c, hipGetLastError());
-    }
-    for (uint32_t q0 = 0; q0 < Q; q0 += 65535) {
-      const uint32_t m = std::min<uint32_t>(65535, Q - q0);
-      hipLaunchKernelGGL(expand_bits_kernel, dim3(gx, m), dim3(256), 0, c->stream, d_qry_bits + (size_t)q0 * words, m, words, ldk8,
-                         b8 + (size_t)q0 * ldk8);
-      HG_HIP(c, hipGetLastError());
-    }
+    const uint32_t groups = kbytes / 16;
+    const unsigned gx = fp4 ? (groups + 255) / 256 : (words + 255) / 256;
+    auto expand = [&](const uint32_t *bits, uint32_t n, uint8_t *out) -> hipError_t {
+      for (uint32_t r0 = 0; r0 < n; r0 += 65535) {
+        const uint32_t m = std::min<uint32_t>(65535, n - r0);
+        if (fp4)
+          hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3(gx, m), dim3(256), 0, c->stream, bits + (size_t)r0 * words, m, words,
+                             groups, ldkb, out + (size_t)r0 * ldkb);
+        else
+          hipLaunchKernelGGL(expand_bits_kernel, dim3(gx, m), dim3(256), 0, c->stream, bits + (size_t)r0 * words, m, words, ldkb,
+                             reinterpret_cast<int8_t *>(out + (size_t)r0 * ldkb));
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    };
+    HG_HIP(c, expand(d_ref_bits, R, a8));
+    HG_HIP(c, expand(d_qry_bits, Q, b8));
   }
   GemmArgs g{};
   g.A = reinterpret_cast<const _Float16 *>(a8), g.B = reinterpret_cast<const _Float16 *>(b8);
-  g.R = R, g.Q = Q, g.Kp = hv_d / 2, g.ldk = ldk8 / 2, g.chunk_steps = ~0u;
+  g.R = R, g.Q = Q, g.Kp = kbytes / 2, g.ldk = ldkb / 2, g.chunk_steps = ~0u;  // in two-byte units (a K-step is 128 bytes)
   g.hits = reinterpret_cast<hg_ani_hit *>(d_hits), g.hit_count = d_count, g.hit_cap = cap;
-  g.ref_off = ref_off, g.qry_off = qry_off, g.hv_d = hv_d;
+  g.ref_off = ref_off, g.qry_off = qry_off, g.hv_d = dims;
   // dist <= max  <=>  G = D - 2*dist >= D - 2*max  (max >= D: everything is a hit)
-  g.ham_thr = max_dist >= hv_d ? -(int32_t)hv_d - 1 : (int32_t)hv_d - 2 * (int32_t)max_dist;
-  // eight waves of 128 x 64 / 128 x 80; the four-wave shape of 128 x 128 (TileCfg) only through the test hook "mfma4":
-  // A/B on 50 000 x 10 000 x 16384: 8.2 ms against 6.5 ms
-  const bool w4 = c->dbg_ham_path == "mfma4";
-  int nt = w4 ? 8 : 4;
-  if (!w4) {
+  g.ham_thr = max_dist >= dims ? -(int32_t)dims - 1 : (int32_t)dims - 2 * (int32_t)max_dist;
+  int nt = 4;
+  {
     const uint64_t tm = (R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
     const uint64_t r4 = (tm * ((Q + 255) / 256) + ncu - 1) / ncu, r5 = (tm * ((Q + 319) / 320) + ncu - 1) / ncu;
-    // a 256 x 320 tile costs 1.25 x 0.9 of a 256 x 256 one: the kernel is co-limited by LDS traffic, and the wide tile
-    // reads 13 % fewer fragment bytes per MFMA (50 000 x 10 000 x 16384: 5.9 ms against 6.55 at equal padded area)
+    // a 256 x 320 tile is priced at 1.25 x 0.9 of a 256 x 256 one (13 % fewer fragment bytes per MFMA; 50 000 x 10 000 x
+    // 16384 on byte operands: 5.9 ms against 6.55 at equal padded area)
     if (r5 * 9 < r4 * 8) nt = 5;
     if (c->dbg_dist_tile == "big") nt = 4;
     else if (c->dbg_dist_tile == "wide") nt = 5;
   }
-  const uint32_t bn = w4 ? 256u : (uint32_t)nt * 64;
-  g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + bn - 1) / bn;
+  g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
                              : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
-  const void *fp = w4        ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 8, true, true, true>)
-                   : nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true, true>)
-                             : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, true>);
-  if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
-    HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    c->lds_attr_done.push_back(fp);
-  }
+  auto launch = [&](auto kern, int threads) -> hipError_t {
+    const void *fp = reinterpret_cast<const void *>(kern);
+    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+      const hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      c->lds_attr_done.push_back(fp);
+    }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(threads), lds, c->stream, g);
+    return hipGetLastError();
+  };
   hg_timed tg(c, HG_T_DIST);
-  if (w4)
-    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 8, true, true, true>), dim3(n_tiles),
-                       dim3(TileCfg<true, 8, true>::THREADS), lds, c->stream, g);
-  else if (nt == 5)
-    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
-                       c->stream, g);
-  else
-    hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true, true>), dim3(n_tiles), dim3(TileCfg<true, 4>::THREADS), lds,
-                       c->stream, g);
-  HG_HIP(c, hipGetLastError());
+  hipError_t le;
+  if (fp4 && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5, true, true, true>, TileCfg<true, 5>::THREADS);
+  else if (fp4) le = launch(&dist_mfma_kernel<false, false, true, true, 4, true, true, true>, TileCfg<true, 4>::THREADS);
+  else if (nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5, true, true>, TileCfg<true, 5>::THREADS);
+  else le = launch(&dist_mfma_kernel<false, false, true, true, 4, true, true>, TileCfg<true, 4>::THREADS);
+  HG_HIP(c, le);
   return HG_OK;
 }
 
@@ -1544,7 +1431,6 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   // big tiles when the problem fills the chip with them (Rp, Qp are multiples of 128: the last big
   // tile may hang over by 128 rows, which the zero padding of the operand copies must cover)
   bool big = !full && whole_k && (uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256;
-  bool dma = true;
   int nt = 4;  // 16-column MFMA tiles per wave: 4 -> 256-wide tiles, 5 -> 320-wide
   if (big) {   // the width that needs fewer rounds over the CUs (a round of 320-wide tiles costs 5/4)
     const uint64_t tm = (a.R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
@@ -1554,11 +1440,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   if (const char *e = c->dbg_dist_tile.empty() ? nullptr : c->dbg_dist_tile.c_str()) {  // test hook (hg_ctx_set_debug): force a geometry
     if (!std::strcmp(e, "big")) big = !full && whole_k, nt = 4;
     else if (!std::strcmp(e, "wide")) big = !full && whole_k, nt = 5;
-    else if (!std::strcmp(e, "nt3")) big = !full && whole_k, nt = 3;
-    else if (!std::strcmp(e, "big_reg")) big = !full && whole_k, dma = false, nt = 4;
     else if (!std::strcmp(e, "small")) big = false;
   }
-  if (!big || !dma) nt = 4;
+  if (!big) nt = 4;
   // several exact f32 windows per row (sketches of more than ~4 000 hashes at D = 4096): the i32 side
   // accumulators double the accumulator registers, so the 256-row geometry narrows to 64 * NT_CHUNKED columns
   constexpr int NT_CHUNKED = 3;
@@ -1581,7 +1465,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(threads), lds, c->stream, g);
     return hipGetLastError();
   };
-  const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16), lds_big = 2 * (256 + 256) * LDS_ROW * sizeof(_Float16);
+  const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16);
   hipError_t le;
   // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
   // (+ the same number of info words for the i8 operand path)
@@ -1590,10 +1474,8 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
                                               8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 256);
   if (big_chunked) le = launch(&dist_mfma_kernel<true, false, true, true, NT_CHUNKED>, TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
-  else if (big && dma && nt == 3) le = launch(&dist_mfma_kernel<false, false, true, true, 3>, TileCfg<true, 3>::THREADS, lds_chunked);
-  else if (big && dma && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
-  else if (big && dma) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
-  else if (big) le = launch(&dist_mfma_kernel<false, false, true, false>, TileCfg<true>::THREADS, lds_big);
+  else if (big && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
+  else if (big) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
   else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);
   else if (whole_k) le = launch(&dist_mfma_kernel<false, false, false>, TileCfg<false>::THREADS, lds_small);
   else if (full) le = launch(&dist_mfma_kernel<true, true, false>, TileCfg<false>::THREADS, lds_small);

@@ -204,15 +204,19 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
   HG_HIP(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
-  // Large searches run as an exact +-1 byte GEMM on the matrix pipe (hg_run_hamming_mfma: G = D - 2 * distance, the
-  // ANI kernel's tiles and hit lists); small ones -- and everything when the hook says "popc" -- on the xor + popcount
-  // kernel above.  Both give the same integers.
-  const bool mfma = c->dbg_ham_path != "popc" && hv_d % 128 == 0 && hv_d <= 65536 && R < 0x7FFFFFFFull && Q < 0x7FFFFFFFull &&
-                    ((uint64_t)R * Q >= (uint64_t)1 << 24 || c->dbg_ham_path == "mfma" || c->dbg_ham_path == "mfma4" || c->dbg_ham_path == "mfmab");
-  c->last_ham_path = mfma ? 1 : 0;
+  // Large searches run as an exact +-1 GEMM on the matrix pipe (hg_run_hamming_mfma: G = D - 2 * distance, the ANI
+  // kernel's tiles and hit lists) -- on e2m1 (FP4) operands, or on byte operands when the hook says "mfma" (the A/B
+  // partner; hv_d % 128 == 0 only); small ones -- and everything when the hook says "popc" -- on the xor + popcount
+  // kernel above.  All three give the same integers.
+  const bool want_i8 = c->dbg_ham_path == "mfma" && hv_d % 128 == 0;
+  const bool mfma = c->dbg_ham_path != "popc" && hv_d <= 65536 && R < 0x7FFFFFFFull && Q < 0x7FFFFFFFull &&
+                    ((uint64_t)R * Q >= (uint64_t)1 << 24 || want_i8 || c->dbg_ham_path == "fp4" ||
+                     ((hv_d + 31) / 32) % 4 != 0 /* the popcount kernel reads rows in 16-byte pieces */);
+  c->last_ham_path = mfma ? (want_i8 ? 1 : 2) : 0;
   if (mfma)
     s = hg_run_hamming_mfma(c, d_ref_bits, (uint32_t)R, d_qry_bits, (uint32_t)Q, hv_d, max_dist, d_out, d_count,
-                            cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, (uint32_t)ref_off, (uint32_t)qry_off);
+                            cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, (uint32_t)ref_off, (uint32_t)qry_off,
+                            c->last_ham_path);
   else
     s = ham_launch(c, d_ref_bits, R, d_qry_bits, Q, hv_d, nullptr, d_out, d_count,
                    cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist, (uint32_t)ref_off, (uint32_t)qry_off);

@@ -38,7 +38,7 @@ struct hg_ctx {
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
-  int last_ham_path = -1;       // last Hamming search: 0 xor + popcount kernel, 1 +-1 byte GEMM on the matrix pipe
+  int last_ham_path = -1;       // last Hamming search: 0 xor + popcount kernel, 1 +-1 byte GEMM (i8), 2 +-1.0 e2m1 GEMM (FP4)
   int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA, 1 i8 MFMA, 2 integer VALU
   const void *i8_sig_ref = nullptr, *i8_sig_qry = nullptr;  // operands of the last call that took the i8 path
   uint32_t i8_sig_r = 0, i8_sig_q = 0, i8_sig_d = 0;
@@ -194,9 +194,9 @@ struct hg_dist_args {
 // its own results and calls again without d_verdict if it is larger.
 hg_status hg_run_dist(hg_ctx *ctx, const hg_dist_args &a, uint32_t *d_verdict = nullptr, int *speculated = nullptr);
 
-// Bit-packed Hamming search as an exact i8 GEMM on the matrix pipe (+-1 byte operands expanded from the bits; the
-// ANI GEMM's tiles, LDS-DMA staging and hit lists): all pairs with distance <= max_dist appended to d_hits through
-// *d_count (zeroed by the caller).  hv_d must be a multiple of 128.
+// Bit-packed Hamming search as an exact GEMM on the matrix pipe (+-1 operands expanded from the bits -- e2m1 nibbles
+// for v_mfma_scale_f32_16x16x128_f8f6f4 or bytes for v_mfma_i32_16x16x64_i8; the ANI GEMM's tiles, LDS-DMA staging and
+// hit lists): all pairs with distance <= max_dist appended to d_hits through *d_count (zeroed by the caller).
 hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R, const uint32_t *d_qry_bits, uint32_t Q,
                               uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_hits, uint32_t *d_count, uint32_t cap,
-                              uint32_t ref_off, uint32_t qry_off);
+                              uint32_t ref_off, uint32_t qry_off, int path /* 1 = +-1 bytes (i8), 2 = e2m1 nibbles (FP4) */);
