@@ -107,6 +107,27 @@ def newest_profile(suffix):
     return c[-1] if c else None
 
 
+def profiled(suffix, kernel):
+    """(summary, path) of the newest committed profiles/rNN<suffix> -- but only if it was taken on THESE sources
+    (`_stamp.source_sha` == hypergen_amd.source_stamp(), written by tools/summarize_prof.py on the GPU box) and names the
+    kernel the library says it has just launched (hg_ctx_last_kernel).  Otherwise (None, reason): a kernel change
+    without a re-profile must report null, not the previous kernel's counters."""
+    path = newest_profile(suffix)
+    if not path:
+        return None, "no profiles/rNN%s" % suffix
+    try:
+        d = json.load(open(path))
+    except Exception as e:
+        return None, "%s unreadable: %s" % (os.path.relpath(path, ROOT), e)
+    st = d.get("_stamp") or {}
+    rel = os.path.relpath(path, ROOT)
+    if st.get("source_sha") != hg.source_stamp():
+        return None, "%s was taken on other sources (%s, this tree %s)" % (rel, st.get("source_sha"), hg.source_stamp())
+    if kernel not in (st.get("kernels") or []) and d.get("kernel") != kernel:
+        return None, "%s does not hold the kernel that ran (%s)" % (rel, kernel)
+    return d, "%s (commit %s, kernel %s)" % (rel, (st.get("head") or "?")[:12], kernel)
+
+
 SETTLE = {"sketch": 25, "dist": 300, "hamming": 30}  # untimed repetitions in front of a leg's warmup steps
 
 
@@ -121,20 +142,25 @@ def settle(fn, n):
     torch.cuda.synchronize()
 
 
-def valu_issue(n_genomes):
+def valu_issue(n_genomes, kernel):
     """Secondary, informative roofline of the k-mer kernel: its VALU instruction rate against the issue rate the
     same instruction mix reaches in tools/gpu_microbench.hip.  Instruction count and kernel cycles: the newest
-    committed PMC passes of this command (SQ_INSTS_VALU, GRBM_GUI_ACTIVE); the slow-class / plain split of the
-    mix: the committed ISA histogram of the kernel (profiles/rNN_kmer_isa.json, tools/count_isa.py)."""
-    ppath, ipath = newest_profile("_pmc.json"), newest_profile("_kmer_isa.json")
+    committed PMC passes of this command (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), quoted only when they belong to this tree
+    and this kernel (profiled()); the slow-class / plain split of the mix: the committed ISA histogram of the kernel
+    (profiles/rNN_kmer_isa.json, tools/kmer_isa.py)."""
+    d, src = profiled("_pmc.json", kernel)
+    if d is None:
+        return {"frac": None, "source": src}
     try:
-        d = json.load(open(ppath))
-        k = max((v for name, v in d.items() if name.startswith("kmer_sample_")), key=lambda v: v.get("GRBM_GUI_ACTIVE", 0))
+        k = d[kernel]
         insts, cycles = k["SQ_INSTS_VALU"], k["GRBM_GUI_ACTIVE"] / 8.0
+        ipath = newest_profile("_kmer_isa.json")
         isa = json.load(open(ipath))
+        if isa.get("kernel") != kernel or isa.get("source_sha") != hg.source_stamp():
+            raise KeyError("ISA histogram of another kernel / tree")
         slow_frac = isa["per_kmer"]["slow_class"] / isa["per_kmer"]["valu"]
-    except Exception:
-        return None
+    except Exception as e:
+        return {"frac": None, "source": "%s; %r" % (src, e)}
     rate = insts / (1024 * cycles)  # wave-instructions per SIMD per cycle, as profiled
     per_kmer = insts * 64.0 / (n_genomes * (L_GENOME + 1 - KSIZE + 1)) if n_genomes == 1000 else None
     # issue cost of the mix: slow class 3.9 cycles, plain 2.3 cycles per wave-instruction (profiles/r01_instruction_rates.txt)
@@ -142,7 +168,7 @@ def valu_issue(n_genomes):
     return {"valu_instr_per_simd_cycle": rate, "mix_issue_bound": bound, "frac": rate / bound,
             "valu_instr_per_kmer": per_kmer, "slow_class_fraction": slow_frac,
             "source": "%s (rocprofv3 --pmc of this command), %s (static ISA histogram), "
-                      "profiles/r01_instruction_rates.txt (issue costs)" % (os.path.relpath(ppath, ROOT), os.path.relpath(ipath, ROOT))}
+                      "profiles/r01_instruction_rates.txt (issue costs)" % (src, os.path.relpath(ipath, ROOT))}
 
 
 def effective_cores():
@@ -304,13 +330,11 @@ def main():
     kmer_avg_ms = kmer_ms / max(kmer_launches, 1)
     bytes_per_launch = N * (L_GENOME + 2 * HV_D)  # L + 2*D algorithmic bytes per genome
     achieved = bytes_per_launch / (kmer_avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = newest_profile("_kmer_traffic.json")
-    if tpath and N == 1000:
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    kmer_kernel = ctx.last_kernel("kmer")
+    traffic, traffic_src = None, "not the profiled shape (1 000 genomes per launch)"
+    if N == 1000:
+        td, traffic_src = profiled("_kmer_traffic.json", kmer_kernel)
+        traffic = td.get("hbm_bytes_per_launch") if td else None
     value = N * world * a.steps / dt
     log("sketch: %.1f genomes/s, kmer kernel %.3f ms/launch (%d launches), nhash mean %.1f" % (
         value, kmer_avg_ms, kmer_launches, nh.float().mean().item()))
@@ -324,12 +348,12 @@ def main():
                                "scaled=1500 seed=123 canonical D=4096 AVX2 layout, inputs resident in HBM" % N,
                    "genomes_per_gpu": N, "genome_bp": L_GENOME, "parallelism": "genome-sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "kmer_sample_grouped<21>", "launch_ms": kmer_avg_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kmer_kernel, "launch_ms": kmer_avg_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "nominally a scan, so priced against HBM; the true binder is integer VALU issue "
                              "(~80 VALU instructions per k-mer, ~51 of them the t1ha2 hash; see valu_issue)",
-                     "valu_issue": valu_issue(N),
+                     "valu_issue": valu_issue(N, kmer_kernel),
                      "kmer_hashes_per_sec": N * (L_GENOME + 1 - KSIZE + 1) / (kmer_avg_ms * 1e-3)},
         "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in tm.items() if v[1]},
     }
@@ -373,7 +397,11 @@ def main():
                        "genomes_per_gpu": M, "parallelism": "genome-sharded x%d, no collective" % world}}
         log("sketch_10k: %.1f genomes/s (%d genomes on this rank, %.1f ms per pass)" % (
             out["sketch_10k"]["value"], M, dt2 / steps2 * 1e3))
-        del seq2, hv2, n22, nh2
+        real_hv = (hv2, n22) if (world == 1 and a.dist_n and M == a.dist_n) else None  # the dist leg times these too
+        del seq2, nh2
+
+    else:
+        real_hv = None
 
     # ---------------- host-fed: the same sketch path from pinned host memory (PCIe-inclusive, never `value`) ---
     if a.hostfed_genomes and rank == 0:
@@ -556,13 +584,12 @@ def main():
         gemm_ms = dtm["dist"][0] / max(a.steps, 1)
         flops_per_launch = 2.0 * HV_D * (rows * world) * rows  # 2*D ops per pair
         ach = flops_per_launch / (gemm_ms * 1e-3) / 1e12
-        dist_traffic = None  # bytes leaving the XCD L2s per launch (PMC, profiles/): 10 000 x 10 000 only
-        dpath = newest_profile("_dist_traffic.json")
-        if dpath and rows * world == 10000 and world == 1:
-            try:
-                dist_traffic = json.load(open(dpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                dist_traffic = None
+        dist_kernel = ctx.last_kernel("dist")
+        # bytes leaving the XCD L2s per launch (PMC, profiles/): 10 000 x 10 000 on one GPU only
+        dist_traffic, dist_traffic_src = None, "not the profiled shape (10 000 x 10 000 on one GPU)"
+        if rows * world == 10000 and world == 1:
+            dd, dist_traffic_src = profiled("_dist_traffic.json", dist_kernel)
+            dist_traffic = dd.get("hbm_bytes_per_launch") if dd else None
         path = ctx.last_dist_path()  # 1: centred i8 operands (v_mfma_i32_16x16x64_i8), 0: f16 operands; same integers
         peak = MFMA_F16_PEAK_TFLOPS * (2.0 if path == 1 else 1.0)  # dense i8 MFMA = 2x the f16 rate (MI355X_MICROARCH.md)
         out["dist"] = {
@@ -571,8 +598,8 @@ def main():
             "config": {"workload": "%d ref x %d query clustered synthetic HVs (BASELINE configs[3]), thresholded "
                                    "output" % (rows * world, rows * world), "hits_per_rank": int(found)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": dist_traffic,
-                         "kernel": "dist_mfma_kernel (%s operands)" % ("i8" if path == 1 else "f16"),
+                         "frac": ach / peak, "traffic": dist_traffic, "traffic_source": dist_traffic_src,
+                         "kernel": dist_kernel, "operands": "i8" if path == 1 else "f16",
                          "peak_dtype": "i8 dense MFMA" if path == 1 else "f16 dense MFMA",
                          "frac_of_f16_peak": ach / MFMA_F16_PEAK_TFLOPS,
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": flops_per_launch},
@@ -580,6 +607,37 @@ def main():
         }
         log("dist: %.0f M pairs/s, gemm %.3f ms/launch = %.1f TFLOP/s, hits/rank %d" % (
             out["dist"]["value"], gemm_ms, ach, found))
+        # the same call on the 10 000 REAL sketches of the sketch_10k leg (N = 1 only: they are all on this GPU): clusters
+        # of 100 genomes at 0 - 9.9 % substitutions, so ani_th = 85 keeps about the within-cluster pairs
+        if real_hv is not None:
+            r_hv, r_n2 = real_hv
+            rfound = 0
+
+            def rstep():
+                nonlocal rfound
+                rfound, _ = ctx.dist_dev(r_hv.data_ptr(), r_n2.data_ptr(), R, r_hv.data_ptr(), r_n2.data_ptr(), R, HV_D, KSIZE,
+                                         False, 85.0, hits.data_ptr(), cap)
+            settle(rstep, 50)
+            ctx.enable_timing(True)
+            ctx.timings()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                rstep()
+            torch.cuda.synchronize()
+            rdt = time.perf_counter() - t0
+            rtm = ctx.timings()
+            ctx.enable_timing(False)
+            rg_ms = rtm["dist"][0] / max(a.steps, 1)
+            out["dist"]["dist_real"] = {
+                "value": R * R * a.steps / rdt / 1e6, "unit": "M ANI-pairs/sec", "ms_per_step": rdt / a.steps * 1e3,
+                "gemm_ms": rg_ms, "tflops": 2.0 * HV_D * R * R / (rg_ms * 1e-3) / 1e12, "hits": int(rfound),
+                "kernel": ctx.last_kernel("dist"), "operands": "i8" if ctx.last_dist_path() == 1 else "f16",
+                "config": {"workload": "the %d x %d ANI matrix of the sketch_10k leg's own sketches (synthetic 5 Mbp genomes, "
+                                       "clusters of 100), thresholded at 85" % (R, R)}}
+            real_hits = hits[: 3 * rfound].clone()
+            log("dist_real: %.0f M pairs/s, gemm %.3f ms, hits %d" % (out["dist"]["dist_real"]["value"], rg_ms, rfound))
+            dstep()  # the synthetic leg's hits back in `hits` for the parity gate below
 
     # ---------------- bit-packed D=16384 Hamming search (BASELINE configs[4], extension) -------------------
     # Sharded database search: the references are sharded by rows, ONE query set lives on rank 0
@@ -669,16 +727,15 @@ def main():
                      "kernel": "hamming_kernel", "launch_ms": hms, "algorithmic_lane_ops_per_launch": word_ops}
         # HBM-side bytes per launch of the search kernel from the newest committed PMC pass of this command (only
         # for the shape that pass was taken on: all 50 000 refs x 10 000 queries on one GPU)
-        ham_traffic = None
+        ham_kernel = ctx.last_kernel("dist")
+        ham_traffic, ham_traffic_src = None, "not the profiled shape (50 000 x 10 000 on one GPU)"
         if hpath in (1, 2) and world == 1 and a.hamming_refs == 50000 and HQ == 10000:
-            try:
-                d = json.load(open(newest_profile("_pmc.json")))
-                ham_traffic = max((v for k, v in d.items() if k.startswith("dist_mfma_kernel") and k.rstrip(">").split(",")[6].strip() == "true"),
-                                  key=lambda v: v.get("GRBM_GUI_ACTIVE", 0)).get("hbm_bytes_per_launch")
-            except Exception:
-                ham_traffic = None
+            hd, ham_traffic_src = profiled("_pmc.json", ham_kernel)
+            ham_traffic = hd.get(ham_kernel, {}).get("hbm_bytes_per_launch") if hd else None
+        hroof["kernel_symbol"] = ham_kernel
         hroof.update(compulsory_bytes_per_launch=(refs + HQ) * words * 4,
-                     compulsory_gbs=(refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, traffic=ham_traffic)
+                     compulsory_gbs=(refs + HQ) * words * 4 / (hms * 1e-3) / 1e9, traffic=ham_traffic,
+                     traffic_source=ham_traffic_src)
         out["hamming"] = {
             "metric": "M Hamming-pairs/sec (D=16384 bit-packed)", "value": a.hamming_refs * HQ * a.steps / hdt / 1e6,
             "unit": "M pairs/sec", "ms_per_step": hdt / a.steps * 1e3, "scaling": "strong",
@@ -729,6 +786,19 @@ def main():
             if err > 1e-4 or herr > 1e-4 or hr.size < n_cpu_hits:
                 raise SystemExit("PARITY GATE FAILED: ANI block max |gpu - cpu| = %g, hits %g, %d < %d" % (err, herr, hr.size, n_cpu_hits))
             gate.update(ani_block="%d x %d" % (br, bq), ani_max_abs_err=err, ani_hits_checked=int(hr.size), ani_hits_max_abs_err=herr)
+            if real_hv is not None:  # ... and the real sketches: a 512 x 2 048 CPU block against the timed run's hits
+                r_hv, r_n2 = real_hv
+                rb = orc.ani_matrix(r_hv[:512].cpu().numpy(), r_n2[:512].cpu().numpy(), r_hv[:2048].cpu().numpy(),
+                                    r_n2[:2048].cpu().numpy(), KSIZE)
+                rh = real_hits.view(-1, 3)
+                sel = (rh[:, 0] < 512) & (rh[:, 1] < 2048)
+                hr, hq = rh[sel, 0].long().cpu().numpy(), rh[sel, 1].long().cpu().numpy()
+                ha = rh[sel, 2].contiguous().view(torch.float32).cpu().numpy()
+                rerr = float(np.abs(ha - rb[hr, hq]).max()) if hr.size else 0.0
+                n_cpu = int((rb >= 85.0 + 1e-4).sum())
+                if rerr > 1e-4 or hr.size < n_cpu or hr.size > int((rb >= 85.0 - 1e-4).sum()):
+                    raise SystemExit("PARITY GATE FAILED: dist on the real sketches: max |gpu - cpu| = %g, %d hits vs %d" % (rerr, hr.size, n_cpu))
+                gate.update(ani_real_block="512 x 2048", ani_real_hits_checked=int(hr.size), ani_real_hits_max_abs_err=rerr)
             out["dist"]["cpu_baseline"] = cb
             out["dist"]["speedup_vs_cpu_baseline"] = out["dist"]["value"] / cb["value"]
         out["parity_gate"] = dict(gate, status="passed")

@@ -67,7 +67,7 @@ EXPORTS = [
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack", "hg_hv_packed_bytes",
     "hg_hv_unpack", "hg_sketch_file_write", "hg_sketch_file_read", "hg_sketch_file_count",
     "hg_sketch_file_get", "hg_sketch_file_free", "hg_read_merge_seq", "hg_read_merge_seq_into", "hg_free",
-    "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings",
+    "hg_synth_genomes_dev", "hg_ctx_enable_timing", "hg_ctx_timings", "hg_ctx_last_kernel",
     "hg_hv_binarize_dev", "hg_hamming_full_dev", "hg_hamming_search_dev",
     "hg_ctx_set_debug", "hg_read_fastx_into", "hg_dist_block_dev", "hg_hamming_search_block_dev",
     "hg_multi_create", "hg_multi_destroy", "hg_multi_size", "hg_multi_ctx", "hg_multi_last_error", "hg_shard_range",
@@ -80,6 +80,21 @@ EXPORTS = [
     "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
     "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
 ]
+
+
+def source_stamp():
+    """sha256 (first 16 hex digits) over the library's sources (csrc/*, include/hypergen.h), names and contents in sorted
+    order.  tools/summarize_prof.py writes it into every profile summary and bench.py quotes a summary's counters only
+    when the stamp equals that of the tree it runs from -- a kernel change without a re-profile then reports null
+    instead of stale counters."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    for f in [os.path.join(src, x) for x in files] + [os.path.join(_HERE, "..", "include", "hypergen.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build(force=False):
@@ -193,6 +208,7 @@ def lib():
         "hg_hamming_full_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, vp]),
         "hg_hamming_search_dev": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, sz, C.POINTER(sz)]),
         "hg_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
+        "hg_ctx_last_kernel": (C.c_char_p, [vp, C.c_int]),
         "hg_ctx_timings": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
         "hg_synth_genomes_dev": (C.c_int, [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, vp]),
@@ -260,6 +276,10 @@ class Context:
 
     def sync(self):
         self._ck(lib().hg_ctx_sync(self._h))
+
+    def last_kernel(self, cls):
+        """Name of the kernel the last call launched for a timing class ("kmer", "dist"), as rocprofv3 prints it."""
+        return lib().hg_ctx_last_kernel(self._h, T_NAMES.index(cls)).decode()
 
     def enable_timing(self, on=True):
         self._ck(lib().hg_ctx_enable_timing(self._h, int(on)))

@@ -164,6 +164,10 @@ extern "C" hg_status hg_ctx_enable_timing(hg_ctx *c, int on) {
   return HG_OK;
 }
 
+extern "C" const char *hg_ctx_last_kernel(const hg_ctx *c, int cls) {
+  return (c && cls >= 0 && cls < HG_T_COUNT) ? c->last_kernel[cls].c_str() : "";
+}
+
 extern "C" hg_status hg_ctx_timings(hg_ctx *c, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]) {
   if (!c || !ms_sum || !launches) return HG_ERR_INVALID;
   for (int i = 0; i < HG_T_COUNT; ++i) ms_sum[i] = 0.f, launches[i] = 0;
@@ -428,6 +432,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     HG_HIP(c, hipMemsetAsync(d_cnt, 0, 2 * n * sizeof(uint32_t), c->stream));
     {
       hg_timed tm(c, HG_T_KMER);
+      c->last_kernel[HG_T_KMER] = hg_kmer_kernel_name(ksize, canonical);
       HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
                                       seed, canonical, norm_mode, d_hits, d_cnt));
     }
@@ -825,6 +830,7 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if (i8_tried && h_res[8] != 1u) c->i8_skip = 16;  // vetoed on the device: f16 ran; do not probe again for a while
   if (h_res[8] == 1u) {
     c->last_dist_path = 1;
+    c->last_kernel[HG_T_DIST] = c->last_kernel_i8;
     c->i8_sig_ref = d_ref_hv, c->i8_sig_qry = d_qry_hv, c->i8_sig_r = (uint32_t)R, c->i8_sig_q = (uint32_t)Q, c->i8_sig_d = hv_d;
   } else {
     c->i8_sig_ref = c->i8_sig_qry = nullptr;

@@ -1055,6 +1055,16 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
 
 }  // namespace
 
+// the instantiation's name as a profiler prints it (hg_ctx_last_kernel: bench.py matches it against the kernel names in
+// the committed rocprofv3 summaries before it quotes their counters)
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false>
+static std::string dist_kernel_name() {
+  auto b = [](bool x) { return x ? "true" : "false"; };
+  return std::string("dist_mfma_kernel<") + b(CHUNKED) + ", " + b(FULL) + ", " + b(BIG) + ", " + b(GLDS) + ", " +
+         std::to_string(NT) + ", " + b(I8) + ", " + b(HAM) + ", " + b(FP4) + ">";
+}
+#define HG_DIST_K(...) &dist_mfma_kernel<__VA_ARGS__>, dist_kernel_name<__VA_ARGS__>()
+
 // ---- bit-packed Hamming search on the matrix pipe ---------------------------------------------------------------
 // bits -> +-1 bytes (bit 1 -> +1, bit 0 -> -1), one lane per 32-bit word: per nibble the four bits are spread to the
 // low bit of four bytes by one multiply ((x * 0x00204081) & 0x01010101: the partial products never collide) and
@@ -1163,7 +1173,8 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
   const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
                              : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
-  auto launch = [&](auto kern, int threads) -> hipError_t {
+  auto launch = [&](auto kern, const std::string &name, int threads) -> hipError_t {
+    c->last_kernel[HG_T_DIST] = name;
     const void *fp = reinterpret_cast<const void *>(kern);
     if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
       const hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1175,10 +1186,10 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   };
   hg_timed tg(c, HG_T_DIST);
   hipError_t le;
-  if (fp4 && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5, true, true, true>, TileCfg<true, 5>::THREADS);
-  else if (fp4) le = launch(&dist_mfma_kernel<false, false, true, true, 4, true, true, true>, TileCfg<true, 4>::THREADS);
-  else if (nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5, true, true>, TileCfg<true, 5>::THREADS);
-  else le = launch(&dist_mfma_kernel<false, false, true, true, 4, true, true>, TileCfg<true, 4>::THREADS);
+  if (fp4 && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true), TileCfg<true, 5>::THREADS);
+  else if (fp4) le = launch(HG_DIST_K(false, false, true, true, 4, true, true, true), TileCfg<true, 4>::THREADS);
+  else if (nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true), TileCfg<true, 5>::THREADS);
+  else le = launch(HG_DIST_K(false, false, true, true, 4, true, true), TileCfg<true, 4>::THREADS);
   HG_HIP(c, le);
   return HG_OK;
 }
@@ -1285,6 +1296,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     }
     {
       hg_timed tmg(c, HG_T_DIST);
+      c->last_kernel_i8 = nt == 5 ? dist_kernel_name<false, false, true, true, 5, true>() : dist_kernel_name<false, false, true, true, 4, true>();
       if (nt == 5)
         hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
                            c->stream, g);
@@ -1405,6 +1417,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   c->last_dist_path = best_c < 0 ? 2 : 0;  // (a valid i8 attempt overrides this after the caller's read-back)
   if (best_c < 0) {  // values too large for the f16 path: exact integer kernel
     dim3 grid((a.Q + FB_T - 1) / FB_T, (a.R + FB_T - 1) / FB_T);
+    c->last_kernel[HG_T_DIST] = "dist_int_kernel";
     hipLaunchKernelGGL(dist_int_kernel, grid, dim3(FB_T * FB_T), 0, c->stream, a.ref_hv, a.qry_hv, a, kf);
     HG_HIP(c, hipGetLastError());
     return HG_OK;
@@ -1455,7 +1468,8 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const uint32_t bm = big ? 256 : 128, bn = big ? (uint32_t)nt * 64 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
-  auto launch = [&](auto kern, int threads, size_t lds) -> hipError_t {
+  auto launch = [&](auto kern, const std::string &name, int threads, size_t lds) -> hipError_t {
+    if (!guard || v_lo == 0) c->last_kernel[HG_T_DIST] = name;  // (a guarded second launch covers verdicts 1..2 only)
     const void *fp = reinterpret_cast<const void *>(kern);
     if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
       hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1473,13 +1487,13 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256);
   const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
                                               8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 256);
-  if (big_chunked) le = launch(&dist_mfma_kernel<true, false, true, true, NT_CHUNKED>, TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
-  else if (big && nt == 5) le = launch(&dist_mfma_kernel<false, false, true, true, 5>, TileCfg<true, 5>::THREADS, lds_wide);
-  else if (big) le = launch(&dist_mfma_kernel<false, false, true, true>, TileCfg<true>::THREADS, lds_dma);
-  else if (whole_k && full) le = launch(&dist_mfma_kernel<false, true, false>, TileCfg<false>::THREADS, lds_small);
-  else if (whole_k) le = launch(&dist_mfma_kernel<false, false, false>, TileCfg<false>::THREADS, lds_small);
-  else if (full) le = launch(&dist_mfma_kernel<true, true, false>, TileCfg<false>::THREADS, lds_small);
-  else le = launch(&dist_mfma_kernel<true, false, false>, TileCfg<false>::THREADS, lds_small);
+  if (big_chunked) le = launch(HG_DIST_K(true, false, true, true, NT_CHUNKED), TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
+  else if (big && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5), TileCfg<true, 5>::THREADS, lds_wide);
+  else if (big) le = launch(HG_DIST_K(false, false, true, true), TileCfg<true>::THREADS, lds_dma);
+  else if (whole_k && full) le = launch(HG_DIST_K(false, true, false), TileCfg<false>::THREADS, lds_small);
+  else if (whole_k) le = launch(HG_DIST_K(false, false, false), TileCfg<false>::THREADS, lds_small);
+  else if (full) le = launch(HG_DIST_K(true, true, false), TileCfg<false>::THREADS, lds_small);
+  else le = launch(HG_DIST_K(true, false, false), TileCfg<false>::THREADS, lds_small);
   HG_HIP(c, le);
   return HG_OK;
   };

@@ -39,6 +39,8 @@ struct hg_ctx {
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
   int last_ham_path = -1;       // last Hamming search: 0 xor + popcount kernel, 1 +-1 byte GEMM (i8), 2 +-1.0 e2m1 GEMM (FP4)
+  std::string last_kernel[HG_T_COUNT];  // name of the last kernel launched per timing class (hg_ctx_last_kernel)
+  std::string last_kernel_i8;           // ... of the last i8 operand attempt (it is the DIST kernel when the attempt was valid)
   int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA, 1 i8 MFMA, 2 integer VALU
   const void *i8_sig_ref = nullptr, *i8_sig_qry = nullptr;  // operands of the last call that took the i8 path
   uint32_t i8_sig_r = 0, i8_sig_q = 0, i8_sig_d = 0;
@@ -115,6 +117,8 @@ struct hg_genome_meta {
 
 // starts handled by one work item (one workgroup) of the fast kernel for a given k
 uint32_t hg_kmer_item_starts(uint32_t ksize);
+// name of the kernel hg_launch_kmer_sample launches for (ksize, canonical), as a profiler prints it
+const char *hg_kmer_kernel_name(uint32_t ksize, bool canonical);
 
 // Launch the hash + sample kernel over all work items.  d_cnt[g] is incremented once per
 // sampled k-mer (it may exceed hit_cap: only the first hit_cap hashes are stored).

@@ -1097,6 +1097,17 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 
 }  // namespace
 
+const char *hg_kmer_kernel_name(uint32_t k, bool canonical) {  // mirrors hg_launch_kmer_sample / launch_fast
+  static thread_local char buf[64];
+  if (k > 32) return "kmer_sample_long";
+  const bool grouped = canonical && HG_KMER_GROUPED && k >= 18 && k <= 25;
+  if (grouped) snprintf(buf, sizeof buf, "kmer_sample_grouped<%u>", k);
+  else if (k >= 22) snprintf(buf, sizeof buf, "kmer_sample_fast64<%u, %s>", k, canonical ? "true" : "false");
+  else if (canonical) snprintf(buf, sizeof buf, "kmer_sample_fast<%u, true, %d>", k, (int)HG_KMER_DEFAULT_VAR);
+  else snprintf(buf, sizeof buf, "kmer_sample_fast<%u, false, 0>", k);
+  return buf;
+}
+
 uint32_t hg_kmer_item_starts(uint32_t k) {
   if (fast64_k(k)) return (uint32_t)(WG * 32 * TILES_PER_ITEM64);
   if (!fast_k(k)) return GEN_ITEM;

@@ -83,6 +83,10 @@ hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
 #define HG_T_COUNT 5
 hg_status hg_ctx_enable_timing(hg_ctx *ctx, int on);
 hg_status hg_ctx_timings(hg_ctx *ctx, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]);
+/* name of the kernel the last call launched for timing class `cls` (HG_T_KMER, HG_T_DIST), spelled as rocprofv3
+ * prints it ("kmer_sample_grouped<21>", "dist_mfma_kernel<false, false, true, true, 5, true, false, false>"); ""
+ * if none.  A measurement harness uses it to check that a committed profile belongs to the kernel that ran. */
+const char *hg_ctx_last_kernel(const hg_ctx *ctx, int cls);
 
 /* minimal device-memory helpers for callers that have no HIP binding of their own
  * (cudarc's htod_copy / alloc_zeros / sync_reclaim, src/sketch_cuda.rs:134,138,156) */

@@ -135,7 +135,9 @@ def main():
         by_class[cls(op)] += n
     valu = sum(n for op, n in main_ops.items() if op.startswith("v_"))
     slow = sum(n for k, n in by_class.items() if k.startswith(("slow", "multiply")))
-    res = {"kernel": NAME, "kmers_per_slice": M, "slices_per_window": GROUPS, "hash_blocks_found": len(clean),
+    sys.path.insert(0, ROOT)
+    import hypergen_amd as hg
+    res = {"kernel": NAME, "source_sha": hg.source_stamp(), "kmers_per_slice": M, "slices_per_window": GROUPS, "hash_blocks_found": len(clean),
            "static_valu_by_period_in_kmers": {str(k): v for k, v in sorted(weights.items())},
            "per_kmer": {"valu": valu, "slow_class": slow, "plain": valu - slow,
                         "multiply": by_class["multiply (v_mad_u64_u32, v_mul_lo_u32)"],

@@ -64,9 +64,16 @@ def main():
             summ[k]["hbm_read_bytes_per_launch_corrected"] = fetch
             summ[k]["hbm_write_bytes_per_launch"] = write
             summ[k]["hbm_bytes_per_launch"] = fetch + write
+    # which tree these counters belong to (bench.py quotes them only for the same sources; tools/derive_prof.py adds the
+    # commit when it copies the summary into profiles/)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import hypergen_amd as hg
+    summ["_stamp"] = {"source_sha": hg.source_stamp(), "kernels": sorted(k for k in summ if not k.startswith("_")),
+                      "command": os.environ.get("HG_PROFILE_COMMAND", "")}
     json.dump(summ, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     for k, d in summ.items():
-        print(k, json.dumps({c: round(v, 1) for c, v in d.items()}))
+        if not k.startswith("_"):
+            print(k, json.dumps({c: round(v, 1) for c, v in d.items()}))
 
 
 if __name__ == "__main__":
