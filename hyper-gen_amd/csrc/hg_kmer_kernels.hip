@@ -211,6 +211,9 @@ constexpr bool fast64_k(uint32_t k) { return k >= FAST64_FROM && k <= 32; }
 #ifndef HG_U2T_HOIST
 #define HG_U2T_HOIST 1  /* the u/U -> T rewrite behind one branch per window (0: one branch per dword) */
 #endif
+#ifndef HG_KMER_SHARED
+#define HG_KMER_SHARED 1  /* k = 1..21: kmer_sample_shared (workgroup-wide phase images in LDS) instead of kmer_sample_grouped / _fast (A/B: -DHG_KMER_SHARED=0) */
+#endif
 #ifndef HG_KMER_GROUPED
 #define HG_KMER_GROUPED 1  /* canonical k = 18..25: kmer_sample_grouped instead of kmer_sample_fast / fast64 (A/B: -DHG_KMER_GROUPED=0) */
 #endif
@@ -747,6 +750,251 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
 }
 
 // =========================================================================================
+// shared-image kernel: compile-time k in [1, 21], both strand modes
+// =========================================================================================
+// What the grouped kernel still pays per k-mer besides the hash is the extraction of the chosen strand's bytes: the
+// k-mer starts at an arbitrary byte of the lane's LDS image, so the six hash dwords are cut out of seven aligned ones
+// with a run-time byte shift (5 v_alignbit + v_bfe), and the shift itself has to be selected with the strand (a second
+// v_cndmask) -- eight slow-class instructions, 12 % of the issue time.  Here the byte shift is taken out of the inner loop
+// altogether: the WORKGROUP keeps one image of its tile in LDS in all four byte phases -- F_phi[i] = bytes
+// [4 i + phi, 4 i + phi + 4) of the tile, phi = 0..3 -- and the same for the reverse complement R[q] = comp(F[N - 1 - q]).
+// A lane owns M = 12 consecutive starts p = 12 tid + j, so the phase of k-mer j is j & 3 on the forward strand and, with
+// N chosen such that (N - K) & 3 == 3, 3 - (j & 3) on the reverse strand: compile-time per j.  Both strands' hash words are
+// then whole dwords at [base + imm(j) + 4 m]: ONE v_cndmask picks the base (forward: FB + 12 tid; reverse: one of three
+// per-lane constants RB' - 12 tid - 8 (j >> 2)), the immediates imm(j) = S (j & 3) + 4 (j >> 2) are shared by both strands
+// (reverse phase psi is stored at S (3 - psi) for that), and the ds_reads deliver the words straight into the register
+// pairs the multiplies take -- no VALU instruction touches the bytes.  The images are written once per tile by the lanes
+// that load the bases (12 bases + one lookahead dword per lane: every base is classified once, not 32/12 times as in
+// kmer_sample_fast or 56/36 as in the grouped kernel); the 2-bit codes for the strand compare and the validity bits go
+// through LDS as well (768 + 1 036 bytes).  Two barriers per tile; 28 KB of LDS per workgroup (5 workgroups per CU).
+template <int K>
+struct GeoS {
+  static constexpr int M = 12;                      // starts per lane and tile (multiple of 4: the phase of start j is j & 3)
+  static constexpr int DW = M / 4;
+  // Every lane stages one unit of M bases; the k-mers of the last lanes' windows would need bases behind the staged
+  // area, so the last LOOK_UNITS lanes hash nothing and the tile advances by (WG - LOOK_UNITS) * M starts: 0.8 % of the
+  // hashing slots of one wave idle -- against a second, three-lane staging pass on the way to the barrier (+2 %)
+  static constexpr int LOOK_UNITS = (32 - M + M - 1) / M;  // the last hashing lane's 32-base window ends inside the staged area: 2 units at M = 12
+  static constexpr int TILE = (WG - LOOK_UNITS) * M;  // 3 048 starts
+  static constexpr int TILES = 9;
+  static constexpr int ITEM = TILE * TILES;         // 27 432 starts per work item
+  static constexpr int UNITS = WG;
+  static constexpr int NB_T = UNITS * M;            // staged bases (3 072)
+  static constexpr int N_R = NB_T + ((K + 3 - NB_T) & 3);  // length the reverse strand is indexed in: (N_R - K) & 3 == 3
+  static constexpr int S = 4 * (NB_T / 4 + 3);      // bytes per phase image
+  static constexpr int ND = (K + 3) / 4, NB = K - 4 * (ND - 1), NW = (K + 7) / 8;
+  static_assert(M + K - 1 <= 32, "a lane's k-mers live in a 32-base code window");
+  static_assert(((N_R - K) & 3) == 3, "reverse phase of start j is 3 - (j & 3)");
+};
+
+template <int K, bool CANON>
+__global__ __launch_bounds__(WG) void kmer_sample_shared(
+    const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
+    const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
+    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  using G = GeoS<K>;
+  constexpr int M = G::M, DW = G::DW, S = G::S, ND = G::ND, NB = G::NB, NW = G::NW, N_R = G::N_R;
+  constexpr uint32_t MASKK = (1u << K) - 1;
+
+  const uint32_t item = blockIdx.x, tid = threadIdx.x;
+  const uint32_t g = item_genome[item];
+  const hg_genome_meta gm = meta[g];
+  const uint64_t n_bps = gm.n_bps;
+  if (n_bps < (uint64_t)K) return;
+  const uint64_t n_starts = n_bps - K + 1;
+  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+
+  __shared__ HitStage stage;
+  __shared__ __attribute__((aligned(16))) uint32_t s_f[4 * S / 4];                 // forward phase images
+  __shared__ __attribute__((aligned(16))) uint32_t s_r[CANON ? 4 * S / 4 : 4];     // reverse phase images (psi at S (3 - psi))
+  __shared__ __attribute__((aligned(16))) uint8_t s_code[CANON ? G::NB_T / 4 + 16 : 16];  // 2-bit codes, base b at bits 2b..2b+1
+  __shared__ uint32_t s_val[G::UNITS + 2];   // per unit of M bases: bit b set <=> base b cannot be part of a k-mer
+  __shared__ uint32_t s_dirty[2];            // "some base of this tile is not ACGT / lies behind the genome end", by tile parity
+  if (tid == 0) stage.n = 0, s_dirty[0] = 0, s_dirty[1] = 0;
+  if (tid < 2) s_val[G::UNITS + tid] = 0;
+  __syncthreads();
+
+  using lds_u8p = __attribute__((address_space(3))) const uint8_t *;
+  using lds_u16p = __attribute__((address_space(3))) const uint16_t *;
+  using lds_u32p = __attribute__((address_space(3))) const uint32_t *;
+  // per-lane read bases (they do not depend on the tile)
+  const uint32_t aF = (uint32_t)(uintptr_t)(lds_u8p)(reinterpret_cast<const uint8_t *>(s_f)) + M * tid;
+  uint32_t aR[M / 4];
+#pragma unroll
+  for (int gq = 0; gq < M / 4; ++gq)
+    aR[gq] = (uint32_t)(uintptr_t)(lds_u8p)(reinterpret_cast<const uint8_t *>(s_r)) + 4u * ((uint32_t)(N_R - K) >> 2) - M * tid - 8u * gq;
+
+  // stage unit u of the tile: bases [M u, M u + M) at genome position P, one lookahead dword
+  auto stage_unit = [&](uint32_t u, uint64_t tile_start, uint32_t par) __attribute__((always_inline)) {
+    const uint64_t P = tile_start + (uint64_t)u * M;
+    uint32_t x[DW + 1];
+    const int64_t rem64 = (int64_t)n_bps - (int64_t)P;  // bases of the genome from P on
+    if (rem64 + 32 >= 4 * (DW + 1)) {  // the caller provides 32 readable bytes behind every genome
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(gseq + P);
+#pragma unroll
+      for (int t = 0; t <= DW; ++t) x[t] = src[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t <= DW; ++t) {
+        uint32_t w = 0;
+        for (int bb = 0; bb < 4; ++bb) {
+          const int64_t o = 4 * t + bb;
+          w |= (uint32_t)(o < rem64 ? gseq[P + o] : (uint8_t)'N') << (8 * bb);
+        }
+        x[t] = w;
+      }
+    }
+    if (u2t) {  // needletail normalize: u/U -> T  ('U' ^ 'T' == 1); one uniform branch
+#pragma unroll
+      for (int t = 0; t <= DW; ++t) {
+        const uint32_t e = (x[t] & 0xDFDFDFDFu) ^ 0x55555555u;
+        const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
+        x[t] ^= (~nz & 0x80808080u) >> 7;
+      }
+    }
+    uint32_t FA[DW + 1], CA[DW + 1];
+    uint32_t dacc = 0, codes = 0;
+#pragma unroll
+    for (int t = 0; t <= DW; ++t) {
+      const uint32_t xv = x[t];
+      const uint32_t tt = xv ^ (xv >> 1);
+      const uint32_t cd = (tt >> 1) & 0x03030303u;            // A,C,G,T -> 0,1,2,3 per byte
+      FA[t] = __builtin_amdgcn_perm(0u, 0x54474341u, cd);     // "ACGT"[code]
+      if (CANON) CA[t] = __builtin_amdgcn_perm(0u, 0x41434754u, cd);  // "TGCA"[code]
+      if (t < DW) {
+        dacc |= (xv & 0xDFDFDFDFu) ^ FA[t];
+        if (CANON) codes |= __builtin_amdgcn_udot4(cd, 0x40100401u, 0u, false) << (8 * t);  // c0 | c1<<2 | c2<<4 | c3<<6
+      }
+    }
+    // validity of the unit's own M bases
+    uint32_t inv = 0;
+    const bool dirty = dacc != 0 || rem64 < M;
+    if (__any(dirty)) {
+#pragma unroll
+      for (int t = 0; t < DW; ++t) {
+        const uint32_t d = (x[t] & 0xDFDFDFDFu) ^ FA[t];
+        const uint32_t z = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+        inv |= ((((z >> 7) * 0x01020408u) >> 24) & 0xFu) << (4 * t);
+      }
+      if (rem64 < M) inv |= rem64 <= 0 ? ~0u : (~0u << (uint32_t)rem64);
+      inv &= (1u << M) - 1;
+      if ((threadIdx.x & 63) == 0 || dirty) s_dirty[par] = 1u;  // (same value from every writer)
+    }
+    s_val[u] = inv;
+    // forward phase images: F_phi[DW u + t] = bytes [4 t + phi, 4 t + phi + 4) of the unit (+ lookahead)
+    uint32_t *const f0 = s_f + DW * u;
+#pragma unroll
+    for (int t = 0; t < DW; ++t) {
+      f0[t] = FA[t];
+      f0[S / 4 + t] = __builtin_amdgcn_alignbyte(FA[t + 1], FA[t], 1);
+      f0[2 * (S / 4) + t] = __builtin_amdgcn_alignbyte(FA[t + 1], FA[t], 2);
+      f0[3 * (S / 4) + t] = __builtin_amdgcn_alignbyte(FA[t + 1], FA[t], 3);
+    }
+    if constexpr (CANON) {
+      // 2-bit codes: M / 4 bytes at byte M u / 4
+#pragma unroll
+      for (int t = 0; t < DW; ++t) s_code[DW * u + t] = (uint8_t)(codes >> (8 * t));
+      // reverse phase images: the forward bytes [s, s + 4), s = 4 i + phi', complemented and byte-reversed, are dword
+      // j = JB(phi') - i of reverse phase psi = (N_R - phi') & 3, which lives at S (3 - psi)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int psi = (N_R - ph) & 3, JB = (N_R - 4 - psi - ph) / 4;
+        const uint32_t sel = (uint32_t)(ph + 3) | ((uint32_t)(ph + 2) << 8) | ((uint32_t)(ph + 1) << 16) | ((uint32_t)ph << 24);
+        uint32_t *const r0 = s_r + (3 - psi) * (S / 4) + JB - (int)(DW * u);
+#pragma unroll
+        for (int t = 0; t < DW; ++t) r0[-t] = __builtin_amdgcn_perm(CA[t + 1], CA[t], sel);
+        // i = -1: the bytes in front of the tile do not exist; what follows them (the tile's first ph bases) does
+        if (ph > 0 && u == 0) r0[1] = __builtin_amdgcn_perm(CA[0], 0u, sel);
+      }
+    }
+  };
+
+#pragma unroll 1
+  for (int tile = 0; tile < G::TILES; ++tile) {
+    const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
+    if (tile_start >= n_starts) break;  // uniform
+    const uint32_t par = (uint32_t)tile & 1u;
+    stage_unit(tid, tile_start, par);
+#ifndef HG_KS_EXP
+#define HG_KS_EXP 0
+#endif
+    if (!(HG_KS_EXP & 1)) __syncthreads();
+
+    const bool tile_dirty = s_dirty[par] != 0u;  // workgroup-uniform
+    uint32_t inv32 = 0;
+    if (tile_dirty) inv32 = s_val[tid] | (s_val[tid + 1] << M) | (s_val[tid + 2] << (2 * M));
+    uint64_t Gm = 0, Gc = 0;
+    if constexpr (CANON) {
+      // the lane's 32-base code window: 64 bits from bit 2 M tid = byte (M / 4) tid of the code image
+      const uint32_t bo = (uint32_t)DW * tid;
+      const uint32_t *cw = reinterpret_cast<const uint32_t *>(s_code) + (bo >> 2);
+      const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], sh = 8u * (bo & 3u);
+      const uint32_t wl = __builtin_amdgcn_alignbit(c1, c0, sh), wh = __builtin_amdgcn_alignbit(c2, c1, sh);
+      auto pairrev = [](uint32_t v) {
+        const uint32_t br = __builtin_bitreverse32(v);
+        return ((br >> 1) & 0x55555555u) | ((br & 0x55555555u) << 1);
+      };
+      Gc = ~mk64(wl, wh);                       // complement codes; read LSB-first this IS the reverse strand
+      Gm = mk64(pairrev(wh), pairrev(wl));      // MSB-first copy: base 0 in the top two bits
+    }
+
+    auto fetch_words = [&](auto jjc, uint64_t *w) __attribute__((always_inline)) {
+      constexpr int jj = decltype(jjc)::value;
+      uint32_t base = aF;
+      if constexpr (CANON) {
+        uint64_t fv, rv;
+        if constexpr ((K & 1) != 0) {
+          // odd K: the compare is decided inside the 2K bits, the values only have to be TOP-aligned
+          fv = Gm << (2 * jj);
+          rv = Gc << (2 * (32 - K - jj));
+        } else {
+          constexpr uint64_t MASK2K = (1ull << (2 * K)) - 1;
+          fv = (Gm >> (2 * (32 - K - jj))) & MASK2K;
+          rv = (Gc >> (2 * jj)) & MASK2K;
+        }
+        uint64_t lt;
+        asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(base) : "v"(aF), "v"(aR[jj >> 2]), "s"(lt));
+      }
+      constexpr int IMM = S * (jj & 3) + 4 * (jj >> 2);
+      const lds_u32p src = (lds_u32p)(uintptr_t)(base + (uint32_t)IMM);
+      uint32_t d[2 * NW];
+#pragma unroll
+      for (int m = 0; m < 2 * NW; ++m) {
+        if (m < ND - 1 || (m == ND - 1 && NB == 4)) d[m] = src[m];
+        else if (m == ND - 1 && NB == 1) d[m] = *(lds_u8p)(uintptr_t)(base + (uint32_t)(IMM + 4 * m));
+        else if (m == ND - 1 && NB == 2) d[m] = *(lds_u16p)(uintptr_t)(base + (uint32_t)(IMM + 4 * m));
+        else if (m == ND - 1) d[m] = src[m] & 0xFFFFFFu;
+        else d[m] = 0;
+      }
+#pragma unroll
+      for (int m = 0; m < NW; ++m) w[m] = mk64(d[2 * m], d[2 * m + 1]);
+    };
+    uint64_t wq[2][NW];
+    const bool hashing = tid < (uint32_t)(WG - G::LOOK_UNITS);  // (the last lanes' windows leave the staged area)
+    auto run_kmers = [&](auto checkc) __attribute__((always_inline)) {
+      constexpr bool CHECK = decltype(checkc)::value;
+      static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const bool valid = !CHECK || ((inv32 >> j) & MASKK) == 0;
+        if constexpr (j == 0) fetch_words(jc, wq[0]);
+        if constexpr (j + 1 < M) fetch_words(std::integral_constant<int, j + 1>{}, wq[(j + 1) & 1]);
+        const uint64_t h = t1ha2_fixed_w<K>(wq[j & 1], seed);
+        if (valid && hashing && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+      });
+    };
+    if (!tile_dirty) run_kmers(std::false_type{});
+    else run_kmers(std::true_type{});
+    if (!(HG_KS_EXP & 1)) __syncthreads();  // every read of the images is done: the next tile may overwrite them
+    if (tid == 0) s_dirty[par] = 0u;  // (raised again in two tiles' time at the earliest, behind the next tile's barriers)
+  }
+  flush_hits(stage, gm, g, hits, cnt);
+}
+
+// =========================================================================================
 // fast kernel, 64-base window: compile-time k in [22, 32]
 // =========================================================================================
 // Same scheme as kmer_sample_fast with a 64-base register window per lane (16 dwords, 32 k-mer starts,
@@ -1079,6 +1327,15 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 #undef HG_V
   }
 #endif
+  if (HG_KMER_SHARED) {
+    if (canonical)
+      hipLaunchKernelGGL((kmer_sample_shared<K, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, threshold,
+                         seed, u2t, d_hits, d_cnt);
+    else
+      hipLaunchKernelGGL((kmer_sample_shared<K, false>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, threshold,
+                         seed, u2t, d_hits, d_cnt);
+    return hipGetLastError();
+  }
   if constexpr (Geo<K>::M == 12) {  // k = 18..21: three slices of 12 k-mers per window
     if (canonical && HG_KMER_GROUPED) {
       hipLaunchKernelGGL((kmer_sample_grouped<K>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, threshold,
@@ -1100,6 +1357,10 @@ hipError_t launch_fast(hipStream_t st, bool canonical, uint32_t n_items, const u
 const char *hg_kmer_kernel_name(uint32_t k, bool canonical) {  // mirrors hg_launch_kmer_sample / launch_fast
   static thread_local char buf[64];
   if (k > 32) return "kmer_sample_long";
+  if (HG_KMER_SHARED && k < FAST64_FROM) {
+    snprintf(buf, sizeof buf, "kmer_sample_shared<%u, %s>", k, canonical ? "true" : "false");
+    return buf;
+  }
   const bool grouped = canonical && HG_KMER_GROUPED && k >= 18 && k <= 25;
   if (grouped) snprintf(buf, sizeof buf, "kmer_sample_grouped<%u>", k);
   else if (k >= 22) snprintf(buf, sizeof buf, "kmer_sample_fast64<%u, %s>", k, canonical ? "true" : "false");
@@ -1111,6 +1372,7 @@ const char *hg_kmer_kernel_name(uint32_t k, bool canonical) {  // mirrors hg_lau
 uint32_t hg_kmer_item_starts(uint32_t k) {
   if (fast64_k(k)) return (uint32_t)(WG * 32 * TILES_PER_ITEM64);
   if (!fast_k(k)) return GEN_ITEM;
+  if (HG_KMER_SHARED) return (uint32_t)GeoS<21>::ITEM;  // (the same for every k <= 21)
   return (uint32_t)(WG * ((33 - k) & ~3u) * tiles_per_item((int)k));
 }
 
