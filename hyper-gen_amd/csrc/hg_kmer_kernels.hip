@@ -767,6 +767,96 @@ __global__ __launch_bounds__(WG) void kmer_sample_grouped(
 // that load the bases (12 bases + one lookahead dword per lane: every base is classified once, not 32/12 times as in
 // kmer_sample_fast or 56/36 as in the grouped kernel); the 2-bit codes for the strand compare and the validity bits go
 // through LDS as well (768 + 1 036 bytes).  Two barriers per tile; 28 KB of LDS per workgroup (5 workgroups per CU).
+
+// ---- the k-mer body of kmer_sample_shared in assembly (17 <= K <= 24: three mixup64 stages + final64) -----------------
+// The compiler's code for t1ha2_fixed_w spends 10 v_mov and 3 v_add_u32 per hash on moving 32-bit halves into the
+// even-aligned register pairs v_mad_u64_u32 / v_lshl_add_u64 take (inline asm operands cannot name the halves of a
+// 64-bit operand, so every product's halves travel as separate values and get re-paired), plus nops behind every carry
+// that goes through an SGPR pair.  Here all temporaries are fixed physical registers, every result is produced in the
+// pair that consumes it, carries go through VCC into a VOP2 v_addc (no SGPR read hazard), and what is left is what the
+// ISA forces: the high dword of a product is an ODD register and a 64-bit addend has to start at an EVEN one -- one
+// v_mov per 128-bit product (into the pair Z = {x, 0}).  57 vector instructions per hash + compare instead of 64.
+//   v[56:61] / v[62:67]  hash words of k-mer j / j+1 (filled by HG_KS_READ one k-mer ahead)
+//   Z v[68:69]  H v[70:71]  X v[72:73]  A v[74:75]  T v[76:77]  U v[78:79]  S1 v[80:81]  S2 v[82:83]  R v[84:85]
+//   Y v[86:87]  C v[88:89]
+#define HG_KS_MUL128(XLO, XHI, PLO, PHI, ADDEND, OUT, OUTHI)                                   \
+  "v_mad_u64_u32 v[74:75], %[junk], " XLO ", " PLO ", 0\n\t"                                   \
+  "v_mov_b32 v68, v75\n\t"                                                                     \
+  "v_mad_u64_u32 v[76:77], %[junk], " XHI ", " PLO ", v[68:69]\n\t"                            \
+  "v_mad_u64_u32 v[76:77], vcc, " XLO ", " PHI ", v[76:77]\n\t"                                \
+  "v_mad_u64_u32 " OUT ", %[junk], v77, 1, " ADDEND "\n\t"                                     \
+  "v_mad_u64_u32 " OUT ", %[junk], " XHI ", " PHI ", " OUT "\n\t"                              \
+  "v_addc_co_u32_e32 " OUTHI ", vcc, 0, " OUTHI ", vcc\n\t"
+// lo64(x * P) -> {OLO, OHI} (a pair): three chained products and one add into the pair's own high half
+#define HG_KS_LO64(XLO, XHI, PLO, PHI, OUT, OLO_UNUSED, OHI)                                   \
+  "v_mad_u64_u32 " OUT ", %[junk], " XLO ", " PLO ", 0\n\t"                                    \
+  "v_mad_u64_u32 v[76:77], %[junk], " XLO ", " PHI ", 0\n\t"                                   \
+  "v_mad_u64_u32 v[76:77], %[junk], " XHI ", " PLO ", v[76:77]\n\t"                            \
+  "v_add_u32_e32 " OHI ", " OHI ", v76\n\t"
+// request the words of one k-mer: cases by (dwords, bytes in the last dword) = K 17 (5,1), 18 (5,2), 19 (5,3), 20 (5,4), 21 (6,1)
+// (four dword reads: a ds_read_b64 at an address that is a multiple of 4 but not of 8 is as slow as a byte-aligned one --
+// measured 18.8 ms against 8.5 for the whole kernel -- and ds_read2_b32's 8-bit offsets cannot hold the phase image's)
+#define HG_KS_READ_HEAD(R0, R1, R2, R3)                                                                              \
+  "ds_read_b32 v" R0 ", %[base] offset:%[o0]\n\tds_read_b32 v" R1 ", %[base] offset:%[o0] + 4\n\t"                   \
+  "ds_read_b32 v" R2 ", %[base] offset:%[o1]\n\tds_read_b32 v" R3 ", %[base] offset:%[o1] + 4\n\t"
+#define HG_KS_READ_TEXT_51(R0, R1, R2, R3, R4, R5) HG_KS_READ_HEAD(R0, R1, R2, R3) "ds_read_u8 v" R4 ", %[base] offset:%[o2]\n\tv_mov_b32 v" R5 ", 0"
+#define HG_KS_READ_TEXT_52(R0, R1, R2, R3, R4, R5) HG_KS_READ_HEAD(R0, R1, R2, R3) "ds_read_u16 v" R4 ", %[base] offset:%[o2]\n\tv_mov_b32 v" R5 ", 0"
+#define HG_KS_READ_TEXT_53(R0, R1, R2, R3, R4, R5) HG_KS_READ_HEAD(R0, R1, R2, R3) "ds_read_b32 v" R4 ", %[base] offset:%[o2]\n\tv_mov_b32 v" R5 ", 0"
+#define HG_KS_READ_TEXT_54(R0, R1, R2, R3, R4, R5) HG_KS_READ_TEXT_53(R0, R1, R2, R3, R4, R5)
+#define HG_KS_READ_TEXT_61(R0, R1, R2, R3, R4, R5) HG_KS_READ_HEAD(R0, R1, R2, R3) "ds_read_b32 v" R4 ", %[base] offset:%[o2]\n\tds_read_u8 v" R5 ", %[base] offset:%[o3]"
+// wait for the words requested one hash ago; K = 19: the last dword carries a byte of the next base
+#define HG_KS_WAIT_TEXT_51(R4) "s_waitcnt lgkmcnt(0)\n\t"
+#define HG_KS_WAIT_TEXT_52(R4) "s_waitcnt lgkmcnt(0)\n\t"
+#define HG_KS_WAIT_TEXT_53(R4) "s_waitcnt lgkmcnt(0)\n\tv_and_b32 v" R4 ", 0xffffff, v" R4 "\n\t"
+#define HG_KS_WAIT_TEXT_54(R4) "s_waitcnt lgkmcnt(0)\n\t"
+#define HG_KS_WAIT_TEXT_61(R4) "s_waitcnt lgkmcnt(0)\n\t"
+#define HG_KS_HASH_TEXT(W0, W1, W2)                                                                                  \
+  /* mixup64<P3>(b, a, w0): x = seed + w0; b = K ^ lo; a = seed + hi */                                              \
+  "v_lshl_add_u64 v[72:73], " W0 ", 0, %[seed]\n\t"                                                                  \
+  HG_KS_MUL128("v72", "v73", "%[p3l]", "%[p3h]", "%[seed]", "v[78:79]", "v79")                                       \
+  "v_xor_b32_e32 v80, %[kk], v74\n\t"                                                                                \
+  "v_mov_b32 v81, v76\n\t"                                                                                           \
+  /* mixup64<P2>(a, b, w1): x = b + w1; a ^= lo; b += hi   (a = U, b = S1 -> a' = S2, b' = R) */                     \
+  "v_lshl_add_u64 v[72:73], v[80:81], 0, " W1 "\n\t"                                                                 \
+  HG_KS_MUL128("v72", "v73", "%[p2l]", "%[p2h]", "v[80:81]", "v[84:85]", "v85")                                      \
+  "v_xor_b32_e32 v82, v78, v74\n\t"                                                                                  \
+  "v_xor_b32_e32 v83, v79, v76\n\t"                                                                                  \
+  /* mixup64<P1>(b, a, w2): x = a + w2; b ^= lo; a += hi   (a = S2, b = R -> b'' = S1, a'' = U) */                   \
+  "v_lshl_add_u64 v[72:73], v[82:83], 0, " W2 "\n\t"                                                                 \
+  HG_KS_MUL128("v72", "v73", "%[p1l]", "%[p1h]", "v[82:83]", "v[78:79]", "v79")                                      \
+  "v_xor_b32_e32 v80, v84, v74\n\t"                                                                                  \
+  "v_xor_b32_e32 v81, v85, v76\n\t"                                                                                  \
+  /* final64(a = U, b = S1): x = (a + rot64(b, 41)) * P0, y = (rot64(a, 23) + b) * P6 (low halves), z = x ^ y */      \
+  "v_alignbit_b32 v86, v80, v81, 9\n\t"                                                                              \
+  "v_alignbit_b32 v87, v81, v80, 9\n\t"                                                                              \
+  "v_lshl_add_u64 v[72:73], v[86:87], 0, v[78:79]\n\t"                                                               \
+  "v_alignbit_b32 v86, v79, v78, 23\n\t"                                                                             \
+  "v_alignbit_b32 v87, v78, v79, 23\n\t"                                                                             \
+  "v_lshl_add_u64 v[88:89], v[86:87], 0, v[80:81]\n\t"                                                               \
+  HG_KS_LO64("v72", "v73", "%[p0l]", "%[p0h]", "v[74:75]", "v74", "v75")                                             \
+  HG_KS_LO64("v88", "v89", "%[p6l]", "%[p6h]", "v[84:85]", "v84", "v85")                                             \
+  "v_xor_b32_e32 v72, v74, v84\n\t"                                                                                  \
+  "v_xor_b32_e32 v73, v75, v85\n\t"                                                                                  \
+  /* mux64(z, P5): lo ^ hi of the 128-bit product */                                                                 \
+  "v_mad_u64_u32 v[74:75], %[junk], v72, %[p5l], 0\n\t"                                                              \
+  "v_mov_b32 v68, v75\n\t"                                                                                           \
+  "v_mad_u64_u32 v[76:77], %[junk], v73, %[p5l], v[68:69]\n\t"                                                       \
+  "v_mad_u64_u32 v[76:77], vcc, v72, %[p5h], v[76:77]\n\t"                                                           \
+  "v_mov_b32 v68, v77\n\t"                                                                                           \
+  "v_mad_u64_u32 v[78:79], %[junk], v73, %[p5h], v[68:69]\n\t"                                                       \
+  "v_addc_co_u32_e32 v79, vcc, 0, v79, vcc\n\t"                                                                      \
+  "v_xor_b32_e32 v70, v74, v78\n\t"                                                                                  \
+  "v_xor_b32_e32 v71, v76, v79\n\t"                                                                                  \
+  "v_cmp_gt_u64_e64 %[mask], %[thr], v[70:71]"
+#define HG_KS_HASH_INPUTS                                                                                            \
+  [seed] "s"(seed), [thr] "s"(threshold), [kk] "n"(K), [p0l] "s"((uint32_t)P0), [p0h] "s"((uint32_t)(P0 >> 32)),     \
+      [p1l] "s"((uint32_t)P1), [p1h] "s"((uint32_t)(P1 >> 32)), [p2l] "s"((uint32_t)P2), [p2h] "s"((uint32_t)(P2 >> 32)), \
+      [p3l] "s"((uint32_t)P3), [p3h] "s"((uint32_t)(P3 >> 32)), [p5l] "s"((uint32_t)P5), [p5h] "s"((uint32_t)(P5 >> 32)), \
+      [p6l] "s"((uint32_t)P6), [p6h] "s"((uint32_t)(P6 >> 32))
+#define HG_KS_HASH_CLOBBERS                                                                                          \
+  "vcc", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",   \
+      "v85", "v86", "v87", "v88", "v89"
+
 template <int K>
 struct GeoS {
   static constexpr int M = 12;                      // starts per lane and tile (multiple of 4: the phase of start j is j & 3)
@@ -975,6 +1065,104 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     };
     uint64_t wq[2][NW];
     const bool hashing = tid < (uint32_t)(WG - G::LOOK_UNITS);  // (the last lanes' windows leave the staged area)
+#ifndef HG_KS_ASM
+#define HG_KS_ASM 1  /* 17 <= K <= 24: the k-mer body in assembly (0: the compiler's code for the same arithmetic, A/B) */
+#endif
+    constexpr bool ASM_BODY = HG_KS_ASM && NW == 3 && (ND == 5 || (ND == 6 && NB == 1));  // K = 17..21
+    // the strand's base address for k-mer jj (ASM_BODY; the compiler path has it inside fetch_words)
+    auto strand_base = [&](auto jjc) __attribute__((always_inline)) -> uint32_t {
+      constexpr int jj = decltype(jjc)::value;
+      uint32_t base = aF;
+      if constexpr (CANON) {
+        uint64_t fv, rv;
+        if constexpr ((K & 1) != 0) {
+          fv = Gm << (2 * jj);
+          rv = Gc << (2 * (32 - K - jj));
+        } else {
+          constexpr uint64_t MASK2K = (1ull << (2 * K)) - 1;
+          fv = (Gm >> (2 * (32 - K - jj))) & MASK2K;
+          rv = (Gc >> (2 * jj)) & MASK2K;
+        }
+        uint64_t lt;
+        asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(lt) : "v"(rv), "v"(fv));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(base) : "v"(aF), "v"(aR[jj >> 2]), "s"(lt));
+      }
+      return base;
+    };
+    // One asm statement per k-mer: wait for this k-mer's words (requested a whole hash earlier), request the next
+    // k-mer's into the other buffer (whole dwords of the chosen strand's phase image: two 8-byte reads at 4-byte aligned
+    // addresses, one dword and the last 1..4 bytes), hash, compare with the threshold.  The buffers are bound to fixed
+    // registers on both sides, so the compiler sees ordinary values and never copies them.
+    uint64_t w0a = 0, w0b = 0, w0c = 0, w1a = 0, w1b = 0, w1c = 0;  // parity 0: v[56:61], parity 1: v[62:67]
+    uint64_t hmask = 0, hjunk = 0, hval = 0;
+    uint64_t zpair = 0;  // Z = {x, 0}: the zero-extension pair of the products' high dwords; every asm statement rewrites
+                         // its low half only, so the zero in the high half is carried from k-mer to k-mer as a value
+    constexpr int KCASE = 10 * ND + NB;
+#define HG_KS_FIRST(C)                                                                                                \
+  if constexpr (KCASE == C)                                                                                           \
+    asm volatile(HG_KS_READ_TEXT_##C("56", "57", "58", "59", "60", "61")                                             \
+                 : "={v[56:57]}"(w0a), "={v[58:59]}"(w0b), "={v[60:61]}"(w0c)                                         \
+                 : [base] "v"(base), [o0] "n"(IMM), [o1] "n"(IMM + 8), [o2] "n"(IMM + 16), [o3] "n"(IMM + 20));
+#define HG_KS_EVEN(C)                                                                                                 \
+  if constexpr (KCASE == C)                                                                                           \
+    asm volatile(HG_KS_WAIT_TEXT_##C("60") HG_KS_READ_TEXT_##C("62", "63", "64", "65", "66", "67") "\n\t"            \
+                 HG_KS_HASH_TEXT("v[56:57]", "v[58:59]", "v[60:61]")                                                  \
+                 : [mask] "=s"(hmask), [junk] "=&s"(hjunk), "={v[70:71]}"(hval), "={v[62:63]}"(w1a), "={v[64:65]}"(w1b), \
+                   "={v[66:67]}"(w1c), "={v[68:69]}"(zpair)                                                           \
+                 : HG_KS_HASH_INPUTS, "{v[68:69]}"(zpair), [base] "v"(base), [o0] "n"(IMM), [o1] "n"(IMM + 8), [o2] "n"(IMM + 16),         \
+                   [o3] "n"(IMM + 20), "{v[56:57]}"(w0a), "{v[58:59]}"(w0b), "{v[60:61]}"(w0c)                        \
+                 : HG_KS_HASH_CLOBBERS);
+#define HG_KS_ODD(C)                                                                                                  \
+  if constexpr (KCASE == C)                                                                                           \
+    asm volatile(HG_KS_WAIT_TEXT_##C("66") HG_KS_READ_TEXT_##C("56", "57", "58", "59", "60", "61") "\n\t"            \
+                 HG_KS_HASH_TEXT("v[62:63]", "v[64:65]", "v[66:67]")                                                  \
+                 : [mask] "=s"(hmask), [junk] "=&s"(hjunk), "={v[70:71]}"(hval), "={v[56:57]}"(w0a), "={v[58:59]}"(w0b), \
+                   "={v[60:61]}"(w0c), "={v[68:69]}"(zpair)                                                           \
+                 : HG_KS_HASH_INPUTS, "{v[68:69]}"(zpair), [base] "v"(base), [o0] "n"(IMM), [o1] "n"(IMM + 8), [o2] "n"(IMM + 16),         \
+                   [o3] "n"(IMM + 20), "{v[62:63]}"(w1a), "{v[64:65]}"(w1b), "{v[66:67]}"(w1c)                        \
+                 : HG_KS_HASH_CLOBBERS);
+#define HG_KS_LAST(C)                                                                                                 \
+  if constexpr (KCASE == C)                                                                                           \
+    asm volatile(HG_KS_WAIT_TEXT_##C("66") HG_KS_HASH_TEXT("v[62:63]", "v[64:65]", "v[66:67]")                        \
+                 : [mask] "=s"(hmask), [junk] "=&s"(hjunk), "={v[70:71]}"(hval), "={v[68:69]}"(zpair)                 \
+                 : HG_KS_HASH_INPUTS, "{v[68:69]}"(zpair), "{v[62:63]}"(w1a), "{v[64:65]}"(w1b), "{v[66:67]}"(w1c)    \
+                 : HG_KS_HASH_CLOBBERS);
+#define HG_KS_ALL_CASES(X) X(51) X(52) X(53) X(54) X(61)
+    auto kmers_asm = [&](auto checkc) __attribute__((always_inline)) {
+      constexpr bool CHECK = decltype(checkc)::value;
+      if constexpr (ASM_BODY) {
+        {
+          const uint32_t base = strand_base(std::integral_constant<int, 0>{});
+          constexpr int IMM = 0;
+          HG_KS_ALL_CASES(HG_KS_FIRST)
+        }
+        static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const bool valid = !CHECK || ((inv32 >> j) & MASKK) == 0;
+          if constexpr (j + 1 < M) {
+            const uint32_t base = strand_base(std::integral_constant<int, j + 1>{});
+            constexpr int IMM = S * ((j + 1) & 3) + 4 * ((j + 1) >> 2);
+            if constexpr ((j & 1) == 0) {
+              HG_KS_ALL_CASES(HG_KS_EVEN)
+            } else {
+              HG_KS_ALL_CASES(HG_KS_ODD)
+            }
+          } else {
+            static_assert((M & 1) == 0, "the last k-mer's words are in the parity-1 buffer");
+            HG_KS_ALL_CASES(HG_KS_LAST)
+          }
+          if (hmask != 0) {  // wave-uniform: some lane's hash is below the threshold (1 k-mer in `scaled`)
+            uint32_t below;
+            asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(below) : "s"(hmask));
+            if (below && valid && hashing) stage_hit(stage, hval, gm, g, hits, cnt);
+          }
+        });
+      }
+    };
+#undef HG_KS_FIRST
+#undef HG_KS_EVEN
+#undef HG_KS_ODD
+#undef HG_KS_LAST
     auto run_kmers = [&](auto checkc) __attribute__((always_inline)) {
       constexpr bool CHECK = decltype(checkc)::value;
       static_for(std::make_integer_sequence<int, M>{}, [&](auto jc) {
@@ -986,8 +1174,13 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
         if (valid && hashing && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
       });
     };
-    if (!tile_dirty) run_kmers(std::false_type{});
-    else run_kmers(std::true_type{});
+    if constexpr (ASM_BODY) {
+      if (!tile_dirty) kmers_asm(std::false_type{});
+      else kmers_asm(std::true_type{});
+    } else {
+      if (!tile_dirty) run_kmers(std::false_type{});
+      else run_kmers(std::true_type{});
+    }
     if (!(HG_KS_EXP & 1)) __syncthreads();  // every read of the images is done: the next tile may overwrite them
     if (tid == 0) s_dirty[par] = 0u;  // (raised again in two tiles' time at the earliest, behind the next tile's barriers)
   }
