@@ -18,7 +18,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("HYPERGEN_LIB") or os.path.join(_HERE, "libhypergen_hip.so")  # override: development builds
+LIB_PATH = (os.environ.get("HYPERGEN_LIB") or None) or os.path.join(_HERE, "libhypergen_hip.so")  # override: development builds
 CLI_PATH = os.path.join(_HERE, "hyper-gen")
 
 LAYOUT_SCALAR, LAYOUT_AVX2 = 0, 1
