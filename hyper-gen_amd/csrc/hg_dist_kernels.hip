@@ -460,7 +460,9 @@ constexpr uint32_t ST = 8;       // super-tile edge, in tiles
 //          CUs (10 000 x 10 000: 1 280 tiles = 5.0 rounds of 256 instead of 1 600 = 6.25 -> 7)
 // (Measured and removed again, see DESIGN.md 4.3 / 4.4 and the history of this file: a four-wave 128 x 128 per-wave shape
 // with AGPR-pinned accumulators, bit-stream operands expanded by the workgroup, a register-staged 256 x 256 variant,
-// the DMA burst spread over all waves, raised priority for the loader waves.)
+// the DMA burst spread over all waves -- also with the two waves of a SIMD half a phase apart --, raised priority for the
+// loader waves, hand-written DMA issue with one M0 write per four pieces, and a ping-pong main loop in which the two
+// waves of a SIMD alternate between a 40-MFMA burst and fragment reads + DMA over a four-slice ring.)
 template <bool BIG, int NT = 4>
 struct TileCfg {
   static constexpr int WTM = BIG ? 8 : 4;   // 16-row MFMA tiles per wave in M
@@ -548,11 +550,9 @@ __device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...
 //           fragment is 16 bytes and a K-step is 128 bytes per row, so staging, swizzle and fragment addressing are
 //           shared; the order of the dims inside a fragment is irrelevant as long as both operands use the same one
 //           (every product is +-1 and they are all summed).
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false,
-          bool PP = false>
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false>
 __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT>;
-  static_assert(!PP || (GLDS && BIG && !CHUNKED && !FULL), "the ping-pong main loop exists for the thresholded LDS-DMA geometries");
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
   static_assert(!FP4 || HAM, "e2m1 operands exist for the Hamming search only");
@@ -617,124 +617,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] = 0;
   }
 
-  if constexpr (PP) {
-    // ---- ping-pong main loop ---------------------------------------------------------------------------------------
-    // The two waves of a SIMD never do the same thing at the same time.  Waves 0..3 (the upper 128 rows of the tile, one
-    // per SIMD) and waves 4..7 (the lower 128 rows) alternate between a COMPUTE slot -- WTM x NT back-to-back MFMAs on
-    // the fragments of one 64-byte K slice, all of them already in registers -- and a LOAD slot: the 8 + NT fragment
-    // reads of the slice they multiply next, then their share of the LDS-DMA of a slice four slices ahead.  One
-    // s_barrier per slot keeps the groups in step, so the matrix pipe always has exactly one wave per SIMD feeding it
-    // while the other one's LDS and VMEM instructions issue beside it.  (The single-loop form above has both waves of a
-    // SIMD read fragments, wait and multiply in the same phases: stamps put its K-step at 4 600 cycles for 2 560 cycles of
-    // MFMA issue, with the matrix pipe 18 % busy during the loaders' DMA burst.)
-    //   time 2j    : waves 0..3 multiply slice j       | waves 4..7 read slice j, DMA operand B of slice j + 3
-    //   time 2j + 1: waves 4..7 multiply slice j       | waves 0..3 read slice j + 1, DMA operand A of slice j + 4
-    // LDS: a ring of four slices, slice s in slot s & 3; a slot is free again once waves 4..7 have read it (time 2s), and
-    // is first read by waves 0..3 at time 2s - 1: the DMA issued at times 2s - 7 (A) and 2s - 6 (B) has four slots to land
-    // (s_waitcnt vmcnt leaves the two youngest groups of a wave in flight).  Rows are 64 bytes = four 16-byte chunks,
-    // chunk position c of row r holds global chunk c ^ ((r >> 2) & 3): the 16 lanes of a fragment read that share a
-    // K chunk then cover all 64 banks.
-    constexpr uint32_t SL_A = BM * 64u, SL_B = BN * 64u, SL = SL_A + SL_B;  // bytes of one slice in LDS
-    constexpr int RING = 4;
-    constexpr int PPA = BM / 16 / 4, PPB = BN / 16 / 4;  // 1 KiB pieces (16 rows x 64 B) per wave: A by waves 0..3, B by waves 4..7
-    static_assert(PPA * 4 * 16 == BM && PPB * 4 * 16 == BN, "whole pieces");
-    const uint32_t nsl = g.Kp / 32;                      // 64-byte slices (Kp counts two-byte units)
-    const uint32_t uwave = __builtin_amdgcn_readfirstlane(wave);  // (in an SGPR: descriptor choice and M0 stay scalar)
-    const uint32_t grp = uwave >> 2, gw = uwave & 3;
-    uint8_t *const lds8 = reinterpret_cast<uint8_t *>(sAB);
-    typedef __attribute__((address_space(3))) void *lds_ptr_t;
-    // DMA: lane l of a piece handles row 16 p + (l >> 2), chunk position l & 3
-    // (piece p's rows are 16 p + (l >> 2): the swizzle term does not depend on p, so ONE per-lane offset serves all the
-    // wave's pieces and the piece's row offset travels in the scalar offset of the load)
-    uint32_t vP0;
-    __amdgpu_buffer_rsrc_t rs;
-    const uint32_t piece_pitch = 16u * g.ldk * 2u;  // bytes between the first rows of consecutive pieces
-    {
-      const uint32_t pr = lane >> 2, pc = lane & 3;
-      vP0 = pr * g.ldk * 2 + (pc ^ ((pr >> 2) & 3)) * 16;
-      rs = grp ? __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000)
-               : __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
-    }
-    // this wave's pieces of slice `sl` (operand A for waves 0..3, B for waves 4..7) into ring slot sl & 3
-    auto dma_slice = [&](uint32_t sl) __attribute__((always_inline)) {
-      uint8_t *dst = lds8 + (sl & (RING - 1)) * SL + (grp ? SL_A + gw * (PPB * 1024u) : gw * (PPA * 1024u));
-      const uint32_t so = sl * 64u + gw * (grp ? PPB : PPA) * piece_pitch;
-      if (grp) {
-#pragma unroll
-        for (int i = 0; i < PPB; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 1024), 16, vP0, so + i * piece_pitch, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < PPA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 1024), 16, vP0, so + i * piece_pitch, 0, 0);
-      }
-    };
-    // fragments: lane (fr, fq) reads row base + fr, chunk position fq ^ ((fr >> 2) & 3)
-    const uint32_t fch = (fq ^ ((fr >> 2) & 3u)) * 16u;
-    const uint32_t fa0 = (wm * (WTM * 16) + fr) * 64u + fch, fb0 = SL_A + (wn * (NT * 16) + fr) * 64u + fch;
-    half8 fa[WTM], fb[NT];
-    auto load_frags = [&](uint32_t sl) __attribute__((always_inline)) {
-      const uint8_t *base = lds8 + (sl & (RING - 1)) * SL;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const half8 *>(base + fb0 + n * 1024);
-#pragma unroll
-      for (int m = 0; m < WTM; ++m) fa[m] = *reinterpret_cast<const half8 *>(base + fa0 + m * 1024);
-    };
-    auto multiply = [&]() __attribute__((always_inline)) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int m = 0; m < WTM; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          if constexpr (FP4)
-            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
-                         : "+v"(acc[m][n])
-                         : "v"(__builtin_bit_cast(int4v, fa[m])), "v"(__builtin_bit_cast(int4v, fb[n])), "v"(0x7f7f7f7f));
-          else if constexpr (I8)
-            acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(int4v, fa[m]), __builtin_bit_cast(int4v, fb[n]),
-                                                               acc[m][n], 0, 0, 0);
-          else
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m], fb[n], acc[m][n], 0, 0, 0);
-        }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // prologue: the first four slices, both operands (each wave its own pieces)
-#pragma unroll
-    for (uint32_t sl = 0; sl < (uint32_t)RING; ++sl)
-      if (sl < nsl) dma_slice(sl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // two separate instruction streams (a shared loop body with the role as a branch makes the register allocator copy the
-    // fragment registers at every merge point: 93 v_mov_b64 per slot); both execute exactly two barriers per slice
-    static_assert(PPA == 4, "vmcnt below = two groups of PPA pieces");
-    if (grp == 0) {
-      load_frags(0);
-      for (uint32_t j = 0; j < nsl; ++j) {
-        multiply();                                    // time 2j
-        __builtin_amdgcn_s_barrier();
-        if (j + 1 < nsl) load_frags(j + 1);            // time 2j + 1
-        if (j + 4 < nsl) dma_slice(j + 4);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-    } else {
-      for (uint32_t j = 0; j < nsl; ++j) {
-        load_frags(j);                                 // time 2j
-        if (j >= 1 && j + 3 < nsl) dma_slice(j + 3);
-        if constexpr (PPB == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if constexpr (PPB == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        multiply();                                    // time 2j + 1
-        __builtin_amdgcn_s_barrier();
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-  } else {
   // staging: thread t moves 4 x 16 B of A and of B per K-step: row = t/8 + SROWS*i, 16-byte piece t%8
   const uint32_t srow = tid >> 3, spc = tid & 7;
   const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.ldk + spc * 8;
@@ -793,11 +675,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // up behind the workgroup's burst cannot issue MFMAs meanwhile, and with every wave loading right after the
   // barrier both waves of a SIMD sit in that queue together while the matrix pipe idles.  With one loader
   // per SIMD its partner keeps the pipe busy and the loader catches up while the partner waits at the barrier.
-#ifndef HG_DMA_STAGGER
-#define HG_DMA_STAGGER 0  /* A/B: every wave issues its share of tile k+1 spread over the first four phases of step k,
-                             the two waves of a SIMD half a phase apart (one before, one behind the phase's MFMAs) */
-#endif
-  constexpr int HG_DMA_LOADER_WAVES = HG_DMA_STAGGER ? 8 : 4;
+  constexpr int HG_DMA_LOADER_WAVES = 4;
   constexpr int LW = HG_DMA_LOADER_WAVES < THREADS / 64 ? HG_DMA_LOADER_WAVES : THREADS / 64, LT = LW * 64;  // loader waves / threads
   constexpr int PA = BM * 8 / LT, PB = BN * 8 / LT;      // 16-byte pieces per loader thread, A / B tile
   // byte offsets of this thread's pieces inside the A / B row block (fixed-size arrays: a template-sized
@@ -830,17 +708,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     }                                                                                                       \
   }                                                                                                         \
   }
-  // pieces [lo, hi) of the wave's PA + PB pieces of one tile (staggered schedule)
-#define HG_DMA_PART(stage, k0, lo, hi)                                                                      \
-  {                                                                                                         \
-    _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8;                                          \
-    _Pragma("unroll") for (int c = (lo); c < (hi); ++c) {                                                   \
-      if (c < PA)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + c * LT * 8), 16, vA[c < PA ? c : 0], (k0) * 2, 0, 0); \
-      else                                                                                                  \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + (c - PA) * LT * 8), 16, vB[c >= PA ? c - PA : 0], (k0) * 2, 0, 0); \
-    }                                                                                                       \
-  }
   // A fragments per phase: 2 (x NT B fragments = 8..10 MFMAs, the other wave of the SIMD covers the fragment latency)
   constexpr int AF = 2;
   const int32_t fp4_unit_scale = 0x7f7f7f7f;  // FP4: E8M0 block scales of 2^0 for every 32-element block
@@ -867,7 +734,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     }
   }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
-  if (GLDS && nsteps > 1 && !HG_DMA_STAGGER) HG_DMA(1, BK)
+  if (GLDS && nsteps > 1) HG_DMA(1, BK)
   if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
@@ -894,13 +761,10 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         HG_STAMP(2)
         if (!HG_EXP(16)) __syncthreads();
         HG_STAMP(3)
-        if (GLDS && ks + 2 < nsteps && !HG_EXP(1) && !HG_DMA_STAGGER) HG_DMA(cur, (ks + 2) * BK)
+        if (GLDS && ks + 2 < nsteps && !HG_EXP(1)) HG_DMA(cur, (ks + 2) * BK)
         HG_STAMP(4)
         if (ks + 1 < nsteps && !HG_EXP(2) && !HG_EXP(32)) HG_FRAGS(0, nA, nB, 0, 0)
       }
-      constexpr int NPC = PA + PB, QP = (NPC + 3) / 4;  // pieces per wave and tile, per issue slot
-      if (GLDS && HG_DMA_STAGGER && t < 4 && ks + 1 < nsteps && wave < 4)
-        HG_DMA_PART(cur ^ 1, (ks + 1) * BK, t * QP < NPC ? t * QP : NPC, (t + 1) * QP < NPC ? (t + 1) * QP : NPC)
       __builtin_amdgcn_sched_barrier(0);
       if (HG_EXP(8)) {  // fragment reads without the MFMAs
 #pragma unroll
@@ -928,10 +792,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
                   __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t & 1][i], bfr[kk & 1][n], acc[AF * mp + i][n], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (GLDS && HG_DMA_STAGGER && t < 4 && ks + 1 < nsteps && wave >= 4) {
-        HG_DMA_PART(cur ^ 1, (ks + 1) * BK, t * QP < NPC ? t * QP : NPC, (t + 1) * QP < NPC ? (t + 1) * QP : NPC)
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
     HG_STAMP(5)
     if (CHUNKED && ++in_chunk == g.chunk_steps) {  // move the exact f32 partial sums into i32
@@ -946,7 +806,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         }
     }
   }
-  }  // !PP
   if constexpr (FP4)  // asm MFMAs: the hazard recogniser does not know that the accumulators come from the matrix pipe
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
   // The epilogue reuses the operand stages (every fragment read was retired by the last in-loop barrier):
@@ -1218,12 +1077,11 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
 
 // the instantiation's name as a profiler prints it (hg_ctx_last_kernel: bench.py matches it against the kernel names in
 // the committed rocprofv3 summaries before it quotes their counters)
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false,
-          bool PP = false>
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false>
 static std::string dist_kernel_name() {
   auto b = [](bool x) { return x ? "true" : "false"; };
   return std::string("dist_mfma_kernel<") + b(CHUNKED) + ", " + b(FULL) + ", " + b(BIG) + ", " + b(GLDS) + ", " +
-         std::to_string(NT) + ", " + b(I8) + ", " + b(HAM) + ", " + b(FP4) + ", " + b(PP) + ">";
+         std::to_string(NT) + ", " + b(I8) + ", " + b(HAM) + ", " + b(FP4) + ">";
 }
 #define HG_DIST_K(...) &dist_mfma_kernel<__VA_ARGS__>, dist_kernel_name<__VA_ARGS__>()
 
@@ -1348,10 +1206,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   };
   hg_timed tg(c, HG_T_DIST);
   hipError_t le;
-  const bool pp = c->dbg_dist_loop != "single";  // ping-pong main loop (the single-loop form: A/B partner)
-  if (fp4 && pp && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true, true), TileCfg<true, 5>::THREADS);
-  else if (fp4 && pp) le = launch(HG_DIST_K(false, false, true, true, 4, true, true, true, true), TileCfg<true, 4>::THREADS);
-  else if (fp4 && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true), TileCfg<true, 5>::THREADS);
+  if (fp4 && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true), TileCfg<true, 5>::THREADS);
   else if (fp4) le = launch(HG_DIST_K(false, false, true, true, 4, true, true, true), TileCfg<true, 4>::THREADS);
   else if (nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true), TileCfg<true, 5>::THREADS);
   else le = launch(HG_DIST_K(false, false, true, true, 4, true, true), TileCfg<true, 4>::THREADS);
@@ -1453,28 +1308,16 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
     const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
                                : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
-    for (const void *fp : {reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>),
-                           reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>),
-                           reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true, false, false, true>),
-                           reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true, false, false, true>)})
-      if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
-        HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        c->lds_attr_done.push_back(fp);
-      }
+    const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
+                             : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
+    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+      HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->lds_attr_done.push_back(fp);
+    }
     {
       hg_timed tmg(c, HG_T_DIST);
-      const bool pp = c->dbg_dist_loop != "single";
-      c->last_kernel_i8 = nt == 5 ? (pp ? dist_kernel_name<false, false, true, true, 5, true, false, false, true>()
-                                        : dist_kernel_name<false, false, true, true, 5, true>())
-                                  : (pp ? dist_kernel_name<false, false, true, true, 4, true, false, false, true>()
-                                        : dist_kernel_name<false, false, true, true, 4, true>());
-      if (pp && nt == 5)
-        hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true, false, false, true>), dim3(n_tiles),
-                           dim3(TileCfg<true, 5>::THREADS), lds, c->stream, g);
-      else if (pp)
-        hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true, false, false, true>), dim3(n_tiles),
-                           dim3(TileCfg<true, 4>::THREADS), lds, c->stream, g);
-      else if (nt == 5)
+      c->last_kernel_i8 = nt == 5 ? dist_kernel_name<false, false, true, true, 5, true>() : dist_kernel_name<false, false, true, true, 4, true>();
+      if (nt == 5)
         hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
                            c->stream, g);
       else
@@ -1665,10 +1508,6 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
                                               8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 256);
   if (big_chunked) le = launch(HG_DIST_K(true, false, true, true, NT_CHUNKED), TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
-  else if (big && nt == 5 && c->dbg_dist_loop != "single")
-    le = launch(HG_DIST_K(false, false, true, true, 5, false, false, false, true), TileCfg<true, 5>::THREADS, lds_wide);
-  else if (big && c->dbg_dist_loop != "single")
-    le = launch(HG_DIST_K(false, false, true, true, 4, false, false, false, true), TileCfg<true>::THREADS, lds_dma);
   else if (big && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5), TileCfg<true, 5>::THREADS, lds_wide);
   else if (big) le = launch(HG_DIST_K(false, false, true, true), TileCfg<true>::THREADS, lds_dma);
   else if (whole_k && full) le = launch(HG_DIST_K(false, true, false), TileCfg<false>::THREADS, lds_small);

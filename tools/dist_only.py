@@ -19,7 +19,6 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-ctx.set_debug("dist_loop", os.environ.get("HG_DIST_LOOP", ""))  # "single": the single-loop GEMM (A/B partner of the ping-pong loop)
 hv = bench.clustered_hvs(a.n, 0, dev, n=a.nhash)
 n2 = (hv.int() ** 2).sum(1).int()
 cap = max(1 << 20, a.n * a.n // 20)

@@ -13,7 +13,6 @@ R, Q, D = int(os.environ.get("HG_HAM_R", 50000)), int(os.environ.get("HG_HAM_Q",
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-ctx.set_debug("dist_loop", os.environ.get("HG_DIST_LOOP", ""))  # "single": the single-loop GEMM (A/B partner of the ping-pong loop)
 g = torch.Generator(device=dev)
 g.manual_seed(5)
 ref = torch.randint(-2**31, 2**31 - 1, (R, D // 32), dtype=torch.int32, device=dev, generator=g)
