@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dist", type=int, default=4096, help="R=Q for the dist timing (0 = skip)")
     ap.add_argument("--k", type=int, default=21)
-    ap.add_argument("--variants", default="", help="comma list of HG_KMER_VARIANT values to A/B (library built with -DHG_KMER_EXPERIMENT)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     ctx = hg.Context(0)
@@ -44,22 +43,6 @@ def main():
             print("sketch: %d genomes x %d bp in %.2f ms -> %.0f genomes/s, %.1f GB/s, nhash mean %.1f" % (
                 a.genomes, a.L, dt * 1e3, a.genomes / dt, a.genomes * (a.L + 2 * p.hv_d) / dt / 1e9,
                 nh.float().mean().item()))
-    if a.variants:
-        vs = [int(v) for v in a.variants.split(",")]
-        ctx.enable_timing(True)
-        res = {v: [] for v in vs}
-        for rnd in range(a.reps + 1):
-            for v in vs:
-                os.environ["HG_KMER_VARIANT"] = str(v)
-                ctx.timings()
-                ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
-                torch.cuda.synchronize()
-                ms = ctx.timings()["kmer"][0]
-                if rnd:
-                    res[v].append(ms)
-        for v in vs:
-            r = sorted(res[v])
-            print("variant %d: kmer kernel median %.3f ms  min %.3f  (%d rounds)" % (v, r[len(r) // 2], r[0], len(r)))
     if a.dist:
         R = a.dist
         g = torch.Generator(device=dev)
