@@ -23,6 +23,8 @@ def short(name):
                 return "kmer_sample_fast" + name.split("kmer_sample_fast")[1].split("(")[0]
             if "kmer_sample_grouped" in name:
                 return "kmer_sample_grouped" + name.split("kmer_sample_grouped")[1].split("(")[0]
+            if "kmer_sample_shared" in name:
+                return "kmer_sample_shared" + name.split("kmer_sample_shared")[1].split("(")[0]
             if "dist_mfma" in name:
                 return "dist_mfma_kernel" + name.split("dist_mfma_kernel")[1].split("(")[0]
             return k
