@@ -80,6 +80,23 @@ def test_hash_sets_ragged_lengths(ctx, orc, n):
             assert got.size == want.size and (got == want).all(), (k, dirty)
 
 
+@pytest.mark.parametrize("n", [3035, 3036, 3037, 3047, 3048, 3049, 3062, 3063, 3064, 3067, 3068, 3069, 6095, 6096, 6097,
+                               27323, 27324, 27325, 27351, 27352, 27431, 27432, 27433, 27452, 27453, 27459, 27460,
+                               54647, 54648, 54649, 54675, 54676, 54863, 54864, 54865, 54884, 54885])
+def test_hash_sets_shared_image_edges(ctx, orc, n):
+    """lengths around the tile / work-item edges of the shared-image kernel (k <= 21: tiles of 3 048 starts, items of
+    27 432; k >= 22: 3 036 and 27 324), +- k - 1, with and without a non-base near the end, both strands' images"""
+    rng = np.random.default_rng(n)
+    s = rand_seq(rng, n)
+    for dirty in (False, True):
+        if dirty:
+            s[n - 1 - int(rng.integers(0, 60))] = ord("N")
+        for k, canon in ((21, True), (28, True), (32, True), (22, True), (17, True), (21, False)):
+            want = orc.kmer_hash_sample(s, k, 3, canonical=canon)
+            got = ctx.kmer_hash_sample(s, k, 3, canonical=canon)
+            assert got.size == want.size and (got == want).all(), (k, canon, dirty)
+
+
 def test_hash_set_scaled1_every_kmer(ctx, orc):
     rng = np.random.default_rng(5)
     s = rand_seq(rng, 30000)
