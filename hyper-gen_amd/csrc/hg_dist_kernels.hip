@@ -473,6 +473,22 @@ struct TileCfg {
   static constexpr int LOADS_B = BN * BK * 2 / 16 / THREADS;  // ... B operand
 };
 
+// Dynamic LDS of dist_mfma_kernel: [ two operand stages | the epilogue's per-wave candidate lists, whichever is larger ]
+// followed by the tile's row / column words (norms, pre-filter thresholds, i8 info words; staged at kernel entry, so
+// they live beside the stages: 159 104 B for the 256 x 320 tile).
+constexpr uint32_t CAND_CAP = 2048;  // candidates per wave list: 16 KiB
+template <bool BIG, int NT, bool GLDS>
+constexpr size_t dist_lds_main_bytes() {
+  using TC = TileCfg<BIG, NT>;
+  const size_t stages = (size_t)2 * (TC::BM + TC::BN) * (GLDS ? BK : LDS_ROW) * sizeof(_Float16);
+  const size_t lists = (size_t)(TC::THREADS / 64) * CAND_CAP * 8;
+  return stages > lists ? stages : lists;
+}
+template <bool BIG, int NT, bool GLDS>
+constexpr size_t dist_lds_bytes() {
+  return dist_lds_main_bytes<BIG, NT, GLDS>() + (size_t)5 * (TileCfg<BIG, NT>::BM + TileCfg<BIG, NT>::BN) * 4 + 192;
+}
+
 struct GemmArgs {
   const _Float16 *A;  // Rp x Kp (ref)
   const _Float16 *B;  // Qp x Kp (query)
@@ -525,8 +541,20 @@ __device__ unsigned long long g_dist_stamps[16][2][8][6];
 #define HG_STAMP(pt)                                                                                       \
   if (lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 16 && ks >= 8 && ks < 16)                      \
     g_dist_stamps[blockIdx.x][wave == 5][ks - 8][pt] = __builtin_amdgcn_s_memtime();
+// ... and of the tile as a whole: lane 0 of every wave of workgroups 512..527 (the third round of tiles) into
+// g_dist_tile_stamps[wg][wave][point].  Points: 0 kernel entry, 1 first stage landed, 2 main loop done, 3 norms staged,
+// 4 accumulator sweep done, 5 lists emptied (tile done); inside the last flush_all: 6 candidates evaluated, 7 range
+// reserved, 8 hits written.
+__device__ unsigned long long g_dist_tile_stamps[16][8][10];
+__device__ unsigned long long g_dist_tile_all[2048][4];  // per workgroup: entry, main loop done, tile done, candidates evaluated
+#define HG_TSTAMP(pt)                                                                                      \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528)                                    \
+    g_dist_tile_stamps[blockIdx.x - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();            \
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 0 || (pt) == 2 || (pt) == 5))                      \
+    g_dist_tile_all[blockIdx.x][(pt) == 0 ? 0 : ((pt) == 2 ? 1 : 2)] = __builtin_amdgcn_s_memtime();
 #else
 #define HG_STAMP(pt)
+#define HG_TSTAMP(pt)
 #endif
 // FULL: every ANI is evaluated and stored (parity / small problems).  Otherwise only pairs that can
 // reach ani_th are evaluated: one multiply-compare rejects the rest (ANI is monotone in the Jaccard
@@ -556,6 +584,10 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
   static_assert(!FP4 || HAM, "e2m1 operands exist for the Hamming search only");
+  HG_TSTAMP(0)
+#ifdef HG_DIST_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 2048) g_dist_tile_all[blockIdx.x][3] = 0;
+#endif
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
   if (I8 && !HAM) {
     const bool ok = i8_attempt_valid(g.i8ctrl, g.ent_cap);
@@ -724,6 +756,36 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     _Pragma("unroll") for (int i_ = 0; i_ < AF; ++i_)                                                       \
         afr[buf][i_] = *reinterpret_cast<const half8 *>((pa) + (AF * (mp) + i_) * 16 * LROW + ko_);         \
   }
+  // The tile's row / column words for the epilogue are staged NOW: their global loads are issued in front of the
+  // first operand tile's, travel with it, and the barrier below publishes what is computed from them (fetched after
+  // the K loop they cost a dependent-load latency per tile with nothing to hide it behind).  Per row / column: the
+  // norm, the i8 path's info / outlier words, and the phase-0 threshold (see the epilogue), so that the accumulator
+  // sweep reads ONE float per row and column.
+  int32_t *s_nr = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(sAB) + dist_lds_main_bytes<BIG, NT, GLDS>()), *s_nq = s_nr + BM;
+  int32_t *s_ir = s_nq + BN, *s_iq = s_ir + BM;                                 // i8 path: 2*S + e per row / column
+  int32_t *s_sr = s_iq + BN, *s_sq = s_sr + BM;                                 // ... the outlier-entry slots
+  uint32_t *s_fr = reinterpret_cast<uint32_t *>(s_sq + BN), *s_fq = s_fr + BM;  // ... and their first entries
+  float *s_ur = reinterpret_cast<float *>(s_fq + BN), *s_tq = s_ur + BM;        // phase-0 thresholds
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_tq + BN);                    // per-wave hit counts + the workgroup's base
+  uint32_t *s_tot = s_cnt + 2 * (THREADS / 64) + 4, *s_fill = s_tot + THREADS / 64;  // (behind the list lengths and flags) candidates per wave: counted / appended
+  constexpr int32_t NORM_SAFE = 1 << 29;
+  constexpr int WORD_PASSES = (BM + BN + THREADS - 1) / THREADS;
+  int32_t w_nv[WORD_PASSES], w_info[WORD_PASSES], w_slot[WORD_PASSES];
+  uint32_t w_first[WORD_PASSES];
+#pragma unroll
+  for (int p = 0; p < WORD_PASSES; ++p) {
+    const uint32_t t = tid + (uint32_t)p * THREADS;
+    const bool is_r = t < (uint32_t)BM;
+    const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
+    const bool in = t < (uint32_t)(BM + BN) && idx < (is_r ? g.R : g.Q);
+    w_nv[p] = (in && !HAM) ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
+    w_info[p] = w_slot[p] = 0, w_first[p] = 0u;
+    if (I8 && !HAM) {
+      w_info[p] = in ? (is_r ? g.info_r[idx] : g.info_q[idx]) : 0;
+      w_slot[p] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
+      w_first[p] = in ? (is_r ? g.first_r[idx] : g.first_q[idx]) : 0u;
+    }
+  }
   if (GLDS) {
     HG_DMA(0, 0)
   } else {
@@ -733,7 +795,47 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       HG_GLOAD(BK)
     }
   }
+  {
+    // Phase 0 (thresholded mode): dot >= j_lo * (nr + nq - dot) rewritten as dot >= c * (nr + nq) with
+    // c = j_lo / (1 + j_lo) shaved by 1e-5, evaluated in f32 straight from the accumulator: one add and one compare
+    // per element.  Invalid rows / columns carry +1e30, norms outside [0, 2^29] -- where the i32 denominator could
+    // wrap -- carry -1e20 (phase 1 decides those).
+    // i8 path: the accumulator holds G = sum a_r*a_q and
+    //   dot = 4*G + 4*corrR(i,j) + 4*corrQ(i,j) - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q,
+    // so dot <= 4*G + [2|S_r| + 1016*B_i] + [2|S_q| + 508*B_j] + D  (B = the row's sum |b| over its clamped entries:
+    // |corrR| <= B_i*254, |corrQ| <= B_j*127).  The bracketed per-row / per-column slacks are folded into the row and
+    // column thresholds (+64 for the i32 -> f32 rounding); rows without clamped entries, the normal case, only pay
+    // 2|S|.  Phase 2 evaluates the exact integer.
+    const float p0_scale = I8 ? 0.25f : 1.f;
+#pragma unroll
+    for (int p = 0; p < WORD_PASSES; ++p) {
+      const uint32_t t = tid + (uint32_t)p * THREADS;
+      if (t >= (uint32_t)(BM + BN)) break;
+      const bool is_r = t < (uint32_t)BM;
+      const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
+      const bool in = idx < (is_r ? g.R : g.Q);
+      const int32_t nv = w_nv[p];
+      s_nr[t] = nv;
+      float slack = 0.f;
+      if (I8 && !HAM) {
+        const int32_t info = w_info[p], slot = w_slot[p];
+        s_ir[t] = info;
+        s_sr[t] = slot;
+        s_fr[t] = w_first[p];
+        const int32_t s2 = info - (info & 1);  // 2*S
+        slack = (float)(s2 < 0 ? -s2 : s2) + (is_r ? 1016.f : 508.f) * (float)(slot & 0x3fff);
+        if (!is_r) slack += (float)g.hv_d + 64.f;
+      }
+      // (finite sentinels, so that `d - ur - tq` is never NaN: "out of range" outweighs "norm outside the safe range")
+      if (HAM) s_ur[t] = !in ? 1e30f : (is_r ? 0.f : (float)g.ham_thr);  // G >= ham_thr, exact while D <= 2^24
+      else s_ur[t] = !in ? 1e30f
+                         : ((nv < 0 || nv > NORM_SAFE) ? -1e20f : (g.pre_c * (float)nv + (is_r ? 0.f : g.pre_b) - slack) * p0_scale);
+    }
+    if (tid < 3) s_cnt[THREADS / 64 + 1 + THREADS / 64 + tid] = 0u;  // "some candidate list is nearly full": three slots in rotation
+    if (tid < (uint32_t)(THREADS / 64)) s_fill[tid] = 0u;
+  }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
+  HG_TSTAMP(1)
   if (GLDS && nsteps > 1) HG_DMA(1, BK)
   if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
@@ -806,35 +908,25 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         }
     }
   }
+  HG_TSTAMP(2)
   if constexpr (FP4)  // asm MFMAs: the hazard recogniser does not know that the accumulators come from the matrix pipe
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-  // The epilogue reuses the operand stages (every fragment read was retired by the last in-loop barrier):
-  // per-wave candidate lists, then the tile's BM + BN norms -- phase 2 gathers them by candidate, and from
-  // global memory each 64-candidate batch paid a full dependent-load latency (0.12 ms per launch at 1.3 M hits).
-  constexpr uint32_t CAND_CAP = 2048;  // 16 KiB per wave
-  int32_t *s_nr = reinterpret_cast<int32_t *>(reinterpret_cast<uint2 *>(sAB) + (THREADS / 64) * CAND_CAP), *s_nq = s_nr + BM;
-  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_nq + BN);  // per-wave hit counts + the workgroup's base
-  int32_t *s_ir = reinterpret_cast<int32_t *>(s_cnt + THREADS / 64 + 1), *s_iq = s_ir + BM;  // i8 path: 2*S + e per row / column
-  int32_t *s_sr = s_iq + BN, *s_sq = s_sr + BM;                                             // ... the outlier-entry slots
-  uint32_t *s_fr = reinterpret_cast<uint32_t *>(s_sq + BN), *s_fq = s_fr + BM;              // ... and their first entries
-  for (uint32_t t = tid; t < (uint32_t)(BM + BN); t += THREADS) {
-    const bool is_r = t < (uint32_t)BM;
-    const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
-    const bool in = idx < (is_r ? g.R : g.Q);
-    s_nr[t] = (in && !HAM) ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
-    if (I8 && !HAM) {
-      s_ir[t] = in ? (is_r ? g.info_r[idx] : g.info_q[idx]) : 0;
-      s_sr[t] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
-      s_fr[t] = in ? (is_r ? g.first_r[idx] : g.first_q[idx]) : 0u;
-    }
-  }
-  if (tid < 3) (s_fq + BN)[THREADS / 64 + tid] = 0u;  // "some candidate list is nearly full": three slots in rotation
-  __syncthreads();
+  // The epilogue reuses the operand stages for its per-wave candidate lists (every fragment read was retired by the
+  // last in-loop barrier); phase 2 gathers the norms staged at kernel entry by candidate (from global memory each
+  // 64-candidate batch paid a full dependent-load latency: 0.12 ms per launch at 1.3 M hits).
 #undef HG_GLOAD
 #undef HG_LSTORE
 #undef HG_DMA
 #undef HG_FRAGS
 
+  // The epilogue's per-lane addressing starts again from an opaque copy of the thread index: derived from the values
+  // above it is loop invariant, gets hoisted in front of the K loop and takes registers the main loop does not have
+  // (the i8 kernels went through scratch: 313 spilled registers).
+  uint32_t tid_opaque = threadIdx.x;
+  asm volatile("" : "+v"(tid_opaque));
+  {  // (closed at the end of the kernel)
+  const uint32_t tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
+  const uint32_t wm = wave / NWN, wn = wave % NWN, fr = lane & 15, fq = lane >> 4;
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
   // Phase 1 (unrolled over the accumulator registers, a handful of instructions per element): one
   // multiply-compare against a conservative Jaccard bound keeps only the pairs that can reach the
@@ -921,10 +1013,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round, and one atomic per
   // wave kept every CU waiting ~25 us per round), and the batches of all lists dealt round-robin to the waves.
   constexpr uint32_t NW_ = THREADS / 64;
-  uint32_t *s_len = s_fq + BN;  // the list lengths + three "some list is nearly full" flags (slot m % 3)
+  uint32_t *s_len = s_cnt + NW_ + 1;  // the list lengths + three "some list is nearly full" flags (slot m % 3)
   auto flush_all = [&]() __attribute__((always_inline)) {
     if (lane == 0) s_len[wave] = staged;
     __syncthreads();
+#ifdef HG_DIST_STAMPS
+    if (tid == 0 && blockIdx.x < 2048)
+      for (uint32_t w = 0; w < NW_; ++w) g_dist_tile_all[blockIdx.x][3] += s_len[w];
+#endif
     uint2 *all = reinterpret_cast<uint2 *>(sAB);
     uint32_t nh = 0, kglob = 0;
     for (uint32_t l = 0; l < NW_; ++l) {
@@ -934,6 +1030,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       for (uint32_t k = first; k < nb; k += NW_) nh += phase2_batch(cl, k * 64, n_list);
       kglob += nb;
     }
+    HG_TSTAMP(6)
     if (lane == 0) s_cnt[wave] = nh;
     __syncthreads();
     if (tid == 0) {
@@ -943,6 +1040,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       s_cnt[NW_] = total ? atomicAdd(g.hit_count, total) : 0u;
     }
     __syncthreads();
+    HG_TSTAMP(7)
     uint32_t off = s_cnt[NW_];
     for (uint32_t w = 0; w < wave; ++w) off += s_cnt[w];
     kglob = 0;
@@ -953,74 +1051,145 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       for (uint32_t k = first; k < nb; k += NW_) off += write_batch(cl, k * 64, n_list, off);
       kglob += nb;
     }
+    HG_TSTAMP(8)
     staged = 0;
     __syncthreads();  // the lists may be refilled only after every wave has read them
   };
-  // Phase 0 (thresholded mode): dot >= j_lo * (nr + nq - dot) rewritten as dot >= c * (nr + nq) with
-  // c = j_lo / (1 + j_lo) shaved by 1e-5, evaluated in f32 straight from the accumulator: one add, one
-  // compare and one wave-uniform branch per element slot.  Only slots where some lane passes (a superset
-  // of what phase 1 keeps: invalid rows/columns carry +inf, norms outside [0, 2^29] -- where the i32
-  // denominator could wrap -- carry -inf) run phase 1.
-  constexpr int32_t NORM_SAFE = 1 << 29;
+  // Phase 0: `d >= ur(row) + tq(column)` with the thresholds staged at kernel entry: the lane's NT column thresholds are
+  // fetched here, the four row thresholds of a slab with one 16-byte read per slab (all 4 * WTM of them kept in
+  // registers from the top push the i8 kernels into scratch).
   int32_t nqv[NT];
   float tq[NT];
-  // i8 path: the accumulator holds G = sum a_r*a_q and
-  //   dot = 4*G + 4*corrR(i,j) + 4*corrQ(i,j) - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q,
-  // so dot <= 4*G + [2|S_r| + 1016*B_i] + [2|S_q| + 508*B_j] + D  (B = the row's sum |b| over its clamped entries:
-  // |corrR| <= B_i*254, |corrQ| <= B_j*127).  Phase 0 stays one convert + add + compare per element: the bracketed
-  // per-row / per-column slacks are folded into the row and column thresholds (+64 for the i32 -> f32 rounding);
-  // rows without clamped entries, the normal case, only pay 2|S|.  Phase 2 evaluates the exact integer.
-  const float p0_scale = I8 ? 0.25f : 1.f;
-  auto i8_row_slack = [&](int32_t info, int32_t slot, float per_b) __attribute__((always_inline)) -> float {
-    const int32_t s2 = info - (info & 1);  // 2*S
-    return (float)(s2 < 0 ? -s2 : s2) + per_b * (float)(slot & 0x3fff);
-  };
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const uint32_t j = col0 + wn * (NT * 16) + n * 16 + fr;
     nqv[n] = s_nq[wn * (NT * 16) + n * 16 + fr];
-    float slack = 0.f;
-    if (I8 && !HAM) slack = i8_row_slack(s_iq[wn * (NT * 16) + n * 16 + fr], s_sq[wn * (NT * 16) + n * 16 + fr], 508.f) + (float)g.hv_d + 64.f;
-    tq[n] = j >= g.Q ? INFINITY
-                     : ((nqv[n] < 0 || nqv[n] > NORM_SAFE) ? -INFINITY
-                                                           : (g.pre_c * (float)nqv[n] + g.pre_b - slack) * p0_scale);
+    tq[n] = s_tq[wn * (NT * 16) + n * 16 + fr];
   }
+  const float4v *s_ur4 = reinterpret_cast<const float4v *>(s_ur + wm * (WTM * 16) + fq * 4);  // slab m: s_ur4[4 m]
+  HG_TSTAMP(3)
+  // Two ways through the accumulators (in-kernel stamps, DESIGN.md 4.3: with one branch per element and the row words
+  // read slab by slab the sweep took 20 000 cycles in a tile without a single candidate and 25 000 more in a tile with
+  // the ~1 000 scattered candidates every tile of a real comparison has):
+  //  * LANE MASKS (i8 / Hamming kernels, tiles off the diagonal of a symmetric comparison -- there a candidate is
+  //    exactly "passes phase 0"): every lane shifts the sign of `d - ur - tq` of its 4 * NT elements of a 16-row slab
+  //    into one mask word per slab, no branches.  One barrier makes the waves' candidate counts known to all: a tile
+  //    without candidates ends there; if no list can overflow, every wave then appends its candidates on its own --
+  //    per slab one LDS atomic per lane that has any reserves its run of the list, predicated stores fill it -- and
+  //    the workgroup meets again in flush_all.
+  //  * SLABS (everything else, and tiles whose candidates may overflow a list): per 16-row slab the 4 * NT compares
+  //    are OR-ed on the scalar side into one wave-uniform branch; a slab with candidates takes one ballot per element,
+  //    and a barrier per slab makes the decision to empty the lists uniform.
+  constexpr bool LANE_MASKS = !FULL && I8;
+  constexpr uint32_t SLAB_BITS = (1u << (4 * NT)) - 1u;
+  bool by_lane = false;  // workgroup-uniform
+  uint32_t notpass[LANE_MASKS ? WTM : 1], lane_cands = 0;
+  if constexpr (LANE_MASKS) {
+    if (!(g.symmetric && row0 + g.ref_off + (uint32_t)BM - 1u >= col0 + g.qry_off)) {
+      uint32_t lane_total = 0;
+      dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        uint32_t np = 0;
+        const float4v ur4 = s_ur4[4 * m];
+        dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            // (the convert as asm: written as a cast it is the same expression as in the slab path below, gets computed
+            // once for both, and 160 converted accumulators stay live next to the 160 originals -- scratch)
+            float d;
+            if constexpr (std::is_same<acc_t, int4v>::value) asm("v_cvt_f32_i32_e32 %0, %1" : "=v"(d) : "v"(acc[m][n][r]));
+            else d = acc[m][n][r];
+            const float margin = (d - ur4[r]) - tq[n];  // (finite sentinels: never NaN)
+            np = __builtin_amdgcn_alignbit(np, __float_as_uint(margin), 31);  // (np << 1) | sign: element e = r * NT + n at bit 4 NT - 1 - e
+          });
+        });
+        notpass[m] = np;
+        lane_total += (uint32_t)__popc(~np & SLAB_BITS);
+      });
+      lane_cands = lane_total;
+      for (int o = 32; o > 0; o >>= 1) lane_total += __shfl_xor(lane_total, o);
+      if (lane == 0) s_tot[wave] = lane_total;
+      __syncthreads();
+      const uint32_t tw = lane < (uint32_t)(THREADS / 64) ? s_tot[lane] : 0u;
+      if (__ballot(tw != 0u) == 0) {  // nothing in this tile
+        HG_TSTAMP(4)
+        HG_TSTAMP(5)
+        return;
+      }
+      by_lane = __ballot(tw > CAND_CAP) == 0;
+    }
+  }
+  if (by_lane) {
+    if constexpr (LANE_MASKS) {
+      uint32_t off = 0;  // one LDS atomic per lane reserves the run of the wave's list that takes all its candidates
+      if (lane_cands != 0u) off = atomicAdd(&s_fill[wave], lane_cands);
+      dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const uint32_t pm = ~notpass[m] & SLAB_BITS;
+        if (__ballot(pm != 0u) == 0) return;  // wave-uniform
+        const uint32_t key0 = ((wm * (WTM * 16) + m * 16 + fq * 4) << 16) | (wn * (NT * 16) + fr);
+        dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            if (pm & (1u << (4 * NT - 1 - (r * NT + n)))) {
+              cand[off] = make_uint2(key0 + ((uint32_t)r << 16) + (uint32_t)n * 16u, (uint32_t)(int32_t)acc[m][n][r]);
+              ++off;
+            }
+          });
+        });
+      });
+      staged = __builtin_amdgcn_readfirstlane(s_fill[wave]);  // (this wave's LDS operations are in order)
+    }
+  } else {
   // (compile-time m, r, n: the accumulator registers must be indexed statically whatever the optimiser thinks of the
   // size of the unrolled body -- a loop it declines to unroll sends all 160 accumulators through scratch)
   dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
     constexpr int m = decltype(mc)::value;
-    dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
-      const bool iok = i < g.R;
-      const int32_t nri = s_nr[li];
-      float rslack = 0.f;
-      if (I8 && !HAM) rslack = i8_row_slack(s_ir[li], s_sr[li], 1016.f);
-      const float ur = !iok ? INFINITY : ((nri < 0 || nri > NORM_SAFE) ? -INFINITY : (g.pre_c * (float)nri - rslack) * p0_scale);
-      dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
-        constexpr int n = decltype(nc)::value;
+    const float4v ur4 = s_ur4[4 * m];
+    auto passes = [&](auto rc, auto nc) __attribute__((always_inline)) -> bool {
+      constexpr int r = decltype(rc)::value, n = decltype(nc)::value;
+      if constexpr (FULL) return true;
+      else if constexpr (HAM) return (int32_t)acc[m][n][r] >= g.ham_thr;
+      else {
         float d = (float)acc[m][n][r];
         if (CHUNKED) d += (float)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
-        bool pass = FULL || d >= ur + tq[n];
-        if constexpr (HAM) pass = (int32_t)acc[m][n][r] >= g.ham_thr;
-        if (__ballot(pass) == 0) return;  // wave-uniform: typically > 80 % of the element slots
-        const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
-        int32_t dot = (int32_t)acc[m][n][r];
-        if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
-        bool live = pass && iok && j < g.Q && !(g.symmetric && i + g.ref_off >= j + g.qry_off);
-        if (!FULL && !I8) {  // (i8 operands: the list carries the raw G, phase 2 forms the exact dot product)
-          const int32_t den = (int32_t)((uint32_t)nri + (uint32_t)nqv[n] - (uint32_t)dot);
-          live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
-        }
-        const unsigned long long bal = __ballot(live);
-        if (live) {
-          const uint32_t pos =
-              staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          cand[pos] = make_uint2((li << 16) | lj, (uint32_t)dot);
-        }
-        staged += (uint32_t)__popcll(bal);
+        return d >= ur4[r] + tq[n];
+      }
+    };
+    unsigned long long slab = FULL ? ~0ull : 0ull;
+    if constexpr (!FULL) {
+      dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+        dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) { slab |= __ballot(passes(rc, nc)); });
       });
-    });
+    }
+    if (slab != 0) {  // wave-uniform
+      dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
+        const bool iok = i < g.R;
+        dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          const bool pass = passes(rc, nc);
+          if (__ballot(pass) == 0) return;  // wave-uniform
+          const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
+          int32_t dot = (int32_t)acc[m][n][r];
+          if (CHUNKED) dot = (int32_t)((uint32_t)dot + (uint32_t)iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]);
+          bool live = pass && iok && j < g.Q && !(g.symmetric && i + g.ref_off >= j + g.qry_off);
+          if (!FULL && !I8) {  // (i8 operands: the list carries the raw G, phase 2 forms the exact dot product)
+            const int32_t den = (int32_t)((uint32_t)s_nr[li] + (uint32_t)nqv[n] - (uint32_t)dot);
+            live = live && (den <= 0 || (float)dot >= g.j_lo * (float)den);
+          }
+          const unsigned long long bal = __ballot(live);
+          if (live) {
+            const uint32_t pos =
+                staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            cand[pos] = make_uint2((li << 16) | lj, (uint32_t)dot);
+          }
+          staged += (uint32_t)__popcll(bal);
+        });
+      });
+    }
     // At most 4 * NT * 64 candidates per m and wave.  A list that might overflow in the next m (dense blocks of hits
     // only) is emptied by the WHOLE workgroup: the decision is made uniform through LDS, one barrier per m.
     if constexpr (m + 1 < WTM) {
@@ -1035,7 +1204,11 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       if (any_full) flush_all();
     }
   });
+  }
+  HG_TSTAMP(4)
   flush_all();  // end of the tile
+  HG_TSTAMP(5)
+  }
 }
 
 // ---- always-exact integer fallback -------------------------------------------------------------------
@@ -1191,8 +1364,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   }
   g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
   const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
-  const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
-                             : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
+  const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
   auto launch = [&](auto kern, const std::string &name, int threads) -> hipError_t {
     c->last_kernel[HG_T_DIST] = name;
     const void *fp = reinterpret_cast<const void *>(kern);
@@ -1306,8 +1478,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
     const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
-    const size_t lds = nt == 5 ? std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256)
-                               : std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
+    const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
     const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
                              : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
     if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
@@ -1499,14 +1670,11 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(threads), lds, c->stream, g);
     return hipGetLastError();
   };
-  const size_t lds_small = 2 * (128 + 128) * LDS_ROW * sizeof(_Float16);
   hipError_t le;
-  // (the epilogue of the big geometry needs 8 x 16 KiB of candidate lists + 2 KiB of norms)
-  // (+ the same number of info words for the i8 operand path)
-  const size_t lds_dma = std::max<size_t>(2 * (256 + 256) * BK * sizeof(_Float16), 8 * 2048 * 8 + 512 * 16 + 256);
-  const size_t lds_wide = std::max<size_t>(2 * (256 + 320) * BK * sizeof(_Float16), 8 * 2048 * 8 + 576 * 16 + 256);
-  const size_t lds_chunked = std::max<size_t>(2 * (256 + 64 * NT_CHUNKED) * BK * sizeof(_Float16),
-                                              8 * 2048 * 8 + (256 + 64 * NT_CHUNKED) * 16 + 256);
+  // (two operand stages or the epilogue's candidate lists, + the tile's row / column words: dist_lds_bytes)
+  const size_t lds_small = dist_lds_bytes<false, 4, false>(), lds_dma = dist_lds_bytes<true, 4, true>();
+  const size_t lds_wide = dist_lds_bytes<true, 5, true>(), lds_chunked = dist_lds_bytes<true, NT_CHUNKED, true>();
+  static_assert(dist_lds_bytes<true, 5, true>() <= 160 * 1024, "the widest tile fits the CU's LDS");
   if (big_chunked) le = launch(HG_DIST_K(true, false, true, true, NT_CHUNKED), TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
   else if (big && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5), TileCfg<true, 5>::THREADS, lds_wide);
   else if (big) le = launch(HG_DIST_K(false, false, true, true), TileCfg<true>::THREADS, lds_dma);
@@ -1532,6 +1700,12 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
 }
 
 #ifdef HG_DIST_STAMPS
+extern "C" int hg_debug_dist_tile_all(unsigned long long *out /* 2048 * 4 */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_all), sizeof(unsigned long long) * 2048 * 4);
+}
+extern "C" int hg_debug_dist_tile_stamps(unsigned long long *out /* 16 * 8 * 10 */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_stamps), sizeof(unsigned long long) * 16 * 8 * 10);
+}
 extern "C" int hg_debug_dist_stamps(unsigned long long *out /* 16 * 2 * 8 * 6 */) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_stamps), sizeof(unsigned long long) * 16 * 2 * 8 * 6);
 }
