@@ -475,7 +475,7 @@ struct TileCfg {
 
 // Dynamic LDS of dist_mfma_kernel: [ two operand stages | the epilogue's per-wave candidate lists, whichever is larger ]
 // followed by the tile's row / column words (norms, pre-filter thresholds, i8 info words; staged at kernel entry, so
-// they live beside the stages: 159 104 B for the 256 x 320 tile).
+// they live beside the stages: 161 472 B for the 256 x 320 tile).
 constexpr uint32_t CAND_CAP = 2048;  // candidates per wave list: 16 KiB
 template <bool BIG, int NT, bool GLDS>
 constexpr size_t dist_lds_main_bytes() {
@@ -486,7 +486,7 @@ constexpr size_t dist_lds_main_bytes() {
 }
 template <bool BIG, int NT, bool GLDS>
 constexpr size_t dist_lds_bytes() {
-  return dist_lds_main_bytes<BIG, NT, GLDS>() + (size_t)5 * (TileCfg<BIG, NT>::BM + TileCfg<BIG, NT>::BN) * 4 + 192;
+  return dist_lds_main_bytes<BIG, NT, GLDS>() + (size_t)6 * (TileCfg<BIG, NT>::BM + TileCfg<BIG, NT>::BN) * 4 + 192;
 }
 
 struct GemmArgs {
@@ -525,7 +525,8 @@ struct GemmArgs {
   int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
-// compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only
+// compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only,
+// 64 no outlier corrections in phase 2
 #ifdef HG_DIST_EXPERIMENT
 #define HG_EXP(bit) ((HG_DIST_EXPERIMENT & (bit)) != 0)
 #else
@@ -766,7 +767,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   int32_t *s_sr = s_iq + BN, *s_sq = s_sr + BM;                                 // ... the outlier-entry slots
   uint32_t *s_fr = reinterpret_cast<uint32_t *>(s_sq + BN), *s_fq = s_fr + BM;  // ... and their first entries
   float *s_ur = reinterpret_cast<float *>(s_fq + BN), *s_tq = s_ur + BM;        // phase-0 thresholds
-  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_tq + BN);                    // per-wave hit counts + the workgroup's base
+  uint32_t *s_er = reinterpret_cast<uint32_t *>(s_tq + BN), *s_eq = s_er + BM;  // i8 path: the first clamped entry itself, d | b << 16
+  uint32_t *s_cnt = s_eq + BN;                                                  // per-wave hit counts + the workgroup's base
   uint32_t *s_tot = s_cnt + 2 * (THREADS / 64) + 4, *s_fill = s_tot + THREADS / 64;  // (behind the list lengths and flags) candidates per wave: counted / appended
   constexpr int32_t NORM_SAFE = 1 << 29;
   constexpr int WORD_PASSES = (BM + BN + THREADS - 1) / THREADS;
@@ -822,6 +824,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         s_ir[t] = info;
         s_sr[t] = slot;
         s_fr[t] = w_first[p];
+        // (phase 2 needs the other operand's value at this entry's dimension: with the entry here that is ONE global
+        // load per candidate that has one instead of two dependent ones, with nothing to hide them behind)
+        uint32_t ew = 0u;
+        if (((uint32_t)slot >> 14) & 255u) {
+          const I8Outlier o = g.ents[w_first[p]];
+          ew = (uint32_t)o.d | ((uint32_t)(uint8_t)o.b << 16);
+        }
+        s_er[t] = ew;
         const int32_t s2 = info - (info & 1);  // 2*S
         slack = (float)(s2 < 0 ? -s2 : s2) + (is_r ? 1016.f : 508.f) * (float)(slot & 0x3fff);
         if (!is_r) slack += (float)g.hv_d + 64.f;
@@ -948,55 +958,96 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   }
   uint2 *cand = reinterpret_cast<uint2 *>(sAB) + wave * CAND_CAP;
   uint32_t staged = 0;  // wave-uniform
-  // i8 operands: G = sum a_r*a_q  ->  the exact dot product.  First the tabulated products of the clamped entries of
-  // row i / column j (rare: ~4 % of the rows have one), then dot = 4*sum c_r*c_q - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q
-  // (info word = 2*S + e).  Runs per candidate in phase 2, outside the unrolled accumulator sweep.
-  auto i8_exact_dot = [&](int32_t G, uint32_t li, uint32_t lj, uint32_t gi, uint32_t gj) __attribute__((always_inline)) -> int32_t {
-    const int32_t sr = s_sr[li], sq = s_sq[lj];
-    const uint32_t ur_ = (uint32_t)sr, uq_ = (uint32_t)sq;  // count (8) | sum |b| (14)
-    const int32_t ir = s_ir[li], iq = s_iq[lj];
-    const int32_t er = ir & 1, eq = iq & 1;
-    for (uint32_t t = 0; t < ((ur_ >> 14) & 255u); ++t) {  // b_i[d] * c_j[d], c = the true centred count of column j
-      const I8Outlier o = g.ents[s_fr[li] + t];
-      G += (int32_t)o.b * (((int32_t)g.raw_q[(size_t)gj * g.hv_d + o.d] + eq) >> 1);
+  // Phase 2 on a list: the reference's float32 ANI of every candidate (src/dist.rs:153-160), threshold; the ANI
+  // overwrites the dot product in place, a miss is marked 0xFFFFFFFF (no non-negative float has that pattern), the
+  // compaction happens on the way out, after the range has been reserved.  Batches of 64 candidates touch only their
+  // own entries, so they are independent: the batches of ALL lists are dealt round-robin to the waves (a cluster's block
+  // of hits sits in two or three waves' lists), and a wave takes them U at a time with the loads of all U in front of
+  // the arithmetic.  That matters on the i8 path: G = sum a_r*a_q becomes the exact dot product through the tabulated
+  // products of the clamped entries of row i / column j (~4 % of the rows have one, so nearly every batch has a lane
+  // that needs them), and those are two DEPENDENT global loads -- the entry, then the other operand's value at the
+  // entry's dimension: taken batch by batch they were most of phase 2's time (in-kernel stamps: 4 000 cycles per batch;
+  // 6 % of the kernel at 1.3 M hits).  Here the first entry of row and column is requested for all U batches before any
+  // of them is used; further entries of a row (rare) run in a loop behind a wave-uniform test.  dot = 4*sum c_r*c_q - 2*e_q*S_r - 2*e_r*S_q + D*e_r*e_q (info word = 2*S + e).
+  constexpr uint32_t NW_ = THREADS / 64;
+  auto phase2_group = [&](uint2 *cl, uint32_t k0, uint32_t nb, uint32_t n_list, auto uc) __attribute__((always_inline)) -> uint32_t {  // batches k0, k0 + NW_, ...; returns their hit count
+    constexpr int U = decltype(uc)::value;
+    uint32_t e[U], key[U], hits = 0;
+    int32_t val[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t k = k0 + (uint32_t)u * NW_;
+      e[u] = k * 64 + lane;
+      valid[u] = k < nb && e[u] < n_list;
+      const uint2 c2 = cl[valid[u] ? e[u] : 0u];  // (entry 0 exists: nb > 0)
+      key[u] = c2.x, val[u] = (int32_t)c2.y;
     }
-    {
-      for (uint32_t t = 0; t < ((uq_ >> 14) & 255u); ++t) {  // a_i[d] * b_j[d], a = the clamped byte of row i
-        const I8Outlier o = g.ents[s_fq[lj] + t];
-        const int32_t cc = ((int32_t)g.raw_r[(size_t)gi * g.hv_d + o.d] + er) >> 1;
-        G += (int32_t)o.b * (cc > 127 ? 127 : (cc < -127 ? -127 : cc));
+    if constexpr (HAM) {  // G = D - 2 * hamming; the pre-filter was exact
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (valid[u]) cl[e[u]].y = (uint32_t)((int32_t)g.hv_d - val[u]) >> 1;
+        hits += (uint32_t)__popcll(__ballot(valid[u]));
       }
-    }
-    return 4 * G - eq * (ir - er) - er * (iq - eq) + (er & eq) * (int32_t)g.hv_d;
-  };
-  // phase 2 on cand[0 .. staged): exact ANI, hits compacted to cand[0 .. nh)
-  // Phase 2 is latency bound (a chain of LDS reads, a log and three divisions per batch, two waves per SIMD to hide it
-  // behind: a tile with a dense block of hits used to take twice as long as a sparse one).  Every batch of 64
-  // candidates therefore touches only ITS OWN list entries -- the ANI overwrites the dot product in place, a miss is
-  // marked 0xFFFFFFFF (no non-negative float has that pattern) -- so batches are independent: several are in flight
-  // per wave, and at the end of the tile the batches of ALL eight lists are dealt round-robin to the eight waves (a
-  // cluster's block of hits sits in two or three waves' lists).  The compaction happens on the way out, after the
-  // range has been reserved.
-  auto phase2_batch = [&](uint2 *cl, uint32_t b, uint32_t n_list) __attribute__((always_inline)) -> uint32_t {  // returns the batch's hit count
-    const uint32_t e = b + lane;
-    bool hit = false;
-    if (e < n_list) {
-      uint2 c2 = cl[e];
-      if constexpr (HAM) {  // G = D - 2 * hamming; the pre-filter was exact
-        hit = true;
-        cl[e].y = (uint32_t)((int32_t)g.hv_d - (int32_t)c2.y) >> 1;
-      } else {
-        const uint32_t gi = row0 + (c2.x >> 16), gj = col0 + (c2.x & 0xffffu);
-        if constexpr (I8) c2.y = (uint32_t)i8_exact_dot((int32_t)c2.y, c2.x >> 16, c2.x & 0xffffu, gi, gj);
-        const float ani = ani_from_dot((int32_t)c2.y, s_nr[c2.x >> 16], s_nq[c2.x & 0xffffu], g.kf);
-        if constexpr (FULL) {
-          if (g.ani_out) g.ani_out[(size_t)gi * g.Q + gj] = ani;
+      return hits;
+    } else {
+      if constexpr (I8) {
+        int32_t ir[U], iq[U], vq[U], vr[U];
+        uint32_t cr[U], cq[U], f_r[U], f_q[U];
+        uint32_t o_r[U], o_q[U];  // first entries: d | b << 16
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t li = key[u] >> 16, lj = key[u] & 0xffffu;
+          ir[u] = s_ir[li], iq[u] = s_iq[lj];
+          cr[u] = (valid[u] && !HG_EXP(64)) ? ((uint32_t)s_sr[li] >> 14) & 255u : 0u;  // count (8) | sum |b| (14)
+          cq[u] = (valid[u] && !HG_EXP(64)) ? ((uint32_t)s_sq[lj] >> 14) & 255u : 0u;
+          f_r[u] = s_fr[li], f_q[u] = s_fq[lj];
+          o_r[u] = s_er[li], o_q[u] = s_eq[lj];
         }
-        hit = g.hit_count && ani >= g.ani_th;
-        cl[e].y = hit ? __float_as_uint(ani) : 0xFFFFFFFFu;
+        // (loads only in the lanes that have an entry -- a handful of cache lines per batch; fetched in every lane, 64
+        // different lines per instruction, the group was slower than the loops it replaces)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t gi = row0 + (key[u] >> 16), gj = col0 + (key[u] & 0xffffu);
+          vq[u] = vr[u] = 0;
+          if (cr[u]) vq[u] = g.raw_q[(size_t)gj * g.hv_d + (o_r[u] & 0xffffu)];
+          if (cq[u]) vr[u] = g.raw_r[(size_t)gi * g.hv_d + (o_q[u] & 0xffffu)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t er = ir[u] & 1, eq = iq[u] & 1;
+          int32_t G = val[u];
+          auto clamp8 = [](int32_t c) { return c > 127 ? 127 : (c < -127 ? -127 : c); };
+          if (cr[u]) G += (int32_t)(int8_t)(o_r[u] >> 16) * ((vq[u] + eq) >> 1);      // b_i[d] * c_j[d], c = the true centred count of column j
+          if (cq[u]) G += (int32_t)(int8_t)(o_q[u] >> 16) * clamp8((vr[u] + er) >> 1);  // a_i[d] * b_j[d], a = the clamped byte of row i
+          if (__ballot(cr[u] > 1u || cq[u] > 1u) != 0) {  // wave-uniform, rare: further entries of a row / column
+            const uint32_t gi = row0 + (key[u] >> 16), gj = col0 + (key[u] & 0xffffu);
+            for (uint32_t t = 1; t < cr[u]; ++t) {
+              const I8Outlier o = g.ents[f_r[u] + t];
+              G += (int32_t)o.b * (((int32_t)g.raw_q[(size_t)gj * g.hv_d + o.d] + eq) >> 1);
+            }
+            for (uint32_t t = 1; t < cq[u]; ++t) {
+              const I8Outlier o = g.ents[f_q[u] + t];
+              G += (int32_t)o.b * clamp8(((int32_t)g.raw_r[(size_t)gi * g.hv_d + o.d] + er) >> 1);
+            }
+          }
+          val[u] = 4 * G - eq * (ir[u] - er) - er * (iq[u] - eq) + (er & eq) * (int32_t)g.hv_d;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (k0 + (uint32_t)u * NW_ >= nb) break;  // wave-uniform: the group is not full
+        const uint32_t li = key[u] >> 16, lj = key[u] & 0xffffu;
+        const float ani = HG_EXP(128) ? (float)val[u] * 1e-9f + 99.f : ani_from_dot(val[u], s_nr[li], s_nq[lj], g.kf);
+        if constexpr (FULL) {
+          if (g.ani_out && valid[u]) g.ani_out[(size_t)(row0 + li) * g.Q + (col0 + lj)] = ani;
+        }
+        const bool hit = valid[u] && g.hit_count && ani >= g.ani_th;
+        if (valid[u]) cl[e[u]].y = hit ? __float_as_uint(ani) : 0xFFFFFFFFu;
+        hits += (uint32_t)__popcll(__ballot(hit));
+      }
+      return hits;
     }
-    return (uint32_t)__popcll(__ballot(hit));
   };
   auto write_batch = [&](const uint2 *cl, uint32_t b, uint32_t n_list, uint32_t off) __attribute__((always_inline)) -> uint32_t {  // hits written
     const uint32_t e = b + lane;
@@ -1012,9 +1063,12 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // Emptying the lists: ONE reservation per workgroup (same-address returning atomics serialise at ~12 ns; with noise
   // hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round, and one atomic per
   // wave kept every CU waiting ~25 us per round), and the batches of all lists dealt round-robin to the waves.
-  constexpr uint32_t NW_ = THREADS / 64;
   uint32_t *s_len = s_cnt + NW_ + 1;  // the list lengths + three "some list is nearly full" flags (slot m % 3)
-  auto flush_all = [&]() __attribute__((always_inline)) {
+#ifndef HG_P2_U
+#define HG_P2_U 4  /* batches a wave keeps in flight in the last phase 2 of a tile (A/B: 1 = one at a time) */
+#endif
+  auto flush_all = [&](auto p2uc) __attribute__((always_inline)) {  // p2uc: batches a wave keeps in flight in phase 2
+    constexpr uint32_t P2_U = decltype(p2uc)::value;
     if (lane == 0) s_len[wave] = staged;
     __syncthreads();
 #ifdef HG_DIST_STAMPS
@@ -1027,7 +1081,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       const uint32_t n_list = s_len[l];
       uint2 *cl = all + l * CAND_CAP;
       const uint32_t nb = (n_list + 63) / 64, first = (wave + NW_ - (kglob % NW_)) % NW_;  // my first batch of this list
-      for (uint32_t k = first; k < nb; k += NW_) nh += phase2_batch(cl, k * 64, n_list);
+      for (uint32_t k = first; k < nb; k += P2_U * NW_) nh += phase2_group(cl, k, nb, n_list, std::integral_constant<int, (int)P2_U>{});
       kglob += nb;
     }
     HG_TSTAMP(6)
@@ -1082,7 +1136,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   constexpr bool LANE_MASKS = !FULL && I8;
   constexpr uint32_t SLAB_BITS = (1u << (4 * NT)) - 1u;
   bool by_lane = false;  // workgroup-uniform
-  uint32_t notpass[LANE_MASKS ? WTM : 1], lane_cands = 0;
+  uint32_t notpass[LANE_MASKS ? WTM : 1], lane_cands = 0, wave_cands = 0;  // (wave_cands: lane w holds wave w's count)
   if constexpr (LANE_MASKS) {
     if (!(g.symmetric && row0 + g.ref_off + (uint32_t)BM - 1u >= col0 + g.qry_off)) {
       uint32_t lane_total = 0;
@@ -1110,19 +1164,30 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       for (int o = 32; o > 0; o >>= 1) lane_total += __shfl_xor(lane_total, o);
       if (lane == 0) s_tot[wave] = lane_total;
       __syncthreads();
-      const uint32_t tw = lane < (uint32_t)(THREADS / 64) ? s_tot[lane] : 0u;
-      if (__ballot(tw != 0u) == 0) {  // nothing in this tile
+      wave_cands = lane < (uint32_t)(THREADS / 64) ? s_tot[lane] : 0u;
+      if (__ballot(wave_cands != 0u) == 0) {  // nothing in this tile
         HG_TSTAMP(4)
         HG_TSTAMP(5)
         return;
       }
-      by_lane = __ballot(tw > CAND_CAP) == 0;
+      by_lane = __ballot(wave_cands > CAND_CAP) == 0;
     }
   }
   if (by_lane) {
     if constexpr (LANE_MASKS) {
-      uint32_t off = 0;  // one LDS atomic per lane reserves the run of the wave's list that takes all its candidates
-      if (lane_cands != 0u) off = atomicAdd(&s_fill[wave], lane_cands);
+      // ONE list for the workgroup (the per-wave regions are contiguous): wave w's candidates start behind those of
+      // the waves below it -- every wave knows all counts --, and one LDS atomic per lane reserves the run that takes
+      // the lane's candidates.  Fewer half-empty batches for phase 2 than eight lists, and flush_all sees list 0 only.
+      const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+      uint32_t off = 0, all_cands = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)(THREADS / 64); ++w) {
+        const uint32_t v = __builtin_amdgcn_readlane(wave_cands, w);
+        off += w < wave_u ? v : 0u;
+        all_cands += v;
+      }
+      if (lane_cands != 0u) off += atomicAdd(&s_fill[wave], lane_cands);
+      uint2 *const cand = reinterpret_cast<uint2 *>(sAB);
       dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
         constexpr int m = decltype(mc)::value;
         const uint32_t pm = ~notpass[m] & SLAB_BITS;
@@ -1139,7 +1204,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
           });
         });
       });
-      staged = __builtin_amdgcn_readfirstlane(s_fill[wave]);  // (this wave's LDS operations are in order)
+      staged = wave_u == 0 ? all_cands : 0u;
     }
   } else {
   // (compile-time m, r, n: the accumulator registers must be indexed statically whatever the optimiser thinks of the
@@ -1201,12 +1266,12 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       __syncthreads();
       const bool any_full = s_len[NW_ + m % 3] != 0u;
       if (wave == 0 && lane == 0) s_len[NW_ + (m + 2) % 3] = 0u;
-      if (any_full) flush_all();
+      if (any_full) flush_all(std::integral_constant<uint32_t, (HG_P2_U < 2 ? HG_P2_U : 2)>{});  // (the accumulators are live: two batches in flight)
     }
   });
   }
   HG_TSTAMP(4)
-  flush_all();  // end of the tile
+  flush_all(std::integral_constant<uint32_t, HG_P2_U>{});  // end of the tile
   HG_TSTAMP(5)
   }
 }
