@@ -547,12 +547,16 @@ __device__ unsigned long long g_dist_stamps[16][2][8][6];
 // 4 accumulator sweep done, 5 lists emptied (tile done); inside the last flush_all: 6 candidates evaluated, 7 range
 // reserved, 8 hits written.
 __device__ unsigned long long g_dist_tile_stamps[16][8][10];
+__device__ unsigned long long g_dist_tile_real[2048][2];  // s_memrealtime (100 MHz) at points 1 and 2: with the stamps of
+                                                          // g_dist_tile_stamps' wave 0 this gives the shader clock of the main loop
 __device__ unsigned long long g_dist_tile_all[2048][4];  // per workgroup: entry, main loop done, tile done, candidates evaluated
 #define HG_TSTAMP(pt)                                                                                      \
   if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528)                                    \
     g_dist_tile_stamps[blockIdx.x - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();            \
   if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 0 || (pt) == 2 || (pt) == 5))                      \
-    g_dist_tile_all[blockIdx.x][(pt) == 0 ? 0 : ((pt) == 2 ? 1 : 2)] = __builtin_amdgcn_s_memtime();
+    g_dist_tile_all[blockIdx.x][(pt) == 0 ? 0 : ((pt) == 2 ? 1 : 2)] = __builtin_amdgcn_s_memtime();       \
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 1 || (pt) == 2))                                   \
+    g_dist_tile_real[blockIdx.x][(pt)-1] = __builtin_amdgcn_s_memrealtime();
 #else
 #define HG_STAMP(pt)
 #define HG_TSTAMP(pt)
@@ -1765,6 +1769,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
 }
 
 #ifdef HG_DIST_STAMPS
+extern "C" int hg_debug_dist_tile_real(unsigned long long *out /* 2048 * 2 */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_real), sizeof(unsigned long long) * 2048 * 2);
+}
 extern "C" int hg_debug_dist_tile_all(unsigned long long *out /* 2048 * 4 */) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_all), sizeof(unsigned long long) * 2048 * 4);
 }
