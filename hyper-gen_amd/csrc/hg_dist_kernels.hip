@@ -1138,6 +1138,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   //    are OR-ed on the scalar side into one wave-uniform branch; a slab with candidates takes one ballot per element,
   //    and a barrier per slab makes the decision to empty the lists uniform.
   constexpr bool LANE_MASKS = !FULL && I8;
+  constexpr uint32_t BNC_LANE = 80, BNC_WAVE = 64 * BNC_LANE;  // bytes of a lane's / a wave's bounce buffer (append loop)
+  static_assert(NT * 16 <= (int)BNC_LANE, "a lane's slab fits its bounce buffer");
   constexpr uint32_t SLAB_BITS = (1u << (4 * NT)) - 1u;
   bool by_lane = false;  // workgroup-uniform
   uint32_t notpass[LANE_MASKS ? WTM : 1], lane_cands = 0, wave_cands = 0;  // (wave_cands: lane w holds wave w's count)
@@ -1174,7 +1176,11 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         HG_TSTAMP(5)
         return;
       }
-      by_lane = __ballot(wave_cands > CAND_CAP) == 0;
+      uint32_t all_c = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)(THREADS / 64); ++w) all_c += __builtin_amdgcn_readlane(wave_cands, w);
+      // (one list of all candidates below the waves' bounce buffers, see the append loop)
+      by_lane = __ballot(wave_cands > CAND_CAP) == 0 && all_c * 8u <= (uint32_t)dist_lds_main_bytes<BIG, NT, GLDS>() - (THREADS / 64) * BNC_WAVE;
     }
   }
   if (by_lane) {
@@ -1192,21 +1198,30 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       }
       if (lane_cands != 0u) off += atomicAdd(&s_fill[wave], lane_cands);
       uint2 *const cand = reinterpret_cast<uint2 *>(sAB);
+      // A lane has ~2 candidates among its 160 accumulators, at positions only it knows, and registers cannot be
+      // indexed per lane: slab by slab the lane's 4 * NT accumulators bounce through LDS (NT 16-byte stores into the
+      // lane's own 80 bytes -- a stride that keeps 16 lanes on 64 different banks), and a loop over the set bits of the
+      // slab's mask reads the ones that pass back by address and appends them.  (The straightforward form -- one
+      // predicated append per element, 160 exec-mask regions per lane -- took 8 000 cycles per tile for ~1 000
+      // candidates: in-kernel stamps.)  The bounce buffers sit at the top of the stage area, the list grows from its
+      // bottom; a wave's LDS operations execute in order, so no barrier is involved.
+      char *const bnc = reinterpret_cast<char *>(sAB) + dist_lds_main_bytes<BIG, NT, GLDS>() - (THREADS / 64 - wave_u) * BNC_WAVE + lane * BNC_LANE;
       dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const uint32_t pm = ~notpass[m] & SLAB_BITS;
-        if (__ballot(pm != 0u) == 0) return;  // wave-uniform
+        uint32_t rest = ~notpass[m] & SLAB_BITS;
+        if (__ballot(rest != 0u) == 0) return;  // wave-uniform
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<acc_t *>(bnc + n * 16) = acc[m][n];
         const uint32_t key0 = ((wm * (WTM * 16) + m * 16 + fq * 4) << 16) | (wn * (NT * 16) + fr);
-        dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
-            constexpr int n = decltype(nc)::value;
-            if (pm & (1u << (4 * NT - 1 - (r * NT + n)))) {
-              cand[off] = make_uint2(key0 + ((uint32_t)r << 16) + (uint32_t)n * 16u, (uint32_t)(int32_t)acc[m][n][r]);
-              ++off;
-            }
-          });
-        });
+        while (rest != 0u) {
+          const uint32_t e = (uint32_t)(4 * NT - 1) - (uint32_t)__builtin_ctz(rest), r = e / (uint32_t)NT, n = e - r * (uint32_t)NT;
+          rest &= rest - 1u;
+          int32_t G;
+          if constexpr (std::is_same<acc_t, int4v>::value) G = *reinterpret_cast<const int32_t *>(bnc + n * 16 + r * 4);
+          else G = (int32_t)*reinterpret_cast<const float *>(bnc + n * 16 + r * 4);
+          cand[off] = make_uint2(key0 + (r << 16) + n * 16u, (uint32_t)G);
+          ++off;
+        }
       });
       staged = wave_u == 0 ? all_cands : 0u;
     }
