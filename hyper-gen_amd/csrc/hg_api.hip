@@ -125,6 +125,7 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   if (k == "dist_tile") c->dbg_dist_tile = v;
   else if (k == "sort_test_buckets") c->dbg_sort_buckets = std::atoi(v.c_str());
   else if (k == "dist_path") c->dbg_dist_path = v;
+  else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;

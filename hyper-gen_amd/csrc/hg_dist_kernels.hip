@@ -452,7 +452,12 @@ __device__ __forceinline__ bool i8_attempt_valid(const uint32_t *ctrl, uint32_t 
 // ---- MFMA GEMM + ANI ------------------------------------------------------------------------------
 constexpr int BK = 64;
 constexpr int LDS_ROW = BK + 8;  // f16 elements per LDS row: 144 B => conflict-free ds_read_b128
-constexpr uint32_t ST = 8;       // super-tile edge, in tiles
+constexpr uint32_t SUP_M = 4, SUP_N = 8;  // super-tile, in tiles: what the 32 workgroups resident on one XCD cover
+// workgroups of a launch: whole rounds of eight super-tiles (one per XCD)
+static inline uint32_t dist_grid(uint32_t tiles_m, uint32_t tiles_n) {
+  const uint32_t n_sup = ((tiles_m + SUP_M - 1) / SUP_M) * ((tiles_n + SUP_N - 1) / SUP_N);
+  return (n_sup + 7) / 8 * 8 * SUP_M * SUP_N;
+}
 // Tile geometries (waves are 2 (M) x NWN (N), each wave owns WTM x NT MFMA tiles of 16 x 16):
 //   small: 128 x 128, 4 waves, 72 KiB LDS, 2 workgroups / CU  -- small problems, little padding
 //   big  : 256 x 256, 8 waves, 144 KiB LDS, 1 workgroup / CU  -- half the LDS and L2 bytes per flop
@@ -522,6 +527,7 @@ struct GemmArgs {
   const int16_t *raw_r, *raw_q;    // the original i16 matrices (rows of hv_d)
   const uint32_t *i8ctrl;          // [0] entries reserved, [1] flags of the prepass
   uint32_t hv_d, same_set;
+  uint32_t diag_first;             // leading workgroup slots that take the tiles on the diagonal (0: plain order)
   int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
@@ -616,21 +622,35 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   constexpr uint32_t STAGE_ELEMS = A_ELEMS + B_ELEMS;
   constexpr uint32_t SROWS = THREADS / 8;            // rows covered by one staging pass
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
-  // contiguous run of tiles (bijective remap, MI355X guide T1)
-  const uint32_t nwg = gridDim.x;
-  uint32_t bid = blockIdx.x;
-  {
-    const uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  // XCD-aware tile order (MI355X guide T1): workgroups b and b + 8 run on the same XCD and share its 4 MiB L2.  The
+  // 32 workgroups resident on an XCD at a time walk one 4 x 8 super-tile -- 4 A row-blocks and 8 B row-blocks through
+  // that L2 instead of 32 different B blocks (measured in round 1: 7.0 GB of L2 misses per 10k x 10k launch with plain
+  // row-major order) --, and the super-tiles are dealt round-robin to the XCDs.  (Until round 3 every XCD owned one
+  // contiguous run of 8 x 8 super-tiles: the same L2 footprint, since only half of such a super-tile is resident at a
+  // time, but the tiles that are expensive in the epilogue -- the diagonal of a database compared with itself -- fell
+  // to the XCDs unevenly: 250 k against 96 k candidates per XCD at 10 000 x 10 000, and workgroups do not migrate
+  // between XCDs.)
+  // A database compared with itself in file order has its hits on the diagonal, and a tile with 20 000 candidates spends
+  // twice as long in its epilogue as in its K loop: with five tiles per CU the launch ends when the last such tile does.
+  // The host may therefore put the tiles that straddle the diagonal in front (g.diag_first workgroup slots, two per tile
+  // row, a multiple of 8 so that the XCD of the remaining workgroups is unchanged): longest jobs first.
+  uint32_t tm, tn;
+  if (blockIdx.x < g.diag_first) {
+    tm = blockIdx.x >> 1;
+    if (tm >= g.tiles_m) return;
+    const uint32_t tn0 = tm * BM / BN, tn1 = (tm * BM + BM - 1) / BN;
+    tn = (blockIdx.x & 1) ? tn1 : tn0;
+    if (((blockIdx.x & 1) && tn1 == tn0) || tn >= g.tiles_n) return;
+  } else {
+    const uint32_t b = blockIdx.x - g.diag_first;
+    const uint32_t xcd = b % 8, kx = b / 8;  // the XCD's kx-th workgroup
+    const uint32_t sup_n = (g.tiles_n + SUP_N - 1) / SUP_N, n_sup = ((g.tiles_m + SUP_M - 1) / SUP_M) * sup_n;
+    const uint32_t sup = (kx / (SUP_M * SUP_N)) * 8 + xcd, within = kx % (SUP_M * SUP_N);
+    if (sup >= n_sup) return;  // padding of the grid to whole rounds of eight super-tiles
+    tm = (sup / sup_n) * SUP_M + within / SUP_N, tn = (sup % sup_n) * SUP_N + within % SUP_N;
+    if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // padding of the super-tile grid
+    if (g.diag_first && (tn == tm * BM / BN || tn == (tm * BM + BM - 1) / BN)) return;  // ran in front
   }
-  // ... and inside that run walk 8 x 8 super-tiles, so that the ~64 workgroups resident on one XCD
-  // share 8 A row-blocks and 8 B row-blocks through its 4 MiB L2 instead of streaming 64 different
-  // B blocks (measured: 7.0 GB of L2 misses per 10k x 10k launch with plain row-major order)
-  const uint32_t sup_n = (g.tiles_n + ST - 1) / ST;
-  const uint32_t sup = bid / (ST * ST), within = bid % (ST * ST);
-  const uint32_t tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
-  if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // padding of the super-tile grid
   const uint32_t row0 = tm * BM, col0 = tn * BN;
   if (g.symmetric && row0 + g.ref_off >= col0 + g.qry_off + BN) return;  // tile entirely on/below the diagonal
 
@@ -1447,7 +1467,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
     else if (c->dbg_dist_tile == "wide") nt = 5;
   }
   g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
-  const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+  const uint32_t n_tiles = dist_grid(g.tiles_m, g.tiles_n);
   const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
   auto launch = [&](auto kern, const std::string &name, int threads) -> hipError_t {
     c->last_kernel[HG_T_DIST] = name;
@@ -1561,7 +1581,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
       else if (c->dbg_dist_tile == "wide") nt = 5;
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
-    const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+    // (the same matrix on both sides at the same global offset: hits cluster on the diagonal -- those tiles first)
+    g.diag_first = (same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? (2 * g.tiles_m + 7) / 8 * 8 : 0u;
+    const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
     const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
     const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
                              : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
@@ -1742,7 +1764,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   if (big_chunked) big = true, nt = NT_CHUNKED;
   const uint32_t bm = big ? 256 : 128, bn = big ? (uint32_t)nt * 64 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
-  const uint32_t n_tiles = ((g.tiles_m + ST - 1) / ST) * ((g.tiles_n + ST - 1) / ST) * ST * ST;
+  // (thresholded self-comparison: the tiles on the diagonal first, as on the i8 path)
+  g.diag_first = (!full && same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? (2 * g.tiles_m + 7) / 8 * 8 : 0u;
+  const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
   auto launch = [&](auto kern, const std::string &name, int threads, size_t lds) -> hipError_t {
     if (!guard || v_lo == 0) c->last_kernel[HG_T_DIST] = name;  // (a guarded second launch covers verdicts 1..2 only)
     const void *fp = reinterpret_cast<const void *>(kern);

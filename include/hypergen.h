@@ -64,9 +64,10 @@ hg_status hg_ctx_reset_stream(hg_ctx *ctx);
 hg_status hg_ctx_sync(hg_ctx *ctx);
 int hg_device_count(void);
 /* development / test hook (no reference counterpart): force an internal code path of THIS ctx.
- * keys: "dist_tile" = "" | "small" | "big" | "big_reg" | "wide" | "nt3"   (GEMM tile geometry)
- *       "dist_path" = "" | "f16" | "i8"                                    (operand format of the ANI GEMM)
- *       "ham_path"  = "" | "popc" | "mfma" | "mfma4" | "mfmab"             (Hamming search: xor+popcount, +-1 byte GEMM, its 4-wave tile, bit-stream operands)
+ * keys: "dist_tile" = "" | "small" | "big" | "wide"      (GEMM tile geometry)
+ *       "dist_path" = "" | "f16" | "i8"                    (operand format of the ANI GEMM)
+ *       "dist_order" = "" | "plain"                        ("plain": a self-comparison does not run its diagonal tiles first)
+ *       "ham_path"  = "" | "popc" | "mfma" | "fp4"         (Hamming search: xor + popcount, +-1 byte GEMM, +-1 e2m1 GEMM)
  *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
  * Nothing in the library reads environment variables. */
 hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
