@@ -604,6 +604,43 @@ def test_dist_i8_operand_path_equals_f16_and_oracle(ctx, orc, same):
         ctx.set_debug("dist_path", "")
 
 
+@pytest.mark.parametrize("path", ["i8", "f16"])
+def test_dist_tile_orders_and_epilogue_paths_agree(ctx, orc, path):
+    """A self-comparison runs its diagonal tiles first (hg_ctx_set_debug "dist_order" = "plain" turns that off): the
+    same hits either way, symmetric or not, on a size with ragged last tiles.  The HVs are clustered in blocks of 150 so
+    that diagonal tiles carry dense blocks (candidate lists that overflow in the middle of a tile: the slab path with
+    its cooperative flushes) while the others see scattered candidates or none (the lane-mask path, one list per tile,
+    and the early exit); a low and a high threshold move tiles between the three."""
+    rng = np.random.default_rng(4242)
+    D, n, R = 4096, 3333, 1900
+    base = rng.binomial(int(n * 0.8), 0.5, (R // 150 + 1, D))
+    cnt = base[np.arange(R) // 150] + rng.binomial(n - int(n * 0.8), 0.5, (R, D))
+    hv = (2 * cnt - n).astype(np.int16)
+    rn = np.array([orc.hv_norm2(x) for x in hv], np.int32)
+    key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
+    want = orc.ani_matrix(hv[:400], rn[:400], hv, rn, 21)
+    try:
+        ctx.set_debug("dist_path", path)
+        for th in (80.0, 95.0):
+            for sym in (False, True):
+                ctx.set_debug("dist_order", "plain")
+                a = key(ctx.dist(hv, rn, hv, rn, 21, symmetric=sym, ani_th=th))
+                ctx.set_debug("dist_order", "")
+                b = key(ctx.dist(hv, rn, hv, rn, 21, symmetric=sym, ani_th=th))
+                assert a.size == b.size > 10000 and np.array_equal(a, b), (th, sym)
+                got = np.zeros((400, R), np.float32)
+                m = b["ref_idx"] < 400
+                got[b["ref_idx"][m], b["qry_idx"][m]] = b["ani"][m]
+                sel = want >= th + 1e-4
+                if sym:
+                    sel &= np.arange(400)[:, None] < np.arange(R)[None, :]
+                assert (got[sel] > 0).all() and np.abs(got[sel] - want[sel]).max() <= 1e-4, (th, sym)
+                assert not (got[want < th - 1e-4] > 0).any()
+    finally:
+        ctx.set_debug("dist_path", "")
+        ctx.set_debug("dist_order", "")
+
+
 @pytest.mark.parametrize("n,expect_i8", [(4400, True), (5200, True), (9000, False)])
 def test_dist_i8_reach_mid_size_sketches(ctx, orc, n, expect_i8):
     """Sketches of 4 000-5 500 hashes have a few clamped entries in most rows (|count - n/2| > 127 at ~3.5 sigma): every
