@@ -813,7 +813,10 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   // [0] hit counter, [1] exactness verdict, [2] its window length, [4..12] control words of the i8 operand attempt
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
-  HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
+  // (zeroed by the previous call on its way out, behind its read-back: one command less in front of the kernels;
+  // the first call, and one after a call that failed half way, does it here)
+  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
+  c->misc_zeroed = nullptr;
   hg_dist_args a{};
   a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
   a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
@@ -847,6 +850,7 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   }
   const uint32_t found = h_res[0];
   *n_out = found;
+  if (hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
   return HG_OK;
 }

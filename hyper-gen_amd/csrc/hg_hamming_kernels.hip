@@ -203,7 +203,8 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   hg_status s;
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
-  HG_HIP(c, hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 64, c->stream));  // (see hg_dist_block_dev)
+  c->misc_zeroed = nullptr;
   // Large searches run as an exact +-1 GEMM on the matrix pipe (hg_run_hamming_mfma: G = D - 2 * distance, the ANI
   // kernel's tiles and hit lists) -- on e2m1 (FP4) operands, or on byte operands when the hook says "mfma" (the A/B
   // partner; hv_d % 128 == 0 only); small ones -- and everything when the hook says "popc" -- on the xor + popcount
@@ -225,6 +226,7 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   HG_HIP(c, hipMemcpyAsync(&found, d_count, sizeof found, hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));
   *n_out = found;
+  if (hipMemsetAsync(d_count, 0, 64, c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
   return HG_OK;
 }

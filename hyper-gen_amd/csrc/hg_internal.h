@@ -31,6 +31,7 @@ struct hg_ctx {
   Buf w_seq;      // staged sequences (host entry points)
   Buf w_hv;       // staged HV output (host entry points)
   Buf w_misc;     // small scalars (hit counters of dist, flags)
+  const void *misc_zeroed = nullptr;  // == w_misc.p while its 64 bytes are zero (or being zeroed on `stream`): a call leaves them so for the next
   Buf w_f16a;     // f16 copies of the HV matrices for the MFMA path
   Buf w_f16b;
   Buf w_stats;    // per-row |max| / block sums of squares
