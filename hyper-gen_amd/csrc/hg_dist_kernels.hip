@@ -452,11 +452,10 @@ __device__ __forceinline__ bool i8_attempt_valid(const uint32_t *ctrl, uint32_t 
 // ---- MFMA GEMM + ANI ------------------------------------------------------------------------------
 constexpr int BK = 64;
 constexpr int LDS_ROW = BK + 8;  // f16 elements per LDS row: 144 B => conflict-free ds_read_b128
-constexpr uint32_t SUP_M = 4, SUP_N = 8;  // super-tile, in tiles: what the 32 workgroups resident on one XCD cover
-// workgroups of a launch: whole rounds of eight super-tiles (one per XCD)
+constexpr uint32_t ST = 8;       // super-tile edge, in tiles
+// workgroups of a launch: whole super-tiles
 static inline uint32_t dist_grid(uint32_t tiles_m, uint32_t tiles_n) {
-  const uint32_t n_sup = ((tiles_m + SUP_M - 1) / SUP_M) * ((tiles_n + SUP_N - 1) / SUP_N);
-  return (n_sup + 7) / 8 * 8 * SUP_M * SUP_N;
+  return ((tiles_m + ST - 1) / ST) * ((tiles_n + ST - 1) / ST) * ST * ST;
 }
 // Tile geometries (waves are 2 (M) x NWN (N), each wave owns WTM x NT MFMA tiles of 16 x 16):
 //   small: 128 x 128, 4 waves, 72 KiB LDS, 2 workgroups / CU  -- small problems, little padding
@@ -622,14 +621,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   constexpr uint32_t STAGE_ELEMS = A_ELEMS + B_ELEMS;
   constexpr uint32_t SROWS = THREADS / 8;            // rows covered by one staging pass
 
-  // XCD-aware tile order (MI355X guide T1): workgroups b and b + 8 run on the same XCD and share its 4 MiB L2.  The
-  // 32 workgroups resident on an XCD at a time walk one 4 x 8 super-tile -- 4 A row-blocks and 8 B row-blocks through
-  // that L2 instead of 32 different B blocks (measured in round 1: 7.0 GB of L2 misses per 10k x 10k launch with plain
-  // row-major order) --, and the super-tiles are dealt round-robin to the XCDs.  (Until round 3 every XCD owned one
-  // contiguous run of 8 x 8 super-tiles: the same L2 footprint, since only half of such a super-tile is resident at a
-  // time, but the tiles that are expensive in the epilogue -- the diagonal of a database compared with itself -- fell
-  // to the XCDs unevenly: 250 k against 96 k candidates per XCD at 10 000 x 10 000, and workgroups do not migrate
-  // between XCDs.)
+  // XCD-aware tile order (MI355X guide T1): workgroups b and b + 8 run on the same XCD and share its 4 MiB L2, so every
+  // XCD gets a contiguous run of tiles (bijective remap) and walks 8 x 8 super-tiles inside it: the 32 workgroups resident
+  // on an XCD cover 4 x 8 tiles -- 4 A row-blocks and 8 B row-blocks through that L2 instead of 32 different B blocks
+  // (measured in round 1: 7.0 GB of L2 misses per 10k x 10k launch with plain row-major order) --, and the next 4 x 8
+  // tiles reuse the same 8 B blocks.  (Round 3 tried 4 x 8 super-tiles dealt round-robin to the XCDs, to spread the
+  // expensive diagonal tiles of a self-comparison evenly: the same time on i8 operands, but the L2 hit rate fell from
+  // 68 % to 64 %, and from 63 % to 49 % on f16 operands -- without the shared B blocks between consecutive groups.  The
+  // diagonal is dealt with below.)
   // A database compared with itself in file order has its hits on the diagonal, and a tile with 20 000 candidates spends
   // twice as long in its epilogue as in its K loop: with five tiles per CU the launch ends when the last such tile does.
   // The host may therefore put the tiles that straddle the diagonal in front (g.diag_first workgroup slots, two per tile
@@ -642,12 +641,12 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     tn = (blockIdx.x & 1) ? tn1 : tn0;
     if (((blockIdx.x & 1) && tn1 == tn0) || tn >= g.tiles_n) return;
   } else {
-    const uint32_t b = blockIdx.x - g.diag_first;
-    const uint32_t xcd = b % 8, kx = b / 8;  // the XCD's kx-th workgroup
-    const uint32_t sup_n = (g.tiles_n + SUP_N - 1) / SUP_N, n_sup = ((g.tiles_m + SUP_M - 1) / SUP_M) * sup_n;
-    const uint32_t sup = (kx / (SUP_M * SUP_N)) * 8 + xcd, within = kx % (SUP_M * SUP_N);
-    if (sup >= n_sup) return;  // padding of the grid to whole rounds of eight super-tiles
-    tm = (sup / sup_n) * SUP_M + within / SUP_N, tn = (sup % sup_n) * SUP_N + within % SUP_N;
+    const uint32_t b = blockIdx.x - g.diag_first, nwg = gridDim.x - g.diag_first;
+    const uint32_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
+    const uint32_t bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    const uint32_t sup_n = (g.tiles_n + ST - 1) / ST;
+    const uint32_t sup = bid / (ST * ST), within = bid % (ST * ST);
+    tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
     if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // padding of the super-tile grid
     if (g.diag_first && (tn == tm * BM / BN || tn == (tm * BM + BM - 1) / BN)) return;  // ran in front
   }
