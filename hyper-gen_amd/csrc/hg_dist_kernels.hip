@@ -1147,8 +1147,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // Two ways through the accumulators (in-kernel stamps, DESIGN.md 4.3: with one branch per element and the row words
   // read slab by slab the sweep took 20 000 cycles in a tile without a single candidate and 25 000 more in a tile with
   // the ~1 000 scattered candidates every tile of a real comparison has):
-  //  * LANE MASKS (i8 / Hamming kernels, tiles off the diagonal of a symmetric comparison -- there a candidate is
-  //    exactly "passes phase 0"): every lane shifts the sign of `d - ur - tq` of its 4 * NT elements of a 16-row slab
+  //  * LANE MASKS (every thresholded kernel but the windowed f16 one, tiles off the diagonal of a symmetric comparison --
+  //    there a candidate is "passes phase 0"; the f16 kernels' denominator test of the slab path is only a cheaper
+  //    filter in front of the exact phase 2, 0.69 -> 0.61 ms at 10 000 x 10 000 without it): every lane shifts the sign of `d - ur - tq` of its 4 * NT elements of a 16-row slab
   //    into one mask word per slab, no branches.  One barrier makes the waves' candidate counts known to all: a tile
   //    without candidates ends there; if no list can overflow, every wave then appends its candidates on its own --
   //    per slab one LDS atomic per lane that has any reserves its run of the list, predicated stores fill it -- and
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   //  * SLABS (everything else, and tiles whose candidates may overflow a list): per 16-row slab the 4 * NT compares
   //    are OR-ed on the scalar side into one wave-uniform branch; a slab with candidates takes one ballot per element,
   //    and a barrier per slab makes the decision to empty the lists uniform.
-  constexpr bool LANE_MASKS = !FULL && I8;
+  constexpr bool LANE_MASKS = !FULL && (I8 || !CHUNKED);  // (f16 operands: phase 2 is exact, the slab path's denominator test is only a cheaper filter)
   constexpr uint32_t BNC_LANE = 80, BNC_WAVE = 64 * BNC_LANE;  // bytes of a lane's / a wave's bounce buffer (append loop)
   static_assert(NT * 16 <= (int)BNC_LANE, "a lane's slab fits its bounce buffer");
   constexpr uint32_t SLAB_BITS = (1u << (4 * NT)) - 1u;
