@@ -45,7 +45,7 @@ def main():
     with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as fo:
         fo.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
         for r in rows:
-            fo.write("%s,%d,%d,%.1f,%d,%d\n" % r)
+            fo.write('"%s",%d,%d,%.1f,%d,%d\n' % r)  # (template arguments carry commas)
             print("%-34s calls %3d  avg %10.1f us" % (r[0], r[1], r[3] / 1e3))
     # ---- counters: average per launch per kernel
     pmc = defaultdict(lambda: defaultdict(list))
