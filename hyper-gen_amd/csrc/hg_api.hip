@@ -864,16 +864,19 @@ hg_status stage_dist(hg_ctx *c, const int16_t *ref_hv, const int32_t *ref_n2, si
                      const int32_t *qry_n2, size_t Q, uint32_t hv_d, StagedDist &o) {
   hg_status s;
   const size_t rb = R * (size_t)hv_d * 2, qb = Q * (size_t)hv_d * 2;
+  // a set compared with itself (src/dist.rs:13, path_r == path_q) travels once, and the device path sees one matrix:
+  // one operand prepass instead of two, the diagonal tiles of the GEMM first
+  const bool same = ref_hv == qry_hv && ref_n2 == qry_n2 && R == Q;
   if ((s = hg_ensure(c, c->w_hv, rb + 64)) != HG_OK) return s;
-  if ((s = hg_ensure(c, c->w_hv2, qb + 64)) != HG_OK) return s;
+  if (!same && (s = hg_ensure(c, c->w_hv2, qb + 64)) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_n2a, R * 4 + 64)) != HG_OK) return s;
-  if ((s = hg_ensure(c, c->w_n2b, Q * 4 + 64)) != HG_OK) return s;
+  if (!same && (s = hg_ensure(c, c->w_n2b, Q * 4 + 64)) != HG_OK) return s;
   HG_HIP(c, hipMemcpyAsync(c->w_hv.p, ref_hv, rb, hipMemcpyHostToDevice, c->stream));
-  HG_HIP(c, hipMemcpyAsync(c->w_hv2.p, qry_hv, qb, hipMemcpyHostToDevice, c->stream));
+  if (!same) HG_HIP(c, hipMemcpyAsync(c->w_hv2.p, qry_hv, qb, hipMemcpyHostToDevice, c->stream));
   HG_HIP(c, hipMemcpyAsync(c->w_n2a.p, ref_n2, R * 4, hipMemcpyHostToDevice, c->stream));
-  HG_HIP(c, hipMemcpyAsync(c->w_n2b.p, qry_n2, Q * 4, hipMemcpyHostToDevice, c->stream));
-  o.d_ref = static_cast<int16_t *>(c->w_hv.p), o.d_qry = static_cast<int16_t *>(c->w_hv2.p);
-  o.d_rn = static_cast<int32_t *>(c->w_n2a.p), o.d_qn = static_cast<int32_t *>(c->w_n2b.p);
+  if (!same) HG_HIP(c, hipMemcpyAsync(c->w_n2b.p, qry_n2, Q * 4, hipMemcpyHostToDevice, c->stream));
+  o.d_ref = static_cast<int16_t *>(c->w_hv.p), o.d_qry = same ? o.d_ref : static_cast<int16_t *>(c->w_hv2.p);
+  o.d_rn = static_cast<int32_t *>(c->w_n2a.p), o.d_qn = same ? o.d_rn : static_cast<int32_t *>(c->w_n2b.p);
   return HG_OK;
 }
 }  // namespace

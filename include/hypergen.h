@@ -182,7 +182,11 @@ typedef struct {
  * ref_idx < qry_idx (src/dist.rs:243-265).  Hits come back in no particular order
  * (hg_sort_ani_hits gives the reference's file order).  *n_out = number of hits found;
  * if it exceeds cap only cap are stored and HG_ERR_CAPACITY is returned.
- * `out` is host memory for hg_dist and device memory for hg_dist_dev. */
+ * `out` is host memory for hg_dist and device memory for hg_dist_dev.
+ * A set compared with itself (the reference's path_r == path_q case, src/dist.rs:13) is recognised by identical
+ * pointers and row counts on both sides: hg_dist uploads it once, and the device path prepares its operands once
+ * and runs the tiles on the matrix diagonal -- where such a comparison has its dense blocks of hits -- first.  The
+ * result is the same set of hits either way. */
 hg_status hg_dist(hg_ctx *ctx, const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
                   const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q, uint32_t hv_d,
                   uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *out, size_t cap,

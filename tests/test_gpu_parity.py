@@ -641,6 +641,44 @@ def test_dist_tile_orders_and_epilogue_paths_agree(ctx, orc, path):
         ctx.set_debug("dist_order", "")
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_dist_random_shapes_thresholded_equals_full(ctx, orc, seed):
+    """Random shapes, dimensions, thresholds and cluster structure, both operand formats: the thresholded hit list must
+    be exactly the full matrix cut at the threshold (ragged last tiles, empty tiles, tiles with a few candidates and
+    tiles that are one dense block meet in one launch)."""
+    rng = np.random.default_rng(9000 + seed)
+    D = int(rng.choice([512, 1000, 2048, 4096, 4096 - 24]))
+    n = int(rng.integers(600, 3400))
+    R, Q = int(rng.integers(1, 1400)), int(rng.integers(1, 1400))
+    nb = int(rng.integers(1, 12))
+    base = rng.binomial(int(n * 0.75), 0.5, (nb, D))
+    def make(rows):
+        cnt = base[rng.integers(0, nb, rows)] + rng.binomial(n - int(n * 0.75), 0.5, (rows, D))
+        return (2 * cnt - n).astype(np.int16)
+    same = bool(rng.integers(0, 2))
+    r = make(R)
+    q = r if same else make(Q)
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = rn if same else np.array([orc.hv_norm2(x) for x in q], np.int32)
+    full = ctx.dist_full(r, rn, q, qn, 21)
+    key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
+    try:
+        for path in ("i8", "f16"):
+            ctx.set_debug("dist_path", path)
+            for th in (float(rng.uniform(60, 90)), 99.5):
+                for sym in ((False, True) if same else (False,)):
+                    h = key(ctx.dist(r, rn, q, qn, 21, symmetric=sym, ani_th=th))
+                    sel = full >= th
+                    if sym:
+                        sel &= np.arange(r.shape[0])[:, None] < np.arange(q.shape[0])[None, :]
+                    wi, wj = np.nonzero(sel)
+                    assert h.size == wi.size, (seed, path, th, sym, h.size, wi.size)
+                    assert np.array_equal(h["ref_idx"], wi) and np.array_equal(h["qry_idx"], wj)
+                    assert np.array_equal(h["ani"], full[wi, wj]), (seed, path, th, sym)
+    finally:
+        ctx.set_debug("dist_path", "")
+
+
 @pytest.mark.parametrize("n,expect_i8", [(4400, True), (5200, True), (9000, False)])
 def test_dist_i8_reach_mid_size_sketches(ctx, orc, n, expect_i8):
     """Sketches of 4 000-5 500 hashes have a few clamped entries in most rows (|count - n/2| > 127 at ~3.5 sigma): every
