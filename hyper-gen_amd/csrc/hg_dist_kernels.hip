@@ -554,7 +554,7 @@ __device__ unsigned long long g_dist_stamps[16][2][8][6];
 __device__ unsigned long long g_dist_tile_stamps[16][8][10];
 __device__ unsigned long long g_dist_tile_real[2048][2];  // s_memrealtime (100 MHz) at points 1 and 2: with the stamps of
                                                           // g_dist_tile_stamps' wave 0 this gives the shader clock of the main loop
-__device__ unsigned long long g_dist_tile_all[2048][4];  // per workgroup: entry, main loop done, tile done, candidates evaluated
+__device__ unsigned long long g_dist_tile_all[2048][5];  // per workgroup: entry, main loop done, tile done, candidates evaluated, XCC id
 #define HG_TSTAMP(pt)                                                                                      \
   if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528)                                    \
     g_dist_tile_stamps[blockIdx.x - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();            \
@@ -596,7 +596,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   static_assert(!FP4 || HAM, "e2m1 operands exist for the Hamming search only");
   HG_TSTAMP(0)
 #ifdef HG_DIST_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x < 2048) g_dist_tile_all[blockIdx.x][3] = 0;
+  if (threadIdx.x == 0 && blockIdx.x < 2048)
+    g_dist_tile_all[blockIdx.x][3] = 0, g_dist_tile_all[blockIdx.x][1] = 0, g_dist_tile_all[blockIdx.x][2] = 0,
+    g_dist_tile_all[blockIdx.x][4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // hwreg(HW_REG_XCC_ID, 0, 4)
 #endif
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
   if (I8 && !HAM) {
@@ -635,11 +637,15 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // row, a multiple of 8 so that the XCD of the remaining workgroups is unchanged): longest jobs first.
   uint32_t tm, tn;
   if (blockIdx.x < g.diag_first) {
-    tm = blockIdx.x >> 1;
+    // slot s: tile row s % (diag_first / 2), its first (s < diag_first / 2) or second diagonal tile -- diag_first / 2 is a
+    // multiple of 8, so the rows' first tiles, the dense ones, go round the XCDs (with two adjacent slots per row they
+    // all fell to the even XCDs: 223 k against 126 k candidates per XCD)
+    const uint32_t half = g.diag_first >> 1, second = blockIdx.x >= half ? 1u : 0u;
+    tm = blockIdx.x - second * half;
     if (tm >= g.tiles_m) return;
     const uint32_t tn0 = tm * BM / BN, tn1 = (tm * BM + BM - 1) / BN;
-    tn = (blockIdx.x & 1) ? tn1 : tn0;
-    if (((blockIdx.x & 1) && tn1 == tn0) || tn >= g.tiles_n) return;
+    tn = second ? tn1 : tn0;
+    if ((second && tn1 == tn0) || tn >= g.tiles_n) return;
   } else {
     const uint32_t b = blockIdx.x - g.diag_first, nwg = gridDim.x - g.diag_first;
     const uint32_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
@@ -1582,7 +1588,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
     // (the same matrix on both sides at the same global offset: hits cluster on the diagonal -- those tiles first)
-    g.diag_first = (same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? (2 * g.tiles_m + 7) / 8 * 8 : 0u;
+    g.diag_first = (same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
     const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
     const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
     const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
@@ -1765,7 +1771,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const uint32_t bm = big ? 256 : 128, bn = big ? (uint32_t)nt * 64 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   // (thresholded self-comparison: the tiles on the diagonal first, as on the i8 path)
-  g.diag_first = (!full && same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? (2 * g.tiles_m + 7) / 8 * 8 : 0u;
+  g.diag_first = (!full && same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
   const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
   auto launch = [&](auto kern, const std::string &name, int threads, size_t lds) -> hipError_t {
     if (!guard || v_lo == 0) c->last_kernel[HG_T_DIST] = name;  // (a guarded second launch covers verdicts 1..2 only)
@@ -1811,8 +1817,8 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
 extern "C" int hg_debug_dist_tile_real(unsigned long long *out /* 2048 * 2 */) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_real), sizeof(unsigned long long) * 2048 * 2);
 }
-extern "C" int hg_debug_dist_tile_all(unsigned long long *out /* 2048 * 4 */) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_all), sizeof(unsigned long long) * 2048 * 4);
+extern "C" int hg_debug_dist_tile_all(unsigned long long *out /* 2048 * 5 */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_all), sizeof(unsigned long long) * 2048 * 5);
 }
 extern "C" int hg_debug_dist_tile_stamps(unsigned long long *out /* 16 * 8 * 10 */) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_stamps), sizeof(unsigned long long) * 16 * 8 * 10);

@@ -36,10 +36,10 @@ for th in (101.0, 85.0):
     rl = rl.astype(np.int64)[512:528]
     ml = st[:, 0, 2] - st[:, 0, 1]
     print("   main loop: %.0f shader ticks in %.0f ticks of the 100 MHz clock = %.0f MHz" % (ml.mean(), (rl[:, 1] - rl[:, 0]).mean(), ml.mean() / (rl[:, 1] - rl[:, 0]).mean() * 100))
-    al = np.zeros((2048, 4), np.uint64)
+    al = np.zeros((2048, 5), np.uint64)
     assert hg.lib().hg_debug_dist_tile_all(C.c_void_p(al.ctypes.data)) == 0
-    al = al.astype(np.int64)[:1280]
-    ok = al[:, 2] > 0
+    al = al.astype(np.int64)[:1440]
+    ok = (al[:, 2] > al[:, 0]) & (al[:, 2] - al[:, 0] < 2000000) & (al[:, 1] > al[:, 0])  # (slots that returned at once keep stale stamps)
     t0 = al[ok, 0].min()
     tot = (al[ok, 2] - al[ok, 0]); epi = al[ok, 2] - al[ok, 1]; cand = al[ok, 3]
     print("   %d tiles stamped; kernel span %.0f ticks; tile total mean %.0f; epilogue mean %.0f (cold tiles %.0f)" % (
@@ -56,3 +56,12 @@ for th in (101.0, 85.0):
         print("   last finishers (wg, xcd, candidates, end before kernel end):", [(int(i), int(i % 8), int(al[i, 3]), int(al[ok, 2].max() - al[i, 2])) for i in idx])
         xc = [(int(x), int(cand[(np.nonzero(ok)[0] % 8) == x].sum()), int((al[ok, 2][(np.nonzero(ok)[0] % 8) == x]).max() - t0)) for x in range(8)]
         print("   per XCD (xcd, candidates, last end):", xc)
+    # per XCD (s_memtime is not synchronised between XCDs): span of its tiles against the sum of their durations / 32 CUs
+    idx = np.nonzero(ok)[0]
+    print("   workgroups whose XCC id is not blockIdx %% 8: %d of %d" % ((al[idx, 4] != idx % 8).sum(), idx.size))
+    for x in range(8):
+        m = al[idx, 4] == x
+        a = al[idx[m]]
+        span = a[:, 2].max() - a[:, 0].min()
+        work = (a[:, 2] - a[:, 0]).sum() / 32.0
+        print("   XCD %d: %3d tiles, span %7d ticks, work / 32 CUs %7d (%.0f %%), candidates %d" % (x, m.sum(), span, work, 100.0 * work / span, a[:, 3].sum()))
