@@ -83,7 +83,10 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
                          &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
-  for (auto &t : c->t_pending) (void)hipEventDestroy(t.e0), (void)hipEventDestroy(t.e1);
+  for (auto &t : c->t_pending) {
+    if (t.own_e0) (void)hipEventDestroy(t.e0);
+    (void)hipEventDestroy(t.e1);
+  }
   for (auto e : c->t_pool) (void)hipEventDestroy(e);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (auto e : c->copy_events) (void)hipEventDestroy(e);
@@ -148,15 +151,19 @@ static hipEvent_t take_event(hg_ctx *c) {
   return e;
 }
 
-hg_timed::hg_timed(hg_ctx *ctx, int cls_) : c(ctx), cls(cls_) {
+hg_timed::hg_timed(hg_ctx *ctx, int cls_, int after_cls) : c(ctx), cls(cls_) {
   if (!c->timing) return;
-  e0 = take_event(c), e1 = take_event(c);
-  if (e0) (void)hipEventRecord(e0, c->stream);
+  if (after_cls >= 0 && c->t_chain && c->t_chain_cls == after_cls) e0 = c->t_chain, own_e0 = false;
+  else e0 = take_event(c);
+  c->t_chain = nullptr;
+  e1 = take_event(c);
+  if (e0 && own_e0) (void)hipEventRecord(e0, c->stream);
 }
 hg_timed::~hg_timed() {
   if (!e0 || !e1) return;
   (void)hipEventRecord(e1, c->stream);
-  c->t_pending.push_back({e0, e1, cls});
+  c->t_pending.push_back({e0, e1, cls, own_e0});
+  c->t_chain = e1, c->t_chain_cls = cls;
 }
 
 extern "C" hg_status hg_ctx_enable_timing(hg_ctx *c, int on) {
@@ -177,9 +184,11 @@ extern "C" hg_status hg_ctx_timings(hg_ctx *c, float ms_sum[HG_T_COUNT], uint32_
     float ms = 0.f;
     HG_HIP(c, hipEventElapsedTime(&ms, t.e0, t.e1));
     if (t.cls >= 0 && t.cls < HG_T_COUNT) ms_sum[t.cls] += ms, launches[t.cls] += 1;
-    c->t_pool.push_back(t.e0), c->t_pool.push_back(t.e1);
+    if (t.own_e0) c->t_pool.push_back(t.e0);
   }
+  for (auto &t : c->t_pending) c->t_pool.push_back(t.e1);  // (after the loop: a chained bracket reads its predecessor's e1)
   c->t_pending.clear();
+  c->t_chain = nullptr;
   return HG_OK;
 }
 
@@ -438,7 +447,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
                                       seed, canonical, norm_mode, d_hits, d_cnt));
     }
     {
-      hg_timed tm(c, HG_T_SORT);
+      hg_timed tm(c, HG_T_SORT, HG_T_KMER);
       HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, pl.max_cap));
     }
     // overflow check on the raw counters (they keep counting past the capacity)

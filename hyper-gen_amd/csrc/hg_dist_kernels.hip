@@ -1598,7 +1598,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
       c->lds_attr_done.push_back(fp);
     }
     {
-      hg_timed tmg(c, HG_T_DIST);
+      hg_timed tmg(c, HG_T_DIST, HG_T_DIST_PREP);
       c->last_kernel_i8 = nt == 5 ? dist_kernel_name<false, false, true, true, 5, true>() : dist_kernel_name<false, false, true, true, 4, true>();
       if (nt == 5)
         hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
