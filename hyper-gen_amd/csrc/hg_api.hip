@@ -2,6 +2,7 @@
 // the sketch and dist kernels.  No CPU fallback lives here: every compute entry point runs
 // HIP kernels or fails.
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +89,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
     (void)hipEventDestroy(t.e1);
   }
   for (auto e : c->t_pool) (void)hipEventDestroy(e);
+  if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (auto e : c->copy_events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) {
@@ -207,6 +209,47 @@ hg_status hg_ensure(hg_ctx *c, hg_ctx::Buf &b, size_t bytes) {
     return hg_fail(c, HG_ERR_OOM, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
   }
   b.cap = want;
+  return HG_OK;
+}
+
+namespace {
+__global__ void publish_words_kernel(const uint32_t *__restrict__ src, uint32_t n, volatile uint32_t *dst, uint32_t seq) {
+  if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dst[16] = seq;
+    __threadfence_system();
+  }
+}
+}  // namespace
+
+hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const uint32_t **out) {
+  if (n > 16) return hg_fail(c, HG_ERR_INVALID, "hg_publish_words: at most 16 words");
+  if (!c->h_res) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, 32 * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) return hg_fail(c, HG_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    c->h_res = static_cast<uint32_t *>(p);
+    std::memset(c->h_res, 0, 32 * sizeof(uint32_t));
+  }
+  const uint32_t seq = ++c->res_seq ? c->res_seq : ++c->res_seq;  // never 0
+  hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, c->stream, d_words, n, c->h_res, seq);
+  HG_HIP(c, hipGetLastError());
+  volatile uint32_t *flag = c->h_res + 16;
+  for (uint32_t spins = 0;; ++spins) {
+    if (*flag == seq) break;
+    if ((spins & 0xfff) == 0xfff) {  // every 4 096 polls: has the stream ended without the word arriving (a failed launch)?
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (*flag == seq) break;
+        return hg_fail(c, HG_ERR_HIP, "hg_publish_words: the stream finished without publishing");
+      }
+      if (q != hipErrorNotReady) return hg_fail(c, HG_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  *out = c->h_res;
   return HG_OK;
 }
 
@@ -835,10 +878,8 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   a.ref_off = (uint32_t)ref_off, a.qry_off = (uint32_t)qry_off;
   int spec_cover = -1;
   if ((s = hg_run_dist(c, a, d_count + 1, &spec_cover)) != HG_OK) return s;
-  if ((s = hg_ensure_pinned(c, 64)) != HG_OK) return s;
-  auto *h_res = static_cast<uint32_t *>(c->h_pin);
-  HG_HIP(c, hipMemcpyAsync(h_res, d_count, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HG_HIP(c, hipStreamSynchronize(c->stream));
+  const uint32_t *h_res = nullptr;
+  if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
   const bool i8_tried = h_res[9] != 0;  // the i8 prepass wrote its K-step count
   if (i8_tried && h_res[8] != 1u) c->i8_skip = 16;  // vetoed on the device: f16 ran; do not probe again for a while
   if (h_res[8] == 1u) {
@@ -853,9 +894,7 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if (h_res[8] != 1u && (spec_cover == -2 || (spec_cover >= 0 && (int)h_res[1] > spec_cover))) {
     HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
-    h_res = static_cast<uint32_t *>(c->h_pin);  // the pinned scratch may have grown meanwhile
-    HG_HIP(c, hipMemcpyAsync(h_res, d_count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HG_HIP(c, hipStreamSynchronize(c->stream));
+    if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
   }
   const uint32_t found = h_res[0];
   *n_out = found;

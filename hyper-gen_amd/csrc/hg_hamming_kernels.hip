@@ -222,9 +222,9 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
     s = ham_launch(c, d_ref_bits, R, d_qry_bits, Q, hv_d, nullptr, d_out, d_count,
                    cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist, (uint32_t)ref_off, (uint32_t)qry_off);
   if (s != HG_OK) return s;
-  uint32_t found = 0;
-  HG_HIP(c, hipMemcpyAsync(&found, d_count, sizeof found, hipMemcpyDeviceToHost, c->stream));
-  HG_HIP(c, hipStreamSynchronize(c->stream));
+  const uint32_t *h_res = nullptr;
+  if ((s = hg_publish_words(c, d_count, 1, &h_res)) != HG_OK) return s;
+  const uint32_t found = h_res[0];
   *n_out = found;
   if (hipMemsetAsync(d_count, 0, 64, c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");

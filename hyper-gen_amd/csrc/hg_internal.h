@@ -85,11 +85,18 @@ struct hg_ctx {
   // pinned host scratch
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;
+  uint32_t *h_res = nullptr;  // 32 words of page-locked host memory the device writes results into (hg_publish_words)
+  uint32_t res_seq = 0;       // sequence number of the last publication
 };
 
 hg_status hg_fail(hg_ctx *ctx, hg_status s, const std::string &msg);
 hg_status hg_ensure(hg_ctx *ctx, hg_ctx::Buf &b, size_t bytes);
 hg_status hg_ensure_pinned(hg_ctx *ctx, size_t bytes);
+// Result words back to the host without a copy command: a one-wave kernel at the end of the stream's work writes
+// n <= 16 words of device memory into the ctx's page-locked result block and raises a sequence number behind them;
+// the host polls that word (and the stream's own completion as a fallback) instead of paying a D2H copy command and a
+// stream synchronisation.  On return everything queued on the stream before the call has finished.  *out -> the n words.
+hg_status hg_publish_words(hg_ctx *ctx, const uint32_t *d_words, uint32_t n, const uint32_t **out);
 
 // RAII bracket: records events around the launches issued while it is alive (no-op unless
 // timing is enabled).
