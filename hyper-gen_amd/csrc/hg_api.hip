@@ -79,7 +79,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort,
+  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort, &c->w_redo,
                          &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
                          &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
@@ -489,9 +489,14 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
                                       seed, canonical, norm_mode, d_hits, d_cnt));
     }
+    uint32_t sort_cap = pl.max_cap;
     {
+      // The LDS sort is sized by the genomes' CAPACITIES (twice the expected count + 1 024: 64 KiB for a 5 Mbp genome,
+      // two workgroups per CU).  When the plan is a repeat, the counts of its last run are known: size by those (+ 12.5 %,
+      // 32 KiB -> five workgroups per CU); a genome that outgrows it is left to the large-set path below, as always.
+      if (reuse && c->plan_max_hits) sort_cap = (uint32_t)std::min<uint64_t>(sort_cap, (uint64_t)c->plan_max_hits + c->plan_max_hits / 8 + 16);
       hg_timed tm(c, HG_T_SORT, HG_T_KMER);
-      HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, pl.max_cap));
+      HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, sort_cap));
     }
     // overflow check on the raw counters (they keep counting past the capacity)
     HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -501,6 +506,22 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     for (size_t g = 0; g < n; ++g)
       if (h_cnt[g] > pl.meta[g].hit_cap) overflow = true, want[g] = h_cnt[g];
     if (!overflow) {
+      if (hg_sort_lds_keys(sort_cap) < hg_sort_lds_keys(pl.max_cap)) {
+        // the count-sized sort left out every genome that grew past its size: those again, with the capacity-sized one
+        std::vector<uint32_t> redo;
+        const uint32_t keys = hg_sort_lds_keys(sort_cap);
+        for (size_t g = 0; g < n; ++g) {
+          const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
+          if (cnt > keys && cnt <= HG_SORT_LDS_MAX_KEYS) redo.push_back((uint32_t)g);
+        }
+        if (!redo.empty()) {
+          if ((s = hg_ensure(c, c->w_redo, redo.size() * 4 + 64)) != HG_OK) return s;
+          HG_HIP(c, hipMemcpy(c->w_redo.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
+          hg_timed tm(c, HG_T_SORT);
+          HG_HIP(c, hg_launch_sort_unique_todo(c->stream, d_meta, static_cast<uint32_t *>(c->w_redo.p), (uint32_t)redo.size(),
+                                               d_hits, d_cnt, d_nd, pl.max_cap));
+        }
+      }
       // hash sets beyond the LDS sort: bucketed multi-workgroup sort (or, where that cannot work, in place)
       if ((s = sort_large_sets(c, pl, h_cnt, n, threshold, d_hits, d_cnt, d_nd)) != HG_OK) return s;
       h_cnt = static_cast<uint32_t *>(c->h_pin);  // (unchanged unless the pinned scratch grew)
@@ -520,6 +541,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
         c->plan_slots = pl.total_slots, c->plan_max_cap = pl.max_cap, c->plan_items = n_items;
         c->plan_valid = true;
       }
+      c->plan_max_hits = pl.max_hits;
       *d_ndistinct_out = d_nd;
       return HG_OK;
     }

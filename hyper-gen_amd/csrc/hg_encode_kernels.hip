@@ -592,13 +592,28 @@ static hipError_t sort_lds_attr() {
   return e;
 }
 
+uint32_t hg_sort_lds_keys(uint32_t max_cap) {
+  uint32_t keys = 1;
+  while (keys < max_cap && keys < SORT_LDS_MAX_KEYS) keys <<= 1;
+  return keys;
+}
+
+hipError_t hg_launch_sort_unique_todo(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo, uint32_t n_todo,
+                                      uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t max_cap) {
+  if (n_todo == 0) return hipSuccess;
+  const uint32_t keys = hg_sort_lds_keys(max_cap);
+  hipError_t e = sort_lds_attr();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_todo), dim3(SORT_WG), (size_t)keys * sizeof(uint64_t), st, d_meta,
+                     d_hits, d_cnt, d_ndistinct, keys, d_todo);
+  return hipGetLastError();
+}
+
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
                                  uint32_t max_cap) {
   if (n_genomes == 0) return hipSuccess;
-  uint32_t keys = 1;
-  while (keys < max_cap) keys <<= 1;
-  if (keys > SORT_LDS_MAX_KEYS) keys = SORT_LDS_MAX_KEYS;
+  const uint32_t keys = hg_sort_lds_keys(max_cap);
   const size_t lds = (size_t)keys * sizeof(uint64_t);
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;

@@ -28,6 +28,7 @@ struct hg_ctx {
   Buf w_cnt;      // per-genome raw hit counters + distinct counts
   Buf w_hits2;    // scratch copy of the hit buffer (bucketed sort of large hash sets)
   Buf w_lsort;    // job / chunk / bucket tables of the bucketed sort
+  Buf w_redo;     // genomes the count-sized LDS sort skipped (see sample_batch)
   Buf w_seq;      // staged sequences (host entry points)
   Buf w_hv;       // staged HV output (host entry points)
   Buf w_misc;     // small scalars (hit counters of dist, flags)
@@ -65,6 +66,7 @@ struct hg_ctx {
   uint32_t plan_ksize = 0;
   uint64_t plan_scaled = 0, plan_slots = 0;
   uint32_t plan_max_cap = 0;
+  uint32_t plan_max_hits = 0;  // largest raw hit count the cached plan's last run saw (sizes the LDS sort of the next)
   size_t plan_items = 0;
   bool plan_valid = false;
   // host-fed batches: uploads run on their own stream, one event per sub-batch (hg_sketch_batch)
@@ -149,6 +151,11 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
 // ---- sort/unique + encode kernels ---------------------------------------------------------
 // Sorts each genome's hits ascending, removes duplicates in place (region start),
 // d_ndistinct[g] = distinct count.  max_cnt_pow2 bounds the LDS sort size.
+// keys the LDS sort launched for capacity `max_cap` holds per genome (a power of two, at most HG_SORT_LDS_MAX_KEYS);
+// with d_todo the launch covers the listed genomes only
+uint32_t hg_sort_lds_keys(uint32_t max_cap);
+hipError_t hg_launch_sort_unique_todo(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo, uint32_t n_todo,
+                                      uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t max_cap);
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
                                  uint32_t max_cap);

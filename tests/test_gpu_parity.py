@@ -550,6 +550,26 @@ def test_sketch_batch_of_many_small_genomes_is_packed_for_upload(ctx, orc, hg):
             assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (rep, i)
 
 
+def test_repeated_batch_geometry_with_growing_hash_sets(ctx, orc, hg):
+    """A batch with the geometry of the previous one reuses its plan, and its LDS sort is sized by the COUNTS the
+    previous run saw: genomes that come back with many more sampled hashes (same lengths, fewer non-bases) must be
+    picked up by the capacity-sized sort again -- and a third run, sized by the larger counts, agrees as well."""
+    rng = np.random.default_rng(31337)
+    p = hg.default_params(scaled=200)
+    full = [rand_seq(rng, int(n)) for n in (300_000, 120_000, 500_000, 64_000)]
+    sparse = []
+    for g in full:
+        h = g.copy()
+        h[rng.random(h.size) < 0.12] = ord("N")  # a non-base every ~8 bases: few 21-mers survive
+        sparse.append(h)
+    for gs in (sparse, full, full, sparse):
+        hv, n2, nh = ctx.sketch_batch(gs, p)
+        for i in range(len(gs)):
+            w_hv, w_n2, w_nh = orc.sketch_genome(gs[i], scaled=200)
+            assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), i
+    assert nh.max() * 8 < ctx.sketch_batch(full, p)[2].max()  # (the sparse sets are indeed much smaller)
+
+
 def _sketch_like(rng, rows, D, n, base=None, share=0.6):
     """HVs with the structure of real sketches: hv = 2*count - n (uniform parity per row), count ~ Binomial."""
     cnt = rng.binomial(n, 0.5, (rows, D))
