@@ -239,6 +239,7 @@ hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const
   volatile uint32_t *flag = c->h_res + 16;
   for (uint32_t spins = 0;; ++spins) {
     if (*flag == seq) break;
+    if (spins > (1u << 20)) std::this_thread::yield();  // a long kernel: stop burning the core (the first ~ms stays a pure poll)
     if ((spins & 0xfff) == 0xfff) {  // every 4 096 polls: has the stream ended without the word arriving (a failed launch)?
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {

@@ -167,9 +167,11 @@ hg_status hg_dist_full_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *
                            size_t Q, uint32_t hv_d, uint32_t ksize, float *d_ani_out);
 /* Completion of the *_dev entry points: their device inputs are read, and their device outputs written,
  * in stream order on the ctx's stream (hg_ctx_set_stream), so work the caller queues on that stream before
- * / after the call is ordered with it.  hg_dist_dev has synchronised the stream when it returns (it reads
- * the hit count back); hg_sketch_batch_dev and hg_dist_full_dev may return with their last kernels still
- * running -- hg_ctx_sync (or the caller's own stream synchronisation) completes them. */
+ * / after the call is ordered with it.  When hg_dist_dev / hg_hamming_search_dev return, everything queued on
+ * the stream before and by the call has finished (the hit count comes back through a page-locked block the
+ * last kernel writes and the host polls -- no copy command, no hipStreamSynchronize); hg_sketch_batch_dev and
+ * hg_dist_full_dev may return with their last kernels still running -- hg_ctx_sync (or the caller's own stream
+ * synchronisation) completes them. */
 
 /* one reported pair: what dump_ani_file prints per line (src/utils.rs:275-285) */
 typedef struct {
