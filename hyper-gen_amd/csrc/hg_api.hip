@@ -228,7 +228,8 @@ hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const
   if (n > 16) return hg_fail(c, HG_ERR_INVALID, "hg_publish_words: at most 16 words");
   if (!c->h_res) {
     void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, 32 * sizeof(uint32_t), hipHostMallocDefault);
+    // (coherent = fine-grained: the device's writes and the fence between words and sequence number are seen by the polling host)
+    hipError_t e = hipHostMalloc(&p, 32 * sizeof(uint32_t), hipHostMallocCoherent);
     if (e != hipSuccess) return hg_fail(c, HG_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     c->h_res = static_cast<uint32_t *>(p);
     std::memset(c->h_res, 0, 32 * sizeof(uint32_t));
