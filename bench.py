@@ -295,6 +295,13 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    # No cyclic-GC passes inside the timed loops: with torch loaded a full collection takes ~10 ms, more than a step
+    # (one run of round 3 showed exactly such a step: 20 steps at 8.73 ms of kernels averaged 9.34 ms).
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
     ctx = hg.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
