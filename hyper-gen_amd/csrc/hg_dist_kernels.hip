@@ -339,7 +339,13 @@ __global__ __launch_bounds__(256) void decide_kernel(const unsigned long long *_
 // parity, residuals beyond a byte, a row with more than 255 clamped entries or an overflow of the entry list veto
 // the path on the device and the f16 kernels queued behind it run instead; the dot product is the same integer
 // either way.
-constexpr uint32_t I8_ROW_ENT_MAX = 256;  // clamped entries one row may have (the slot word counts to 255)
+constexpr uint32_t I8_ROW_ENT_MAX = 256;  // clamped entries of a row the prepass looks at (the slot word counts to 255)
+// Every row owns I8_ROW_SLOTS consecutive entries of the list (row r of side s at (s ? R : 0) * SLOTS + r * SLOTS): no
+// reservation at all.  (Until round 3 the rows appended to one compact list through ONE atomic counter: the same-address
+// atomics of 10 000 rows serialise at ~9 ns, and the prepass of sketches with an entry in every row -- 4 500 hashes and
+// more -- took 0.075-0.135 ms instead of 0.03.)  A row with more entries than slots vetoes the i8 path for the call:
+// at 16 slots that is one row in 10^5 at 6 000 hashes (4.2 entries per row on average), every call at 7 000.
+constexpr uint32_t I8_ROW_SLOTS = 16;
 struct I8Outlier {
   uint32_t row;
   uint16_t d;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
                                                       uint32_t kp8, uint32_t ldk8, int8_t *__restrict__ out_a,
                                                       int32_t *__restrict__ rowinfo, int32_t *__restrict__ rowslot,
                                                       uint32_t *__restrict__ rowfirst, I8Outlier *__restrict__ list,
-                                                      uint32_t list_cap, uint32_t *__restrict__ ctrl, uint32_t side) {
+                                                      uint32_t list_base, uint32_t *__restrict__ ctrl, uint32_t side) {
   // the row's clamped entries are collected in LDS (one wave = one row) and go to the global list as ONE contiguous
   // range reserved with a single atomic: no sort, no second kernel, and the list can be as long as memory allows
   __shared__ uint32_t s_ent[4][I8_ROW_ENT_MAX];
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const uint32_t n_raw = s_n[wv], n = n_raw < I8_ROW_ENT_MAX ? n_raw : I8_ROW_ENT_MAX;
+  const uint32_t n_st = n < I8_ROW_SLOTS ? n : I8_ROW_SLOTS;  // entries stored
   uint32_t bs = 0;  // sum |b| over the row's entries (the epilogue's per-row slack)
   for (uint32_t t = lane; t < n; t += 64) {
     const int32_t bb = (int8_t)(uint8_t)(s_ent[wv][t] >> 16);
@@ -422,30 +429,26 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) bs += __shfl_xor(bs, o);
-  if (n_raw > 255u || bs >= (1u << 14)) bad |= 2u;  // more than the slot word can describe
-  uint32_t base = 0;
-  if (lane == 0 && n) base = atomicAdd(&ctrl[0], n);
-  base = __shfl(base, 0);
-  if (n && (uint64_t)base + n <= list_cap) {
-    for (uint32_t t = lane; t < n; t += 64) {
-      const uint32_t v = s_ent[wv][t];
-      list[base + t] = I8Outlier{row, (uint16_t)(v & 0xffffu), (int8_t)(uint8_t)(v >> 16), (uint8_t)side};
-    }
+  if (n_raw > I8_ROW_SLOTS || bs >= (1u << 14)) bad |= 2u;  // more than the row's slots / the slot word can describe
+  const uint32_t base = list_base + row * I8_ROW_SLOTS;
+  if (lane < n_st) {
+    const uint32_t v = s_ent[wv][lane];
+    list[base + lane] = I8Outlier{row, (uint16_t)(v & 0xffffu), (int8_t)(uint8_t)(v >> 16), (uint8_t)side};
   }
   const bool anypar = __any(par != 0), anybad4 = __any((bad & 4u) != 0), anybad2 = __any((bad & 2u) != 0);
   if (lane == 0) {
     rowinfo[row] = 2 * S + e;
     rowfirst[row] = base;
-    rowslot[row] = n ? (int32_t)(((n & 255u) << 14) | (bs & 0x3fffu)) : 0;  // entries (8 bits) | sum |b| (14 bits); 0 = none
+    rowslot[row] = n_st ? (int32_t)(((n_st & 255u) << 14) | (bs & 0x3fffu)) : 0;  // entries (8 bits) | sum |b| (14 bits); 0 = none
     const uint32_t fl = (anypar ? 1u : 0u) | (anybad2 ? 2u : 0u) | (anybad4 ? 4u : 0u);
     if (fl) atomicOr(&ctrl[1], fl);
   }
 }
 
-// The i8 attempt is valid iff no row broke the scheme (ctrl[1]: parity / residual / per-row limits) and the entry list
-// did not overflow (ctrl[0] counts every reserved entry).  Every workgroup of the GEMM evaluates this by itself.
-__device__ __forceinline__ bool i8_attempt_valid(const uint32_t *ctrl, uint32_t list_cap) {
-  return ctrl[1] == 0u && ctrl[0] <= list_cap;
+// The i8 attempt is valid iff no row broke the scheme (ctrl[1]: parity / residual / per-row limits, among them the
+// row's list slots).  Every workgroup of the GEMM evaluates this by itself.
+__device__ __forceinline__ bool i8_attempt_valid(const uint32_t *ctrl, uint32_t) {
+  return ctrl[1] == 0u;
 }
 
 
@@ -1528,19 +1531,20 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const uint32_t *veto = nullptr;
   const bool want_i8 = c->dbg_dist_path != "f16" && d_verdict && !a.ani_out && a.hits && a.hv_d <= 8192 && a.hv_d % 8 == 0 &&
                        ((uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256 || c->dbg_dist_path == "i8") &&
-                       (c->i8_skip == 0 || c->dbg_dist_path == "i8");
+                       (c->i8_skip == 0 || c->dbg_dist_path == "i8") &&
+                       ((uint64_t)a.R + a.Q) * I8_ROW_SLOTS < ((uint64_t)1 << 31);  // (32-bit entry indices)
   if (!want_i8 && c->i8_skip) --c->i8_skip;
   if (want_i8) {
     const uint32_t kp8 = (a.hv_d + 127) / 128 * 128, ldk8 = kp8 + 128;
     if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
     if (!same && (s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldk8)) != HG_OK) return s;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    // misc block: info, slot and first-entry words per row / column, the list of clamped entries
-    // capacity = 2 entries per row on average: beyond that (sketches of more than ~5 500 hashes at D = 4096) the
-    // per-candidate corrections and the wider pre-filter slack cost more than the i8 GEMM saves (10 000 x 10 000,
-    // 1.29 M hits: 4 500 hashes 0.62 ms vs 0.89 ms f16, 5 500: 0.84 vs 0.89, 6 666: 1.17 vs 0.87) -- the overflow vetoes
-    const uint64_t cap64 = std::min<uint64_t>(((uint64_t)a.R + a.Q) * 2 + 1024, (uint64_t)1 << 26);
-    const uint32_t ent_cap = (uint32_t)cap64;
+    // misc block: info, slot and first-entry words per row / column, the list of clamped entries: I8_ROW_SLOTS per row.
+    // (Where the path stops paying is the per-candidate corrections and the wider pre-filter slack, not the list:
+    // 10 000 x 10 000, 1.29 M hits, GEMM + prepass -- 3 333 hashes 0.40 + 0.03 ms (f16 operands 0.66 + 0.05), 4 500:
+    // 0.42 + 0.04 (0.77 + 0.04), 5 500: 0.50 + 0.04 (0.77 + 0.04), 6 000: 0.57 + 0.04 (0.75 + 0.05); beyond ~6 300
+    // hashes some row of 10 000 overflows its slots and the call runs on f16 operands.)
+    const uint32_t ent_cap = (uint32_t)(((uint64_t)a.R + (same ? 0 : a.Q)) * I8_ROW_SLOTS);
     const size_t o_iq = al((size_t)a.R * 4), o_sr = o_iq + al((size_t)a.Q * 4), o_sq = o_sr + al((size_t)a.R * 4);
     const size_t o_fr = o_sq + al((size_t)a.Q * 4), o_fq = o_fr + al((size_t)a.R * 4), o_list = o_fq + al((size_t)a.Q * 4);
     if ((s = hg_ensure(c, c->w_i8misc, o_list + al((size_t)ent_cap * sizeof(I8Outlier)) + 256)) != HG_OK) return s;
@@ -1556,11 +1560,11 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     {
       hg_timed tmp(c, HG_T_DIST_PREP);
       hipLaunchKernelGGL(prep_i8_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, kp8, ldk8, a8,
-                         info_r, slot_r, first_r, list, ent_cap, ctrl, 0u);
+                         info_r, slot_r, first_r, list, 0u, ctrl, 0u);
       HG_HIP(c, hipGetLastError());
       if (!same) {
         hipLaunchKernelGGL(prep_i8_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, kp8, ldk8, b8,
-                           info_q, slot_q, first_q, list, ent_cap, ctrl, 1u);
+                           info_q, slot_q, first_q, list, a.R * I8_ROW_SLOTS, ctrl, 1u);
         HG_HIP(c, hipGetLastError());
       }
     }
