@@ -1156,17 +1156,17 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // Two ways through the accumulators (in-kernel stamps, DESIGN.md 4.3: with one branch per element and the row words
   // read slab by slab the sweep took 20 000 cycles in a tile without a single candidate and 25 000 more in a tile with
   // the ~1 000 scattered candidates every tile of a real comparison has):
-  //  * LANE MASKS (every thresholded kernel but the windowed f16 one, tiles off the diagonal of a symmetric comparison --
-  //    there a candidate is "passes phase 0"; the f16 kernels' denominator test of the slab path is only a cheaper
-  //    filter in front of the exact phase 2, 0.69 -> 0.61 ms at 10 000 x 10 000 without it): every lane shifts the sign of `d - ur - tq` of its 4 * NT elements of a 16-row slab
+  //  * LANE MASKS (every thresholded kernel, tiles off the diagonal of a symmetric comparison -- there a candidate is
+  //    "passes phase 0"; the f16 kernels' denominator test of the slab path is only a cheaper filter in front of the
+  //    exact phase 2: 0.69 -> 0.61 ms at 10 000 x 10 000 without it, the windowed kernel 0.85 -> 0.78): every lane shifts the sign of `d - ur - tq` of its 4 * NT elements of a 16-row slab
   //    into one mask word per slab, no branches.  One barrier makes the waves' candidate counts known to all: a tile
   //    without candidates ends there; if no list can overflow, every wave then appends its candidates on its own --
   //    per slab one LDS atomic per lane that has any reserves its run of the list, predicated stores fill it -- and
   //    the workgroup meets again in flush_all.
-  //  * SLABS (everything else, and tiles whose candidates may overflow a list): per 16-row slab the 4 * NT compares
+  //  * SLABS (the full-matrix mode, diagonal tiles of a symmetric comparison, and tiles whose candidates may overflow a list): per 16-row slab the 4 * NT compares
   //    are OR-ed on the scalar side into one wave-uniform branch; a slab with candidates takes one ballot per element,
   //    and a barrier per slab makes the decision to empty the lists uniform.
-  constexpr bool LANE_MASKS = !FULL && (I8 || !CHUNKED);  // (f16 operands: phase 2 is exact, the slab path's denominator test is only a cheaper filter)
+  constexpr bool LANE_MASKS = !FULL;  // (f16 operands: phase 2 is exact, the slab path's denominator test is only a cheaper filter)
   constexpr uint32_t BNC_LANE = 80, BNC_WAVE = 64 * BNC_LANE;  // bytes of a lane's / a wave's bounce buffer (append loop)
   static_assert(NT * 16 <= (int)BNC_LANE, "a lane's slab fits its bounce buffer");
   constexpr uint32_t SLAB_BITS = (1u << (4 * NT)) - 1u;
@@ -1188,6 +1188,11 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
             float d;
             if constexpr (std::is_same<acc_t, int4v>::value) asm("v_cvt_f32_i32_e32 %0, %1" : "=v"(d) : "v"(acc[m][n][r]));
             else d = acc[m][n][r];
+            if constexpr (CHUNKED) {  // (+ the windows already moved into the integer accumulator; asm for the same reason)
+              float di;
+              asm("v_cvt_f32_i32_e32 %0, %1" : "=v"(di) : "v"(iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r]));
+              d += di;
+            }
             const float margin = (d - ur4[r]) - tq[n];  // (finite sentinels: never NaN)
             np = __builtin_amdgcn_alignbit(np, __float_as_uint(margin), 31);  // (np << 1) | sign: element e = r * NT + n at bit 4 NT - 1 - e
           });
@@ -1240,13 +1245,22 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         uint32_t rest = ~notpass[m] & SLAB_BITS;
         if (__ballot(rest != 0u) == 0) return;  // wave-uniform
 #pragma unroll
-        for (int n = 0; n < NT; ++n) *reinterpret_cast<acc_t *>(bnc + n * 16) = acc[m][n];
+        for (int n = 0; n < NT; ++n) {
+          if constexpr (CHUNKED) {  // the exact dot product = last window (f32, exact) + the integer windows
+            int4v v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (int32_t)acc[m][n][r] + iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r];
+            *reinterpret_cast<int4v *>(bnc + n * 16) = v;
+          } else {
+            *reinterpret_cast<acc_t *>(bnc + n * 16) = acc[m][n];
+          }
+        }
         const uint32_t key0 = ((wm * (WTM * 16) + m * 16 + fq * 4) << 16) | (wn * (NT * 16) + fr);
         while (rest != 0u) {
           const uint32_t e = (uint32_t)(4 * NT - 1) - (uint32_t)__builtin_ctz(rest), r = e / (uint32_t)NT, n = e - r * (uint32_t)NT;
           rest &= rest - 1u;
           int32_t G;
-          if constexpr (std::is_same<acc_t, int4v>::value) G = *reinterpret_cast<const int32_t *>(bnc + n * 16 + r * 4);
+          if constexpr (std::is_same<acc_t, int4v>::value || CHUNKED) G = *reinterpret_cast<const int32_t *>(bnc + n * 16 + r * 4);
           else G = (int32_t)*reinterpret_cast<const float *>(bnc + n * 16 + r * 4);
           cand[off] = make_uint2(key0 + (r << 16) + n * 16u, (uint32_t)G);
           ++off;
