@@ -1163,9 +1163,10 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   //    without candidates ends there; if no list can overflow, every wave then appends its candidates on its own --
   //    per slab one LDS atomic per lane that has any reserves its run of the list, predicated stores fill it -- and
   //    the workgroup meets again in flush_all.
-  //  * SLABS (the full-matrix mode, diagonal tiles of a symmetric comparison, and tiles whose candidates may overflow a list): per 16-row slab the 4 * NT compares
-  //    are OR-ed on the scalar side into one wave-uniform branch; a slab with candidates takes one ballot per element,
-  //    and a barrier per slab makes the decision to empty the lists uniform.
+  //  * SLABS (the full-matrix mode, diagonal tiles of a symmetric comparison, tiles whose candidates may overflow a
+  //    list): per 16-row slab the 4 * NT compares are OR-ed on the scalar side into one wave-uniform branch; a slab
+  //    with candidates takes one ballot per element, and a barrier per slab makes the decision to empty the lists
+  //    uniform.
   constexpr bool LANE_MASKS = !FULL;  // (f16 operands: phase 2 is exact, the slab path's denominator test is only a cheaper filter)
   constexpr uint32_t BNC_LANE = 80, BNC_WAVE = 64 * BNC_LANE;  // bytes of a lane's / a wave's bounce buffer (append loop)
   static_assert(NT * 16 <= (int)BNC_LANE, "a lane's slab fits its bounce buffer");
