@@ -870,8 +870,13 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       }
       // (finite sentinels, so that `d - ur - tq` is never NaN: "out of range" outweighs "norm outside the safe range")
       if (HAM) s_ur[t] = !in ? 1e30f : (is_r ? 0.f : (float)g.ham_thr);  // G >= ham_thr, exact while D <= 2^24
-      else s_ur[t] = !in ? 1e30f
-                         : ((nv < 0 || nv > NORM_SAFE) ? -1e20f : (g.pre_c * (float)nv + (is_r ? 0.f : g.pre_b) - slack) * p0_scale);
+      else {
+        // (clamped: pre_b is -inf when every pair passes -- ani_th <= 0 -- and +inf when none can; left infinite, a
+        // column threshold of -inf would cancel the "out of range" of a row: inf - inf, and with it the only thing
+        // that keeps the rows past R out of the lane-mask path's lists)
+        const float thr = fminf(fmaxf((g.pre_c * (float)nv + (is_r ? 0.f : g.pre_b) - slack) * p0_scale, -1e20f), 1e20f);
+        s_ur[t] = !in ? 1e30f : ((nv < 0 || nv > NORM_SAFE) ? -1e20f : thr);
+      }
     }
     if (tid < 3) s_cnt[THREADS / 64 + 1 + THREADS / 64 + tid] = 0u;  // "some candidate list is nearly full": three slots in rotation
     if (tid < (uint32_t)(THREADS / 64)) s_fill[tid] = 0u;

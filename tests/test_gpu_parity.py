@@ -661,6 +661,32 @@ def test_dist_tile_orders_and_epilogue_paths_agree(ctx, orc, path):
         ctx.set_debug("dist_order", "")
 
 
+@pytest.mark.parametrize("path", ["i8", "f16"])
+def test_dist_every_pair_passes_on_ragged_corner_tiles(ctx, orc, path):
+    """ani_th <= 0 makes the pre-filter's column bound -inf; the corner tile of a ragged matrix has a few valid rows and
+    columns next to many padded ones, few enough candidates for the lane-mask path -- the padded rows must stay out
+    (their "out of range" threshold used to cancel against the -inf: garbage hits beyond R)."""
+    rng = np.random.default_rng(515)
+    D, n = 4096, 3001
+    for R, Q in ((300, 325), (260, 330), (129, 131)):
+        r = (2 * rng.binomial(n, 0.5, (R, D)) - n).astype(np.int16)
+        q = (2 * rng.binomial(n, 0.5, (Q, D)) - n).astype(np.int16)
+        rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+        qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+        try:
+            ctx.set_debug("dist_path", path)
+            for tile in ("wide", "big", ""):
+                ctx.set_debug("dist_tile", tile)
+                for th in (0.0, -3.0):
+                    h = ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=th)
+                    assert h.size == R * Q, (R, Q, tile, th, h.size)
+                    assert h["ref_idx"].max() < R and h["qry_idx"].max() < Q
+                    assert np.unique(h["ref_idx"].astype(np.int64) * Q + h["qry_idx"]).size == R * Q
+        finally:
+            ctx.set_debug("dist_path", "")
+            ctx.set_debug("dist_tile", "")
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_dist_random_shapes_thresholded_equals_full(ctx, orc, seed):
     """Random shapes, dimensions, thresholds and cluster structure, both operand formats: the thresholded hit list must
