@@ -498,7 +498,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       // 32 KiB -> five workgroups per CU); a genome that outgrows it is left to the large-set path below, as always.
       if (reuse && c->plan_max_hits) sort_cap = (uint32_t)std::min<uint64_t>(sort_cap, (uint64_t)c->plan_max_hits + c->plan_max_hits / 8 + 16);
       hg_timed tm(c, HG_T_SORT, HG_T_KMER);
-      HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, sort_cap));
+      HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, sort_cap, threshold));
     }
     // overflow check on the raw counters (they keep counting past the capacity)
     HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -521,7 +521,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
           HG_HIP(c, hipMemcpy(c->w_redo.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
           hg_timed tm(c, HG_T_SORT);
           HG_HIP(c, hg_launch_sort_unique_todo(c->stream, d_meta, static_cast<uint32_t *>(c->w_redo.p), (uint32_t)redo.size(),
-                                               d_hits, d_cnt, d_nd, pl.max_cap));
+                                               d_hits, d_cnt, d_nd, pl.max_cap, threshold));
         }
       }
       // hash sets beyond the LDS sort: bucketed multi-workgroup sort (or, where that cannot work, in place)

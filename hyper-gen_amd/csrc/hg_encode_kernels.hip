@@ -79,11 +79,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratc
 
 // One workgroup per genome.  USE_LDS: keys are staged in dynamic LDS; otherwise the sort runs
 // in place in the genome's hit region (which must have next_pow2(count) slots).
+// Counting-sort fast path of the LDS sort (bucket_mul != 0, 512 <= n, lds_keys <= SORT_BUCKET_MAX_KEYS): sampled
+// hashes are uniform below the threshold, so the monotone map b = floor(h * n2 / threshold) puts 0.8 keys into each of
+// n2 buckets on average.  Count (one returning LDS atomic per key: its rank inside the bucket), scan, scatter, then
+// every thread orders the few keys of its buckets by insertion: five passes over the keys instead of the bitonic
+// network's 78.  A bucket with more than SORT_BUCKET_LIMIT keys (repeats: equal hashes share a bucket) sends the genome
+// to the bitonic sort after all -- the keys are in LDS by then.
+constexpr uint32_t SORT_BUCKET_MAX_KEYS = 8192, SORT_BUCKET_LIMIT = 16, SORT_KPT = SORT_BUCKET_MAX_KEYS / SORT_WG;
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
     const hg_genome_meta *__restrict__ meta, uint64_t *__restrict__ hits,
     const uint32_t *__restrict__ cnt, uint32_t *__restrict__ ndistinct, uint32_t lds_keys,
-    const uint32_t *__restrict__ todo) {
+    const uint32_t *__restrict__ todo, uint64_t bucket_mul) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
   __shared__ uint32_t s_scan[SORT_WG / 64 + 1];
   const uint32_t g = todo ? todo[blockIdx.x] : blockIdx.x;
@@ -101,9 +109,65 @@ __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
     return;
   }
   if (in_lds) {
-    for (uint32_t i = tid; i < n2; i += SORT_WG) s_keys[i] = (i < n) ? region[i] : ~0ull;
-    __syncthreads();
-    bitonic_sort(s_keys, n2, tid, SORT_WG);
+    bool sorted = false;  // workgroup-uniform
+    if (USE_LDS && bucket_mul != 0 && n >= (uint32_t)SORT_WG && lds_keys <= SORT_BUCKET_MAX_KEYS) {
+      __shared__ uint32_t s_over;
+      uint32_t *s_bk = reinterpret_cast<uint32_t *>(s_keys + lds_keys);  // n2 bucket counters, then bucket starts
+      const uint32_t shift = (uint32_t)(__builtin_ctz(lds_keys) - __builtin_ctz(n2)), per = n2 / SORT_WG;
+      for (uint32_t i = tid; i < n2; i += SORT_WG) s_bk[i] = 0;
+      if (tid == 0) s_over = 0;
+      __syncthreads();
+      uint64_t kk[SORT_KPT];
+      uint32_t bb[SORT_KPT], rr[SORT_KPT];
+#pragma unroll
+      for (uint32_t u = 0; u < SORT_KPT; ++u) {
+        const uint32_t i = tid + u * SORT_WG;
+        if (i < n) {
+          kk[u] = region[i];
+          const uint32_t b = (uint32_t)__umul64hi(kk[u], bucket_mul) >> shift;
+          bb[u] = b < n2 ? b : n2 - 1;
+          rr[u] = atomicAdd(&s_bk[bb[u]], 1u);
+        }
+      }
+      __syncthreads();
+      {  // exclusive scan of the counters: thread t owns buckets [t * per, (t + 1) * per)
+        uint32_t c[SORT_KPT], sum = 0, mx = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < SORT_KPT; ++q)
+          if (q < per) c[q] = s_bk[tid * per + q], sum += c[q], mx = c[q] > mx ? c[q] : mx;
+        if (mx > SORT_BUCKET_LIMIT) s_over = 1u;  // (same value from every writer)
+        uint32_t total;
+        uint32_t run = block_excl_scan(sum, s_scan, &total);
+#pragma unroll
+        for (uint32_t q = 0; q < SORT_KPT; ++q)
+          if (q < per) s_bk[tid * per + q] = run, run += c[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t u = 0; u < SORT_KPT; ++u)
+        if (tid + u * SORT_WG < n) s_keys[s_bk[bb[u]] + rr[u]] = kk[u];
+      __syncthreads();
+      sorted = s_over == 0u;
+      if (sorted) {
+        for (uint32_t q = 0; q < per; ++q) {  // order the keys inside each of this thread's buckets
+          const uint32_t b = tid * per + q, lo = s_bk[b], hi = b + 1 < n2 ? s_bk[b + 1] : n;
+          for (uint32_t i = lo + 1; i < hi; ++i) {
+            const uint64_t v = s_keys[i];
+            uint32_t j = i;
+            while (j > lo && s_keys[j - 1] > v) s_keys[j] = s_keys[j - 1], --j;
+            s_keys[j] = v;
+          }
+        }
+      } else {
+        for (uint32_t i = n + tid; i < n2; i += SORT_WG) s_keys[i] = ~0ull;  // the keys are all here: bitonic after all
+      }
+      __syncthreads();
+      if (!sorted) bitonic_sort(s_keys, n2, tid, SORT_WG);
+    } else {
+      for (uint32_t i = tid; i < n2; i += SORT_WG) s_keys[i] = (i < n) ? region[i] : ~0ull;
+      __syncthreads();
+      bitonic_sort(s_keys, n2, tid, SORT_WG);
+    }
   } else {
     for (uint32_t i = n + tid; i < n2; i += SORT_WG) region[i] = ~0ull;  // hashes are < threshold < ~0
     __syncthreads();
@@ -603,29 +667,43 @@ uint32_t hg_sort_lds_keys(uint32_t max_cap) {
   return keys;
 }
 
+// dynamic LDS of the LDS sort: the keys, and the bucket counters of the counting-sort fast path where it applies
+static size_t sort_lds_bytes(uint32_t keys, uint64_t bucket_mul) {
+  return (size_t)keys * sizeof(uint64_t) + ((bucket_mul && keys <= SORT_BUCKET_MAX_KEYS) ? (size_t)keys * sizeof(uint32_t) : 0);
+}
+// bucket_mul for hashes below `threshold` and `keys` buckets: ceil(keys * 2^64 / threshold) (0: no fast path)
+static uint64_t sort_bucket_mul(uint32_t keys, uint64_t threshold) {
+  if (threshold == 0 || keys > SORT_BUCKET_MAX_KEYS) return 0;
+  const unsigned __int128 q = (((unsigned __int128)keys << 64) + threshold - 1) / threshold;
+  return q > (unsigned __int128)UINT64_MAX ? UINT64_MAX : (uint64_t)q;
+}
+
 hipError_t hg_launch_sort_unique_todo(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo, uint32_t n_todo,
-                                      uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t max_cap) {
+                                      uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t max_cap,
+                                      uint64_t threshold) {
   if (n_todo == 0) return hipSuccess;
   const uint32_t keys = hg_sort_lds_keys(max_cap);
+  const uint64_t bucket_mul = sort_bucket_mul(keys, threshold);
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_todo), dim3(SORT_WG), (size_t)keys * sizeof(uint64_t), st, d_meta,
-                     d_hits, d_cnt, d_ndistinct, keys, d_todo);
+  hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_todo), dim3(SORT_WG), sort_lds_bytes(keys, bucket_mul), st, d_meta,
+                     d_hits, d_cnt, d_ndistinct, keys, d_todo, bucket_mul);
   return hipGetLastError();
 }
 
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
-                                 uint32_t max_cap) {
+                                 uint32_t max_cap, uint64_t threshold) {
   if (n_genomes == 0) return hipSuccess;
   const uint32_t keys = hg_sort_lds_keys(max_cap);
-  const size_t lds = (size_t)keys * sizeof(uint64_t);
+  const uint64_t bucket_mul = sort_bucket_mul(keys, threshold);
+  const size_t lds = sort_lds_bytes(keys, bucket_mul);
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
   // genomes whose hit count exceeds the LDS budget are skipped here: the caller learns the counts and
   // runs hg_launch_sort_large / hg_launch_sort_inplace for them
   hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_genomes), dim3(SORT_WG), lds, st, d_meta,
-                     d_hits, d_cnt, d_ndistinct, keys, (const uint32_t *)nullptr);
+                     d_hits, d_cnt, d_ndistinct, keys, (const uint32_t *)nullptr, bucket_mul);
   return hipGetLastError();
 }
 
@@ -633,7 +711,7 @@ hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, 
                                   uint32_t n_todo, uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct) {
   if (n_todo == 0) return hipSuccess;
   hipLaunchKernelGGL((sort_unique_kernel<false>), dim3(n_todo), dim3(SORT_WG), 0, st, d_meta, d_hits, d_cnt,
-                     d_ndistinct, SORT_LDS_MAX_KEYS, d_todo);
+                     d_ndistinct, SORT_LDS_MAX_KEYS, d_todo, (uint64_t)0);
   return hipGetLastError();
 }
 

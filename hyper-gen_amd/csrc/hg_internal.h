@@ -155,10 +155,13 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
 // with d_todo the launch covers the listed genomes only
 uint32_t hg_sort_lds_keys(uint32_t max_cap);
 hipError_t hg_launch_sort_unique_todo(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo, uint32_t n_todo,
-                                      uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t max_cap);
+                                      uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t max_cap,
+                                      uint64_t threshold);
+// (threshold: every key is below it -- the sampling threshold; it scales the buckets of the counting-sort fast path,
+// 0 = bitonic only)
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
-                                 uint32_t max_cap);
+                                 uint32_t max_cap, uint64_t threshold);
 
 // Genomes with more than HG_SORT_LDS_MAX_KEYS sampled hashes: keys are bucketed by value (monotone map, so
 // the concatenation of sorted buckets is sorted), every bucket is sorted + de-duplicated in LDS by its own

@@ -550,6 +550,29 @@ def test_sketch_batch_of_many_small_genomes_is_packed_for_upload(ctx, orc, hg):
             assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (rep, i)
 
 
+def test_hash_sets_with_repeats_take_the_sort_fallback(ctx, orc):
+    """The LDS sort's counting-sort fast path buckets the sampled hashes by value (0.8 keys per bucket for uniform
+    hashes); equal hashes share a bucket, so a genome with a segment repeated 40 times piles 40 keys into ~100 buckets:
+    past the per-bucket limit the genome must take the bitonic network after all.  Unique genomes of the same batch stay
+    on the fast path."""
+    rng = np.random.default_rng(777)
+    unit = rand_seq(rng, 2000)
+    rep = np.concatenate([rand_seq(rng, 150_000)] + [unit] * 40 + [rand_seq(rng, 50_000)])
+    mild = np.concatenate([rand_seq(rng, 200_000), unit, unit, unit])   # three copies: inside the limit
+    uniq = rand_seq(rng, 260_000)
+    for s in (rep, mild, uniq):
+        for scaled in (20, 60):
+            want = orc.kmer_hash_sample(s, 21, scaled)
+            got = ctx.kmer_hash_sample(s, 21, scaled)
+            assert want.size >= 512 and got.size == want.size and (got == want).all(), scaled
+    import hypergen_amd as hg
+    p = hg.default_params(scaled=20)
+    hv, n2, nh = ctx.sketch_batch([rep, mild, uniq, rep], p)
+    for i, g in enumerate((rep, mild, uniq, rep)):
+        w_hv, w_n2, w_nh = orc.sketch_genome(g, scaled=20)
+        assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), i
+
+
 def test_repeated_batch_geometry_with_growing_hash_sets(ctx, orc, hg):
     """A batch with the geometry of the previous one reuses its plan, and its LDS sort is sized by the COUNTS the
     previous run saw: genomes that come back with many more sampled hashes (same lengths, fewer non-bases) must be
