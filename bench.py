@@ -609,7 +609,10 @@ def main():
                          "kernel": dist_kernel, "operands": "i8" if path == 1 else "f16",
                          "peak_dtype": "i8 dense MFMA" if path == 1 else "f16 dense MFMA",
                          "frac_of_f16_peak": ach / MFMA_F16_PEAK_TFLOPS,
-                         "launch_ms": gemm_ms, "algorithmic_flops_per_launch": flops_per_launch},
+                         "launch_ms": gemm_ms, "algorithmic_flops_per_launch": flops_per_launch,
+                         "note": "the peak is the nominal one (2.4 GHz); the kernel's loop shape sustains 0.63-0.78 of it on "
+                                 "random operand bytes because the chip lowers the shader clock to 1.7-2.0 GHz "
+                                 "(profiles/r03_mfma_ceiling.txt, tools/mfma_microbench.hip; DESIGN.md 4.3)"},
             "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in dtm.items() if v[1]},
         }
         log("dist: %.0f M pairs/s, gemm %.3f ms/launch = %.1f TFLOP/s, hits/rank %d" % (
