@@ -79,6 +79,7 @@ EXPORTS = [
     "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node",
     "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
     "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
+    "hg_sketch_batch_dev_packed", "hg_pack2_batch_dev", "hg_pack2_dev",
 ]
 
 
@@ -173,6 +174,9 @@ def lib():
         "hg_pack2_size": (sz, [sz]),
         "hg_pack2": (C.c_int, [vp, sz, C.c_uint32, vp]),
         "hg_unpack2_dev": (C.c_int, [vp, vp, sz, vp]),
+        "hg_sketch_batch_dev_packed": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(SketchParams), vp, vp, vp]),
+        "hg_pack2_batch_dev": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint32, vp, vp]),
+        "hg_pack2_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
         "hg_sketch_stream_finish": (C.c_int, [vp]),
         "hg_sketch_stream_last_error": (C.c_char_p, [vp]),
         "hg_sketch_stream_close": (None, [vp]),
@@ -232,6 +236,12 @@ def default_params(**kw):
     return p
 
 
+# Harness-side defaults for hg_ctx_set_debug, applied to every Context created while they are set (the test-suite's
+# "run this module in both input forms" switch: tests/conftest.py sets {"kmer_input": "packed"}).  The library itself
+# reads neither this nor the environment.
+default_debug = {}
+
+
 class Context:
     """One device + stream + workspaces (hg_ctx).  Not thread-safe."""
 
@@ -240,6 +250,8 @@ class Context:
         st = lib().hg_ctx_create(device, C.byref(self._h))
         if st != OK:
             raise HgError(st, lib().hg_last_error(None).decode())
+        for k, v in default_debug.items():
+            self.set_debug(k, v)
 
     def close(self):
         if self._h:
@@ -369,6 +381,23 @@ class Context:
         ln = np.ascontiguousarray(lens, np.uint64)
         self._ck(lib().hg_sketch_batch_dev(self._h, _ptr(d_seq), _ptr(off), _ptr(ln), off.size,
                                            C.byref(params), _ptr(d_hv), _ptr(d_norm2), _ptr(d_nhash)))
+
+    def sketch_batch_dev_packed(self, d_blobs, offsets, n_bps, params, d_hv, d_norm2, d_nhash):
+        """hg_sketch_batch_dev_packed: genome i is the hg_pack2 blob at d_blobs + offsets[i] (multiples of 16)"""
+        off = np.ascontiguousarray(offsets, np.uint64)
+        ln = np.ascontiguousarray(n_bps, np.uint64)
+        self._ck(lib().hg_sketch_batch_dev_packed(self._h, _ptr(d_blobs), _ptr(off), _ptr(ln), off.size,
+                                                  C.byref(params), _ptr(d_hv), _ptr(d_norm2), _ptr(d_nhash)))
+
+    def pack2_batch_dev(self, d_seq, offsets, lens, d_blobs, blob_offsets, norm_mode=NORM_ACGT):
+        """hg_pack2_batch_dev: ASCII genomes resident in HBM -> hg_pack2 blobs (device pointers are ints)"""
+        off = np.ascontiguousarray(offsets, np.uint64)
+        ln = np.ascontiguousarray(lens, np.uint64)
+        bo = np.ascontiguousarray(blob_offsets, np.uint64)
+        self._ck(lib().hg_pack2_batch_dev(self._h, _ptr(d_seq), _ptr(off), _ptr(ln), off.size, norm_mode, _ptr(d_blobs), _ptr(bo)))
+
+    def pack2_dev(self, d_seq, n_bps, d_blob, norm_mode=NORM_ACGT):
+        self._ck(lib().hg_pack2_dev(self._h, C.c_void_p(d_seq), n_bps, norm_mode, C.c_void_p(d_blob)))
 
     def synth_genomes_dev(self, first, n, L, stride, d_out, cluster_size=100, sub_ppm_per_member=1000):
         done = 0
@@ -678,14 +707,19 @@ class SketchStream:
             iid = self._next
             self._next += 1
             self._keep[iid] = (tag, a)
-        while True:
-            st = lib().hg_sketch_stream_try_push(self._h, _ptr(a), n_bps, iid, int(packed))
-            if st != ERR_CAPACITY:
-                break
-            r = self._pop_c()
-            if r is not None:
-                with self._lock:
-                    self._ready.append(r)
+        try:
+            while True:
+                st = lib().hg_sketch_stream_try_push(self._h, _ptr(a), n_bps, iid, int(packed))
+                if st != ERR_CAPACITY:
+                    break
+                r = self._pop_c()
+                if r is not None:
+                    with self._lock:
+                        self._ready.append(r)
+        except BaseException:  # a stream error surfaced by the pop: the genome was never queued, drop its keep-alive
+            with self._lock:
+                self._keep.pop(iid, None)
+            raise
         if st != OK:
             with self._lock:
                 self._keep.pop(iid, None)

@@ -12,7 +12,10 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+
 #include "hg_host.h"
+
 #include "hg_internal.h"
 
 static thread_local std::string g_create_err;
@@ -79,7 +82,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort, &c->w_redo,
+  hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort, &c->w_redo, &c->w_pk, &c->w_pktab,
                          &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
                          &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
@@ -132,6 +135,7 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   else if (k == "dist_path") c->dbg_dist_path = v;
   else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;
+  else if (k == "kmer_input") c->dbg_kmer_input = v;  // "packed": ASCII batches are 2-bit packed on the device first and take the packed kernels
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;
 }
@@ -154,10 +158,13 @@ static hipEvent_t take_event(hg_ctx *c) {
 }
 
 hg_timed::hg_timed(hg_ctx *ctx, int cls_, int after_cls) : c(ctx), cls(cls_) {
-  if (!c->timing) return;
-  if (after_cls >= 0 && c->t_chain && c->t_chain_cls == after_cls) e0 = c->t_chain, own_e0 = false;
-  else e0 = take_event(c);
+  // (the chain is consumed by the next bracket whether or not that one records: a bracket opened while timing is off,
+  // or one that never closes because its caller returned early, must not leave a stale event to chain to)
+  hipEvent_t chain = c->t_chain;
   c->t_chain = nullptr;
+  if (!c->timing) return;
+  if (after_cls >= 0 && chain && c->t_chain_cls == after_cls) e0 = chain, own_e0 = false;
+  else e0 = take_event(c);
   e1 = take_event(c);
   if (e0 && own_e0) (void)hipEventRecord(e0, c->stream);
 }
@@ -171,6 +178,7 @@ hg_timed::~hg_timed() {
 extern "C" hg_status hg_ctx_enable_timing(hg_ctx *c, int on) {
   if (!c) return HG_ERR_INVALID;
   c->timing = on != 0;
+  c->t_chain = nullptr, c->t_chain_cls = -1;  // (nothing recorded before the switch may open a later bracket)
   return HG_OK;
 }
 
@@ -181,16 +189,28 @@ extern "C" const char *hg_ctx_last_kernel(const hg_ctx *c, int cls) {
 extern "C" hg_status hg_ctx_timings(hg_ctx *c, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]) {
   if (!c || !ms_sum || !launches) return HG_ERR_INVALID;
   for (int i = 0; i < HG_T_COUNT; ++i) ms_sum[i] = 0.f, launches[i] = 0;
+  // read first, recycle afterwards -- on the error path too: every event goes back to the pool exactly once and the
+  // pending list is emptied whatever happens (a second call must not pool the same events again)
+  hipError_t first_err = hipSuccess;
+  const char *first_what = "";
   for (auto &t : c->t_pending) {
-    HG_HIP(c, hipEventSynchronize(t.e1));
+    if (first_err != hipSuccess) break;
+    hipError_t e = hipEventSynchronize(t.e1);
     float ms = 0.f;
-    HG_HIP(c, hipEventElapsedTime(&ms, t.e0, t.e1));
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.e0, t.e1);
+    if (e != hipSuccess) {
+      first_err = e, first_what = "hg_ctx_timings: event read";
+      break;
+    }
     if (t.cls >= 0 && t.cls < HG_T_COUNT) ms_sum[t.cls] += ms, launches[t.cls] += 1;
-    if (t.own_e0) c->t_pool.push_back(t.e0);
   }
-  for (auto &t : c->t_pending) c->t_pool.push_back(t.e1);  // (after the loop: a chained bracket reads its predecessor's e1)
+  for (auto &t : c->t_pending) {  // (after the reads: a chained bracket reads its predecessor's e1)
+    if (t.own_e0) c->t_pool.push_back(t.e0);
+    c->t_pool.push_back(t.e1);
+  }
   c->t_pending.clear();
   c->t_chain = nullptr;
+  if (first_err != hipSuccess) return hg_fail(c, HG_ERR_HIP, std::string(first_what) + ": " + hipGetErrorString(first_err));
   return HG_OK;
 }
 
@@ -238,17 +258,25 @@ hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const
   hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, c->stream, d_words, n, c->h_res, seq);
   HG_HIP(c, hipGetLastError());
   volatile uint32_t *flag = c->h_res + 16;
-  for (uint32_t spins = 0;; ++spins) {
-    if (*flag == seq) break;
-    if (spins > (1u << 20)) std::this_thread::yield();  // a long kernel: stop burning the core (the first ~ms stays a pure poll)
-    if ((spins & 0xfff) == 0xfff) {  // every 4 096 polls: has the stream ended without the word arriving (a failed launch)?
-      const hipError_t q = hipStreamQuery(c->stream);
-      if (q == hipSuccess) {
-        if (*flag == seq) break;
-        return hg_fail(c, HG_ERR_HIP, "hg_publish_words: the stream finished without publishing");
-      }
-      if (q != hipErrorNotReady) return hg_fail(c, HG_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+  // Poll for a bounded time (the common case: a sub-millisecond GEMM, the word arrives within the poll), then hand the
+  // core back: a search that runs for many milliseconds -- or one shard thread per GPU in hg_multi -- must not burn a host
+  // core per ctx for its whole duration.
+  const auto t0 = std::chrono::steady_clock::now();
+  bool seen = false;
+  for (uint32_t spins = 0; !seen; ++spins) {
+    if (*flag == seq) {
+      seen = true;
+      break;
     }
+    __builtin_ia32_pause();
+    if ((spins & 0x3ff) == 0x3ff &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(800))
+      break;
+  }
+  if (!seen) {
+    const hipError_t e = hipStreamSynchronize(c->stream);  // blocks in the driver (interrupt), no spinning
+    if (e != hipSuccess) return hg_fail(c, HG_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    if (*flag != seq) return hg_fail(c, HG_ERR_HIP, "hg_publish_words: the stream finished without publishing");
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   *out = c->h_res;
@@ -434,17 +462,57 @@ hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt,
 
 // Runs hash+sample and sort/unique.  On return (stream synchronised) the device hit buffer holds
 // each genome's ascending distinct hashes at meta[g].hit_off and *d_ndistinct_out the counts.
+// ASCII genomes -> hg_pack2 blobs on the device (stream-ordered): genome i of d_seq (seq_offs[i], lens[i]) to
+// d_blobs + blob_offs[i].  The offset tables travel through the ctx's pinned scratch (overwritten: callers stage
+// nothing there across this call).
+hg_status pack_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *seq_offs, const uint64_t *lens, size_t n,
+                     uint32_t norm_mode, uint8_t *d_blobs, const uint64_t *blob_offs) {
+  if (n == 0) return HG_OK;
+  hg_status s;
+  if ((s = hg_ensure(c, c->w_pktab, 3 * n * sizeof(uint64_t) + 64)) != HG_OK) return s;
+  if ((s = hg_ensure_pinned(c, 3 * n * sizeof(uint64_t) + 64)) != HG_OK) return s;
+  HG_HIP(c, hipStreamSynchronize(c->stream));  // (the scratch may still feed an earlier upload)
+  auto *tab = static_cast<uint64_t *>(c->h_pin);
+  uint64_t max_len = 0;
+  for (size_t g = 0; g < n; ++g) {
+    if ((seq_offs[g] & 3) || (blob_offs[g] & 15)) return hg_fail(c, HG_ERR_INVALID, "pack2: sequence offsets must be multiples of 4, blob offsets of 16");
+    tab[3 * g] = seq_offs[g], tab[3 * g + 1] = lens[g], tab[3 * g + 2] = blob_offs[g];
+    max_len = std::max(max_len, lens[g]);
+  }
+  HG_HIP(c, hipMemcpyAsync(c->w_pktab.p, tab, 3 * n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  const uint64_t groups = ((((max_len + 7) / 8 + 15) & ~(uint64_t)15) + 3) / 4;  // lanes per genome: one per 4 bitmap bytes
+  const uint64_t blocks = (groups + 255) / 256;
+  if (blocks > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "pack2: genome too long for one launch");
+  if (blocks)
+    HG_HIP(c, hg_launch_pack2(c->stream, d_seq, static_cast<const uint64_t *>(c->w_pktab.p), (uint32_t)n, (uint32_t)blocks,
+                              norm_mode == HG_NORM_U2T ? 1u : 0u, d_blobs));
+  HG_HIP(c, hipStreamSynchronize(c->stream));  // (the pinned table is free again)
+  return HG_OK;
+}
+
 hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
                        size_t n, uint32_t ksize, uint64_t threshold, uint64_t scaled_for_cap, uint64_t seed,
-                       bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out) {
+                       bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out, bool packed = false) {
   if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
+  std::vector<uint64_t> hook_offs;
+  if (!packed && c->dbg_kmer_input == "packed") {
+    // test hook: the batch arrived as ASCII -- pack it here and run the packed kernels on the blobs, so that every
+    // ASCII entry point (and with it every parity test) can be driven through both input forms
+    hook_offs.resize(n);
+    uint64_t total = 0;
+    for (size_t g = 0; g < n; ++g) hook_offs[g] = total, total += hg_pack2_size(lens[g]);
+    hg_status s;
+    if ((s = hg_ensure(c, c->w_pk, total + 64)) != HG_OK) return s;
+    if ((s = pack_batch(c, d_seq, offsets, lens, n, norm_mode, static_cast<uint8_t *>(c->w_pk.p), hook_offs.data())) != HG_OK) return s;
+    d_seq = static_cast<const uint8_t *>(c->w_pk.p), offsets = hook_offs.data(), packed = true;
+  }
   std::vector<uint32_t> want;
   for (int attempt = 0; attempt < 3; ++attempt) {
     hg_status s;
     // same geometry as the previous call (typical for a stream of equally shaped batches): the
     // work-item table and the per-genome records are still on the device
     const bool reuse = attempt == 0 && c->plan_valid && c->plan_ksize == ksize && c->plan_scaled == scaled_for_cap &&
-                       c->plan_offs.size() == n && std::memcmp(c->plan_offs.data(), offsets, n * 8) == 0 &&
+                       c->plan_packed == packed && c->plan_offs.size() == n && std::memcmp(c->plan_offs.data(), offsets, n * 8) == 0 &&
                        std::memcmp(c->plan_lens.data(), lens, n * 8) == 0;
     size_t n_items;
     if (reuse) {
@@ -487,9 +555,9 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     HG_HIP(c, hipMemsetAsync(d_cnt, 0, 2 * n * sizeof(uint32_t), c->stream));
     {
       hg_timed tm(c, HG_T_KMER);
-      c->last_kernel[HG_T_KMER] = hg_kmer_kernel_name(ksize, canonical);
+      c->last_kernel[HG_T_KMER] = hg_kmer_kernel_name(ksize, canonical, packed);
       HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
-                                      seed, canonical, norm_mode, d_hits, d_cnt));
+                                      seed, canonical, norm_mode, d_hits, d_cnt, packed));
     }
     uint32_t sort_cap = pl.max_cap;
     {
@@ -518,7 +586,20 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
         }
         if (!redo.empty()) {
           if ((s = hg_ensure(c, c->w_redo, redo.size() * 4 + 64)) != HG_OK) return s;
-          HG_HIP(c, hipMemcpy(c->w_redo.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
+          // staged in the ctx's page-locked scratch behind the counters (which were consumed above) and uploaded on the
+          // ctx's own stream like every other command of this path: no legacy-stream copy that would also synchronise
+          // with the other ctxs of the device
+          const size_t redo_off = (n * sizeof(uint32_t) + 63) & ~(size_t)63;
+          if (c->h_pin_cap < redo_off + redo.size() * 4) {
+            std::vector<uint32_t> keep(h_cnt, h_cnt + n);  // (growing the scratch frees the block the counters live in)
+            if ((s = hg_ensure_pinned(c, redo_off + redo.size() * 4)) != HG_OK) return s;
+            h_cnt = static_cast<uint32_t *>(c->h_pin);
+            std::memcpy(h_cnt, keep.data(), n * sizeof(uint32_t));
+          }
+          uint32_t *h_redo = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->h_pin) + redo_off);
+          std::memcpy(h_redo, redo.data(), redo.size() * 4);
+          HG_HIP(c, hipMemcpyAsync(c->w_redo.p, h_redo, redo.size() * 4, hipMemcpyHostToDevice, c->stream));
+          HG_HIP(c, hipStreamSynchronize(c->stream));  // (rare path; the next call may rewrite the scratch at once)
           hg_timed tm(c, HG_T_SORT);
           HG_HIP(c, hg_launch_sort_unique_todo(c->stream, d_meta, static_cast<uint32_t *>(c->w_redo.p), (uint32_t)redo.size(),
                                                d_hits, d_cnt, d_nd, pl.max_cap, threshold));
@@ -539,7 +620,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
         c->plan_lens.assign(lens, lens + n);
         c->plan_caps.resize(n);
         for (size_t g = 0; g < n; ++g) c->plan_caps[g] = pl.meta[g].hit_cap;
-        c->plan_ksize = ksize, c->plan_scaled = scaled_for_cap;
+        c->plan_ksize = ksize, c->plan_scaled = scaled_for_cap, c->plan_packed = packed;
         c->plan_slots = pl.total_slots, c->plan_max_cap = pl.max_cap, c->plan_items = n_items;
         c->plan_valid = true;
       }
@@ -564,9 +645,43 @@ hg_status check_params(hg_ctx *c, const hg_sketch_params *p) {
 
 }  // namespace
 
+static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
+                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed);
+
 extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
                                          const uint64_t *lens, size_t n, const hg_sketch_params *p,
                                          int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash) {
+  return sketch_batch_dev_impl(c, d_seq, offsets, lens, n, p, d_hv, d_norm2, d_nhash, false);
+}
+
+extern "C" hg_status hg_sketch_batch_dev_packed(hg_ctx *c, const uint8_t *d_blobs, const uint64_t *offsets,
+                                                const uint64_t *n_bps, size_t n, const hg_sketch_params *p,
+                                                int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash) {
+  if (c && offsets)
+    for (size_t g = 0; g < n; ++g)
+      if (offsets[g] & 15) return hg_fail(c, HG_ERR_INVALID, "blob offsets must be multiples of 16");
+  return sketch_batch_dev_impl(c, d_blobs, offsets, n_bps, n, p, d_hv, d_norm2, d_nhash, true);
+}
+
+extern "C" hg_status hg_pack2_batch_dev(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
+                                        uint32_t norm_mode, uint8_t *d_blobs, const uint64_t *blob_offsets) {
+  if (!c) return HG_ERR_INVALID;
+  if (n == 0) return HG_OK;
+  if (!d_seq || !offsets || !lens || !d_blobs || !blob_offsets || norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad argument");
+  if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
+  HG_HIP(c, hipSetDevice(c->device));
+  return pack_batch(c, d_seq, offsets, lens, n, norm_mode, d_blobs, blob_offsets);
+}
+
+extern "C" hg_status hg_pack2_dev(hg_ctx *c, const uint8_t *d_seq, size_t n_bps, uint32_t norm_mode, uint8_t *d_blob) {
+  if (!c) return HG_ERR_INVALID;
+  if (((uintptr_t)d_seq & 3) || ((uintptr_t)d_blob & 15)) return hg_fail(c, HG_ERR_INVALID, "hg_pack2_dev: d_seq must be 4-byte, d_blob 16-byte aligned");
+  const uint64_t zero = 0, len = n_bps;
+  return hg_pack2_batch_dev(c, d_seq, &zero, &len, 1, norm_mode, d_blob, &zero);
+}
+
+static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
+                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed) {
   if (!c) return HG_ERR_INVALID;
   hg_status s = check_params(c, p);
   if (s != HG_OK) return s;
@@ -577,7 +692,7 @@ extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const 
   uint32_t *d_nd = nullptr;
   const uint64_t threshold = UINT64_MAX / p->scaled;  // src/sketch.rs:73
   s = sample_batch(c, d_seq, offsets, lens, n, p->ksize, threshold, p->scaled, p->seed, p->canonical != 0,
-                   p->norm_mode, pl, &d_nd);
+                   p->norm_mode, pl, &d_nd, packed);
   if (s != HG_OK) return s;
   // genomes with very large hash sets are encoded by several workgroups each (plan from the raw hit counts)
   hg_encode_split split{};

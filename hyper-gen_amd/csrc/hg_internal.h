@@ -29,6 +29,8 @@ struct hg_ctx {
   Buf w_hits2;    // scratch copy of the hit buffer (bucketed sort of large hash sets)
   Buf w_lsort;    // job / chunk / bucket tables of the bucketed sort
   Buf w_redo;     // genomes the count-sized LDS sort skipped (see sample_batch)
+  Buf w_pk;       // hg_pack2 blobs of a batch that arrived as ASCII (debug hook "kmer_input" = "packed", hg_pack2_batch_dev scratch)
+  Buf w_pktab;    // ... and the per-genome offset tables of the packing kernel
   Buf w_seq;      // staged sequences (host entry points)
   Buf w_hv;       // staged HV output (host entry points)
   Buf w_misc;     // small scalars (hit counters of dist, flags)
@@ -64,6 +66,7 @@ struct hg_ctx {
   std::vector<uint64_t> plan_offs, plan_lens;
   std::vector<uint32_t> plan_caps;  // hit_cap per genome of the cached plan
   uint32_t plan_ksize = 0;
+  bool plan_packed = false;  // the cached plan's genomes were hg_pack2 blobs
   uint64_t plan_scaled = 0, plan_slots = 0;
   uint32_t plan_max_cap = 0;
   uint32_t plan_max_hits = 0;  // largest raw hit count the cached plan's last run saw (sizes the LDS sort of the next)
@@ -82,7 +85,7 @@ struct hg_ctx {
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // development / test hooks (hg_ctx_set_debug); never read from the environment
-  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order;
+  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input;
   int dbg_sort_buckets = 0;
   // pinned host scratch
   void *h_pin = nullptr;
@@ -135,14 +138,19 @@ struct hg_genome_meta {
 // starts handled by one work item (one workgroup) of the fast kernel for a given k
 uint32_t hg_kmer_item_starts(uint32_t ksize);
 // name of the kernel hg_launch_kmer_sample launches for (ksize, canonical), as a profiler prints it
-const char *hg_kmer_kernel_name(uint32_t ksize, bool canonical);
+const char *hg_kmer_kernel_name(uint32_t ksize, bool canonical, bool packed);
 
 // Launch the hash + sample kernel over all work items.  d_cnt[g] is incremented once per
 // sampled k-mer (it may exceed hit_cap: only the first hit_cap hashes are stored).
+// packed: genome g is a hg_pack2 blob at d_seq + seq_off (n_bps = its bases), not ASCII.
 hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
                                  const uint32_t *d_item_genome, uint32_t n_items, uint32_t ksize,
                                  uint64_t threshold, uint64_t seed, bool canonical, uint32_t norm_mode,
-                                 uint64_t *d_hits, uint32_t *d_cnt);
+                                 uint64_t *d_hits, uint32_t *d_cnt, bool packed = false);
+// ASCII -> hg_pack2 blobs on the device (bit-identical to the host's hg_pack2): genome i of d_seq at seq_offs[i] with
+// lens[i] bases goes to d_blobs + blob_offs[i] (multiples of 16).  d_tab: 3 * n uint64 of device scratch for the tables.
+hipError_t hg_launch_pack2(hipStream_t st, const uint8_t *d_seq, const uint64_t *d_tab, uint32_t n, uint32_t blocks_max,
+                           uint32_t u2t, uint8_t *d_blobs);
 
 // keys one workgroup can sort in LDS; genomes with more sampled hashes are sorted in place in
 // global memory, which needs a power-of-two sized hit region (the host rounds hit_cap up).

@@ -398,7 +398,13 @@ struct GeoS {
   static_assert(((N_R - K) & 3) == 3, "reverse phase of start j is 3 - (j & 3)");
 };
 
-template <int K, bool CANON>
+// PACKED: the genome is a hg_pack2 blob (include/hypergen.h: 2-bit codes, 4 bases per byte, then the not-a-base bitmap;
+// 0.375 bytes per base in HBM instead of 1) and the tile level does no classification at all: a lane fetches its whole
+// 32- / 48-base code window (the canonical compare's operand, as loaded) and the window's validity bits with two
+// unaligned loads, and the forward / reverse-complement ASCII of four bases comes out of ONE 8-byte LDS table read
+// indexed by the code byte (256 entries x {ASCII, complement ASCII byte-reversed}) -- the pattern of the reference's
+// second kernel (src/cuda_kernel.cu:15-69, NT4 codes from src/sketch_cuda.rs:23-32), not its data path.
+template <int K, bool CANON, bool PACKED>
 __global__ __launch_bounds__(WG) void kmer_sample_shared(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
@@ -420,11 +426,24 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
   __shared__ HitStage stage;
   __shared__ __attribute__((aligned(16))) uint32_t s_f[4 * S / 4];                 // forward phase images
   __shared__ __attribute__((aligned(16))) uint32_t s_r[CANON ? 4 * S / 4 : 4];     // reverse phase images (psi at S (3 - psi))
-  __shared__ __attribute__((aligned(16))) uint8_t s_code[CANON ? G::NB_T / 4 + 16 : 16];  // 2-bit codes, base b at bits 2b..2b+1
-  __shared__ uint32_t s_val[G::UNITS + 4];   // per unit of M bases: bit b set <=> base b cannot be part of a k-mer
+  __shared__ __attribute__((aligned(16))) uint8_t s_code[(CANON && !PACKED) ? G::NB_T / 4 + 16 : 16];  // 2-bit codes, base b at bits 2b..2b+1
+  __shared__ uint32_t s_val[PACKED ? 4 : G::UNITS + 4];   // per unit of M bases: bit b set <=> base b cannot be part of a k-mer
   __shared__ uint32_t s_dirty[2];            // "some base of this tile is not ACGT / lies behind the genome end", by tile parity
+  __shared__ __attribute__((aligned(8))) uint2 s_lut[PACKED ? 256 : 1];  // code byte -> {ASCII of its 4 bases, complement ASCII byte-reversed}
   if (tid == 0) stage.n = 0, s_dirty[0] = 0, s_dirty[1] = 0;
-  if (tid < 4) s_val[G::UNITS + tid] = 0;
+  if constexpr (!PACKED) {
+    if (tid < 4) s_val[G::UNITS + tid] = 0;
+  } else {
+    static_assert(WG == 256, "one table entry per lane");
+    uint32_t f = 0, r = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t cd = (tid >> (2 * b)) & 3u;
+      f |= ((0x54474341u >> (8 * cd)) & 0xFFu) << (8 * b);        // "ACGT"[code]
+      r |= ((0x41434754u >> (8 * cd)) & 0xFFu) << (8 * (3 - b));  // "TGCA"[code], base b at byte 3 - b
+    }
+    s_lut[tid] = make_uint2(f, r);
+  }
   __syncthreads();
 
   using lds_u8p = __attribute__((address_space(3))) const uint8_t *;
@@ -524,12 +543,67 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     }
   };
 
+  // PACKED staging of unit u: the lane's code window (c0 = bases [P, P + 16): its own M bases + the lookahead dword;
+  // c1, c2 = the rest of its WIN-base window) and the window's validity bits straight from the blob.  Positions behind
+  // the genome end are invalid whatever the blob's padding says.
+  typedef uint32_t __attribute__((aligned(1))) u32u;
+  typedef uint64_t __attribute__((aligned(1))) u64u;
+  const uint8_t *__restrict__ gmask = gseq + ((((size_t)n_bps + 3) / 4 + 15) & ~(size_t)15);
+  auto stage_unit_packed = [&](uint32_t u, uint64_t tile_start, uint32_t par, uint32_t &c0, uint32_t &c1, uint32_t &c2,
+                               inv_t &invw) __attribute__((always_inline)) {
+    const uint64_t P = tile_start + (uint64_t)u * M;  // a multiple of 4: whole code bytes
+    const int64_t rem64 = (int64_t)n_bps - (int64_t)P;
+    const uint64_t Pc = rem64 > 0 ? P : 0;            // (a window that starts behind the end reads the blob's first bytes: all invalid anyway)
+    // the blob (codes padded to 16 bytes + >= 16 bytes of bitmap) and the 32 readable bytes the caller leaves behind it cover
+    // every byte fetched here
+    const uint8_t *cp = gseq + (Pc >> 2);
+    c0 = *reinterpret_cast<const u32u *>(cp);
+    c1 = *reinterpret_cast<const u32u *>(cp + 4);
+    c2 = WIN > 32 ? *reinterpret_cast<const u32u *>(cp + 8) : 0u;
+    const uint64_t mb = *reinterpret_cast<const u64u *>(gmask + (Pc >> 3));
+    invw = (inv_t)(mb >> (uint32_t)(Pc & 7));
+    if (rem64 < WIN) invw |= rem64 <= 0 ? ~(inv_t)0 : (inv_t)(~(inv_t)0 << (uint32_t)rem64);
+    const bool dirty = invw != 0;
+    if (__any(dirty)) {
+      if ((threadIdx.x & 63) == 0 || dirty) s_dirty[par] = 1u;  // (same value from every writer)
+    }
+    uint32_t FA[DW + 1], RW[DW + 1];  // RW[t]: byte k = complement of base 4 t + 3 - k
+#pragma unroll
+    for (int t = 0; t <= DW; ++t) {
+      const uint2 e = s_lut[(c0 >> (8 * t)) & 0xFFu];
+      FA[t] = e.x, RW[t] = e.y;
+    }
+    uint32_t *const f0 = s_f + DW * u;
+#pragma unroll
+    for (int t = 0; t < DW; ++t) {
+      f0[t] = FA[t];
+      f0[S / 4 + t] = __builtin_amdgcn_alignbyte(FA[t + 1], FA[t], 1);
+      f0[2 * (S / 4) + t] = __builtin_amdgcn_alignbyte(FA[t + 1], FA[t], 2);
+      f0[3 * (S / 4) + t] = __builtin_amdgcn_alignbyte(FA[t + 1], FA[t], 3);
+    }
+    if constexpr (CANON) {
+      // reverse phase images as in stage_unit: dword JB - (DW u + t) of phase psi holds the complements of bases
+      // 4 t + ph + 3 .. 4 t + ph -- bytes [4 - ph, 8 - ph) of {RW[t] : RW[t + 1]}
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int psi = (N_R - ph) & 3, JB = (N_R - 4 - psi - ph) / 4;
+        uint32_t *const r0 = s_r + (3 - psi) * (S / 4) + JB - (int)(DW * u);
+#pragma unroll
+        for (int t = 0; t < DW; ++t) r0[-t] = ph == 0 ? RW[t] : __builtin_amdgcn_alignbyte(RW[t], RW[t + 1], 4 - ph);
+        if (ph > 0 && u == 0) r0[1] = __builtin_amdgcn_alignbyte(0u, RW[0], 4 - ph);
+      }
+    }
+  };
+
 #pragma unroll 1
   for (int tile = 0; tile < G::TILES; ++tile) {
     const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
     if (tile_start >= n_starts) break;  // uniform
     const uint32_t par = (uint32_t)tile & 1u;
-    stage_unit(tid, tile_start, par);
+    uint32_t pc0 = 0, pc1 = 0, pc2 = 0;
+    inv_t pinv = 0;
+    if constexpr (PACKED) stage_unit_packed(tid, tile_start, par, pc0, pc1, pc2, pinv);
+    else stage_unit(tid, tile_start, par);
 #ifndef HG_KS_EXP
 #define HG_KS_EXP 0
 #endif
@@ -537,7 +611,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
 
     const bool tile_dirty = s_dirty[par] != 0u;  // workgroup-uniform
     inv_t inv_w = 0;
-    if (tile_dirty) {
+    if constexpr (PACKED) {
+      if (tile_dirty) inv_w = pinv;
+    } else if (tile_dirty) {
       if constexpr (WIN > 32)
         inv_w = (inv_t)((uint64_t)s_val[tid] | ((uint64_t)s_val[tid + 1] << M) | ((uint64_t)s_val[tid + 2] << (2 * M)) |
                         ((uint64_t)s_val[tid + 3] << (3 * M)));
@@ -550,10 +626,16 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     uint64_t Gm = 0, Gc = 0;
     uint32_t gf[3] = {0, 0, 0}, wc[3] = {0, 0, 0};
     if constexpr (CANON) {
-      const uint32_t bo = (uint32_t)DW * tid;
-      const uint32_t *cw = reinterpret_cast<const uint32_t *>(s_code) + (bo >> 2);
-      const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], sh = 8u * (bo & 3u);
-      const uint32_t wl = __builtin_amdgcn_alignbit(c1, c0, sh), wh = __builtin_amdgcn_alignbit(c2, c1, sh);
+      uint32_t wl, wh, w2 = 0;
+      if constexpr (PACKED) {
+        wl = pc0, wh = pc1, w2 = pc2;  // the window as loaded
+      } else {
+        const uint32_t bo = (uint32_t)DW * tid;
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(s_code) + (bo >> 2);
+        const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], sh = 8u * (bo & 3u);
+        wl = __builtin_amdgcn_alignbit(c1, c0, sh), wh = __builtin_amdgcn_alignbit(c2, c1, sh);
+        if constexpr (WIN > 32) w2 = __builtin_amdgcn_alignbit(cw[3], c2, sh);
+      }
       auto pairrev = [](uint32_t v) {
         const uint32_t br = __builtin_bitreverse32(v);
         return ((br >> 1) & 0x55555555u) | ((br & 0x55555555u) << 1);
@@ -562,7 +644,6 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
         Gc = ~mk64(wl, wh);
         Gm = mk64(pairrev(wh), pairrev(wl));
       } else {
-        const uint32_t w2 = __builtin_amdgcn_alignbit(cw[3], c2, sh);
         wc[0] = ~wl, wc[1] = ~wh, wc[2] = ~w2;
         gf[0] = pairrev(wl), gf[1] = pairrev(wh), gf[2] = pairrev(w2);
       }
@@ -799,6 +880,7 @@ __device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len
   return final64(a, b);
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(WG) void kmer_sample_long(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
@@ -814,6 +896,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
   if (n_bps < ksize) return;
   const uint64_t n_starts = n_bps - ksize + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
+  const uint8_t *__restrict__ gmask = gseq + ((((size_t)n_bps + 3) / 4 + 15) & ~(size_t)15);  // PACKED: the blob's not-a-base bitmap
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * GEN_ITEM;
   if (tid == 0) stage.n = 0;
   const uint32_t n_stage = LONG_TILE + ksize - 1;  // bytes a full tile needs
@@ -831,7 +914,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
       const uint32_t i = tid * 6 + j;
       const uint64_t pos = tile0 + i;
       uint32_t code = 4;
-      if (i < n_stage && pos < n_bps) code = base_code(gseq[pos], u2t);
+      if (i < n_stage && pos < n_bps) {
+        if constexpr (PACKED) code = ((gmask[pos >> 3] >> (pos & 7)) & 1u) ? 4u : (uint32_t)(gseq[pos >> 2] >> (2 * (pos & 3))) & 3u;
+        else code = base_code(gseq[pos], u2t);
+      }
       fbyte[j] = code < 4 ? (uint8_t)(0x54474341u >> (8 * code)) : (uint8_t)0;  // "ACGT"
       nbad += code < 4 ? 0u : 1u;
       if (i < n_stage) {
@@ -886,10 +972,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
 
 }  // namespace
 
-const char *hg_kmer_kernel_name(uint32_t k, bool canonical) {  // mirrors hg_launch_kmer_sample
+const char *hg_kmer_kernel_name(uint32_t k, bool canonical, bool packed) {  // mirrors hg_launch_kmer_sample
   static thread_local char buf[64];
-  if (k > 32) return "kmer_sample_long";
-  snprintf(buf, sizeof buf, "kmer_sample_shared<%u, %s>", k, canonical ? "true" : "false");
+  if (k > 32) return packed ? "kmer_sample_long<true>" : "kmer_sample_long<false>";
+  snprintf(buf, sizeof buf, "kmer_sample_shared<%u, %s, %s>", k, canonical ? "true" : "false", packed ? "true" : "false");
   return buf;
 }
 
@@ -901,17 +987,18 @@ uint32_t hg_kmer_item_starts(uint32_t k) {
 hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
                                  const uint32_t *d_item_genome, uint32_t n_items, uint32_t ksize,
                                  uint64_t threshold, uint64_t seed, bool canonical, uint32_t norm_mode,
-                                 uint64_t *d_hits, uint32_t *d_cnt) {
+                                 uint64_t *d_hits, uint32_t *d_cnt, bool packed) {
   if (n_items == 0) return hipSuccess;
-  const uint32_t u2t = (norm_mode == HG_NORM_U2T) ? 1u : 0u;
+  const uint32_t u2t = (norm_mode == HG_NORM_U2T && !packed) ? 1u : 0u;  // (a blob was normalised when it was packed)
+#define HG_K_LAUNCH(KK, CN, PK)                                                                            \
+  hipLaunchKernelGGL((kmer_sample_shared<KK, CN, PK>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,      \
+                     d_item_genome, threshold, seed, u2t, d_hits, d_cnt)
 #define HG_K_CASE(KK)                                                                                     \
   case KK:                                                                                                \
-    if (canonical)                                                                                        \
-      hipLaunchKernelGGL((kmer_sample_shared<KK, true>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,   \
-                         d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                             \
-    else                                                                                                  \
-      hipLaunchKernelGGL((kmer_sample_shared<KK, false>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,  \
-                         d_item_genome, threshold, seed, u2t, d_hits, d_cnt);                             \
+    if (canonical && packed) HG_K_LAUNCH(KK, true, true);                                                 \
+    else if (canonical) HG_K_LAUNCH(KK, true, false);                                                     \
+    else if (packed) HG_K_LAUNCH(KK, false, true);                                                        \
+    else HG_K_LAUNCH(KK, false, false);                                                                   \
     return hipGetLastError();
   switch (ksize) {
     HG_K_CASE(1) HG_K_CASE(2) HG_K_CASE(3) HG_K_CASE(4) HG_K_CASE(5) HG_K_CASE(6) HG_K_CASE(7) HG_K_CASE(8)
@@ -922,8 +1009,13 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
       break;
   }
 #undef HG_K_CASE
+#undef HG_K_LAUNCH
   // 33 <= k <= 255
-  hipLaunchKernelGGL(kmer_sample_long, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
-                     threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+  if (packed)
+    hipLaunchKernelGGL(kmer_sample_long<true>, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
+                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+  else
+    hipLaunchKernelGGL(kmer_sample_long<false>, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
+                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
   return hipGetLastError();
 }

@@ -13,9 +13,29 @@
 // the R x D i16 ref matrix + R i32 norms"): one communicator per shard from ncclCommInitAll, the collective queued
 // on every shard's stream inside one ncclGroupStart/End -- ncclAllGather when the row blocks have equal sizes,
 // one ncclBroadcast per owner otherwise (the all-gather-v idiom).  librccl is opened with dlopen the first time
-// the mode is selected, so the library carries no link-time dependency on it.
+// the mode is selected, so the library carries no link-time dependency on it (the Makefile links -ldl for dlopen itself:
+// glibc < 2.34 keeps it in libdl), and no build-time one either: without the rccl-dev header the handful of
+// declarations used here are restated from the public NCCL API.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, int root,
+                           ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGetVersion(int *version);
+}
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -299,7 +319,10 @@ hg_status gather_refs(hg_multi *m, const int16_t *const *d_ref, const int32_t *c
     ncclResult_t e = r.GroupStart();
     for (int s = 0; s < ns && e == ncclSuccess; ++s) {
       if (!g_hv[s]) continue;  // (a shard without query rows still has to take part: see the caller)
-      if (hipSetDevice(m->dev[s]) != hipSuccess) return mfail(m, HG_ERR_HIP, "hipSetDevice failed");
+      if (hipSetDevice(m->dev[s]) != hipSuccess) {  // (no return inside the group: GroupEnd below closes it on every path)
+        e = ncclSystemError;
+        break;
+      }
       hipStream_t st = m->ctx[s]->stream;
       if (equal) {
         const size_t rows = pl.rhi[s] - pl.rlo[s];

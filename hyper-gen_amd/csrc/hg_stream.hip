@@ -54,9 +54,12 @@ struct Chunk {
   uint8_t *stage = nullptr;  // page-locked mirror for runs of small genomes (lazily allocated, CHUNK_BYTES)
   size_t run_lo = 0, run_hi = 0;
   std::vector<uint64_t> offs, lens, tags;
+  std::vector<uint64_t> pk_offs;  // per genome: its blob's offset in dpk (packed genomes only; parallel to offs when ALL are packed)
   size_t bytes = 0;
   hipEvent_t uploaded = nullptr;
-  // hg_pack2 blobs (hg_sketch_stream_push_packed): their own device area, expanded into `d` by unpack2_kernel
+  // hg_pack2 blobs (hg_sketch_stream_push_packed): their own device area.  A chunk made of blobs only goes to the
+  // packed-input kernels as it is (hg_sketch_batch_dev_packed); a chunk that mixes blobs and ASCII genomes has its blobs
+  // expanded into `d` by unpack2_kernel first
   uint8_t *dpk = nullptr;
   size_t pk_cap = 0, pk_bytes = 0;
   UnpackJob *h_jobs = nullptr, *d_jobs = nullptr;  // CHUNK_GENOMES entries each (page-locked / device), lazily allocated
@@ -108,6 +111,59 @@ __global__ __launch_bounds__(256) void unpack2_kernel(const uint8_t *__restrict_
     const uint64_t g = g0 + 256u * r;
     if (g < groups) unpack2_group(pk + jb.pk_off, code_bytes, out + jb.out_off, g);
   }
+}
+
+// ASCII -> hg_pack2 blob, 32 bases per lane (8 code bytes + 4 bitmap bytes), bit-identical to the host's hg_pack2
+// (hg_formats.cpp): A,C,G,T = 0..3 in either case (+ u/U -> T under u2t), anything else code 0 + its not-a-base bit;
+// the paddings of both areas (to 16 bytes) and everything behind the last base are zero.  tab: {seq_off, n_bps, blob_off}
+// per genome; blockIdx.y = genome.
+__global__ __launch_bounds__(256) void pack2_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ tab,
+                                                    uint32_t u2t, uint8_t *__restrict__ blobs) {
+  const uint64_t seq_off = tab[3 * blockIdx.y], n = tab[3 * blockIdx.y + 1], blob_off = tab[3 * blockIdx.y + 2];
+  const uint64_t cb = ((n + 3) / 4 + 15) & ~(uint64_t)15, mb = ((n + 7) / 8 + 15) & ~(uint64_t)15;
+  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x, i0 = 32 * q;
+  if (4 * q >= mb) return;  // (the bitmap's padding reaches further than the codes')
+  const uint8_t *__restrict__ src = seq + seq_off;
+  uint32_t x[8];
+  if (i0 + 32 <= n) {
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + i0);  // seq_off is a multiple of 4
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = s4[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      uint32_t w = 0;
+      for (int b = 0; b < 4; ++b) {
+        const uint64_t i = i0 + 4 * t + b;
+        w |= (uint32_t)(i < n ? src[i] : (uint8_t)0) << (8 * b);
+      }
+      x[t] = w;
+    }
+  }
+  uint32_t codes[2] = {0u, 0u}, bad = 0u;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    uint32_t xv = x[t];
+    if (u2t) {  // u/U -> T ('U' ^ 'T' == 1)
+      const uint32_t e = (xv & 0xDFDFDFDFu) ^ 0x55555555u;
+      const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
+      xv ^= (~nz & 0x80808080u) >> 7;
+    }
+    const uint32_t tt = xv ^ (xv >> 1);
+    uint32_t cd = (tt >> 1) & 0x03030303u;
+    const uint32_t d = (xv & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x54474341u, cd);
+    const uint32_t z = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;  // 1 per byte that is not a base
+    cd &= ~(z * 0xFFu);
+    codes[t >> 2] |= ((cd | (cd >> 6) | (cd >> 12) | (cd >> 18)) & 0xFFu) << (8 * (t & 3));
+    uint32_t nb = ((z * 0x01020408u) >> 24) & 0xFu;
+    // positions at or behind the end are not flagged (the host leaves those bits zero)
+    const uint64_t p0 = i0 + 4 * t;
+    if (p0 + 4 > n) nb &= p0 >= n ? 0u : ((1u << (uint32_t)(n - p0)) - 1u);
+    bad |= nb << (4 * t);
+  }
+  uint8_t *blob = blobs + blob_off;
+  if (8 * q < cb) *reinterpret_cast<uint2 *>(blob + 8 * q) = make_uint2(codes[0], codes[1]);
+  *reinterpret_cast<uint32_t *>(blob + cb + 4 * q) = bad;
 }
 
 __global__ __launch_bounds__(256) void unpack2_one_kernel(const uint8_t *__restrict__ blob, uint8_t *__restrict__ out, uint64_t n_bps) {
@@ -229,7 +285,7 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         cur = e.free_chunks.front();
         e.free_chunks.pop_front();
         Chunk &c = e.chunk[cur];
-        c.offs.clear(), c.lens.clear(), c.tags.clear();
+        c.offs.clear(), c.lens.clear(), c.tags.clear(), c.pk_offs.clear();
         c.bytes = 0, c.run_lo = c.run_hi = 0;
         c.pk_bytes = 0, c.n_jobs = 0, c.n_blocks = 0;
       }
@@ -248,11 +304,11 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
       const double tc = now_s();
       if (it.len && it.packed) {
         const size_t blob = hg_pack2_size(it.len);
-        if (c.pk_bytes + blob > c.pk_cap) {  // the packed area grows between chunks' uses (nothing of this chunk is in flight
+        if (c.pk_bytes + blob + 64 > c.pk_cap) {  // (+ the readable slack behind the last blob) the packed area grows between chunks' uses (nothing of this chunk is in flight
           // unless earlier genomes of it are: wait for their copies before the old block goes away)
           ST_HIP(s, hipStreamSynchronize(e.copy));
           uint8_t *nb = nullptr;
-          const size_t want = std::max(c.pk_bytes + blob + blob / 8, (size_t)(CHUNK_BYTES * 3 / 8 + (1u << 20)));
+          const size_t want = std::max(c.pk_bytes + blob + blob / 8 + 64, (size_t)(CHUNK_BYTES * 3 / 8 + (1u << 20)));
           hipError_t he = hipMalloc(reinterpret_cast<void **>(&nb), want);
           if (he != hipSuccess) {
             fail(s, HG_ERR_OOM, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(he));
@@ -270,6 +326,7 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         UnpackJob &jb = c.h_jobs[c.n_jobs++];
         jb.pk_off = c.pk_bytes, jb.out_off = c.bytes, jb.n_bps = it.len, jb.first_block = c.n_blocks, jb.pad = 0;
         c.n_blocks += (uint32_t)(((it.len + 15) / 16 + UNPACK_GROUPS_PER_BLOCK - 1) / UNPACK_GROUPS_PER_BLOCK);
+        c.pk_offs.push_back(c.pk_bytes);
         c.pk_bytes += blob;
       } else if (it.len) {
         if (it.len < SMALL_BYTES && c.bytes + padded <= CHUNK_BYTES) {
@@ -325,11 +382,26 @@ void computer(hg_sketch_stream *s, Engine *ep, int wi) {
       const size_t m = c.tags.size();
       const double tr = now_s();
       ST_HIP(s, hipStreamWaitEvent(w.ctx->stream, c.uploaded, 0));
-      if (c.n_jobs) {
-        hipLaunchKernelGGL(unpack2_kernel, dim3(c.n_blocks), dim3(256), 0, w.ctx->stream, c.dpk, c.d, c.d_jobs, c.n_jobs);
-        ST_HIP(s, hipGetLastError());
+      // (empty genomes of an otherwise packed chunk have no blob: offset 0, length 0 -- nothing is read for them)
+      bool all_packed = c.n_jobs > 0;
+      if (all_packed && c.pk_offs.size() != m) {
+        size_t nonempty = 0;
+        for (size_t g = 0; g < m; ++g) nonempty += c.lens[g] != 0;
+        all_packed = nonempty == c.pk_offs.size();
       }
-      const hg_status st = hg_sketch_batch_dev(w.ctx, c.d, c.offs.data(), c.lens.data(), m, &s->p, w.d_hv, w.d_n2, w.d_nh);
+      hg_status st;
+      if (all_packed) {
+        std::vector<uint64_t> po(m, 0);
+        for (size_t g = 0, k = 0; g < m; ++g)
+          if (c.lens[g]) po[g] = c.pk_offs[k++];
+        st = hg_sketch_batch_dev_packed(w.ctx, c.dpk, po.data(), c.lens.data(), m, &s->p, w.d_hv, w.d_n2, w.d_nh);
+      } else {
+        if (c.n_jobs) {
+          hipLaunchKernelGGL(unpack2_kernel, dim3(c.n_blocks), dim3(256), 0, w.ctx->stream, c.dpk, c.d, c.d_jobs, c.n_jobs);
+          ST_HIP(s, hipGetLastError());
+        }
+        st = hg_sketch_batch_dev(w.ctx, c.d, c.offs.data(), c.lens.data(), m, &s->p, w.d_hv, w.d_n2, w.d_nh);
+      }
       if (st != HG_OK) {
         fail(s, st, std::string("device ") + std::to_string(e.device) + ": " + hg_last_error(w.ctx));
         return false;
@@ -518,6 +590,17 @@ extern "C" const char *hg_sketch_stream_last_error(hg_sketch_stream *s) {
   if (!s) return "";
   std::lock_guard<std::mutex> lk(s->mu);
   return s->msg.c_str();
+}
+
+hipError_t hg_launch_pack2(hipStream_t st, const uint8_t *d_seq, const uint64_t *d_tab, uint32_t n, uint32_t blocks_max,
+                           uint32_t u2t, uint8_t *d_blobs) {
+  for (uint32_t g0 = 0; g0 < n; g0 += 65535) {
+    const uint32_t m = std::min<uint32_t>(65535u, n - g0);
+    hipLaunchKernelGGL(pack2_kernel, dim3(blocks_max, m), dim3(256), 0, st, d_seq, d_tab + 3 * (size_t)g0, u2t, d_blobs);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 extern "C" hg_status hg_unpack2_dev(hg_ctx *c, const uint8_t *d_blob, size_t n_bps, uint8_t *d_seq_out) {

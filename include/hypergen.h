@@ -68,6 +68,8 @@ int hg_device_count(void);
  *       "dist_path" = "" | "f16" | "i8"                    (operand format of the ANI GEMM)
  *       "dist_order" = "" | "plain"                        ("plain": a self-comparison does not run its diagonal tiles first)
  *       "ham_path"  = "" | "popc" | "mfma" | "fp4"         (Hamming search: xor + popcount, +-1 byte GEMM, +-1 e2m1 GEMM)
+ *       "kmer_input" = "" | "packed"                       ("packed": batches that arrive as ASCII are 2-bit packed on the
+ *                                                           device first and take the packed-input kernels)
  *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
  * Nothing in the library reads environment variables. */
 hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
@@ -85,8 +87,8 @@ hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
 hg_status hg_ctx_enable_timing(hg_ctx *ctx, int on);
 hg_status hg_ctx_timings(hg_ctx *ctx, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]);
 /* name of the kernel the last call launched for timing class `cls` (HG_T_KMER, HG_T_DIST), spelled as rocprofv3
- * prints it ("kmer_sample_grouped<21>", "dist_mfma_kernel<false, false, true, true, 5, true, false, false>"); ""
- * if none.  A measurement harness uses it to check that a committed profile belongs to the kernel that ran. */
+ * prints it ("kmer_sample_shared<21, true, false>", "dist_mfma_kernel<false, false, true, true, 5, true, false, false>");
+ * "" if none.  A measurement harness uses it to check that a committed profile belongs to the kernel that ran. */
 const char *hg_ctx_last_kernel(const hg_ctx *ctx, int cls);
 
 /* minimal device-memory helpers for callers that have no HIP binding of their own
@@ -105,7 +107,7 @@ hg_status hg_copy_d2h(hg_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 /* mirrors SketchParams (src/types.rs:83-113); defaults k=21 scaled=1500 seed=123
  * canonical=1 hv_d=4096 */
 typedef struct {
-  uint32_t ksize;     /* 1..255 (u8 in the reference); 9..29 take the fast kernel   */
+  uint32_t ksize;     /* 1..255 (u8 in the reference): 1..32 kmer_sample_shared, 33..255 kmer_sample_long */
   uint32_t canonical; /* 0/1 (honoured like src/cuda_kernel.cu:306-314)             */
   uint64_t scaled;    /* threshold = UINT64_MAX / scaled (src/sketch.rs:73)          */
   uint64_t seed;
@@ -148,6 +150,15 @@ hg_status hg_hv_encode(hg_ctx *ctx, const uint64_t *hashes, size_t n, uint32_t h
 hg_status hg_sketch_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t *offsets,
                               const uint64_t *lens, size_t n, const hg_sketch_params *p,
                               int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash);
+/* The same batch with the genomes resident as 2-bit PACKED bases: genome i is the hg_pack2 blob (layout below:
+ * 4 bases per byte + the not-a-base bitmap, 0.375 bytes per base in HBM instead of 1) at d_blobs + offsets[i]
+ * (multiples of 16; 32 readable bytes behind every blob), n_bps[i] = its number of bases.  The k-mer kernels read the
+ * codes as they lie -- no ASCII copy exists on the device -- and the result is bit-identical to hg_sketch_batch_dev on
+ * the sequences the blobs were packed from (under the norm_mode they were packed with; p->norm_mode is not applied
+ * again).  The pattern of the reference's second kernel (src/cuda_kernel.cu:15-69 on NT4 codes, src/sketch_cuda.rs:23-32). */
+hg_status hg_sketch_batch_dev_packed(hg_ctx *ctx, const uint8_t *d_blobs, const uint64_t *offsets,
+                                     const uint64_t *n_bps, size_t n, const hg_sketch_params *p,
+                                     int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash);
 /* host buffers in, host results out (one H2D of the sequences, one D2H of the HVs) */
 hg_status hg_sketch_batch(hg_ctx *ctx, const uint8_t *const *seqs, const size_t *lens,
                           size_t n, const hg_sketch_params *p, int16_t *hv_out,
@@ -167,9 +178,11 @@ hg_status hg_dist_full_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *
                            size_t Q, uint32_t hv_d, uint32_t ksize, float *d_ani_out);
 /* Completion of the *_dev entry points: their device inputs are read, and their device outputs written,
  * in stream order on the ctx's stream (hg_ctx_set_stream), so work the caller queues on that stream before
- * / after the call is ordered with it.  When hg_dist_dev / hg_hamming_search_dev return, everything queued on
- * the stream before and by the call has finished (the hit count comes back through a page-locked block the
- * last kernel writes and the host polls -- no copy command, no hipStreamSynchronize); hg_sketch_batch_dev and
+ * / after the call is ordered with it.  When hg_dist_dev / hg_hamming_search_dev (and their _block forms) return, every
+ * kernel queued on the stream before and by the call has finished (the hit count comes back through a page-locked
+ * block the last kernel writes and the host polls for a bounded time before it falls back to a blocking stream
+ * synchronisation); one 64-byte hipMemsetAsync that re-zeroes the call's counter words may still be pending on the
+ * stream -- it touches nothing the caller sees.  hg_sketch_batch_dev and
  * hg_dist_full_dev may return with their last kernels still running -- hg_ctx_sync (or the caller's own stream
  * synchronisation) completes them. */
 
@@ -208,7 +221,8 @@ hg_status hg_dist_block_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t 
 
 /* Which exact operand path the last hg_dist / hg_dist_dev / hg_dist_block_dev call of this ctx took (all give the same
  * integers): 0 = f16 operands on v_mfma_f32_16x16x32_f16 (exact f32 windows), 1 = centred i8 operands on
- * v_mfma_i32_16x16x64_i8 (sketches of up to ~3 500 hashes; decided on the device), 2 = integer VALU fallback; -1 = none yet. */
+ * v_mfma_i32_16x16x64_i8 (sketches of up to ~6 000 hashes at D = 4096; decided on the device), 2 = integer VALU fallback;
+ * -1 = none yet. */
 int hg_ctx_last_dist_path(const hg_ctx *ctx);
 
 /* order of dump_ani_file (src/utils.rs:262-269): stable ascending sort by ANI over the
@@ -281,8 +295,8 @@ void hg_sketch_file_free(hg_sketch_file *f);
 typedef struct hg_sketch_stream hg_sketch_stream;
 hg_status hg_sketch_stream_open(const int *device_ids, int n_devices, const hg_sketch_params *p, hg_sketch_stream **out);
 hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t n_bps, uint64_t tag);
-/* the same genome as a hg_pack2 blob (3 bits per base over the link instead of 8; expanded on the device into the
- * ASCII the kernels would have classified the same way: results are bit-identical).  The blob must have been
+/* the same genome as a hg_pack2 blob (3 bits per base over the link instead of 8; the chunk's blobs go to the
+ * packed-input kernels as they arrive, hg_sketch_batch_dev_packed: results are bit-identical).  The blob must have been
  * packed with the stream's norm_mode. */
 hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
 /* non-blocking push of either form (packed != 0: `data` is a hg_pack2 blob); HG_ERR_CAPACITY = would block */
@@ -307,6 +321,13 @@ void hg_sketch_stream_close(hg_sketch_stream *s);
 size_t hg_pack2_size(size_t n_bps);
 hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out);
 hg_status hg_unpack2_dev(hg_ctx *ctx, const uint8_t *d_blob, size_t n_bps, uint8_t *d_seq_out);
+/* hg_pack2 on the device, byte for byte the host's output: ASCII genomes already in HBM (d_seq + offsets[i], multiples
+ * of 4, lens[i] bases) become blobs at d_blobs + blob_offsets[i] (multiples of 16, hg_pack2_size(lens[i]) bytes each) --
+ * the input form of hg_sketch_batch_dev_packed.  Host offset arrays, device data; complete on return.
+ * hg_pack2_dev: one genome (d_seq 4-byte, d_blob 16-byte aligned). */
+hg_status hg_pack2_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
+                             uint32_t norm_mode, uint8_t *d_blobs, const uint64_t *blob_offsets);
+hg_status hg_pack2_dev(hg_ctx *ctx, const uint8_t *d_seq, size_t n_bps, uint32_t norm_mode, uint8_t *d_blob);
 
 /* ---- FASTA ingest (host side; src/fastx_reader.rs:6-29) ------------------------------- */
 /* read_merge_seq: returns a malloc'ed buffer (free with hg_free) and its length */
@@ -355,9 +376,12 @@ hg_status hg_hamming_search_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t 
                                 size_t Q, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap,
                                 size_t *n_out);
 
-/* Searches of 2^24 pairs or more (hv_d a multiple of 128) run as an exact +-1 byte GEMM on the matrix pipe
- * (G = D - 2 * distance on v_mfma_i32_16x16x64_i8, the ANI kernel's tiles and hit lists), smaller ones on the
- * xor + popcount kernel; both give the same integers.  hg_ctx_last_hamming_path: 0 = popcount, 1 = matrix pipe. */
+/* Searches of 2^24 pairs or more, and every hv_d that is not a multiple of 128, run as an exact GEMM on the matrix pipe
+ * with the bits expanded to +-1.0 e2m1 nibbles (G = D - 2 * distance on v_mfma_scale_f32_16x16x128_f8f6f4 with unit
+ * block scales; the ANI kernel's tiles and hit lists), smaller ones on the xor + popcount kernel; the +-1 BYTE GEMM
+ * (v_mfma_i32_16x16x64_i8) stays reachable through the "ham_path" = "mfma" hook.  All three give the same integers.
+ * hg_ctx_last_hamming_path: 0 = xor + popcount, 1 = byte GEMM, 2 = e2m1 (FP4) GEMM (the default for large searches);
+ * -1 = none yet. */
 int hg_ctx_last_hamming_path(const hg_ctx *ctx);
 /* one shard of a sharded reference database: hits carry ref_off + local row, qry_off + local column */
 hg_status hg_hamming_search_block_dev(hg_ctx *ctx, const uint32_t *d_ref_bits, size_t R, size_t ref_off,

@@ -32,6 +32,21 @@ def test_every_declared_symbol_is_exported(hg):
     assert not re.search(r"\borc_", nm), "the product must not contain the oracle"
 
 
+def test_kernel_names_in_the_header_exist_in_the_library(hg):
+    """the header's prose names kernels (hg_ctx_last_kernel's examples, the ksize ranges, the Hamming paths): every such
+    name must be a kernel the built library really contains -- prose that drifts from the code fails here"""
+    hdr = open(os.path.join(ROOT, "include", "hypergen.h")).read()
+    names = set(re.findall(r"\b(kmer_sample_[a-z0-9_]+|[a-z0-9_]+_kernel)\b(?!\.cu)", hdr)) - {"cuda_kernel"}
+    names = {n for n in names if not n.startswith("hg_")}  # (hg_ctx_last_kernel is an entry point, not a kernel)
+    assert {"kmer_sample_shared", "kmer_sample_long", "dist_mfma_kernel"} <= names
+    nm = subprocess.run(["nm", "-C", hg.LIB_PATH], capture_output=True, text=True).stdout
+    for n in sorted(names):
+        assert re.search(r"::%s[<(]" % re.escape(n), nm), "include/hypergen.h names `%s`, the library has no such kernel" % n
+    # ... and fully spelled instantiations (name<args>) must exist with exactly those template arguments
+    for full in re.findall(r"\"((?:kmer_sample|dist_mfma)[a-z_]*<[^\">]+>)\"", hdr):
+        assert ("::" + full + "(") in nm, "include/hypergen.h spells `%s`, no such instantiation in the library" % full
+
+
 def test_product_does_not_reference_oracle():
     for dp, _, fs in os.walk(os.path.join(ROOT, "hyper-gen_amd")):
         for f in fs:

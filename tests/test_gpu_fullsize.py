@@ -116,13 +116,46 @@ def test_host_fed_batch_in_several_uploads_equals_resident(sketched, orc):
         assert r_nh[i] == w_nh and r_n2[i] == w_n2 and np.array_equal(r_hv[i], w_hv), i
 
 
+def _independent_block(orc, hv, n2, rows, k=21):
+    """ANI of rows `rows` against every column from two sources that share no code with the kernels: the CPU oracle
+    (orc_ani_matrix: scalar i16 dot per pair, src/dist.rs:139-161) and an fp64 torch GEMM (exact dots: |dot| << 2^53)
+    pushed through the reference's float32 formula (src/dist.rs:153-160).  Returns both as float32 tensors on the device."""
+    hvc, n2c = hv.cpu().numpy(), n2.cpu().numpy()
+    o = torch.from_numpy(orc.ani_matrix(hvc[rows], n2c[rows], hvc, n2c, k)).to(hv.device)
+    dots = (hv[rows].double() @ hv.double().T).round().long()
+    den = (n2[rows].long()[:, None] + n2.long()[None, :] - dots).int().float()  # i32 wrapping sum, then f32
+    j = dots.float() / den
+    a = 1.0 + torch.log(2.0 / (1.0 / j + 1.0)) / float(k)
+    a = torch.nan_to_num(a, nan=0.0).clamp(0.0, 1.0) * 100.0
+    return o, a
+
+
+def _check_hits_against_block(h, rows, indep, th, sym):
+    """thresholded hits whose reference row lies in `rows` == the independent matrix thresholded (pairs within 1e-4 of
+    the threshold may fall either way); reported ANI within 1e-4 of the independent value"""
+    lo, hi = rows.start, rows.stop
+    sel = (h[:, 0] >= lo) & (h[:, 0] < hi)
+    ri, qi, ani = h[sel, 0].long() - lo, h[sel, 1].long(), h[sel, 2].contiguous().view(torch.float32)
+    got = torch.zeros_like(indep, dtype=torch.bool)
+    got[ri, qi] = True
+    live = torch.ones_like(got)
+    if sym:
+        live = torch.arange(lo, hi, device=indep.device)[:, None] < torch.arange(indep.shape[1], device=indep.device)[None, :]
+    sure_in, sure_out = (indep >= th + 1e-4) & live, (indep < th - 1e-4) | ~live
+    assert bool(got[sure_in].all()) and not bool(got[sure_out].any())
+    assert float((ani - indep[ri, qi]).abs().max()) <= 1e-4
+    return int(sel.sum())
+
+
 @pytest.mark.parametrize("tile,nhash", [("", 3333), ("big", 3333), ("wide", 3333), ("nt3", 3333), ("small", 3333),
                                         ("", 6666), ("small", 6666), ("", 20000)])
-def test_dist_10k_thresholded_equals_full_matrix(tile, nhash):
+def test_dist_10k_thresholded_equals_full_matrix(orc, tile, nhash):
     """BASELINE configs[3] size: the thresholded entry point (speculative schedule, 256-wide / 320-wide / 192-wide
     / 128 tiles, LDS-DMA with loader waves, phase-0 filter, one reservation per workgroup) must report exactly the
     pairs whose ANI in the full-matrix mode (a different kernel variant) reaches the threshold, with the same
-    float, for an asymmetric and a symmetric call.  nhash > 4096: sketches whose dot products need several exact
+    float, for an asymmetric and a symmetric call.  Kernel-vs-kernel is not the only check: a 512-row block that
+    straddles the diagonal and a cluster boundary is compared -- full matrix AND the hits of every tile variant -- with
+    the CPU oracle and with an fp64 torch GEMM through the reference's float32 formula.  nhash > 4096: sketches whose dot products need several exact
     f32 accumulation windows (speculation vetoed, windowed statistics, i32 side accumulators, 256 x 192 tiles)."""
     import os
     import bench
@@ -136,6 +169,9 @@ def test_dist_10k_thresholded_equals_full_matrix(tile, nhash):
     full = torch.empty((n, n), dtype=torch.float32, device=dev)
     ctx.dist_full_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, full.data_ptr())
     torch.cuda.synchronize()
+    rows = slice(3900, 4412)
+    ind_orc, ind_f64 = _independent_block(orc, hv, n2, rows)
+    assert float((full[rows] - ind_orc).abs().max()) <= 1e-4 and float((full[rows] - ind_f64).abs().max()) <= 1e-4
     cap = 4_000_000
     hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
     try:
@@ -155,6 +191,8 @@ def test_dist_10k_thresholded_equals_full_matrix(tile, nhash):
             got[ri, qi] = True
             assert bool((got == want).all())
             assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+            for indep in (ind_orc, ind_f64):  # ... and not only against another variant of the same kernel
+                assert _check_hits_against_block(h, rows, indep, th, sym) > 0
     finally:
         ctx.close()
 
@@ -299,6 +337,11 @@ def test_config2_sketch_10k_x_5mbp_resident_and_sharded(orc):
         got[ri, qi] = True
         assert int(sel.sum()) == int(want.sum()) and bool((got == want).all())
         assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+        # independent of the kernels: CPU oracle and fp64 GEMM on a 512-row block of the REAL sketches
+        rows = slice(1490, 2002)
+        for indep in _independent_block(orc, hv, n2, rows):
+            assert float((full[rows] - indep).abs().max()) <= 1e-4
+            assert _check_hits_against_block(h, rows, indep, 90.0, True) > 0
         # estimator sanity on real data: member m of cluster 0 vs its root
         est = full[0, 1:100].cpu().numpy()
         assert np.abs(est - 100.0 * (1.0 - 0.001 * np.arange(1, 100))).max() < 1.0

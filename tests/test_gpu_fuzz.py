@@ -19,9 +19,13 @@ def hg():
     return hypergen_amd
 
 
-@pytest.fixture(scope="module")
-def ctx(hg):
+@pytest.fixture(scope="module", params=["ascii", "packed"])
+def ctx(hg, request):
+    """every test of this module that sketches runs in both input forms: "packed" makes the library 2-bit pack each ASCII
+    batch on the device and run the packed-input kernels (hg_ctx_set_debug "kmer_input"); conftest drops the second form
+    for the tests that never touch a sequence (dist, Hamming, encode)"""
     c = hg.Context(0)
+    c.set_debug("kmer_input", "packed" if request.param == "packed" else "")
     yield c
     c.close()
 

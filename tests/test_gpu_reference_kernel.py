@@ -51,3 +51,38 @@ def test_three_way_hash_sets(orc, g, L, k, scaled, canon, slots):
         got = ctx.kmer_hash_sample(seq, k, scaled, 123, canon)
     assert ref.size == want.size and (ref == want).all(), "reference kernel vs oracle"
     assert got.size == want.size and (got == want).all(), "product vs oracle"
+
+
+def _g2_cases():
+    from conftest import golden
+    return golden("g2_ref_kernel.json")
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_g2_reference_fixture_through_the_product(orc, idx):
+    """The hash sets the reference's own kernel (src/cuda_kernel.cu:250-321, built in place by hipcc,
+    tools/gen_golden_ref_gpu.py) produced on the MI355X, committed as tests/golden/g2_ref_kernel.json, against
+    hg_kmer_hash_sample -- size, xor, sum and the stored hashes.  Needs nothing from oracle/_ref/ on the box: the
+    fixture is what survives without the reference checkout.  (orc only regenerates the seeded INPUT.)"""
+    import hypergen_amd as hg
+    cases = _g2_cases()
+    assert len(cases) == 13
+    c = cases[idx]
+    seq = orc.synth_genome(c["genome"], c["L"])
+    if c["mutated"]:  # the generator's edits (tools/gen_golden_ref_gpu.py): 50 N's and a lower-case stretch
+        rng = np.random.default_rng(c["genome"])
+        seq = seq.copy()
+        seq[rng.choice(c["L"], 50, replace=False) + 1] = ord("N")
+        seq[5000:6000] = np.char.lower(seq[5000:6000].view("S1")).view(np.uint8)
+    with hg.Context(0) as ctx:
+        for form in ("ascii", "packed"):
+            ctx.set_debug("kmer_input", form)
+            got = ctx.kmer_hash_sample(seq, c["k"], c["scaled"], 123, c["canonical"])
+            assert got.size == c["n"], (c["name"], form)
+            assert "%016x" % int(np.bitwise_xor.reduce(got) if got.size else 0) == c["xor"], (c["name"], form)
+            assert "%016x" % (int(got.astype(object).sum()) % 2**64 if got.size else 0) == c["sum"], (c["name"], form)
+            want = np.array([int(h, 16) for h in c["hashes"]], np.uint64)
+            if c["subsampled"]:
+                assert np.isin(want, got).all(), (c["name"], form)
+            else:
+                assert (want == got).all(), (c["name"], form)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Static instruction budget of the canonical k = 21 sampling kernel (kmer_sample_shared<21, true>) by class, per k-mer.
+"""Static instruction budget of the canonical k = 21 sampling kernel (kmer_sample_shared<21, true, PACKED>) by class, per k-mer.
 
-usage: tools/kmer_isa.py <tag>      writes profiles/<tag>_kmer_isa.txt and profiles/<tag>_kmer_isa.json
+usage: tools/kmer_isa.py <tag> [packed]     writes profiles/<tag>_kmer_isa.txt and profiles/<tag>_kmer_isa.json
+       (with `packed`: the hg_pack2-input instantiation, into profiles/<tag>_kmer_packed_isa.*)
 
 The kernel is compiled to gfx950 assembly with the flags of hyper-gen_amd/csrc/Makefile and cut into basic blocks
 (labels and branches).  Main path, per k-mer:
@@ -29,8 +30,10 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "hyper-gen_amd", "csrc", "hg_kmer_kernels.hip")
-KERNEL = "kmer_sample_sharedILi21ELb1EE"
-NAME = "kmer_sample_shared<21, true>"
+PACKED = len(sys.argv) > 2 and sys.argv[2] == "packed"   # tools/kmer_isa.py <tag> packed: the hg_pack2-input instantiation
+KERNEL = "kmer_sample_sharedILi21ELb1ELb%dEE" % (1 if PACKED else 0)
+NAME = "kmer_sample_shared<21, true, %s>" % ("true" if PACKED else "false")
+SUFFIX = "_kmer_packed_isa" if PACKED else "_kmer_isa"
 M = 12            # k-mers per lane and tile
 
 SLOW = ("v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_perm_b32", "v_alignbyte_b32",
@@ -64,6 +67,8 @@ def main():
                                "-amdgpu-atomic-optimizer-strategy=None", "-S", "--cuda-device-only", "-o", f.name, SRC],
                               stderr=subprocess.DEVNULL)
         lines = open(f.name).read().split("\n")
+        if os.environ.get("HG_KEEP_ASM"):
+            open(os.environ["HG_KEEP_ASM"], "w").write("\n".join(lines))
     start = [i for i, l in enumerate(lines) if l.startswith("_Z") and ":" in l and KERNEL in l.split(":")[0]][0]
     end = start
     while "s_endpgm" not in lines[end]:
@@ -137,8 +142,8 @@ def main():
            "method": "tools/kmer_isa.py: hipcc -S of hg_kmer_kernels.hip (Makefile flags); the twelve k-mer body blocks of one "
                      "copy of the loop + the tile-level blocks, per k-mer (see the tool's header)"}
     out = os.path.join(ROOT, "profiles")
-    json.dump(res, open(os.path.join(out, tag + "_kmer_isa.json"), "w"), indent=1, sort_keys=True)
-    with open(os.path.join(out, tag + "_kmer_isa.txt"), "w") as fo:
+    json.dump(res, open(os.path.join(out, tag + SUFFIX + ".json"), "w"), indent=1, sort_keys=True)
+    with open(os.path.join(out, tag + SUFFIX + ".txt"), "w") as fo:
         fo.write("%s: static instruction budget of the main path, per k-mer\n" % NAME)
         fo.write("(static VALU per 12 k-mers and lane: %s)\n" % ", ".join("%s %d" % kv for kv in sorted(weights.items())))
         fo.write("VALU per k-mer %.1f = slow class %.1f (of which multiplies %.1f) + plain %.1f (of which v_mov %.1f)\n\n" % (
@@ -151,7 +156,7 @@ def main():
             fo.write("%-28s %10.2f   %s\n" % (op, n, cls(op)))
         fo.write("\nrare paths (u/U -> T rewrite, validity mask, second loop copy, hit staging, tails, prologue/epilogue): %d static VALU instructions\n"
                  % res["rare_paths_static_valu"])
-    print(open(os.path.join(out, tag + "_kmer_isa.txt")).read())
+    print(open(os.path.join(out, tag + SUFFIX + ".txt")).read())
 
 
 if __name__ == "__main__":

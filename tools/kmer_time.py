@@ -18,6 +18,7 @@ ap.add_argument("--k", type=int, default=21)
 ap.add_argument("--canonical", type=int, default=1)
 ap.add_argument("--reps", type=int, default=15)
 ap.add_argument("--settle", type=int, default=25)
+ap.add_argument("--packed", type=int, default=0, help="1: the genomes are resident as hg_pack2 blobs (hg_sketch_batch_dev_packed)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
@@ -31,14 +32,27 @@ p = hg.default_params(ksize=a.k, canonical=a.canonical)
 hv = torch.empty((a.genomes, p.hv_d), dtype=torch.int16, device=dev)
 n2 = torch.empty(a.genomes, dtype=torch.int32, device=dev)
 nh = torch.empty(a.genomes, dtype=torch.int32, device=dev)
+if a.packed:
+    bsz = hg.lib().hg_pack2_size(a.L + 1)
+    boffs = np.arange(a.genomes, dtype=np.uint64) * bsz
+    blobs = torch.empty(a.genomes * bsz + 64, dtype=torch.uint8, device=dev)
+    ctx.pack2_batch_dev(seq.data_ptr(), offs, lens, blobs.data_ptr(), boffs)
+    del seq
+    torch.cuda.empty_cache()
+
+    def step():
+        ctx.sketch_batch_dev_packed(blobs.data_ptr(), boffs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+else:
+    def step():
+        ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
 for _ in range(a.settle):
-    ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+    step()
 torch.cuda.synchronize()
 ctx.enable_timing(True)
 ts = []
 for _ in range(a.reps):
     ctx.timings()
-    ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+    step()
     torch.cuda.synchronize()
     ts.append(ctx.timings()["kmer"][0])
 ts.sort()
