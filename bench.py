@@ -154,7 +154,7 @@ def valu_issue(n_genomes, kernel):
     try:
         k = d[kernel]
         insts, cycles = k["SQ_INSTS_VALU"], k["GRBM_GUI_ACTIVE"] / 8.0
-        ipath = newest_profile("_kmer_isa.json")
+        ipath = newest_profile("_kmer_packed_isa.json" if kernel.endswith(", true>") else "_kmer_isa.json")
         isa = json.load(open(ipath))
         if isa.get("kernel") != kernel or isa.get("source_sha") != hg.source_stamp():
             raise KeyError("ISA histogram of another kernel / tree")
@@ -317,8 +317,20 @@ def main():
     n2 = torch.empty(N, dtype=torch.int32, device=dev)
     nh = torch.empty(N, dtype=torch.int32, device=dev)
 
+    # The headline runs on 2-bit PACKED bases (north_star: "coalesced HBM reads of packed bases"): the synthetic ASCII
+    # genomes are packed once, on the device and outside every timed region (hg_pack2_batch_dev = the host's hg_pack2
+    # byte for byte), and the step is hg_sketch_batch_dev_packed on the blobs.  The ASCII-resident form of the same step
+    # is timed right after it (`ascii_resident`) and must give identical sketches.
+    blob_sz = hg.lib().hg_pack2_size(L_GENOME + 1)
+    boffs = np.arange(N, dtype=np.uint64) * blob_sz
+    blobs = torch.empty(N * blob_sz + 64, dtype=torch.uint8, device=dev)
+    ctx.pack2_batch_dev(seq.data_ptr(), offs, lens, blobs.data_ptr(), boffs)
+
     def step():
-        ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+        ctx.sketch_batch_dev_packed(blobs.data_ptr(), boffs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+
+    def step_ascii():
+        ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv_a.data_ptr(), n2_a.data_ptr(), nh_a.data_ptr())
 
     settle(step, SETTLE["sketch"])
     for _ in range(a.warmup):
@@ -345,6 +357,31 @@ def main():
     value = N * world * a.steps / dt
     log("sketch: %.1f genomes/s, kmer kernel %.3f ms/launch (%d launches), nhash mean %.1f" % (
         value, kmer_avg_ms, kmer_launches, nh.float().mean().item()))
+    # the same step on ASCII-resident genomes (1 byte per base in HBM), identical sketches required
+    hv_a, n2_a, nh_a = torch.empty_like(hv), torch.empty_like(n2), torch.empty_like(nh)
+    settle(step_ascii, 5)
+    ctx.enable_timing(True)
+    ctx.timings()
+    steps_a = max(2, min(a.steps, 10))
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps_a):
+        step_ascii()
+    barrier_sync(world)
+    dt_a = max_over_ranks(time.perf_counter() - t0, world, dev)
+    tm_a = ctx.timings()
+    ctx.enable_timing(False)
+    ascii_kernel = ctx.last_kernel("kmer")
+    if not (torch.equal(hv_a, hv) and torch.equal(n2_a, n2) and torch.equal(nh_a, nh)):
+        raise SystemExit("PARITY GATE FAILED: sketches of the packed and of the ASCII-resident genomes differ")
+    ascii_ms = tm_a["kmer"][0] / max(tm_a["kmer"][1], 1)
+    log("sketch, ASCII-resident: %.1f genomes/s, kmer kernel %.3f ms/launch" % (N * world * steps_a / dt_a, ascii_ms))
+    del hv_a, n2_a, nh_a
+    isa_path = newest_profile("_kmer_packed_isa.json")
+    try:
+        isa_valu = json.load(open(isa_path))["per_kmer"]["valu"]
+    except Exception:
+        isa_valu = None
 
     out = {
         "metric": "genomes/sec sketch (k=21,s=1500,D=4096)", "value": value, "unit": "genomes/sec",
@@ -352,17 +389,27 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": "%d synthetic 5 Mbp genomes per GPU (BASELINE configs[1]), sketch k=21 "
-                               "scaled=1500 seed=123 canonical D=4096 AVX2 layout, inputs resident in HBM" % N,
+                               "scaled=1500 seed=123 canonical D=4096 AVX2 layout, inputs resident in HBM as 2-bit packed "
+                               "bases (hg_pack2 blobs: codes + not-a-base bitmap, 0.375 B per base)" % N,
                    "genomes_per_gpu": N, "genome_bp": L_GENOME, "parallelism": "genome-sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": kmer_kernel, "launch_ms": kmer_avg_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "note": "nominally a scan, so priced against HBM; the true binder is integer VALU issue "
-                             "(~80 VALU instructions per k-mer, ~51 of them the t1ha2 hash; see valu_issue)",
+                     "input_bytes_per_launch": int(N * blob_sz),
+                     "note": "algorithmic bytes = SURVEY 8(d)'s L + 2 D per genome (one byte per base in, i16 HV out) whatever "
+                             "the resident form; the packed blobs the kernel actually reads are input_bytes_per_launch. "
+                             "Nominally a scan, so priced against HBM; the true binder is integer VALU issue (%s static VALU "
+                             "instructions per k-mer, 25 of them the 64-bit multiply-adds of t1ha2; see valu_issue)" % (
+                                 ("%.1f" % isa_valu) if isa_valu else "~65"),
                      "valu_issue": valu_issue(N, kmer_kernel),
                      "kmer_hashes_per_sec": N * (L_GENOME + 1 - KSIZE + 1) / (kmer_avg_ms * 1e-3)},
         "kernel_ms_per_step": {k: v[0] / max(a.steps, 1) for k, v in tm.items() if v[1]},
+        "ascii_resident": {"value": N * world * steps_a / dt_a, "unit": "genomes/sec", "steps": steps_a,
+                           "ms_per_step": dt_a / steps_a * 1e3, "kernel": ascii_kernel, "launch_ms": ascii_ms,
+                           "frac_of_hbm_peak": bytes_per_launch / (ascii_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "config": {"workload": "the same %d genomes resident as ASCII (1 B per base, %.1f GB), "
+                                                  "hg_sketch_batch_dev; sketches identical to the headline's" % (N, N * stride / 1e9)}},
     }
 
     # ---------------- configs[2]: 10 000 genomes TOTAL, sharded over the ranks -------------------------------
@@ -372,16 +419,22 @@ def main():
         from hypergen_amd import shard
         glo, ghi = shard.shard_range(a.genomes_10k, rank, world)
         M = ghi - glo
-        seq2 = torch.empty(M * stride + 64, dtype=torch.uint8, device=dev)
-        ctx.synth_genomes_dev(glo, M, L_GENOME, stride, seq2.data_ptr())
-        offs2 = np.arange(M, dtype=np.uint64) * stride
+        # resident as packed blobs (18.75 GB for 10 000 genomes instead of 50 GB): generated and packed 1 000 at a time
+        # through the headline's ASCII buffer
+        seq2 = torch.empty(M * blob_sz + 64, dtype=torch.uint8, device=dev)
+        boffs2 = np.arange(M, dtype=np.uint64) * blob_sz
+        for g0 in range(0, M, N):
+            m = min(N, M - g0)
+            ctx.synth_genomes_dev(glo + g0, m, L_GENOME, stride, seq.data_ptr())
+            ctx.pack2_batch_dev(seq.data_ptr(), offs[:m], lens[:m], seq2.data_ptr() + g0 * blob_sz, boffs[:m])
+        ctx.synth_genomes_dev(rank * N, N, L_GENOME, stride, seq.data_ptr())  # (the later legs read the headline's genomes)
         lens2 = np.full(M, L_GENOME + 1, np.uint64)
         hv2 = torch.empty((M, HV_D), dtype=torch.int16, device=dev)
         n22 = torch.empty(M, dtype=torch.int32, device=dev)
         nh2 = torch.empty(M, dtype=torch.int32, device=dev)
 
         def step2():
-            ctx.sketch_batch_dev(seq2.data_ptr(), offs2, lens2, p, hv2.data_ptr(), n22.data_ptr(), nh2.data_ptr())
+            ctx.sketch_batch_dev_packed(seq2.data_ptr(), boffs2, lens2, p, hv2.data_ptr(), n22.data_ptr(), nh2.data_ptr())
 
         step2()
         steps2 = max(2, min(a.steps, 5))
@@ -399,8 +452,8 @@ def main():
             "metric": "genomes/sec sketch (k=21,s=1500,D=4096)", "value": a.genomes_10k * steps2 / dt2,
             "unit": "genomes/sec", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3, "scaling": "strong",
             "config": {"workload": "%d synthetic 5 Mbp genomes in total (BASELINE configs[2]), rank r sketches "
-                                   "shard_range(%d, r, %d); inputs resident in HBM (%.1f GB per GPU)" % (
-                                       a.genomes_10k, a.genomes_10k, world, M * stride / 1e9),
+                                   "shard_range(%d, r, %d); inputs resident in HBM as 2-bit packed bases (%.2f GB per GPU)" % (
+                                       a.genomes_10k, a.genomes_10k, world, M * blob_sz / 1e9),
                        "genomes_per_gpu": M, "parallelism": "genome-sharded x%d, no collective" % world}}
         log("sketch_10k: %.1f genomes/s (%d genomes on this rank, %.1f ms per pass)" % (
             out["sketch_10k"]["value"], M, dt2 / steps2 * 1e3))
@@ -444,41 +497,58 @@ def main():
         def pack_some(t):
             for g in range(t, HF, T):
                 blobs[g] = torch.from_numpy(hg.pack2(host_rows[g])).pin_memory().numpy()
+                sp = hg.pack2s(host_rows[g])
+                sblobs[g] = None if sp is None else torch.from_numpy(sp).pin_memory().numpy()
+        sblobs = [None] * HF
         t0 = time.perf_counter()
         for g in range(min(HF, 2 * T)):  # timing of the packer alone, one thread
-            hg.pack2(host_rows[g])
+            hg.pack2s(host_rows[g])
         pack_ms = (time.perf_counter() - t0) / min(HF, 2 * T) * 1e3
         th = [threading.Thread(target=pack_some, args=(t,)) for t in range(T)]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        with hg.SketchStream((local,), p) as st:
-            best = None
-            for rep in range(reps + 1):
-                t0 = time.perf_counter()
-                for g in range(HF):
-                    st.push_packed(blobs[g], L_GENOME + 1, rep * HF + g)
-                got = {}
-                for _ in range(HF):
-                    r = st.pop()
-                    got[r[0] - rep * HF] = r
-                dtp = time.perf_counter() - t0
-                if rep:
-                    best = dtp if best is None else min(best, dtp)
-            st.finish()
         ref_hv, ref_n2 = hv[:HF].cpu().numpy(), n2[:HF].cpu().numpy()
-        if not all(np.array_equal(got[g][1], ref_hv[g]) and got[g][2] == ref_n2[g] for g in range(HF)):
-            raise SystemExit("PARITY GATE FAILED: sketches of the 2-bit packed genomes differ from the HBM-resident ones")
-        pk_bytes = sum(b.size for b in blobs)
+
+        def stream_pass(sparse):
+            """the HF genomes through push_packed(_sparse) / pop, best of `reps` passes; returns (seconds, bytes over the link)"""
+            with hg.SketchStream((local,), p) as st:
+                best = None
+                for rep in range(reps + 1):
+                    t0 = time.perf_counter()
+                    for g in range(HF):
+                        if sparse and sblobs[g] is not None:
+                            st.push_packed_sparse(sblobs[g], L_GENOME + 1, rep * HF + g)
+                        else:
+                            st.push_packed(blobs[g], L_GENOME + 1, rep * HF + g)
+                    got = {}
+                    for _ in range(HF):
+                        r = st.pop()
+                        got[r[0] - rep * HF] = r
+                    dtp = time.perf_counter() - t0
+                    if rep:
+                        best = dtp if best is None else min(best, dtp)
+                st.finish()
+            if not all(np.array_equal(got[g][1], ref_hv[g]) and got[g][2] == ref_n2[g] for g in range(HF)):
+                raise SystemExit("PARITY GATE FAILED: sketches of the 2-bit packed genomes differ from the HBM-resident ones")
+            nbytes = sum((sblobs[g] if sparse and sblobs[g] is not None else blobs[g]).size for g in range(HF))
+            return best, nbytes
+
+        best_b, bytes_b = stream_pass(False)
+        best, pk_bytes = stream_pass(True)
         out["host_fed"]["packed_stream"] = {
             "value": HF / best, "unit": "genomes/sec", "pcie_gbs": pk_bytes / best / 1e9,
             "bytes_per_base": pk_bytes / (HF * (L_GENOME + 1.0)), "host_pack_ms_per_genome_one_thread": pack_ms,
-            "config": {"workload": "the same %d genomes as hg_pack2 blobs from pinned memory through "
-                                   "hg_sketch_stream_push_packed / pop (device-side expansion + sketch), best of %d "
-                                   "passes; packing time not included" % (HF, reps)}}
-        log("host-fed, 2-bit packed stream: %.0f genomes/s (%.1f GB/s over PCIe, host packing %.2f ms per genome and thread)" % (
-            HF / best, pk_bytes / best / 1e9, pack_ms))
+            "bitmap_form": {"value": HF / best_b, "unit": "genomes/sec", "pcie_gbs": bytes_b / best_b / 1e9,
+                            "bytes_per_base": bytes_b / (HF * (L_GENOME + 1.0))},
+            "config": {"workload": "the same %d genomes as hg_pack2s blobs (2-bit codes + a table of the not-a-base runs: "
+                                   "0.25 B per base over the link) from pinned memory through "
+                                   "hg_sketch_stream_push_packed_sparse / pop -- the device rebuilds the bitmap and the blobs go "
+                                   "to the packed-input kernels as they arrive --, best of %d passes; packing time not "
+                                   "included.  bitmap_form: the same through hg_pack2 blobs (0.375 B per base)" % (HF, reps)}}
+        log("host-fed, 2-bit packed stream: %.0f genomes/s sparse (%.1f GB/s over PCIe), %.0f genomes/s bitmap form (%.1f GB/s); "
+            "host packing %.2f ms per genome and thread" % (HF / best, pk_bytes / best / 1e9, HF / best_b, bytes_b / best_b / 1e9, pack_ms))
         # ---- per_call: the literal drop-in of the reference's inner seam (src/sketch_cuda.rs:79-96,120-166) ------
         # T host threads (the reference's rayon workers), each with its OWN hg_ctx on this GPU, one synchronous
         # hg_kmer_hash_sample call per genome from pinned memory, the sampled hash list back on the host -- what a

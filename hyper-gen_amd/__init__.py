@@ -80,6 +80,7 @@ EXPORTS = [
     "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
     "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
     "hg_sketch_batch_dev_packed", "hg_pack2_batch_dev", "hg_pack2_dev",
+    "hg_pack2s_size", "hg_pack2s", "hg_sketch_stream_push_packed_sparse",
 ]
 
 
@@ -177,6 +178,9 @@ def lib():
         "hg_sketch_batch_dev_packed": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(SketchParams), vp, vp, vp]),
         "hg_pack2_batch_dev": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint32, vp, vp]),
         "hg_pack2_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
+        "hg_pack2s_size": (sz, [sz, sz]),
+        "hg_pack2s": (C.c_int, [vp, sz, C.c_uint32, vp, sz, C.POINTER(sz)]),
+        "hg_sketch_stream_push_packed_sparse": (C.c_int, [vp, vp, sz, C.c_uint64]),
         "hg_sketch_stream_finish": (C.c_int, [vp]),
         "hg_sketch_stream_last_error": (C.c_char_p, [vp]),
         "hg_sketch_stream_close": (None, [vp]),
@@ -629,6 +633,22 @@ def read_merge_seq(path, mode=READ_MERGE):
         lib().hg_free(p)
 
 
+def pack2s(seq, norm_mode=0, cap=None):
+    """hg_pack2s: the sparse link form (2-bit codes + a table of the not-a-base runs), or None if the table does not fit
+    `cap` bytes (default: the size of the hg_pack2 blob -- beyond that the bitmap form is the smaller one)."""
+    a = np.ascontiguousarray(seq, np.uint8)
+    n = a.size
+    cap = lib().hg_pack2_size(n) if cap is None else cap
+    out = np.empty(max(cap, 16), np.uint8)
+    size = C.c_size_t(0)
+    st = lib().hg_pack2s(_ptr(a), n, norm_mode, _ptr(out), out.size, C.byref(size))
+    if st == ERR_CAPACITY:
+        return None
+    if st != OK:
+        raise HgError(st, "hg_pack2s")
+    return out[:size.value]
+
+
 def pack2(seq, norm_mode=0, in_place=False):
     """hg_pack2: uint8 blob of hg_pack2_size(len(seq)) bytes (2-bit codes + not-a-base bits)."""
     a = np.ascontiguousarray(seq, np.uint8)
@@ -727,12 +747,17 @@ class SketchStream:
 
     def push(self, seq, tag):
         a = np.ascontiguousarray(seq, np.uint8)
-        self._push(a, a.size, tag, False)
+        self._push(a, a.size, tag, 0)
 
     def push_packed(self, blob, n_bps, tag):
         a = np.ascontiguousarray(blob, np.uint8)
         assert a.size >= lib().hg_pack2_size(n_bps)
-        self._push(a, n_bps, tag, True)
+        self._push(a, n_bps, tag, 1)
+
+    def push_packed_sparse(self, blob, n_bps, tag):
+        """a hg_pack2s blob (pack2s()): codes + run table"""
+        a = np.ascontiguousarray(blob, np.uint8)
+        self._push(a, n_bps, tag, 2)
 
     def finish(self):
         self._check(lib().hg_sketch_stream_finish(self._h), "hg_sketch_stream_finish")

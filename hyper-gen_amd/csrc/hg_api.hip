@@ -361,7 +361,7 @@ uint32_t round_cap(uint64_t cap) {
 
 // want_caps: optional per-genome minimum capacities (retry after overflow)
 hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize,
-                    uint64_t scaled, const std::vector<uint32_t> *want_caps, BatchPlan &pl) {
+                    uint64_t scaled, const std::vector<uint32_t> *want_caps, BatchPlan &pl, const uint64_t *mask_offs = nullptr) {
   const uint64_t item_starts = hg_kmer_item_starts(ksize);
   pl.meta.resize(n);
   pl.item_genome.clear();
@@ -372,6 +372,7 @@ hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, si
     hg_genome_meta &m = pl.meta[g];
     m.seq_off = offsets[g];
     m.n_bps = lens[g];
+    m.mask_off = mask_offs ? mask_offs[g] : offsets[g] + (((lens[g] + 3) / 4 + 15) & ~(uint64_t)15);  // (read by the packed kernels only)
     const uint64_t n_starts = lens[g] >= ksize ? lens[g] - ksize + 1 : 0;
     uint64_t cap = n_starts / scaled * 2 + 1024;  // expected n_starts/scaled; sd ~ sqrt of that
     if (cap > n_starts) cap = n_starts;             // can never exceed the number of k-mers
@@ -492,7 +493,8 @@ hg_status pack_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *seq_offs, 
 
 hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
                        size_t n, uint32_t ksize, uint64_t threshold, uint64_t scaled_for_cap, uint64_t seed,
-                       bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out, bool packed = false) {
+                       bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out, bool packed = false,
+                       const uint64_t *mask_offs = nullptr) {
   if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
   std::vector<uint64_t> hook_offs;
   if (!packed && c->dbg_kmer_input == "packed") {
@@ -513,7 +515,8 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     // work-item table and the per-genome records are still on the device
     const bool reuse = attempt == 0 && c->plan_valid && c->plan_ksize == ksize && c->plan_scaled == scaled_for_cap &&
                        c->plan_packed == packed && c->plan_offs.size() == n && std::memcmp(c->plan_offs.data(), offsets, n * 8) == 0 &&
-                       std::memcmp(c->plan_lens.data(), lens, n * 8) == 0;
+                       std::memcmp(c->plan_lens.data(), lens, n * 8) == 0 &&
+                       (mask_offs ? (c->plan_masks.size() == n && std::memcmp(c->plan_masks.data(), mask_offs, n * 8) == 0) : c->plan_masks.empty());
     size_t n_items;
     if (reuse) {
       n_items = c->plan_items;
@@ -527,7 +530,7 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       }
     } else {
       c->plan_valid = false;
-      if ((s = make_plan(c, offsets, lens, n, ksize, scaled_for_cap, attempt ? &want : nullptr, pl)) != HG_OK) return s;
+      if ((s = make_plan(c, offsets, lens, n, ksize, scaled_for_cap, attempt ? &want : nullptr, pl, mask_offs)) != HG_OK) return s;
       n_items = pl.item_genome.size();
     }
     if ((s = hg_ensure(c, c->w_gmeta, n * sizeof(hg_genome_meta) + 16)) != HG_OK) return s;
@@ -618,6 +621,8 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       if (!reuse) {  // remember this plan for the next call
         c->plan_offs.assign(offsets, offsets + n);
         c->plan_lens.assign(lens, lens + n);
+        if (mask_offs) c->plan_masks.assign(mask_offs, mask_offs + n);
+        else c->plan_masks.clear();
         c->plan_caps.resize(n);
         for (size_t g = 0; g < n; ++g) c->plan_caps[g] = pl.meta[g].hit_cap;
         c->plan_ksize = ksize, c->plan_scaled = scaled_for_cap, c->plan_packed = packed;
@@ -646,7 +651,14 @@ hg_status check_params(hg_ctx *c, const hg_sketch_params *p) {
 }  // namespace
 
 static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
-                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed);
+                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed,
+                                       const uint64_t *mask_offs = nullptr);
+
+hg_status hg_sketch_batch_dev_packed_masks(hg_ctx *c, const uint8_t *d_blobs, const uint64_t *code_offs, const uint64_t *mask_offs,
+                                           const uint64_t *n_bps, size_t n, const hg_sketch_params *p, int16_t *d_hv,
+                                           int32_t *d_norm2, uint32_t *d_nhash) {
+  return sketch_batch_dev_impl(c, d_blobs, code_offs, n_bps, n, p, d_hv, d_norm2, d_nhash, true, mask_offs);
+}
 
 extern "C" hg_status hg_sketch_batch_dev(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
                                          const uint64_t *lens, size_t n, const hg_sketch_params *p,
@@ -681,7 +693,8 @@ extern "C" hg_status hg_pack2_dev(hg_ctx *c, const uint8_t *d_seq, size_t n_bps,
 }
 
 static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
-                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed) {
+                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed,
+                                       const uint64_t *mask_offs) {
   if (!c) return HG_ERR_INVALID;
   hg_status s = check_params(c, p);
   if (s != HG_OK) return s;
@@ -692,7 +705,7 @@ static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const ui
   uint32_t *d_nd = nullptr;
   const uint64_t threshold = UINT64_MAX / p->scaled;  // src/sketch.rs:73
   s = sample_batch(c, d_seq, offsets, lens, n, p->ksize, threshold, p->scaled, p->seed, p->canonical != 0,
-                   p->norm_mode, pl, &d_nd, packed);
+                   p->norm_mode, pl, &d_nd, packed, mask_offs);
   if (s != HG_OK) return s;
   // genomes with very large hash sets are encoded by several workgroups each (plan from the raw hit counts)
   hg_encode_split split{};

@@ -300,6 +300,66 @@ void pack2_finish(uint8_t *out, size_t n_bps, uint8_t *mask) {
 }
 }  // namespace
 
+// Sparse form for the PCIe link: the same codes, but the not-a-base positions as a sorted table of runs instead of a bit
+// per base -- an assembly has a handful of them (N gaps between contigs, the 'N' per record start), so the link carries
+// 0.25 bytes per base instead of 0.375.  Layout: [codes, padded to 16 bytes][u32 n_runs, u32 0, n_runs x {u32 start,
+// u32 length}, padded to 16 bytes].  The device rebuilds the bitmap from the table (hg_stream.hip: expand_runs_kernel).
+extern "C" size_t hg_pack2s_size(size_t n_bps, size_t n_runs) { return al16((n_bps + 3) / 4) + al16(8 + 8 * n_runs); }
+
+extern "C" hg_status hg_pack2s(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t cap, size_t *size_out) {
+  if ((n_bps && !seq) || !out || !size_out || norm_mode > HG_NORM_U2T) return HG_ERR_INVALID;
+  if (n_bps >= ((size_t)1 << 32)) return HG_ERR_UNSUPPORTED;  // (32-bit run positions; such a genome takes hg_pack2)
+  const size_t cb = al16((n_bps + 3) / 4), used = (n_bps + 3) / 4, mwords = (n_bps + 63) / 64;
+  *size_out = cb + 16;
+  if (cap < cb + 16) return HG_ERR_CAPACITY;
+  uint8_t *mask = thread_mask(8 * mwords + 64);
+  if (!mask) return HG_ERR_OOM;
+  pack2_span(seq, n_bps, norm_mode == HG_NORM_U2T, out, mask);
+  if (cb > used) std::memset(out + used, 0, cb - used);
+  if (n_bps & 63) std::memset(mask + (n_bps + 7) / 8, 0, 8 * mwords - (n_bps + 7) / 8);  // whole 64-bit words below
+  // runs of set bits, in order (bits at or behind n_bps are zero: pack2_span sets none, the tail was cleared above)
+  const size_t max_runs = (cap - cb - 8) / 8;
+  uint32_t *tab = reinterpret_cast<uint32_t *>(out + cb);
+  size_t n_runs = 0;
+  bool open = false;
+  uint64_t start = 0;
+  auto emit = [&](uint64_t st, uint64_t len) {
+    if (n_runs < max_runs) tab[2 + 2 * n_runs] = (uint32_t)st, tab[3 + 2 * n_runs] = (uint32_t)len;
+    ++n_runs;
+  };
+  for (size_t w = 0; w < mwords; ++w) {
+    uint64_t x;
+    std::memcpy(&x, mask + 8 * w, 8);
+    if (open) {  // a run came in from the word below: it ends at this word's first zero bit
+      if (x == ~(uint64_t)0) continue;
+      const unsigned z = (unsigned)__builtin_ctzll(~x);
+      emit(start, 64 * w + z - start);
+      open = false;
+      x = z ? (x >> z) << z : x;
+    }
+    while (x) {
+      const unsigned p = (unsigned)__builtin_ctzll(x);
+      const uint64_t y = ~(x >> p);  // (the shift fills zeros from the top: a run that reaches bit 63 gives 64 - p)
+      const unsigned len = y ? (unsigned)__builtin_ctzll(y) : 64u;
+      if (p + len >= 64) {
+        start = 64 * w + p, open = true;
+        break;
+      }
+      emit(64 * w + p, len);
+      x &= ~((((uint64_t)1 << len) - 1) << p);
+    }
+  }
+  if (open) {  // a run that ends with the sequence
+    emit(start, n_bps - start);
+  }
+  *size_out = hg_pack2s_size(n_bps, n_runs);
+  if (n_runs > max_runs || *size_out > cap) return HG_ERR_CAPACITY;
+  tab[0] = (uint32_t)n_runs, tab[1] = 0;
+  const size_t tb = 8 + 8 * n_runs;
+  if (al16(tb) > tb) std::memset(out + cb + tb, 0, al16(tb) - tb);
+  return HG_OK;
+}
+
 // `out` may be `seq` itself (packing in place): the codes trail the reads, the mask is collected aside.
 extern "C" hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out) {
   if ((n_bps && !seq) || !out || norm_mode > HG_NORM_U2T) return HG_ERR_INVALID;

@@ -63,7 +63,7 @@ struct hg_ctx {
   std::vector<hipEvent_t> t_pool;       // reusable events
   // cached batch plan of the last sketch call: when the next call has the same geometry the host
   // neither rebuilds the work-item table nor uploads it again (see sample_batch)
-  std::vector<uint64_t> plan_offs, plan_lens;
+  std::vector<uint64_t> plan_offs, plan_lens, plan_masks;
   std::vector<uint32_t> plan_caps;  // hit_cap per genome of the cached plan
   uint32_t plan_ksize = 0;
   bool plan_packed = false;  // the cached plan's genomes were hg_pack2 blobs
@@ -128,12 +128,18 @@ struct hg_timed {
 // ---- k-mer sampling kernel interface ---------------------------------------------------
 // One record per genome of a batch, in device memory.
 struct hg_genome_meta {
-  uint64_t seq_off;     // byte offset of the genome in d_seq (multiple of 4)
-  uint64_t n_bps;       // length in bytes
+  uint64_t seq_off;     // byte offset of the genome in d_seq (multiple of 4); packed input: of its 2-bit codes
+  uint64_t n_bps;       // length in bytes (bases)
   uint64_t hit_off;     // first slot of the genome's region in the hit buffer
   uint32_t hit_cap;     // slots in that region
   uint32_t item_first;  // index of the genome's first work item
+  uint64_t mask_off;    // packed input: byte offset of the genome's not-a-base bitmap in d_seq (hg_pack2: seq_off + padded code bytes)
 };
+// hg_sketch_batch_dev_packed with the bitmaps at explicit offsets (the streaming path: a genome that came over the link as
+// codes + run table has its bitmap rebuilt behind the table, not directly behind the codes)
+hg_status hg_sketch_batch_dev_packed_masks(hg_ctx *c, const uint8_t *d_blobs, const uint64_t *code_offs, const uint64_t *mask_offs,
+                                           const uint64_t *n_bps, size_t n, const hg_sketch_params *p, int16_t *d_hv,
+                                           int32_t *d_norm2, uint32_t *d_nhash);
 
 // starts handled by one work item (one workgroup) of the fast kernel for a given k
 uint32_t hg_kmer_item_starts(uint32_t ksize);

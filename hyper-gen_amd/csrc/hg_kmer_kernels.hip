@@ -548,7 +548,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
   // the genome end are invalid whatever the blob's padding says.
   typedef uint32_t __attribute__((aligned(1))) u32u;
   typedef uint64_t __attribute__((aligned(1))) u64u;
-  const uint8_t *__restrict__ gmask = gseq + ((((size_t)n_bps + 3) / 4 + 15) & ~(size_t)15);
+  const uint8_t *__restrict__ gmask = seq + gm.mask_off;
   auto stage_unit_packed = [&](uint32_t u, uint64_t tile_start, uint32_t par, uint32_t &c0, uint32_t &c1, uint32_t &c2,
                                inv_t &invw) __attribute__((always_inline)) {
     const uint64_t P = tile_start + (uint64_t)u * M;  // a multiple of 4: whole code bytes
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
   if (n_bps < ksize) return;
   const uint64_t n_starts = n_bps - ksize + 1;
   const uint8_t *__restrict__ gseq = seq + gm.seq_off;
-  const uint8_t *__restrict__ gmask = gseq + ((((size_t)n_bps + 3) / 4 + 15) & ~(size_t)15);  // PACKED: the blob's not-a-base bitmap
+  const uint8_t *__restrict__ gmask = seq + gm.mask_off;  // PACKED: the genome's not-a-base bitmap
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * GEN_ITEM;
   if (tid == 0) stage.n = 0;
   const uint32_t n_stage = LONG_TILE + ksize - 1;  // bytes a full tile needs

@@ -34,18 +34,26 @@ constexpr int N_CHUNKS = 3;
 // 8.3-9.6 k -- two contexts' small kernels and synchronisations get in each other's way; kept configurable
 constexpr int N_WORKERS = 1;
 
+enum : int { KIND_ASCII = 0, KIND_PACK2 = 1, KIND_PACK2S = 2 };
 struct Item {
-  const uint8_t *seq;  // ASCII sequence, or a hg_pack2 blob when packed
+  const uint8_t *seq;  // ASCII sequence, a hg_pack2 blob (KIND_PACK2) or a hg_pack2s blob (KIND_PACK2S)
   size_t len;          // bases
   uint64_t tag;
-  bool packed;
+  int kind;
+  size_t blob_bytes;   // KIND_PACK2S: bytes of the host blob (codes + run table)
 };
 
 // one packed genome of a chunk: where its blob sits in the chunk's packed area, where its ASCII goes
 struct UnpackJob {
-  uint64_t pk_off, out_off, n_bps;
+  uint64_t pk_off, out_off, n_bps, mask_off;  // (mask_off: where the genome's not-a-base bitmap lies in the packed area)
   uint32_t first_block, pad;
 };
+// one sparse genome of a chunk: its run table lies behind its codes, its bitmap is rebuilt at mask_off
+struct SparseJob {
+  uint64_t codes_off, mask_off, n_bps;
+  uint32_t first_block, pad;
+};
+constexpr uint32_t SLICE_WORDS = 1024;  // bitmap words one workgroup rebuilds: 4 KiB = 32 768 bases
 constexpr uint32_t UNPACK_GROUPS_PER_BLOCK = 1024;  // 256 threads x 4 groups of 16 bases
 
 struct Chunk {
@@ -64,6 +72,11 @@ struct Chunk {
   size_t pk_cap = 0, pk_bytes = 0;
   UnpackJob *h_jobs = nullptr, *d_jobs = nullptr;  // CHUNK_GENOMES entries each (page-locked / device), lazily allocated
   uint32_t n_jobs = 0, n_blocks = 0;
+  SparseJob *h_sjobs = nullptr, *d_sjobs = nullptr;  // hg_pack2s genomes: bitmap rebuild jobs
+  uint32_t n_sjobs = 0, n_sblocks = 0;
+  std::vector<uint64_t> mask_offs;  // parallel to pk_offs
+  bool has_ascii = false;           // some genome of the chunk arrived as ASCII (its bytes live in `d`)
+  size_t link_bytes = 0;            // bytes this chunk moves over the link
 };
 
 struct Done {  // the results of one chunk
@@ -78,10 +91,10 @@ struct Done {  // the results of one chunk
 
 namespace {
 // 16 bases per step: 4 code bytes -> 16 ASCII bytes through a v_perm table ("ACGT"), non-bases -> 'N'
-__device__ __forceinline__ void unpack2_group(const uint8_t *__restrict__ blob, size_t code_bytes, uint8_t *__restrict__ out,
+__device__ __forceinline__ void unpack2_group(const uint8_t *__restrict__ blob, const uint8_t *__restrict__ mask, uint8_t *__restrict__ out,
                                               uint64_t grp) {
   const uint32_t codes = *reinterpret_cast<const uint32_t *>(blob + 4 * grp);
-  const uint32_t bad = *reinterpret_cast<const uint16_t *>(blob + code_bytes + 2 * grp);
+  const uint32_t bad = *reinterpret_cast<const uint16_t *>(mask + 2 * grp);
   uint32_t w[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
@@ -104,13 +117,56 @@ __global__ __launch_bounds__(256) void unpack2_kernel(const uint8_t *__restrict_
   }
   const UnpackJob jb = jobs[lo];
   const uint64_t groups = (jb.n_bps + 15) / 16;
-  const size_t code_bytes = (((size_t)jb.n_bps + 3) / 4 + 15) & ~(size_t)15;
   const uint64_t g0 = (uint64_t)(blockIdx.x - jb.first_block) * UNPACK_GROUPS_PER_BLOCK + threadIdx.x;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t g = g0 + 256u * r;
-    if (g < groups) unpack2_group(pk + jb.pk_off, code_bytes, out + jb.out_off, g);
+    if (g < groups) unpack2_group(pk + jb.pk_off, pk + jb.mask_off, out + jb.out_off, g);
   }
+}
+
+// hg_pack2s genomes: the not-a-base bitmap of the hg_pack2 layout rebuilt from the run table that came over the link.
+// One workgroup per 4 KiB slice of a genome's bitmap: zeroed in LDS, the runs that overlap it OR-ed in, written out
+// once -- the chunk's memory is reused, so every word is written whether it has a bit or not.
+__global__ __launch_bounds__(256) void expand_runs_kernel(uint8_t *__restrict__ pk, const SparseJob *__restrict__ jobs, uint32_t n_jobs) {
+  __shared__ uint32_t s_bits[SLICE_WORDS];
+  uint32_t lo = 0, hi = n_jobs;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+    else hi = mid;
+  }
+  const SparseJob jb = jobs[lo];
+  const uint64_t cb = ((jb.n_bps + 3) / 4 + 15) & ~(uint64_t)15, words = (((jb.n_bps + 7) / 8 + 15) & ~(uint64_t)15) / 4;
+  const uint64_t w0 = (uint64_t)(blockIdx.x - jb.first_block) * SLICE_WORDS;
+  if (w0 >= words) return;
+  const uint32_t nw = (uint32_t)(words - w0 < SLICE_WORDS ? words - w0 : SLICE_WORDS);
+  for (uint32_t i = threadIdx.x; i < nw; i += 256) s_bits[i] = 0u;
+  __syncthreads();
+  const uint32_t *__restrict__ tab = reinterpret_cast<const uint32_t *>(pk + jb.codes_off + cb);
+  const uint32_t n_runs = tab[0];
+  const uint64_t b0 = 32 * w0, b1 = b0 + 32ull * nw;
+  uint32_t a = 0, z = n_runs;  // first run that ends behind b0 (runs are sorted and disjoint)
+  while (a < z) {
+    const uint32_t mid = (a + z) >> 1;
+    if ((uint64_t)tab[2 + 2 * mid] + tab[3 + 2 * mid] > b0) z = mid;
+    else a = mid + 1;
+  }
+  for (uint32_t r = a; r < n_runs; ++r) {  // uniform: a slice sees a handful of runs
+    const uint64_t st = tab[2 + 2 * r], en = st + tab[3 + 2 * r];
+    if (st >= b1) break;
+    const uint64_t s_ = st > b0 ? st : b0, e_ = en < b1 ? en : b1;  // e_ > s_
+    const uint32_t fw = (uint32_t)((s_ - b0) >> 5), lw = (uint32_t)((e_ - 1 - b0) >> 5);
+    for (uint32_t w = fw + threadIdx.x; w <= lw; w += 256) {
+      uint32_t m = ~0u;
+      if (w == fw) m &= ~0u << (uint32_t)(s_ & 31);
+      if (w == lw) m &= ~0u >> (31u - (uint32_t)((e_ - 1) & 31));
+      atomicOr(&s_bits[w], m);
+    }
+  }
+  __syncthreads();
+  uint32_t *__restrict__ dst = reinterpret_cast<uint32_t *>(pk + jb.mask_off) + w0;
+  for (uint32_t i = threadIdx.x; i < nw; i += 256) dst[i] = s_bits[i];
 }
 
 // ASCII -> hg_pack2 blob, 32 bases per lane (8 code bytes + 4 bitmap bytes), bit-identical to the host's hg_pack2
@@ -173,7 +229,7 @@ __global__ __launch_bounds__(256) void unpack2_one_kernel(const uint8_t *__restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t g = g0 + 256u * r;
-    if (g < groups) unpack2_group(blob, code_bytes, out, g);
+    if (g < groups) unpack2_group(blob, blob + code_bytes, out, g);
   }
 }
 }  // namespace
@@ -244,6 +300,7 @@ bool hand_over(hg_sketch_stream *s, Engine &e, int ci) {
   Chunk &c = e.chunk[ci];
   if (!flush_run(s, e, c)) return false;
   if (c.n_jobs) ST_HIP(s, hipMemcpyAsync(c.d_jobs, c.h_jobs, c.n_jobs * sizeof(UnpackJob), hipMemcpyHostToDevice, e.copy));
+  if (c.n_sjobs) ST_HIP(s, hipMemcpyAsync(c.d_sjobs, c.h_sjobs, c.n_sjobs * sizeof(SparseJob), hipMemcpyHostToDevice, e.copy));
   ST_HIP(s, hipEventRecord(c.uploaded, e.copy));
   std::lock_guard<std::mutex> lk(s->mu);
   e.full_chunks.push_back(ci);
@@ -256,12 +313,18 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
   auto body = [&]() -> bool {
     ST_HIP(s, hipSetDevice(e.device));
     int cur = -1;
+    // Chunk size ramp: after the input ran dry the first chunk of a new burst closes at CHUNK_BYTES / 8 and every
+    // further one at twice the previous size (up to CHUNK_BYTES), so that the kernels start ~0.15 ms after the burst
+    // does instead of after a whole 64 MB upload -- with a burst of a few hundred genomes that idle start was a fifth
+    // of the pass (256 genomes x 1.25 MB: 28.7 k genomes/s; the bench's packed_stream leg)
+    size_t limit = CHUNK_BYTES / 8;
     for (;;) {
       Item it{};
       bool idle_after;
       {
         const double tw = now_s();
         std::unique_lock<std::mutex> lk(s->mu);
+        if (e.in.empty() && cur < 0) limit = CHUNK_BYTES / 8;  // (about to wait with nothing open: a new burst)
         s->cv_in.wait(lk, [&] { return !e.in.empty() || s->finishing || s->err != HG_OK; });
         e.t_up_idle += now_s() - tw;
         if (s->err != HG_OK) return false;
@@ -271,10 +334,19 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         idle_after = e.in.empty();
       }
       const size_t padded = (it.len + 15) & ~(size_t)15;
-      if (cur >= 0 && e.chunk[cur].bytes &&
-          (e.chunk[cur].bytes + padded > CHUNK_BYTES || e.chunk[cur].tags.size() >= CHUNK_GENOMES)) {
-        if (!hand_over(s, e, cur)) return false;
-        cur = -1;
+      // what the genome moves over the link (and what a chunk is sized by): its ASCII bytes or its blob
+      const size_t link = it.kind == KIND_ASCII ? padded : (it.kind == KIND_PACK2 ? hg_pack2_size(it.len) : it.blob_bytes);
+      if (cur >= 0 && !e.chunk[cur].tags.empty()) {
+        const Chunk &cc = e.chunk[cur];
+        // a chunk that holds (or is about to hold) ASCII genomes is bounded by its ASCII buffer `d`; a chunk of blobs only
+        // never touches `d` and is bounded by the bytes it uploads -- three to four times as many genomes per chunk, so
+        // that the fixed cost of a chunk (two stream synchronisations, ~0.3 ms) is shared by more of them
+        const bool ascii_rule = cc.has_ascii || it.kind == KIND_ASCII;
+        const bool full = ascii_rule ? cc.bytes + padded > limit : cc.link_bytes + link > limit;
+        if (full || cc.tags.size() >= CHUNK_GENOMES) {
+          if (!hand_over(s, e, cur)) return false;
+          cur = -1, limit = std::min(CHUNK_BYTES, 2 * limit);
+        }
       }
       if (cur < 0) {
         const double tw = now_s();
@@ -287,10 +359,12 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         Chunk &c = e.chunk[cur];
         c.offs.clear(), c.lens.clear(), c.tags.clear(), c.pk_offs.clear();
         c.bytes = 0, c.run_lo = c.run_hi = 0;
-        c.pk_bytes = 0, c.n_jobs = 0, c.n_blocks = 0;
+        c.pk_bytes = 0, c.n_jobs = 0, c.n_blocks = 0, c.n_sjobs = 0, c.n_sblocks = 0;
+        c.mask_offs.clear(), c.has_ascii = false, c.link_bytes = 0;
       }
       Chunk &c = e.chunk[cur];
-      if (c.bytes + padded + 64 > c.cap) {  // one genome larger than the chunk (bytes == 0 here): the chunk grows
+      if (it.kind == KIND_ASCII) c.has_ascii = true;
+      if ((it.kind == KIND_ASCII || c.has_ascii) && c.bytes + padded + 64 > c.cap) {  // one genome larger than the chunk (bytes == 0 here): the chunk grows
         if (c.d) ST_HIP(s, hipFree(c.d));
         c.d = nullptr, c.cap = 0;
         const size_t want = padded + padded / 8 + 64;
@@ -302,13 +376,16 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         c.cap = want;
       }
       const double tc = now_s();
-      if (it.len && it.packed) {
-        const size_t blob = hg_pack2_size(it.len);
+      if (it.len && it.kind != KIND_ASCII) {
+        const size_t cbytes = (((it.len + 3) / 4) + 15) & ~(size_t)15, mbytes = (((it.len + 7) / 8) + 15) & ~(size_t)15;
+        // device region: hg_pack2 = [codes][bitmap]; hg_pack2s = [codes][run table][bitmap, rebuilt by expand_runs_kernel]
+        const size_t up = it.kind == KIND_PACK2 ? cbytes + mbytes : it.blob_bytes;
+        const size_t blob = it.kind == KIND_PACK2 ? up : it.blob_bytes + mbytes;
         if (c.pk_bytes + blob + 64 > c.pk_cap) {  // (+ the readable slack behind the last blob) the packed area grows between chunks' uses (nothing of this chunk is in flight
           // unless earlier genomes of it are: wait for their copies before the old block goes away)
           ST_HIP(s, hipStreamSynchronize(e.copy));
           uint8_t *nb = nullptr;
-          const size_t want = std::max(c.pk_bytes + blob + blob / 8 + 64, (size_t)(CHUNK_BYTES * 3 / 8 + (1u << 20)));
+          const size_t want = std::max(c.pk_bytes + blob + blob / 8 + 64, (size_t)(CHUNK_BYTES * 3 / 2 + (1u << 20)));  // (a chunk of blobs uploads up to CHUNK_BYTES; sparse ones add their rebuilt bitmaps)
           hipError_t he = hipMalloc(reinterpret_cast<void **>(&nb), want);
           if (he != hipSuccess) {
             fail(s, HG_ERR_OOM, "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(he));
@@ -321,12 +398,20 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         if (!c.h_jobs) {
           ST_HIP(s, hipHostMalloc(reinterpret_cast<void **>(&c.h_jobs), CHUNK_GENOMES * sizeof(UnpackJob), hipHostMallocDefault));
           ST_HIP(s, hipMalloc(reinterpret_cast<void **>(&c.d_jobs), CHUNK_GENOMES * sizeof(UnpackJob)));
+          ST_HIP(s, hipHostMalloc(reinterpret_cast<void **>(&c.h_sjobs), CHUNK_GENOMES * sizeof(SparseJob), hipHostMallocDefault));
+          ST_HIP(s, hipMalloc(reinterpret_cast<void **>(&c.d_sjobs), CHUNK_GENOMES * sizeof(SparseJob)));
         }
-        ST_HIP(s, hipMemcpyAsync(c.dpk + c.pk_bytes, it.seq, blob, hipMemcpyHostToDevice, e.copy));
+        ST_HIP(s, hipMemcpyAsync(c.dpk + c.pk_bytes, it.seq, up, hipMemcpyHostToDevice, e.copy));
+        const uint64_t mask_off = c.pk_bytes + (blob - mbytes);
         UnpackJob &jb = c.h_jobs[c.n_jobs++];
-        jb.pk_off = c.pk_bytes, jb.out_off = c.bytes, jb.n_bps = it.len, jb.first_block = c.n_blocks, jb.pad = 0;
+        jb.pk_off = c.pk_bytes, jb.out_off = c.bytes, jb.n_bps = it.len, jb.mask_off = mask_off, jb.first_block = c.n_blocks, jb.pad = 0;
         c.n_blocks += (uint32_t)(((it.len + 15) / 16 + UNPACK_GROUPS_PER_BLOCK - 1) / UNPACK_GROUPS_PER_BLOCK);
-        c.pk_offs.push_back(c.pk_bytes);
+        if (it.kind == KIND_PACK2S) {
+          SparseJob &sj = c.h_sjobs[c.n_sjobs++];
+          sj.codes_off = c.pk_bytes, sj.mask_off = mask_off, sj.n_bps = it.len, sj.first_block = c.n_sblocks, sj.pad = 0;
+          c.n_sblocks += (uint32_t)((mbytes / 4 + SLICE_WORDS - 1) / SLICE_WORDS);
+        }
+        c.pk_offs.push_back(c.pk_bytes), c.mask_offs.push_back(mask_off);
         c.pk_bytes += blob;
       } else if (it.len) {
         if (it.len < SMALL_BYTES && c.bytes + padded <= CHUNK_BYTES) {
@@ -342,13 +427,13 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
       }
       e.t_up_copy += now_s() - tc;
       c.offs.push_back(c.bytes), c.lens.push_back(it.len), c.tags.push_back(it.tag);
-      c.bytes += padded;
+      c.bytes += padded, c.link_bytes += link;
       // hand the chunk on when it is full -- or when nothing else is waiting: the kernels start at once and the
       // next genome opens a new chunk.  (A/B: keeping the chunk open while the kernels are busy halves the number of
       // chunks and is 7-10 % slower end to end -- results come back later, the readers' buffers free up later.)
-      if (idle_after || c.bytes >= CHUNK_BYTES || c.tags.size() >= CHUNK_GENOMES) {
+      if (idle_after || (c.has_ascii ? c.bytes : c.link_bytes) >= limit || c.tags.size() >= CHUNK_GENOMES) {
         if (!hand_over(s, e, cur)) return false;
-        cur = -1;
+        cur = -1, limit = std::min(CHUNK_BYTES, 2 * limit);
       }
     }
     if (cur >= 0 && !e.chunk[cur].tags.empty() && !hand_over(s, e, cur)) return false;
@@ -390,11 +475,15 @@ void computer(hg_sketch_stream *s, Engine *ep, int wi) {
         all_packed = nonempty == c.pk_offs.size();
       }
       hg_status st;
+      if (c.n_sjobs) {  // the bitmaps of the genomes that came as codes + run table
+        hipLaunchKernelGGL(expand_runs_kernel, dim3(c.n_sblocks), dim3(256), 0, w.ctx->stream, c.dpk, c.d_sjobs, c.n_sjobs);
+        ST_HIP(s, hipGetLastError());
+      }
       if (all_packed) {
-        std::vector<uint64_t> po(m, 0);
+        std::vector<uint64_t> po(m, 0), mo(m, 0);
         for (size_t g = 0, k = 0; g < m; ++g)
-          if (c.lens[g]) po[g] = c.pk_offs[k++];
-        st = hg_sketch_batch_dev_packed(w.ctx, c.dpk, po.data(), c.lens.data(), m, &s->p, w.d_hv, w.d_n2, w.d_nh);
+          if (c.lens[g]) po[g] = c.pk_offs[k], mo[g] = c.mask_offs[k], ++k;
+        st = hg_sketch_batch_dev_packed_masks(w.ctx, c.dpk, po.data(), mo.data(), c.lens.data(), m, &s->p, w.d_hv, w.d_n2, w.d_nh);
       } else {
         if (c.n_jobs) {
           hipLaunchKernelGGL(unpack2_kernel, dim3(c.n_blocks), dim3(256), 0, w.ctx->stream, c.dpk, c.d, c.d_jobs, c.n_jobs);
@@ -454,6 +543,8 @@ void destroy(hg_sketch_stream *s) {
       if (c.dpk) (void)hipFree(c.dpk);
       if (c.h_jobs) (void)hipHostFree(c.h_jobs);
       if (c.d_jobs) (void)hipFree(c.d_jobs);
+      if (c.h_sjobs) (void)hipHostFree(c.h_sjobs);
+      if (c.d_sjobs) (void)hipFree(c.d_sjobs);
       if (c.uploaded) (void)hipEventDestroy(c.uploaded);
     }
     for (auto &w : e->w) {
@@ -524,24 +615,37 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
   return HG_OK;
 }
 
-static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed, bool wait);
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, int kind, bool wait);
 
 extern "C" hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag) {
-  return push_item(s, seq, len, tag, false, true);
+  return push_item(s, seq, len, tag, KIND_ASCII, true);
 }
 
 extern "C" hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag) {
-  return push_item(s, blob, n_bps, tag, true, true);
+  return push_item(s, blob, n_bps, tag, KIND_PACK2, true);
+}
+
+extern "C" hg_status hg_sketch_stream_push_packed_sparse(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag) {
+  return push_item(s, blob, n_bps, tag, KIND_PACK2S, true);
 }
 
 extern "C" hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_t *data, size_t n_bps, uint64_t tag, int packed) {
-  return push_item(s, data, n_bps, tag, packed != 0, false);
+  if (packed < 0 || packed > 2) return HG_ERR_INVALID;
+  return push_item(s, data, n_bps, tag, packed, false);
 }
 
 extern "C" size_t hg_sketch_stream_max_pending(const hg_sketch_stream *s) { return s ? s->max_pending : 0; }
 
-static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, bool packed, bool wait) {
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, int kind, bool wait) {
   if (!s || (len && !seq)) return HG_ERR_INVALID;
+  size_t blob_bytes = 0;
+  if (kind == KIND_PACK2S && len) {  // the blob says how long its run table is
+    if (len >= ((size_t)1 << 32)) return HG_ERR_UNSUPPORTED;
+    uint32_t n_runs;
+    std::memcpy(&n_runs, seq + ((((len + 3) / 4) + 15) & ~(size_t)15), 4);
+    if ((size_t)n_runs > len) return HG_ERR_INVALID;
+    blob_bytes = hg_pack2s_size(len, n_runs);
+  }
   std::unique_lock<std::mutex> lk(s->mu);
   if (s->finishing) return HG_ERR_INVALID;
   if (!wait && s->err == HG_OK && s->pushed - s->popped >= s->max_pending) return HG_ERR_CAPACITY;  // would block
@@ -550,7 +654,7 @@ static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, 
   Engine *best = s->eng[0];
   for (Engine *e : s->eng)
     if (e->load < best->load) best = e;
-  best->in.push_back(Item{seq, len, tag, packed});
+  best->in.push_back(Item{seq, len, tag, kind, blob_bytes});
   best->load += (len + 15) & ~(size_t)15;
   ++s->pushed;
   s->cv_in.notify_all();

@@ -299,7 +299,11 @@ hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t 
  * packed-input kernels as they arrive, hg_sketch_batch_dev_packed: results are bit-identical).  The blob must have been
  * packed with the stream's norm_mode. */
 hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
-/* non-blocking push of either form (packed != 0: `data` is a hg_pack2 blob); HG_ERR_CAPACITY = would block */
+/* ... or as a hg_pack2s blob: the codes plus a TABLE of the not-a-base runs instead of the bitmap -- 0.25 bytes per base
+ * over the link for an ordinary assembly; the device rebuilds the bitmap.  Results are bit-identical. */
+hg_status hg_sketch_stream_push_packed_sparse(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
+/* non-blocking push of any form (packed: 0 = ASCII, 1 = `data` is a hg_pack2 blob, 2 = a hg_pack2s blob);
+ * HG_ERR_CAPACITY = would block */
 hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_t *data, size_t n_bps, uint64_t tag, int packed);
 size_t hg_sketch_stream_max_pending(const hg_sketch_stream *s);
 hg_status hg_sketch_stream_pop(hg_sketch_stream *s, uint64_t *tag, int16_t *hv_out, int32_t *norm2_out,
@@ -321,6 +325,13 @@ void hg_sketch_stream_close(hg_sketch_stream *s);
 size_t hg_pack2_size(size_t n_bps);
 hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out);
 hg_status hg_unpack2_dev(hg_ctx *ctx, const uint8_t *d_blob, size_t n_bps, uint8_t *d_seq_out);
+/* The sparse form for the link: [codes as in hg_pack2, padded to 16 bytes][uint32 n_runs, uint32 0, n_runs x {uint32 first
+ * position, uint32 length} of the maximal runs of not-a-base positions, ascending, padded to 16 bytes].  hg_pack2s
+ * writes hg_pack2s_size(n_bps, n_runs) bytes to `out` (*size_out) if they fit `cap`; HG_ERR_CAPACITY (*size_out = needed)
+ * if not -- a sequence littered with non-bases is better served by hg_pack2 --, HG_ERR_UNSUPPORTED for n_bps >= 2^32.
+ * `out` may equal `seq` (cap >= the blob). */
+size_t hg_pack2s_size(size_t n_bps, size_t n_runs);
+hg_status hg_pack2s(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t cap, size_t *size_out);
 /* hg_pack2 on the device, byte for byte the host's output: ASCII genomes already in HBM (d_seq + offsets[i], multiples
  * of 4, lens[i] bases) become blobs at d_blobs + blob_offsets[i] (multiples of 16, hg_pack2_size(lens[i]) bytes each) --
  * the input form of hg_sketch_batch_dev_packed.  Host offset arrays, device data; complete on return.

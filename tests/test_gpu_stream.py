@@ -154,6 +154,40 @@ def test_stream_packed_equals_ascii(hg, orc, norm):
     assert nh[5] == w_nh and n2[5] == w_n2 and np.array_equal(hv[5], w_hv)
 
 
+@pytest.mark.parametrize("norm", [0, 1])
+def test_stream_sparse_packed_equals_ascii(hg, orc, norm):
+    """hg_pack2s over the link (codes + run table, the bitmap rebuilt on the device): chunks of sparse blobs only, and
+    chunks that mix all three forms; a genome littered with non-bases, one that is ONE run, runs on slice borders"""
+    rng = np.random.default_rng(61 + norm)
+    lens = [0, 5, 21, 40, 3_000, 32_768, 100_000, 777_777, 5_000_000, 20_000_000, 2_222, 65_536, 131_073]
+    genomes = [_dirty(orc, 50 + i, L, rng) for i, L in enumerate(lens)]
+    genomes[5][:] = ord("N")                         # nothing but one run: exactly one bitmap slice of ones
+    genomes[6][32_760:32_776] = ord("n")             # a run across the border of two slices
+    genomes[11][np.arange(0, 65_536, 7)] = ord("-")  # ~9 400 runs: still fits the bitmap's size as a table? (no: falls back)
+    p = hg.default_params(scaled=100, norm_mode=norm)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch(genomes, p)
+    for mixed in (False, True):
+        with hg.SketchStream((0,), p) as st:
+            n_sparse = 0
+            for i, g in enumerate(genomes):
+                blob = hg.pack2s(g, norm)
+                if mixed and i % 3 == 1:
+                    st.push(g, i)
+                elif blob is None or (mixed and i % 3 == 2):
+                    st.push_packed(hg.pack2(g, norm), g.size, i)
+                else:
+                    st.push_packed_sparse(blob, g.size, i)
+                    n_sparse += 1
+            st.finish()
+            out = _drain(st, len(genomes))
+        assert n_sparse >= (4 if mixed else 10)
+        for i in range(len(genomes)):
+            assert out[i][2] == nh[i] and out[i][1] == n2[i] and np.array_equal(out[i][0], hv[i]), (mixed, i)
+    w_hv, w_n2, w_nh = orc.sketch_genome(genomes[6], scaled=100, norm=norm)
+    assert nh[6] == w_nh and n2[6] == w_n2 and np.array_equal(hv[6], w_hv)
+
+
 def test_read_fastx_pinned_pack_flag(hg, orc, tmp_path):
     seq = _dirty(orc, 9, 200_000, np.random.default_rng(2))
     f = tmp_path / "g.fna"
