@@ -135,7 +135,6 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   else if (k == "dist_path") c->dbg_dist_path = v;
   else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;
-  else if (k == "dist_persist") c->dbg_dist_persist = v;  // "on": persistent workgroups (a measured negative: profiles/r04_dist_persistent_negative.txt)
   else if (k == "kmer_input") c->dbg_kmer_input = v;  // "packed": ASCII batches are 2-bit packed on the device first and take the packed kernels
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;
@@ -1015,13 +1014,12 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   HG_HIP(c, hipSetDevice(c->device));
-  if ((s = hg_ensure(c, c->w_misc, 128)) != HG_OK) return s;
-  // [0] hit counter, [1] exactness verdict, [2] its window length, [4..12] control words of the i8 operand attempt,
-  // [16..23] the persistent GEMM's tile queue positions, one per XCD
+  if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
+  // [0] hit counter, [1] exactness verdict, [2] its window length, [4..12] control words of the i8 operand attempt
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
   // (zeroed by the previous call on its way out, behind its read-back: one command less in front of the kernels;
   // the first call, and one after a call that failed half way, does it here)
-  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 32 * sizeof(uint32_t), c->stream));
+  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
   c->misc_zeroed = nullptr;
   hg_dist_args a{};
   a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
@@ -1046,13 +1044,13 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   // no guarded launch applied (or the f16 chain was not queued behind a trusted i8 attempt that failed after all):
   // statistics-driven schedule
   if (h_res[8] != 1u && (spec_cover == -2 || (spec_cover >= 0 && (int)h_res[1] > spec_cover))) {
-    HG_HIP(c, hipMemsetAsync(d_count, 0, 32 * sizeof(uint32_t), c->stream));
+    HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
     if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
   }
   const uint32_t found = h_res[0];
   *n_out = found;
-  if (hipMemsetAsync(d_count, 0, 32 * sizeof(uint32_t), c->stream) == hipSuccess) c->misc_zeroed = d_count;
+  if (hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
   return HG_OK;
 }

@@ -491,13 +491,6 @@ constexpr size_t dist_lds_main_bytes() {
   const size_t lists = (size_t)(TC::THREADS / 64) * CAND_CAP * 8;
   return stages > lists ? stages : lists;
 }
-// PERSIST: the epilogue's lists live in ONE operand stage (the other one holds the next tile's first K-step, see
-// dist_mfma_kernel): per-wave capacity = a stage's bytes / waves / 8
-template <bool BIG, int NT, bool GLDS>
-constexpr uint32_t dist_cand_cap_persist() {
-  using TC = TileCfg<BIG, NT>;
-  return (uint32_t)((size_t)(TC::BM + TC::BN) * (GLDS ? BK : LDS_ROW) * sizeof(_Float16) / (TC::THREADS / 64) / 8);
-}
 template <bool BIG, int NT, bool GLDS>
 constexpr size_t dist_lds_bytes() {
   return dist_lds_main_bytes<BIG, NT, GLDS>() + (size_t)6 * (TileCfg<BIG, NT>::BM + TileCfg<BIG, NT>::BN) * 4 + 192;
@@ -538,8 +531,6 @@ struct GemmArgs {
   uint32_t hv_d, same_set;
   uint32_t diag_first;             // leading workgroup slots that take the tiles on the diagonal (0: plain order)
   int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
-  uint32_t *tile_ctr;              // PERSIST: eight zeroed words, one tile queue position per XCD
-  uint32_t n_virtual;              // PERSIST: workgroup slots of the non-persistent launch = tile queue entries
 };
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only,
@@ -557,8 +548,8 @@ struct GemmArgs {
 #ifdef HG_DIST_STAMPS
 __device__ unsigned long long g_dist_stamps[16][2][8][6];
 #define HG_STAMP(pt)                                                                                       \
-  if (lane == 0 && (wave == 0 || wave == 5) && v_cur >= 512 && v_cur < 528 && ks >= 8 && ks < 16)            \
-    g_dist_stamps[v_cur - 512][wave == 5][ks - 8][pt] = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < 16 && ks >= 8 && ks < 16)                      \
+    g_dist_stamps[blockIdx.x][wave == 5][ks - 8][pt] = __builtin_amdgcn_s_memtime();
 // ... and of the tile as a whole: lane 0 of every wave of workgroups 512..527 (the third round of tiles) into
 // g_dist_tile_stamps[wg][wave][point].  Points: 0 kernel entry, 1 first stage landed, 2 main loop done, 3 norms staged,
 // 4 accumulator sweep done, 5 lists emptied (tile done); inside the last flush_all: 6 candidates evaluated, 7 range
@@ -567,14 +558,13 @@ __device__ unsigned long long g_dist_tile_stamps[16][8][10];
 __device__ unsigned long long g_dist_tile_real[2048][2];  // s_memrealtime (100 MHz) at points 1 and 2: with the stamps of
                                                           // g_dist_tile_stamps' wave 0 this gives the shader clock of the main loop
 __device__ unsigned long long g_dist_tile_all[2048][5];  // per workgroup: entry, main loop done, tile done, candidates evaluated, XCC id
-// (v_cur: the tile's slot in the one-tile-per-workgroup order -- blockIdx.x unless the workgroups are persistent)
 #define HG_TSTAMP(pt)                                                                                      \
-  if ((threadIdx.x & 63) == 0 && v_cur >= 512 && v_cur < 528)                                              \
-    g_dist_tile_stamps[v_cur - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();                 \
-  if (threadIdx.x == 0 && v_cur < 2048 && ((pt) == 0 || (pt) == 2 || (pt) == 5))                            \
-    g_dist_tile_all[v_cur][(pt) == 0 ? 0 : ((pt) == 2 ? 1 : 2)] = __builtin_amdgcn_s_memtime();            \
-  if (threadIdx.x == 0 && v_cur < 2048 && ((pt) == 1 || (pt) == 2))                                        \
-    g_dist_tile_real[v_cur][(pt)-1] = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528)                                    \
+    g_dist_tile_stamps[blockIdx.x - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();            \
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 0 || (pt) == 2 || (pt) == 5))                      \
+    g_dist_tile_all[blockIdx.x][(pt) == 0 ? 0 : ((pt) == 2 ? 1 : 2)] = __builtin_amdgcn_s_memtime();       \
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 1 || (pt) == 2))                                   \
+    g_dist_tile_real[blockIdx.x][(pt)-1] = __builtin_amdgcn_s_memrealtime();
 #else
 #define HG_STAMP(pt)
 #define HG_TSTAMP(pt)
@@ -601,23 +591,17 @@ __device__ __forceinline__ void dist_static_for(std::integer_sequence<int, Js...
 //           fragment is 16 bytes and a K-step is 128 bytes per row, so staging, swizzle and fragment addressing are
 //           shared; the order of the dims inside a fragment is irrelevant as long as both operands use the same one
 //           (every product is +-1 and they are all summed).
-// PERSIST (LDS-DMA geometries, thresholded, whole-K): the launch is one workgroup per CU and every workgroup walks the
-// tile queue of its XCD (the same order as the one-tile-per-workgroup launch: a workgroup slot v of that launch is
-// queue entry v / 8 of XCD v % 8, taken with one atomic per tile, requested a whole tile early).  While a tile's last
-// K-steps multiply, the FIRST K-step of the workgroup's next tile is LDS-DMA'd into the stage that has just become
-// free, its row / column words are fetched under the accumulator sweep, and the epilogue's candidate lists alias only
-// the other stage: the next main loop starts on operands that are already in LDS instead of behind a kernel launch, two
-// dependent global-load latencies and a barrier (in-kernel stamps of round 3: 5 000-6 000 of ~141 000 ticks per tile).
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false,
-          bool PERSIST = false>
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false>
 __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(GemmArgs g) {
   using TC = TileCfg<BIG, NT>;
-  static_assert(!PERSIST || (GLDS && BIG && !FULL && !CHUNKED), "persistent tiles exist for the thresholded whole-K LDS-DMA geometries");
   static_assert(!I8 || (GLDS && !CHUNKED && !FULL), "the i8 operand path exists for the thresholded LDS-DMA geometries");
   static_assert(!HAM || I8, "the Hamming epilogue rides on the i8 operand path");
   static_assert(!FP4 || HAM, "e2m1 operands exist for the Hamming search only");
+  HG_TSTAMP(0)
 #ifdef HG_DIST_STAMPS
-  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && blockIdx.x < 2048)
+    g_dist_tile_all[blockIdx.x][3] = 0, g_dist_tile_all[blockIdx.x][1] = 0, g_dist_tile_all[blockIdx.x][2] = 0,
+    g_dist_tile_all[blockIdx.x][4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // hwreg(HW_REG_XCC_ID, 0, 4)
 #endif
   if (g.veto && g.veto[0] == 1u) return;  // uniform: the i8 kernel queued before this one did the work
   if (I8 && !HAM) {
@@ -654,85 +638,51 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // twice as long in its epilogue as in its K loop: with five tiles per CU the launch ends when the last such tile does.
   // The host may therefore put the tiles that straddle the diagonal in front (g.diag_first workgroup slots, two per tile
   // row, a multiple of 8 so that the XCD of the remaining workgroups is unchanged): longest jobs first.
-  // slot v of the one-tile-per-workgroup launch (n_slots of them) -> tile; false: the slot has no tile to run
-  const uint32_t n_slots = PERSIST ? g.n_virtual : gridDim.x;
-  auto decode_tile = [&](uint32_t v, uint32_t &tm, uint32_t &tn) __attribute__((always_inline)) -> bool {
-    if (v < g.diag_first) {
-      // slot s: tile row s % (diag_first / 2), its first (s < diag_first / 2) or second diagonal tile -- diag_first / 2 is a
-      // multiple of 8, so the rows' first tiles, the dense ones, go round the XCDs (with two adjacent slots per row they
-      // all fell to the even XCDs: 223 k against 126 k candidates per XCD)
-      const uint32_t half = g.diag_first >> 1, second = v >= half ? 1u : 0u;
-      tm = v - second * half;
-      if (tm >= g.tiles_m) return false;
-      const uint32_t tn0 = tm * BM / BN, tn1 = (tm * BM + BM - 1) / BN;
-      tn = second ? tn1 : tn0;
-      if ((second && tn1 == tn0) || tn >= g.tiles_n) return false;
-    } else {
-      const uint32_t b = v - g.diag_first, nwg = n_slots - g.diag_first;
-      const uint32_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
-      const uint32_t bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-      const uint32_t sup_n = (g.tiles_n + ST - 1) / ST;
-      const uint32_t sup = bid / (ST * ST), within = bid % (ST * ST);
-      tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
-      if (tm >= g.tiles_m || tn >= g.tiles_n) return false;  // padding of the super-tile grid
-      if (g.diag_first && (tn == tm * BM / BN || tn == (tm * BM + BM - 1) / BN)) return false;  // ran in front
-    }
-    if (g.symmetric && tm * BM + g.ref_off >= tn * BN + g.qry_off + BN) return false;  // tile entirely on/below the diagonal
-    return true;
-  };
-  // PERSIST: the next queue entry of this workgroup's XCD (slots v = xcd + 8 i, i from one counter per XCD); ONE thread
-  const uint32_t my_xcd = blockIdx.x & 7u;
-  auto next_valid_from = [&](uint32_t idx) __attribute__((always_inline)) -> uint32_t {  // idx: a fetched queue position
-    for (;;) {
-      const uint32_t v = my_xcd + 8u * idx;
-      if (v >= n_slots) return ~0u;
-      uint32_t a_, b_;
-      if (decode_tile(v, a_, b_)) return v;
-      idx = atomicAdd(&g.tile_ctr[my_xcd], 1u);
-    }
-  };
-  uint32_t tm = 0, tn = 0;
-  if constexpr (!PERSIST) {
-    if (!decode_tile(blockIdx.x, tm, tn)) return;
+  uint32_t tm, tn;
+  if (blockIdx.x < g.diag_first) {
+    // slot s: tile row s % (diag_first / 2), its first (s < diag_first / 2) or second diagonal tile -- diag_first / 2 is a
+    // multiple of 8, so the rows' first tiles, the dense ones, go round the XCDs (with two adjacent slots per row they
+    // all fell to the even XCDs: 223 k against 126 k candidates per XCD)
+    const uint32_t half = g.diag_first >> 1, second = blockIdx.x >= half ? 1u : 0u;
+    tm = blockIdx.x - second * half;
+    if (tm >= g.tiles_m) return;
+    const uint32_t tn0 = tm * BM / BN, tn1 = (tm * BM + BM - 1) / BN;
+    tn = second ? tn1 : tn0;
+    if ((second && tn1 == tn0) || tn >= g.tiles_n) return;
+  } else {
+    const uint32_t b = blockIdx.x - g.diag_first, nwg = gridDim.x - g.diag_first;
+    const uint32_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
+    const uint32_t bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    const uint32_t sup_n = (g.tiles_n + ST - 1) / ST;
+    const uint32_t sup = bid / (ST * ST), within = bid % (ST * ST);
+    tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
+    if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // padding of the super-tile grid
+    if (g.diag_first && (tn == tm * BM / BN || tn == (tm * BM + BM - 1) / BN)) return;  // ran in front
   }
-  uint32_t row0 = tm * BM, col0 = tn * BN;  // (PERSIST: set below, once the first tile is known)
-  // state carried from tile to tile (PERSIST; everything else is recomputed per tile from an opaque copy of the thread
-  // index, so that the main loop's per-lane constants are dead while the epilogue's 160 accumulators + masks are live
-  // and vice versa -- kept live across the tile loop they cost 240 spilled registers)
-  __amdgpu_buffer_rsrc_t rsA, rsB, rsAn, rsBn;  // this tile's row blocks / the next tile's
-  uint32_t v_cur = blockIdx.x;  // the tile's slot in the one-tile-per-workgroup order (stamps)
-#ifdef HG_DIST_STAMPS
-  unsigned long long t_prev_end = 0;
-#endif
-  uint32_t sb = 0;              // the stage that holds K-step 0 of the current tile; K-step ks lives in stage (sb + ks) & 1
-#pragma clang loop unroll(disable)
-  for (bool first_tile = true;; first_tile = false) {  // one iteration per tile (a single one unless PERSIST)
-  uint32_t tid_main = threadIdx.x;
-  asm volatile("" : "+v"(tid_main));
-  const uint32_t tid = tid_main, lane = tid & 63, wave = tid >> 6;
+  const uint32_t row0 = tm * BM, col0 = tn * BN;
+  if (g.symmetric && row0 + g.ref_off >= col0 + g.qry_off + BN) return;  // tile entirely on/below the diagonal
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t wm = wave / NWN, wn = wave % NWN;  // 2 x NWN waves, (WTM*16) x 64 each
   const uint32_t fr = lane & 15, fq = lane >> 4;
 
   typedef typename std::conditional<I8 && !FP4, int4v, float4v>::type acc_t;  // i8 operands accumulate in exact i32
   acc_t acc[WTM][NT];
   int32_t iacc[CHUNKED ? WTM : 1][CHUNKED ? NT : 1][4];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+  for (int m = 0; m < WTM; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{};
+  if (CHUNKED) {
 #pragma unroll
     for (int m = 0; m < WTM; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{};
-    if (CHUNKED) {
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int m = 0; m < WTM; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] = 0;
-    }
-  };
+        for (int r = 0; r < 4; ++r) iacc[CHUNKED ? m : 0][CHUNKED ? n : 0][r] = 0;
+  }
 
   // staging: thread t moves 4 x 16 B of A and of B per K-step: row = t/8 + SROWS*i, 16-byte piece t%8
-  // (register-staged geometries only: never PERSIST, row0 / col0 are final here)
   const uint32_t srow = tid >> 3, spc = tid & 7;
   const _Float16 *gA = g.A + (size_t)(row0 + srow) * g.ldk + spc * 8;
   const _Float16 *gB = g.B + (size_t)(col0 + srow) * g.ldk + spc * 8;
@@ -797,10 +747,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // array here makes hipcc drop the kernel's host stub without a diagnostic)
   uint32_t vA[8], vB[10];
   static_assert(!GLDS || (PA <= 8 && PB <= 10), "piece tables too small");
-  auto make_rsrc = [&](uint32_t r0, uint32_t c0, __amdgpu_buffer_rsrc_t &ra, __amdgpu_buffer_rsrc_t &rb) __attribute__((always_inline)) {
-    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)r0 * g.ldk), 0, 0x7fffffff, 0x00020000);
-    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)c0 * g.ldk), 0, 0x7fffffff, 0x00020000);
-  };
+  __amdgpu_buffer_rsrc_t rsA, rsB;
   if (GLDS) {
     constexpr int PMAX = PA > PB ? PA : PB;
 #pragma unroll
@@ -810,22 +757,22 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       if (i < PB) vB[i] = off;
       if (i < PA) vA[i] = off;
     }
-    if (!PERSIST) make_rsrc(row0, col0, rsA, rsB), rsAn = rsA, rsBn = rsB;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
   }
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
-#define HG_DMA_RS(stage, k0, RA, RB)                                                                        \
+#define HG_DMA(stage, k0)                                                                                   \
   {                                                                                                         \
   if (wave < (uint32_t)LW) {                                                                                \
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
     _Pragma("unroll") for (int i = 0; i < (PA > PB ? PA : PB); ++i) {                                       \
       if (i < PA)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
       if (i < PB)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
     }                                                                                                       \
   }                                                                                                         \
   }
-#define HG_DMA(stage, k0) HG_DMA_RS(stage, k0, rsA, rsB)
   // A fragments per phase: 2 (x NT B fragments = 8..10 MFMAs, the other wave of the SIMD covers the fragment latency)
   constexpr int AF = 2;
   const int32_t fp4_unit_scale = 0x7f7f7f7f;  // FP4: E8M0 block scales of 2^0 for every 32-element block
@@ -855,51 +802,34 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   uint32_t *s_er = reinterpret_cast<uint32_t *>(s_tq + BN), *s_eq = s_er + BM;  // i8 path: the first clamped entry itself, d | b << 16
   uint32_t *s_cnt = s_eq + BN;                                                  // per-wave hit counts + the workgroup's base
   uint32_t *s_tot = s_cnt + 2 * (THREADS / 64) + 4, *s_fill = s_tot + THREADS / 64;  // (behind the list lengths and flags) candidates per wave: counted / appended
-  uint32_t *s_next = s_fill + THREADS / 64;  // PERSIST: [0] the slot of the workgroup's next tile (~0u: none)
   constexpr int32_t NORM_SAFE = 1 << 29;
   constexpr int WORD_PASSES = (BM + BN + THREADS - 1) / THREADS;
   int32_t w_nv[WORD_PASSES], w_info[WORD_PASSES], w_slot[WORD_PASSES];
-  uint32_t w_first[WORD_PASSES], w_ew[WORD_PASSES];
-  // the global loads of a tile's row / column words (r0, c0 = its first row / column) ...
-  // (PERSIST: volatile -- ordered memory references stay where they are written.  As plain loads the compiler sank them
-  // from in front of the append / phase 2, where their latency is hidden, down to their first use at the end of the
-  // tile: in-kernel stamps showed 8 000-9 000 ticks between "tile done" and the barrier that opens the next one.)
-  auto ldw = [&](const auto *ptr) __attribute__((always_inline)) {
-    if constexpr (PERSIST) return *const_cast<const volatile std::remove_cv_t<std::remove_reference_t<decltype(*ptr)>> *>(ptr);
-    else return *ptr;
-  };
-  auto load_words = [&](uint32_t r0, uint32_t c0) __attribute__((always_inline)) {
+  uint32_t w_first[WORD_PASSES];
 #pragma unroll
-    for (int p = 0; p < WORD_PASSES; ++p) {
-      const uint32_t t = tid + (uint32_t)p * THREADS;
-      const bool is_r = t < (uint32_t)BM;
-      const uint32_t idx = is_r ? r0 + t : c0 + (t - BM);
-      const bool in = t < (uint32_t)(BM + BN) && idx < (is_r ? g.R : g.Q);
-      w_nv[p] = 0;
-      if (in && !HAM) w_nv[p] = ldw((is_r ? g.nr : g.nq) + idx);
-      w_info[p] = w_slot[p] = 0, w_first[p] = 0u;
-      if (I8 && !HAM && in) {
-        w_info[p] = ldw((is_r ? g.info_r : g.info_q) + idx);
-        w_slot[p] = ldw((is_r ? g.slot_r : g.slot_q) + idx);
-        w_first[p] = ldw((is_r ? g.first_r : g.first_q) + idx);
-      }
+  for (int p = 0; p < WORD_PASSES; ++p) {
+    const uint32_t t = tid + (uint32_t)p * THREADS;
+    const bool is_r = t < (uint32_t)BM;
+    const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
+    const bool in = t < (uint32_t)(BM + BN) && idx < (is_r ? g.R : g.Q);
+    w_nv[p] = (in && !HAM) ? (is_r ? g.nr[idx] : g.nq[idx]) : 0;
+    w_info[p] = w_slot[p] = 0, w_first[p] = 0u;
+    if (I8 && !HAM) {
+      w_info[p] = in ? (is_r ? g.info_r[idx] : g.info_q[idx]) : 0;
+      w_slot[p] = in ? (is_r ? g.slot_r[idx] : g.slot_q[idx]) : 0;
+      w_first[p] = in ? (is_r ? g.first_r[idx] : g.first_q[idx]) : 0u;
     }
-  };
-  // ... the second level: the first clamped entry of the rows / columns that have one (needs w_slot / w_first in registers)
-  auto load_ents = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < WORD_PASSES; ++p) {
-      w_ew[p] = 0u;
-      if (I8 && !HAM) {
-        if (((uint32_t)w_slot[p] >> 14) & 255u) {
-          const uint32_t lo = ldw(reinterpret_cast<const uint32_t *>(g.ents + w_first[p]) + 1);  // {u16 d, i8 b, u8 side}
-          w_ew[p] = lo & 0x00FFFFFFu;  // d | b << 16
-        }
-      }
+  }
+  if (GLDS) {
+    HG_DMA(0, 0)
+  } else {
+    HG_GLOAD(0)
+    HG_LSTORE(0)
+    if (nsteps > 1) {
+      HG_GLOAD(BK)
     }
-  };
-  // ... and what is computed from them, into LDS (nobody may still read the previous tile's words)
-  auto store_words = [&](uint32_t r0, uint32_t c0) __attribute__((always_inline)) {
+  }
+  {
     // Phase 0 (thresholded mode): dot >= j_lo * (nr + nq - dot) rewritten as dot >= c * (nr + nq) with
     // c = j_lo / (1 + j_lo) shaved by 1e-5, evaluated in f32 straight from the accumulator: one add and one compare
     // per element.  Invalid rows / columns carry +1e30, norms outside [0, 2^29] -- where the i32 denominator could
@@ -916,7 +846,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       const uint32_t t = tid + (uint32_t)p * THREADS;
       if (t >= (uint32_t)(BM + BN)) break;
       const bool is_r = t < (uint32_t)BM;
-      const uint32_t idx = is_r ? r0 + t : c0 + (t - BM);
+      const uint32_t idx = is_r ? row0 + t : col0 + (t - BM);
       const bool in = idx < (is_r ? g.R : g.Q);
       const int32_t nv = w_nv[p];
       s_nr[t] = nv;
@@ -928,7 +858,12 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         s_fr[t] = w_first[p];
         // (phase 2 needs the other operand's value at this entry's dimension: with the entry here that is ONE global
         // load per candidate that has one instead of two dependent ones, with nothing to hide them behind)
-        s_er[t] = w_ew[p];  // (load_ents)
+        uint32_t ew = 0u;
+        if (((uint32_t)slot >> 14) & 255u) {
+          const I8Outlier o = g.ents[w_first[p]];
+          ew = (uint32_t)o.d | ((uint32_t)(uint8_t)o.b << 16);
+        }
+        s_er[t] = ew;
         const int32_t s2 = info - (info & 1);  // 2*S
         slack = (float)(s2 < 0 ? -s2 : s2) + (is_r ? 1016.f : 508.f) * (float)(slot & 0x3fff);
         if (!is_r) slack += (float)g.hv_d + 64.f;
@@ -945,69 +880,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     }
     if (tid < 3) s_cnt[THREADS / 64 + 1 + THREADS / 64 + tid] = 0u;  // "some candidate list is nearly full": three slots in rotation
     if (tid < (uint32_t)(THREADS / 64)) s_fill[tid] = 0u;
-  };
-  // ---- the workgroup's first tile ----------------------------------------------------------------------------------
-  if (first_tile) {
-  if constexpr (PERSIST) {
-    if (tid == 0) s_next[0] = next_valid_from(atomicAdd(&g.tile_ctr[my_xcd], 1u));
-    __syncthreads();
-    v_cur = __builtin_amdgcn_readfirstlane(s_next[0]);
-    __syncthreads();  // (s_next is rewritten below)
-    if (v_cur == ~0u) return;  // uniform: this XCD's queue is empty
-    decode_tile(v_cur, tm, tn);
-    row0 = tm * BM, col0 = tn * BN;
-    make_rsrc(row0, col0, rsA, rsB);
-    rsAn = rsA, rsBn = rsB;
-  }
-  load_words(row0, col0);
-  if (GLDS) {
-    HG_DMA(0, 0)
-  } else {
-    HG_GLOAD(0)
-    HG_LSTORE(0)
-    if (nsteps > 1) {
-      HG_GLOAD(BK)
-    }
-  }
-  load_ents();
-  store_words(row0, col0);
-  if constexpr (PERSIST) {
-    if (tid == 0) s_next[0] = next_valid_from(atomicAdd(&g.tile_ctr[my_xcd], 1u));  // the tile after this one
   }
   __syncthreads();  // (with DMA in flight hipcc's barrier also waits vmcnt(0): stage 0 has landed)
-  }  // first tile
-#ifdef HG_DIST_STAMPS
-  if (threadIdx.x == 0 && v_cur < 2048) {
-    g_dist_tile_all[v_cur][3] = 0, g_dist_tile_all[v_cur][1] = 0, g_dist_tile_all[v_cur][2] = 0;
-    g_dist_tile_all[v_cur][4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // hwreg(HW_REG_XCC_ID, 0, 4)
-    // point 0: the tile's start = kernel entry for a workgroup's first tile, else the end of the previous tile
-    g_dist_tile_all[v_cur][0] = first_tile ? t_entry : t_prev_end;
-  }
-  if ((threadIdx.x & 63) == 0 && v_cur >= 512 && v_cur < 528) g_dist_tile_stamps[v_cur - 512][threadIdx.x >> 6][0] = first_tile ? t_entry : t_prev_end;
-#endif
   HG_TSTAMP(1)
-  // PERSIST: the next tile (its slot was published before the barrier that ended the previous iteration) and, requested
-  // now and looked at when this tile is done, the queue position of the one after it
-  bool has_next = false;
-  uint32_t v_next = ~0u, row0n = 0, col0n = 0, pending_idx = 0;
-  if constexpr (PERSIST) {
-    v_next = __builtin_amdgcn_readfirstlane(s_next[0]);
-    has_next = v_next != ~0u;
-    if (has_next) {
-      uint32_t tmn, tnn;
-      decode_tile(v_next, tmn, tnn);
-      row0n = tmn * BM, col0n = tnn * BN;
-      make_rsrc(row0n, col0n, rsAn, rsBn);
-      if (tid == 0) pending_idx = atomicAdd(&g.tile_ctr[my_xcd], 1u);
-    }
-  }
-  zero_acc();
-  if (GLDS && nsteps > 1) HG_DMA(sb ^ 1u, BK)
-  if (PERSIST && nsteps == 1 && has_next) HG_DMA_RS(sb ^ 1u, 0, rsAn, rsBn)  // (one K-step: the other stage is free from the start)
-  if (!HG_EXP(2)) HG_FRAGS(0, sAB + sb * STAGE_ELEMS + fa_off, sAB + sb * STAGE_ELEMS + fb_off, 0, 0)
+  if (GLDS && nsteps > 1) HG_DMA(1, BK)
+  if (!HG_EXP(2)) HG_FRAGS(0, sAB + fa_off, sAB + fb_off, 0, 0)
   uint32_t in_chunk = 0;
   for (uint32_t ks = 0; ks < nsteps; ++ks) {
-    const uint32_t cur = (ks + sb) & 1;
+    const uint32_t cur = ks & 1;
     HG_STAMP(0)
     if (!GLDS && ks + 1 < nsteps) {
       HG_LSTORE(cur ^ 1)
@@ -1031,9 +911,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         if (!HG_EXP(16)) __syncthreads();
         HG_STAMP(3)
         if (GLDS && ks + 2 < nsteps && !HG_EXP(1)) HG_DMA(cur, (ks + 2) * BK)
-        // PERSIST, second-to-last K-step: this stage is free for good -- the NEXT tile's first K-step lands in it while
-        // the last K-step multiplies and the epilogue runs
-        if (PERSIST && ks + 2 == nsteps && has_next && !HG_EXP(1)) HG_DMA_RS(cur, 0, rsAn, rsBn)
         HG_STAMP(4)
         if (ks + 1 < nsteps && !HG_EXP(2) && !HG_EXP(32)) HG_FRAGS(0, nA, nB, 0, 0)
       }
@@ -1092,15 +969,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // The epilogue's per-lane addressing starts again from an opaque copy of the thread index: derived from the values
   // above it is loop invariant, gets hoisted in front of the K loop and takes registers the main loop does not have
   // (the i8 kernels went through scratch: 313 spilled registers).
-  // PERSIST: the lists alias ONE stage -- the one the last K-step was read from; the other one is receiving the next
-  // tile's first K-step.  The next tile's row / column words are requested now: the loads fly under the accumulator sweep.
-  constexpr uint32_t LIST_CAP = PERSIST ? dist_cand_cap_persist<BIG, NT, GLDS>() : CAND_CAP;  // candidates per wave list
-  constexpr uint32_t LIST_BYTES = PERSIST ? (uint32_t)(STAGE_ELEMS * sizeof(_Float16)) : (uint32_t)dist_lds_main_bytes<BIG, NT, GLDS>();
-  _Float16 *const lbase = PERSIST ? sAB + ((sb + nsteps - 1u) & 1u) * STAGE_ELEMS : sAB;
   uint32_t tid_opaque = threadIdx.x;
   asm volatile("" : "+v"(tid_opaque));
-  bool tile_empty = false;  // workgroup-uniform: the sweep found no candidate, the rest of the epilogue is skipped
-  {  // (closed at the end of the tile)
+  {  // (closed at the end of the kernel)
   const uint32_t tid = tid_opaque, lane = tid & 63, wave = tid >> 6;
   const uint32_t wm = wave / NWN, wn = wave % NWN, fr = lane & 15, fq = lane >> 4;
   // ---- epilogue: C[row = (lane>>4)*4 + r][col = lane&15] per 16x16 tile ------------------------
@@ -1122,7 +993,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     }
     return;
   }
-  uint2 *cand = reinterpret_cast<uint2 *>(lbase) + wave * LIST_CAP;
+  uint2 *cand = reinterpret_cast<uint2 *>(sAB) + wave * CAND_CAP;
   uint32_t staged = 0;  // wave-uniform
   // Phase 2 on a list: the reference's float32 ANI of every candidate (src/dist.rs:153-160), threshold; the ANI
   // overwrites the dot product in place, a miss is marked 0xFFFFFFFF (no non-negative float has that pattern), the
@@ -1238,14 +1109,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     if (lane == 0) s_len[wave] = staged;
     __syncthreads();
 #ifdef HG_DIST_STAMPS
-    if (tid == 0 && v_cur < 2048)
-      for (uint32_t w = 0; w < NW_; ++w) g_dist_tile_all[v_cur][3] += s_len[w];
+    if (tid == 0 && blockIdx.x < 2048)
+      for (uint32_t w = 0; w < NW_; ++w) g_dist_tile_all[blockIdx.x][3] += s_len[w];
 #endif
-    uint2 *all = reinterpret_cast<uint2 *>(lbase);
+    uint2 *all = reinterpret_cast<uint2 *>(sAB);
     uint32_t nh = 0, kglob = 0;
     for (uint32_t l = 0; l < NW_; ++l) {
       const uint32_t n_list = s_len[l];
-      uint2 *cl = all + l * LIST_CAP;
+      uint2 *cl = all + l * CAND_CAP;
       const uint32_t nb = (n_list + 63) / 64, first = (wave + NW_ - (kglob % NW_)) % NW_;  // my first batch of this list
       for (uint32_t k = first; k < nb; k += P2_U * NW_) nh += phase2_group(cl, k, nb, n_list, std::integral_constant<int, (int)P2_U>{});
       kglob += nb;
@@ -1266,7 +1137,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     kglob = 0;
     for (uint32_t l = 0; l < NW_; ++l) {  // the same batches again: compact them into this wave's part of the range
       const uint32_t n_list = s_len[l];
-      const uint2 *cl = all + l * LIST_CAP;
+      const uint2 *cl = all + l * CAND_CAP;
       const uint32_t nb = (n_list + 63) / 64, first = (wave + NW_ - (kglob % NW_)) % NW_;
       for (uint32_t k = first; k < nb; k += NW_) off += write_batch(cl, k * 64, n_list, off);
       kglob += nb;
@@ -1343,22 +1214,16 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       if (__ballot(wave_cands != 0u) == 0) {  // nothing in this tile
         HG_TSTAMP(4)
         HG_TSTAMP(5)
-        if constexpr (!PERSIST) return;
-        tile_empty = true;
+        return;
       }
       uint32_t all_c = 0;
 #pragma unroll
       for (uint32_t w = 0; w < (uint32_t)(THREADS / 64); ++w) all_c += __builtin_amdgcn_readlane(wave_cands, w);
       // (one list of all candidates below the waves' bounce buffers, see the append loop)
-      by_lane = __ballot(wave_cands > LIST_CAP) == 0 && all_c * 8u <= LIST_BYTES - (THREADS / 64) * BNC_WAVE;
+      by_lane = __ballot(wave_cands > CAND_CAP) == 0 && all_c * 8u <= (uint32_t)dist_lds_main_bytes<BIG, NT, GLDS>() - (THREADS / 64) * BNC_WAVE;
     }
   }
-  // PERSIST: the next tile's row / column words are requested now -- the lane-mask sweep is over, its accumulators and
-  // masks no longer compete for registers with the eight words, and the loads fly under the append and phase 2
-  if (PERSIST && has_next) load_words(row0n, col0n);
-  if (tile_empty) {
-    // (PERSIST only: on to the next tile)
-  } else if (by_lane) {
+  if (by_lane) {
     if constexpr (LANE_MASKS) {
       // ONE list for the workgroup (the per-wave regions are contiguous): wave w's candidates start behind those of
       // the waves below it -- every wave knows all counts --, and one LDS atomic per lane reserves the run that takes
@@ -1372,7 +1237,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         all_cands += v;
       }
       if (lane_cands != 0u) off += atomicAdd(&s_fill[wave], lane_cands);
-      uint2 *const cand = reinterpret_cast<uint2 *>(lbase);
+      uint2 *const cand = reinterpret_cast<uint2 *>(sAB);
       // A lane has ~2 candidates among its 160 accumulators, at positions only it knows, and registers cannot be
       // indexed per lane: slab by slab the lane's 4 * NT accumulators bounce through LDS (NT 16-byte stores into the
       // lane's own 80 bytes -- a stride that keeps 16 lanes on 64 different banks), and a loop over the set bits of the
@@ -1380,7 +1245,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       // predicated append per element, 160 exec-mask regions per lane -- took 8 000 cycles per tile for ~1 000
       // candidates: in-kernel stamps.)  The bounce buffers sit at the top of the stage area, the list grows from its
       // bottom; a wave's LDS operations execute in order, so no barrier is involved.
-      char *const bnc = reinterpret_cast<char *>(lbase) + LIST_BYTES - (THREADS / 64 - wave_u) * BNC_WAVE + lane * BNC_LANE;
+      char *const bnc = reinterpret_cast<char *>(sAB) + dist_lds_main_bytes<BIG, NT, GLDS>() - (THREADS / 64 - wave_u) * BNC_WAVE + lane * BNC_LANE;
       dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
         constexpr int m = decltype(mc)::value;
         uint32_t rest = ~notpass[m] & SLAB_BITS;
@@ -1431,20 +1296,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) { slab |= __ballot(passes(rc, nc)); });
       });
     }
-    // PERSIST: a wave's list holds LIST_CAP < 4 * NT * 64 candidates (one stage instead of two under the lists), so a slab
-    // goes through in two halves of two rows each, with the flush decision behind each half
-    constexpr int PARTS = PERSIST ? 2 : 1, PART_ROWS = 4 / PARTS;
-    static_assert(LIST_CAP >= (uint32_t)(PART_ROWS * NT * 64), "a part fits an empty list");
-    dist_static_for(std::make_integer_sequence<int, PARTS>{}, [&](auto pc) {
-    constexpr int part = decltype(pc)::value;
     if (slab != 0) {  // wave-uniform
-      dist_static_for(std::make_integer_sequence<int, PART_ROWS>{}, [&](auto rc) {
-        constexpr int r = part * PART_ROWS + decltype(rc)::value;
+      dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
         const uint32_t li = wm * (WTM * 16) + m * 16 + fq * 4 + r, i = row0 + li;
         const bool iok = i < g.R;
         dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
           constexpr int n = decltype(nc)::value;
-          const bool pass = passes(std::integral_constant<int, r>{}, nc);
+          const bool pass = passes(rc, nc);
           if (__ballot(pass) == 0) return;  // wave-uniform
           const uint32_t lj = wn * (NT * 16) + n * 16 + fr, j = col0 + lj;
           int32_t dot = (int32_t)acc[m][n][r];
@@ -1464,44 +1323,25 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         });
       });
     }
-    // At most PART_ROWS * NT * 64 candidates per part and wave.  A list that might overflow in the next part (dense blocks
-    // of hits only) is emptied by the WHOLE workgroup: the decision is made uniform through LDS, one barrier per part.
-    constexpr int h = m * PARTS + part;  // check point
-    if constexpr (h + 1 < WTM * PARTS) {
-      // Three flag slots in rotation: slot h % 3 is raised before this check point's barrier and read after it; the slot
-      // of h + 2 is cleared here, between barrier h and barrier h + 1 -- every wave read it (as slot h - 1) before it
-      // arrived at barrier h, and nobody raises it before barrier h + 1.  (With ONE slot a fast wave could raise the
-      // flag for h + 1 before a slow one had read it for h: the two would then disagree about the flush.)
-      if (lane == 0 && staged > LIST_CAP - PART_ROWS * NT * 64) s_len[NW_ + h % 3] = 1u;
+    // At most 4 * NT * 64 candidates per m and wave.  A list that might overflow in the next m (dense blocks of hits
+    // only) is emptied by the WHOLE workgroup: the decision is made uniform through LDS, one barrier per m.
+    if constexpr (m + 1 < WTM) {
+      // Three flag slots in rotation: slot m % 3 is raised before this m's barrier and read after it; the slot of
+      // m + 2 is cleared here, between barrier m and barrier m + 1 -- every wave read it (as slot m - 1) before it
+      // arrived at barrier m, and nobody raises it before barrier m + 1.  (With ONE slot a fast wave could raise the
+      // flag for m + 1 before a slow one had read it for m: the two would then disagree about the flush.)
+      if (lane == 0 && staged > CAND_CAP - 4 * NT * 64) s_len[NW_ + m % 3] = 1u;
       __syncthreads();
-      const bool any_full = s_len[NW_ + h % 3] != 0u;
-      if (wave == 0 && lane == 0) s_len[NW_ + (h + 2) % 3] = 0u;
+      const bool any_full = s_len[NW_ + m % 3] != 0u;
+      if (wave == 0 && lane == 0) s_len[NW_ + (m + 2) % 3] = 0u;
       if (any_full) flush_all(std::integral_constant<uint32_t, (HG_P2_U < 2 ? HG_P2_U : 2)>{});  // (the accumulators are live: two batches in flight)
     }
-    });
   });
   }
   HG_TSTAMP(4)
-  if (PERSIST && has_next) load_ents();  // (the first level has landed under the append; this one lands under phase 2)
-  if (!tile_empty) flush_all(std::integral_constant<uint32_t, HG_P2_U>{});  // end of the tile
+  flush_all(std::integral_constant<uint32_t, HG_P2_U>{});  // end of the tile
   HG_TSTAMP(5)
   }
-  // ---- PERSIST: on to the next tile --------------------------------------------------------------------------------
-  // Every wave is past its last read of this tile's words and lists (flush_all ends with a barrier; an empty tile's waves
-  // left the sweep's barrier and read nothing since): the next tile's words go to LDS, thread 0 publishes the slot of the
-  // tile after it, and the barrier that closes the iteration also finds the prefetched K-step landed (vmcnt(0)).
-  if constexpr (!PERSIST) break;
-  if (!has_next) break;
-  store_words(row0n, col0n);
-  if (threadIdx.x == 0) s_next[0] = next_valid_from(pending_idx);
-  __syncthreads();
-#ifdef HG_DIST_STAMPS
-  t_prev_end = __builtin_amdgcn_s_memtime();
-  if ((threadIdx.x & 63) == 0 && v_cur >= 512 && v_cur < 528) g_dist_tile_stamps[v_cur - 512][threadIdx.x >> 6][9] = t_prev_end;
-#endif
-  v_cur = v_next, row0 = row0n, col0 = col0n, rsA = rsAn, rsB = rsBn;
-  sb = (sb + nsteps) & 1u;
-  }  // tiles
 }
 
 // ---- always-exact integer fallback -------------------------------------------------------------------
@@ -1543,18 +1383,11 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
 
 // the instantiation's name as a profiler prints it (hg_ctx_last_kernel: bench.py matches it against the kernel names in
 // the committed rocprofv3 summaries before it quotes their counters)
-#undef HG_DMA_RS
-template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false,
-          bool PERSIST = false>
+template <bool CHUNKED, bool FULL, bool BIG, bool GLDS = false, int NT = 4, bool I8 = false, bool HAM = false, bool FP4 = false>
 static std::string dist_kernel_name() {
   auto b = [](bool x) { return x ? "true" : "false"; };
   return std::string("dist_mfma_kernel<") + b(CHUNKED) + ", " + b(FULL) + ", " + b(BIG) + ", " + b(GLDS) + ", " +
-         std::to_string(NT) + ", " + b(I8) + ", " + b(HAM) + ", " + b(FP4) + ", " + b(PERSIST) + ">";
-}
-// PERSIST launches: one workgroup per CU (a multiple of 8, at most the tile queue's length), the queue's eight counters
-static inline uint32_t persist_grid(const hg_ctx *c, uint32_t n_virtual) {
-  const uint32_t cus = (uint32_t)std::max(c->n_cu, 8) / 8 * 8;
-  return std::min(cus, n_virtual);
+         std::to_string(NT) + ", " + b(I8) + ", " + b(HAM) + ", " + b(FP4) + ">";
 }
 #define HG_DIST_K(...) &dist_mfma_kernel<__VA_ARGS__>, dist_kernel_name<__VA_ARGS__>()
 
@@ -1663,9 +1496,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
     else if (c->dbg_dist_tile == "wide") nt = 5;
   }
   g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
-  const bool persist = c->dbg_dist_persist == "on" && kbytes >= 256;  // (two K-steps at least)
-  g.n_virtual = dist_grid(g.tiles_m, g.tiles_n), g.tile_ctr = d_count + 16;
-  const uint32_t n_tiles = persist ? persist_grid(c, g.n_virtual) : g.n_virtual;
+  const uint32_t n_tiles = dist_grid(g.tiles_m, g.tiles_n);
   const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
   auto launch = [&](auto kern, const std::string &name, int threads) -> hipError_t {
     c->last_kernel[HG_T_DIST] = name;
@@ -1680,12 +1511,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   };
   hg_timed tg(c, HG_T_DIST);
   hipError_t le;
-  if (persist) {
-    if (fp4 && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true, true), TileCfg<true, 5>::THREADS);
-    else if (fp4) le = launch(HG_DIST_K(false, false, true, true, 4, true, true, true, true), TileCfg<true, 4>::THREADS);
-    else if (nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, false, true), TileCfg<true, 5>::THREADS);
-    else le = launch(HG_DIST_K(false, false, true, true, 4, true, true, false, true), TileCfg<true, 4>::THREADS);
-  } else if (fp4 && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true), TileCfg<true, 5>::THREADS);
+  if (fp4 && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true, true), TileCfg<true, 5>::THREADS);
   else if (fp4) le = launch(HG_DIST_K(false, false, true, true, 4, true, true, true), TileCfg<true, 4>::THREADS);
   else if (nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, true, true), TileCfg<true, 5>::THREADS);
   else le = launch(HG_DIST_K(false, false, true, true, 4, true, true), TileCfg<true, 4>::THREADS);
@@ -1787,29 +1613,24 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
     // (the same matrix on both sides at the same global offset: hits cluster on the diagonal -- those tiles first)
     g.diag_first = (same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
-    const bool persist = c->dbg_dist_persist == "on" && kp8 >= 256;  // (two K-steps at least)
-    g.n_virtual = g.diag_first + dist_grid(g.tiles_m, g.tiles_n), g.tile_ctr = a.hit_count + 16;
-    const uint32_t n_tiles = persist ? persist_grid(c, g.n_virtual) : g.n_virtual;
+    const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
     const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
-    auto launch_i8 = [&](auto kern, const std::string &name, int threads) -> hipError_t {
-      const void *fp = reinterpret_cast<const void *>(kern);
-      if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
-        const hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        c->lds_attr_done.push_back(fp);
-      }
-      c->last_kernel_i8 = name;
-      hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(threads), lds, c->stream, g);
-      return hipGetLastError();
-    };
+    const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
+                             : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
+    if (std::find(c->lds_attr_done.begin(), c->lds_attr_done.end(), fp) == c->lds_attr_done.end()) {
+      HG_HIP(c, hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->lds_attr_done.push_back(fp);
+    }
     {
       hg_timed tmg(c, HG_T_DIST, HG_T_DIST_PREP);
-      hipError_t le;
-      if (persist && nt == 5) le = launch_i8(HG_DIST_K(false, false, true, true, 5, true, false, false, true), TileCfg<true, 5>::THREADS);
-      else if (persist) le = launch_i8(HG_DIST_K(false, false, true, true, 4, true, false, false, true), TileCfg<true, 4>::THREADS);
-      else if (nt == 5) le = launch_i8(HG_DIST_K(false, false, true, true, 5, true), TileCfg<true, 5>::THREADS);
-      else le = launch_i8(HG_DIST_K(false, false, true, true, 4, true), TileCfg<true, 4>::THREADS);
-      HG_HIP(c, le);
+      c->last_kernel_i8 = nt == 5 ? dist_kernel_name<false, false, true, true, 5, true>() : dist_kernel_name<false, false, true, true, 4, true>();
+      if (nt == 5)
+        hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 5, true>), dim3(n_tiles), dim3(TileCfg<true, 5>::THREADS), lds,
+                           c->stream, g);
+      else
+        hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true>), dim3(n_tiles), dim3(TileCfg<true, 4>::THREADS), lds,
+                           c->stream, g);
+      HG_HIP(c, hipGetLastError());
     }
     veto = ctrl + 4;
     // The previous call on exactly these operands took the i8 path: the f16 fallback chain (five launches that would
@@ -1975,10 +1796,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   // (thresholded self-comparison: the tiles on the diagonal first, as on the i8 path)
   g.diag_first = (!full && same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
-  // (persistent tiles: the thresholded whole-K LDS-DMA geometries; the thresholded calls always carry the counter block)
-  const bool persist = big && !big_chunked && a.hit_count && !full && c->dbg_dist_persist == "on" && Kp >= 2 * BK;
-  g.n_virtual = g.diag_first + dist_grid(g.tiles_m, g.tiles_n), g.tile_ctr = a.hit_count ? a.hit_count + 16 : nullptr;
-  const uint32_t n_tiles = persist ? persist_grid(c, g.n_virtual) : g.n_virtual;
+  const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
   auto launch = [&](auto kern, const std::string &name, int threads, size_t lds) -> hipError_t {
     if (!guard || v_lo == 0) c->last_kernel[HG_T_DIST] = name;  // (a guarded second launch covers verdicts 1..2 only)
     const void *fp = reinterpret_cast<const void *>(kern);
@@ -1996,8 +1814,6 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const size_t lds_wide = dist_lds_bytes<true, 5, true>(), lds_chunked = dist_lds_bytes<true, NT_CHUNKED, true>();
   static_assert(dist_lds_bytes<true, 5, true>() <= 160 * 1024, "the widest tile fits the CU's LDS");
   if (big_chunked) le = launch(HG_DIST_K(true, false, true, true, NT_CHUNKED), TileCfg<true, NT_CHUNKED>::THREADS, lds_chunked);
-  else if (persist && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5, false, false, false, true), TileCfg<true, 5>::THREADS, lds_wide);
-  else if (persist) le = launch(HG_DIST_K(false, false, true, true, 4, false, false, false, true), TileCfg<true>::THREADS, lds_dma);
   else if (big && nt == 5) le = launch(HG_DIST_K(false, false, true, true, 5), TileCfg<true, 5>::THREADS, lds_wide);
   else if (big) le = launch(HG_DIST_K(false, false, true, true), TileCfg<true>::THREADS, lds_dma);
   else if (whole_k && full) le = launch(HG_DIST_K(false, true, false), TileCfg<false>::THREADS, lds_small);

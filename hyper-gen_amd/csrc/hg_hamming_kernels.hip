@@ -201,9 +201,9 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   if (ref_off + R > 0xFFFFFFFFull || qry_off + Q > 0xFFFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "global indices must fit 32 bits");
   HG_HIP(c, hipSetDevice(c->device));
   hg_status s;
-  if ((s = hg_ensure(c, c->w_misc, 128)) != HG_OK) return s;
+  if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
-  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 128, c->stream));  // (see hg_dist_block_dev)
+  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 64, c->stream));  // (see hg_dist_block_dev)
   c->misc_zeroed = nullptr;
   // Large searches run as an exact +-1 GEMM on the matrix pipe (hg_run_hamming_mfma: G = D - 2 * distance, the ANI
   // kernel's tiles and hit lists) -- on e2m1 (FP4) operands, or on byte operands when the hook says "mfma" (the A/B
@@ -226,7 +226,7 @@ extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_re
   if ((s = hg_publish_words(c, d_count, 1, &h_res)) != HG_OK) return s;
   const uint32_t found = h_res[0];
   *n_out = found;
-  if (hipMemsetAsync(d_count, 0, 128, c->stream) == hipSuccess) c->misc_zeroed = d_count;
+  if (hipMemsetAsync(d_count, 0, 64, c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
   return HG_OK;
 }

@@ -67,8 +67,6 @@ int hg_device_count(void);
  * keys: "dist_tile" = "" | "small" | "big" | "wide"      (GEMM tile geometry)
  *       "dist_path" = "" | "f16" | "i8"                    (operand format of the ANI GEMM)
  *       "dist_order" = "" | "plain"                        ("plain": a self-comparison does not run its diagonal tiles first)
- *       "dist_persist" = "" | "on"                         ("on": persistent workgroups -- a measured negative, see profiles/r04_dist_persistent_negative.txt -- that
- *                                                           walk per-XCD tile queues and prefetch their next tile)
  *       "ham_path"  = "" | "popc" | "mfma" | "fp4"         (Hamming search: xor + popcount, +-1 byte GEMM, +-1 e2m1 GEMM)
  *       "kmer_input" = "" | "packed"                       ("packed": batches that arrive as ASCII are 2-bit packed on the
  *                                                           device first and take the packed-input kernels)

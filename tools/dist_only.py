@@ -14,7 +14,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10000)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--th", type=float, default=85.0)
-ap.add_argument("--settle", type=int, default=200, help="untimed calls first (the clock)")
 ap.add_argument("--nhash", type=int, default=3333, help="hashes per sketch (3333 = 5 Mbp at scaled 1500); > 4096 needs two exact f32 windows at D = 4096")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -24,19 +23,14 @@ hv = bench.clustered_hvs(a.n, 0, dev, n=a.nhash)
 n2 = (hv.int() ** 2).sum(1).int()
 cap = max(1 << 20, a.n * a.n // 20)
 hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
-for _ in range(a.settle):
-    ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False, a.th, hits.data_ptr(), cap)
-torch.cuda.synchronize()
 ctx.enable_timing(True)
-# HG_DIST_VARIANTS = comma list of "<tile>[:<path>[:<persist>]]" (hg_ctx_set_debug keys dist_tile / dist_path / dist_persist),
-# e.g. ",:f16,wide:i8,::off"
+# HG_DIST_VARIANTS = comma list of "<tile>[:<path>]" (hg_ctx_set_debug keys dist_tile / dist_path), e.g. ",:f16,wide:i8"
 variants = os.environ.get("HG_DIST_VARIANTS", "").split(",")
 res = {v: [] for v in variants}
 for r in range(a.reps + 1):
     for v in variants:  # interleaved so that clock / thermal drift hits every variant alike
         ctx.set_debug("dist_tile", v.split(":")[0])
         ctx.set_debug("dist_path", v.split(":")[1] if ":" in v else "")
-        ctx.set_debug("dist_persist", v.split(":")[2] if v.count(":") > 1 else "")
         ctx.timings()
         found, _ = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False,
                                 a.th, hits.data_ptr(), cap)

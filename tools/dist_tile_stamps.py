@@ -12,7 +12,6 @@ n = 10000
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-ctx.set_debug("dist_persist", os.environ.get("HG_PERSIST", ""))  # "off": one tile per workgroup
 hv = bench.clustered_hvs(n, 0, dev)
 n2 = (hv.int() ** 2).sum(1).int()
 cap = 1 << 23
@@ -32,9 +31,6 @@ for th in (101.0, 85.0):
     for i, nm in enumerate(names):
         print("   %-26s mean %8.0f  min %8.0f  max %8.0f" % (nm, d[:, :, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
     print("   per-wg flush:", (st[:, 0, 5] - st[:, 0, 4]).tolist())
-    if (st[:, :, 9] > st[:, :, 5]).any():  # persistent workgroups: from "tile done" to the barrier that opens the next tile
-        tail = (st[:, :, 9] - st[:, :, 5])[st[:, :, 9] > st[:, :, 5]]
-        print("   tail (next tile's words to LDS, queue, barrier): mean %.0f  min %.0f  max %.0f" % (tail.mean(), tail.min(), tail.max()))
     rl = np.zeros((2048, 2), np.uint64)
     assert hg.lib().hg_debug_dist_tile_real(C.c_void_p(rl.ctypes.data)) == 0
     rl = rl.astype(np.int64)[512:528]

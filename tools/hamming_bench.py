@@ -26,8 +26,7 @@ ref_hits = None
 for path in os.environ.get("HG_HAM_PATHS", "fp4,mfma,fp4,mfma,popc").split(","):
     ctx.set_debug("ham_path", path)
     for tile in os.environ.get("HG_HAM_TILES", "").split(","):
-        ctx.set_debug("dist_tile", tile.split(":")[0])
-        ctx.set_debug("dist_persist", tile.split(":")[1] if ":" in tile else "")  # "<tile>:off" = one tile per workgroup
+        ctx.set_debug("dist_tile", tile)
         best = None
         for rep in range(6):
             ctx.timings()
