@@ -81,6 +81,7 @@ EXPORTS = [
     "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
     "hg_sketch_batch_dev_packed", "hg_pack2_batch_dev", "hg_pack2_dev",
     "hg_pack2s_size", "hg_pack2s", "hg_sketch_stream_push_packed_sparse",
+    "hg_dist_ops_row_bytes", "hg_dist_ops_meta_bytes", "hg_dist_ops_padded_rows", "hg_dist_prep_ops_dev", "hg_dist_block_ops_dev",
 ]
 
 
@@ -178,6 +179,12 @@ def lib():
         "hg_sketch_batch_dev_packed": (C.c_int, [vp, vp, vp, vp, sz, C.POINTER(SketchParams), vp, vp, vp]),
         "hg_pack2_batch_dev": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint32, vp, vp]),
         "hg_pack2_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp]),
+        "hg_dist_ops_row_bytes": (sz, [C.c_uint32]),
+        "hg_dist_ops_meta_bytes": (sz, []),
+        "hg_dist_ops_padded_rows": (sz, [sz]),
+        "hg_dist_prep_ops_dev": (C.c_int, [vp, vp, sz, C.c_uint32, vp, vp, vp]),
+        "hg_dist_block_ops_dev": (C.c_int, [vp, vp, vp, vp, sz, sz, vp, vp, sz, vp, vp, sz, sz, C.c_uint32, C.c_uint32, C.c_int,
+                                            C.c_float, vp, sz, C.POINTER(sz)]),
         "hg_pack2s_size": (sz, [sz, sz]),
         "hg_pack2s": (C.c_int, [vp, sz, C.c_uint32, vp, sz, C.POINTER(sz)]),
         "hg_sketch_stream_push_packed_sparse": (C.c_int, [vp, vp, sz, C.c_uint64]),
@@ -436,6 +443,21 @@ class Context:
                                      qry_off, hv_d, ksize, int(symmetric), C.c_float(ani_th), _ptr(d_out), cap,
                                      C.byref(n))
         self._ck(st, allow=(ERR_CAPACITY,))
+        return n.value, st
+
+    def dist_prep_ops_dev(self, d_hv, rows, hv_d, d_ops, d_meta, d_flag):
+        """hg_dist_prep_ops_dev: byte operands + control records of this rank's reference rows (device pointers)"""
+        self._ck(lib().hg_dist_prep_ops_dev(self._h, _ptr(d_hv), rows, hv_d, _ptr(d_ops), _ptr(d_meta), _ptr(d_flag)))
+
+    def dist_block_ops_dev(self, d_ref_ops, d_ref_meta, d_rn, R, ref_off, d_ref_index, d_flags, n_flags, d_qry, d_qn, Q, qry_off,
+                           hv_d, ksize, symmetric, ani_th, d_out, cap):
+        """hg_dist_block_ops_dev; returns (hits, status) -- status ERR_INEXACT: vetoed, fall back to dist_block_dev"""
+        n = C.c_size_t(0)
+        st = lib().hg_dist_block_ops_dev(self._h, _ptr(d_ref_ops), _ptr(d_ref_meta), _ptr(d_rn), R, ref_off,
+                                         _ptr(d_ref_index) if d_ref_index else None, _ptr(d_flags) if d_flags else None, n_flags,
+                                         _ptr(d_qry), _ptr(d_qn), Q, qry_off, hv_d, ksize, int(symmetric), C.c_float(ani_th),
+                                         _ptr(d_out), cap, C.byref(n))
+        self._ck(st, allow=(ERR_CAPACITY, ERR_INEXACT))
         return n.value, st
 
     def hamming_search_block_dev(self, d_ref, R, ref_off, d_qry, Q, qry_off, hv_d, max_dist, d_out, cap):

@@ -1055,6 +1055,69 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   return HG_OK;
 }
 
+// ---- sharded dist: the reference operands are prepared where the rows live (the reference has no such step) ----
+extern "C" size_t hg_dist_ops_row_bytes(uint32_t hv_d) { return hg_dist_ops_row_bytes_impl(hv_d); }
+extern "C" size_t hg_dist_ops_meta_bytes(void) { return hg_dist_ops_meta_bytes_impl(); }
+extern "C" size_t hg_dist_ops_padded_rows(size_t rows) { return hg_dist_ops_padded_rows_impl(rows); }
+
+extern "C" hg_status hg_dist_prep_ops_dev(hg_ctx *c, const int16_t *d_hv, size_t rows, uint32_t hv_d, uint8_t *d_ops,
+                                          uint8_t *d_meta, uint32_t *d_flag) {
+  if (!c) return HG_ERR_INVALID;
+  if (rows == 0) return HG_OK;
+  if (!d_hv || !d_ops || !d_meta || !d_flag || hv_d == 0) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  if (rows > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 rows");
+  HG_HIP(c, hipSetDevice(c->device));
+  return hg_run_dist_prep_ops(c, d_hv, (uint32_t)rows, hv_d, d_ops, d_meta, d_flag);
+}
+
+extern "C" hg_status hg_dist_block_ops_dev(hg_ctx *c, const uint8_t *d_ref_ops, const uint8_t *d_ref_meta, const int32_t *d_ref_norm2,
+                                           size_t R, size_t ref_off, const uint32_t *d_ref_index, const uint32_t *d_flags,
+                                           size_t n_flags, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
+                                           size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
+                                           hg_ani_hit *d_out, size_t cap, size_t *n_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
+  *n_out = 0;
+  hg_status s = check_dist(c, R, Q, hv_d, ksize);
+  if (s != HG_OK) return s;
+  if (ref_off + R > 0x7FFFFFFFull || qry_off + Q > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "global indices must be < 2^31");
+  if (R == 0 || Q == 0) return HG_OK;
+  if (!d_ref_ops || !d_ref_meta || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out) || (n_flags && !d_flags))
+    return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  if (d_ref_index && symmetric) return hg_fail(c, HG_ERR_UNSUPPORTED, "symmetric needs contiguous reference indices (no d_ref_index)");
+  HG_HIP(c, hipSetDevice(c->device));
+  if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
+  auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
+  if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
+  c->misc_zeroed = nullptr;
+  hg_dist_args a{};
+  a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
+  a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
+  a.hits = d_out, a.hit_count = d_count;
+  a.hit_cap = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+  a.ani_th = ani_th, a.symmetric = symmetric;
+  a.ref_off = (uint32_t)ref_off, a.qry_off = (uint32_t)qry_off;
+  a.ref_ops = d_ref_ops, a.ref_meta = d_ref_meta, a.ref_flags = d_flags, a.n_flags = (uint32_t)n_flags, a.ref_index = d_ref_index;
+  int spec = -1;
+  if ((s = hg_run_dist(c, a, d_count + 1, &spec)) != HG_OK) return s;
+  const uint32_t *h_res = nullptr;
+  if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
+  const bool valid = h_res[8] == 1u;
+  const uint32_t found = h_res[0];
+  c->i8_sig_ref = c->i8_sig_qry = nullptr;
+  if (hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess) c->misc_zeroed = d_count;
+  if (!valid) {
+    // an owner's rows, or this call's query rows, do not fit the byte-operand scheme (mixed parity, a residual beyond a
+    // byte, more clamped entries than a row's slots): nothing was reported; the caller gathers the i16 rows instead
+    return hg_fail(c, HG_ERR_INEXACT, "prepared operands vetoed on the device: fall back to hg_dist_block_dev on the i16 rows");
+  }
+  c->last_dist_path = 1;
+  c->last_kernel[HG_T_DIST] = c->last_kernel_i8;
+  *n_out = found;
+  if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
+  return HG_OK;
+}
+
 namespace {
 struct StagedDist {
   const int16_t *d_ref, *d_qry;

@@ -354,11 +354,21 @@ struct I8Outlier {
 };
 // ctrl words (device): [0] outlier count, [1] failure bits, [2] phase-0 slack of the GEMM epilogue, [3] entries of side 0,
 //                      [4] verdict (1 = i8 path valid), [5] K-steps of 128 bytes
+// A row's control record as it travels between GPUs (hg_dist_prep_ops_dev -> hg_dist_block_ops_dev): what the rank that owns
+// the row computed for it, 72 bytes against the row's 4 KiB of byte operands
+struct I8RowMeta {
+  int32_t info;                 // 2 * S + e
+  int32_t slot;                 // entries (8 bits) << 14 | sum |b| (14 bits); 0 = none
+  uint32_t ent[I8_ROW_SLOTS];   // the clamped entries: d | (uint8)b << 16
+};
+static_assert(sizeof(I8RowMeta) == 72, "hg_dist_ops_meta_bytes");
+// meta != nullptr: the per-row words go into packed records instead of the rowinfo / rowslot / rowfirst / list arrays
 __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict__ hv, uint32_t rows, uint32_t hv_d,
                                                       uint32_t kp8, uint32_t ldk8, int8_t *__restrict__ out_a,
                                                       int32_t *__restrict__ rowinfo, int32_t *__restrict__ rowslot,
                                                       uint32_t *__restrict__ rowfirst, I8Outlier *__restrict__ list,
-                                                      uint32_t list_base, uint32_t *__restrict__ ctrl, uint32_t side) {
+                                                      uint32_t list_base, uint32_t *__restrict__ ctrl, uint32_t side,
+                                                      I8RowMeta *__restrict__ meta = nullptr) {
   // the row's clamped entries are collected in LDS (one wave = one row) and go to the global list as ONE contiguous
   // range reserved with a single atomic: no sort, no second kernel, and the list can be as long as memory allows
   __shared__ uint32_t s_ent[4][I8_ROW_ENT_MAX];
@@ -431,17 +441,45 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
   for (int o = 32; o > 0; o >>= 1) bs += __shfl_xor(bs, o);
   if (n_raw > I8_ROW_SLOTS || bs >= (1u << 14)) bad |= 2u;  // more than the row's slots / the slot word can describe
   const uint32_t base = list_base + row * I8_ROW_SLOTS;
-  if (lane < n_st) {
+  const int32_t slotw = n_st ? (int32_t)(((n_st & 255u) << 14) | (bs & 0x3fffu)) : 0;  // entries (8 bits) | sum |b| (14 bits); 0 = none
+  if (meta) {
+    if (lane < I8_ROW_SLOTS) meta[row].ent[lane] = lane < n_st ? (s_ent[wv][lane] & 0x00FFFFFFu) : 0u;
+    if (lane == 0) meta[row].info = 2 * S + e, meta[row].slot = slotw;
+  } else if (lane < n_st) {
     const uint32_t v = s_ent[wv][lane];
     list[base + lane] = I8Outlier{row, (uint16_t)(v & 0xffffu), (int8_t)(uint8_t)(v >> 16), (uint8_t)side};
   }
   const bool anypar = __any(par != 0), anybad4 = __any((bad & 4u) != 0), anybad2 = __any((bad & 2u) != 0);
   if (lane == 0) {
-    rowinfo[row] = 2 * S + e;
-    rowfirst[row] = base;
-    rowslot[row] = n_st ? (int32_t)(((n_st & 255u) << 14) | (bs & 0x3fffu)) : 0;  // entries (8 bits) | sum |b| (14 bits); 0 = none
+    if (!meta) {
+      rowinfo[row] = 2 * S + e;
+      rowfirst[row] = base;
+      rowslot[row] = slotw;
+    }
     const uint32_t fl = (anypar ? 1u : 0u) | (anybad2 ? 2u : 0u) | (anybad4 ? 4u : 0u);
     if (fl) atomicOr(&ctrl[1], fl);
+  }
+}
+
+// gathered records -> the arrays the GEMM's epilogue reads (side 0); workgroup 0 also folds the owners' failure flags into
+// the call's control words
+__global__ __launch_bounds__(256) void unpack_meta_kernel(const I8RowMeta *__restrict__ meta, uint32_t rows, int32_t *__restrict__ rowinfo,
+                                                          int32_t *__restrict__ rowslot, uint32_t *__restrict__ rowfirst,
+                                                          I8Outlier *__restrict__ list, const uint32_t *__restrict__ flags,
+                                                          uint32_t n_flags, uint32_t *__restrict__ ctrl) {
+  if (blockIdx.x == 0) {
+    uint32_t fl = 0;
+    for (uint32_t i = threadIdx.x; i < n_flags; i += blockDim.x) fl |= flags[i];
+    if (fl) atomicOr(&ctrl[1], fl);
+  }
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, row = t / I8_ROW_SLOTS, k = t % I8_ROW_SLOTS;
+  if (row >= rows) return;
+  const I8RowMeta &m = meta[row];
+  const uint32_t n_st = ((uint32_t)m.slot >> 14) & 255u;
+  if (k == 0) rowinfo[row] = m.info, rowslot[row] = m.slot, rowfirst[row] = row * I8_ROW_SLOTS;
+  if (k < n_st) {
+    const uint32_t v = m.ent[k];
+    list[row * I8_ROW_SLOTS + k] = I8Outlier{row, (uint16_t)(v & 0xffffu), (int8_t)(uint8_t)(v >> 16), (uint8_t)0};
   }
 }
 
@@ -526,7 +564,10 @@ struct GemmArgs {
   uint32_t *i8verdict;             // [0] <- 1 when the i8 attempt is valid, [1] <- K-steps (written by workgroup 0: the
                                    // host's read-back and the veto word of the f16 kernels queued behind)
   const I8Outlier *ents;           // clamped entries sorted by (side, row, dim)
-  const int16_t *raw_r, *raw_q;    // the original i16 matrices (rows of hv_d)
+  const int16_t *raw_q;            // the original i16 query matrix (rows of hv_d): c_j[d] for the reference rows' clamped entries
+                                   // (a_i[d] for the query columns' entries is the reference's byte operand itself: A)
+  const uint32_t *ref_index;       // optional: global index of reference row i (a gathered block whose rows are not one
+                                   // contiguous range of the global enumeration); nullptr: ref_off + i
   const uint32_t *i8ctrl;          // [0] entries reserved, [1] flags of the prepass
   uint32_t hv_d, same_set;
   uint32_t diag_first;             // leading workgroup slots that take the tiles on the diagonal (0: plain order)
@@ -1048,15 +1089,14 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
           const uint32_t gi = row0 + (key[u] >> 16), gj = col0 + (key[u] & 0xffffu);
           vq[u] = vr[u] = 0;
           if (cr[u]) vq[u] = g.raw_q[(size_t)gj * g.hv_d + (o_r[u] & 0xffffu)];
-          if (cq[u]) vr[u] = g.raw_r[(size_t)gi * g.hv_d + (o_q[u] & 0xffffu)];
+          if (cq[u]) vr[u] = reinterpret_cast<const int8_t *>(g.A)[(size_t)gi * g.ldk * 2 + (o_q[u] & 0xffffu)];  // a_i[d]: the clamped byte
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int32_t er = ir[u] & 1, eq = iq[u] & 1;
           int32_t G = val[u];
-          auto clamp8 = [](int32_t c) { return c > 127 ? 127 : (c < -127 ? -127 : c); };
           if (cr[u]) G += (int32_t)(int8_t)(o_r[u] >> 16) * ((vq[u] + eq) >> 1);      // b_i[d] * c_j[d], c = the true centred count of column j
-          if (cq[u]) G += (int32_t)(int8_t)(o_q[u] >> 16) * clamp8((vr[u] + er) >> 1);  // a_i[d] * b_j[d], a = the clamped byte of row i
+          if (cq[u]) G += (int32_t)(int8_t)(o_q[u] >> 16) * vr[u];  // a_i[d] * b_j[d], a = the clamped byte of row i (its operand)
           if (__ballot(cr[u] > 1u || cq[u] > 1u) != 0) {  // wave-uniform, rare: further entries of a row / column
             const uint32_t gi = row0 + (key[u] >> 16), gj = col0 + (key[u] & 0xffffu);
             for (uint32_t t = 1; t < cr[u]; ++t) {
@@ -1065,7 +1105,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
             }
             for (uint32_t t = 1; t < cq[u]; ++t) {
               const I8Outlier o = g.ents[f_q[u] + t];
-              G += (int32_t)o.b * clamp8(((int32_t)g.raw_r[(size_t)gi * g.hv_d + o.d] + er) >> 1);
+              G += (int32_t)o.b * (int32_t)reinterpret_cast<const int8_t *>(g.A)[(size_t)gi * g.ldk * 2 + o.d];
             }
           }
           val[u] = 4 * G - eq * (ir[u] - er) - er * (iq[u] - eq) + (er & eq) * (int32_t)g.hv_d;
@@ -1093,8 +1133,10 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     const bool hit = h2.y != 0xFFFFFFFFu;
     const unsigned long long bal = __ballot(hit);
     const uint32_t pos = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-    if (hit && pos < g.hit_cap)
-      g.hits[pos] = hg_ani_hit{row0 + g.ref_off + (h2.x >> 16), col0 + g.qry_off + (h2.x & 0xffffu), __uint_as_float(h2.y)};
+    if (hit && pos < g.hit_cap) {
+      const uint32_t li = row0 + (h2.x >> 16);
+      g.hits[pos] = hg_ani_hit{g.ref_index ? g.ref_index[li] : li + g.ref_off, col0 + g.qry_off + (h2.x & 0xffffu), __uint_as_float(h2.y)};
+    }
     return (uint32_t)__popcll(bal);
   };
   // Emptying the lists: ONE reservation per workgroup (same-address returning atomics serialise at ~12 ns; with noise
@@ -1543,20 +1585,26 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     return std::max(std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320), (n + 191) / 192 * 192);
   };
   const uint32_t Rp = padded(a.R), Qp = padded(a.Q);
-  const bool same = (a.ref_hv == a.qry_hv) && (a.R == a.Q);
+  // ops_given: the reference side arrives as byte operands + control records prepared where the rows live
+  // (hg_dist_prep_ops_dev on the owning GPUs, gathered by the caller): no reference prepass here, and no f16 fallback --
+  // there are no i16 reference rows to fall back on; a veto comes back to the caller as HG_ERR_INEXACT
+  const bool ops_given = a.ref_ops != nullptr;
+  const bool same = !ops_given && (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
   // ---- i8 operand attempt (thresholded, large problems): queued first; every f16 kernel below carries its verdict
   // word as a veto and returns at once when the i8 kernels did the work.  After a failed attempt the next few calls
   // go straight to f16 (large sketches never qualify; probing them every time would cost ~50 us per call).
   const uint32_t *veto = nullptr;
-  const bool want_i8 = c->dbg_dist_path != "f16" && d_verdict && !a.ani_out && a.hits && a.hv_d <= 8192 && a.hv_d % 8 == 0 &&
-                       ((uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256 || c->dbg_dist_path == "i8") &&
-                       (c->i8_skip == 0 || c->dbg_dist_path == "i8") &&
-                       ((uint64_t)a.R + a.Q) * I8_ROW_SLOTS < ((uint64_t)1 << 31);  // (32-bit entry indices)
+  const bool i8_possible = d_verdict && !a.ani_out && a.hits && a.hv_d <= 8192 && a.hv_d % 8 == 0 &&
+                           ((uint64_t)a.R + a.Q) * I8_ROW_SLOTS < ((uint64_t)1 << 31);  // (32-bit entry indices)
+  if (ops_given && !i8_possible) return hg_fail(c, HG_ERR_UNSUPPORTED, "prepared operands: thresholded calls with hv_d <= 8192, hv_d % 8 == 0 only");
+  const bool want_i8 = ops_given || (c->dbg_dist_path != "f16" && i8_possible &&
+                                     ((uint64_t)a.R * a.Q >= (uint64_t)256 * 256 * 256 || c->dbg_dist_path == "i8") &&
+                                     (c->i8_skip == 0 || c->dbg_dist_path == "i8"));
   if (!want_i8 && c->i8_skip) --c->i8_skip;
   if (want_i8) {
     const uint32_t kp8 = (a.hv_d + 127) / 128 * 128, ldk8 = kp8 + 128;
-    if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
+    if (!ops_given && (s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldk8)) != HG_OK) return s;
     if (!same && (s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldk8)) != HG_OK) return s;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     // misc block: info, slot and first-entry words per row / column, the list of clamped entries: I8_ROW_SLOTS per row.
@@ -1568,7 +1616,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     const size_t o_iq = al((size_t)a.R * 4), o_sr = o_iq + al((size_t)a.Q * 4), o_sq = o_sr + al((size_t)a.R * 4);
     const size_t o_fr = o_sq + al((size_t)a.Q * 4), o_fq = o_fr + al((size_t)a.R * 4), o_list = o_fq + al((size_t)a.Q * 4);
     if ((s = hg_ensure(c, c->w_i8misc, o_list + al((size_t)ent_cap * sizeof(I8Outlier)) + 256)) != HG_OK) return s;
-    auto *a8 = static_cast<int8_t *>(c->w_i8a.p), *b8 = same ? a8 : static_cast<int8_t *>(c->w_i8b.p);
+    // (prepared operands: the caller's buffer holds hg_dist_ops_padded_rows(R) rows; the rows behind R are zeroed below)
+    auto *a8 = ops_given ? reinterpret_cast<int8_t *>(const_cast<uint8_t *>(a.ref_ops)) : static_cast<int8_t *>(c->w_i8a.p);
+    auto *b8 = same ? a8 : static_cast<int8_t *>(c->w_i8b.p);
     auto *mb = static_cast<uint8_t *>(c->w_i8misc.p);
     auto *info_r = reinterpret_cast<int32_t *>(mb), *info_q = same ? info_r : reinterpret_cast<int32_t *>(mb + o_iq);
     auto *slot_r = reinterpret_cast<int32_t *>(mb + o_sr), *slot_q = same ? slot_r : reinterpret_cast<int32_t *>(mb + o_sq);
@@ -1579,12 +1629,16 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)a.Q * ldk8, 0, (size_t)(Qp - a.Q) * ldk8, c->stream));
     {
       hg_timed tmp(c, HG_T_DIST_PREP);
-      hipLaunchKernelGGL(prep_i8_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, kp8, ldk8, a8,
-                         info_r, slot_r, first_r, list, 0u, ctrl, 0u);
+      if (ops_given)
+        hipLaunchKernelGGL(unpack_meta_kernel, dim3((a.R * I8_ROW_SLOTS + 255) / 256), dim3(256), 0, c->stream,
+                           static_cast<const I8RowMeta *>(a.ref_meta), a.R, info_r, slot_r, first_r, list, a.ref_flags, a.n_flags, ctrl);
+      else
+        hipLaunchKernelGGL(prep_i8_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, a.ref_hv, a.R, a.hv_d, kp8, ldk8, a8,
+                           info_r, slot_r, first_r, list, 0u, ctrl, 0u, static_cast<I8RowMeta *>(nullptr));
       HG_HIP(c, hipGetLastError());
       if (!same) {
         hipLaunchKernelGGL(prep_i8_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, c->stream, a.qry_hv, a.Q, a.hv_d, kp8, ldk8, b8,
-                           info_q, slot_q, first_q, list, a.R * I8_ROW_SLOTS, ctrl, 1u);
+                           info_q, slot_q, first_q, list, a.R * I8_ROW_SLOTS, ctrl, 1u, static_cast<I8RowMeta *>(nullptr));
         HG_HIP(c, hipGetLastError());
       }
     }
@@ -1601,7 +1655,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     else g.pre_c = (float)((double)g.j_lo / (1.0 + (double)g.j_lo) * (1.0 - 1e-5)), g.pre_b = 0.f;
     g.info_r = info_r, g.info_q = info_q, g.slot_r = slot_r, g.slot_q = slot_q, g.ents = list;
     g.first_r = first_r, g.first_q = first_q, g.ent_cap = ent_cap, g.i8verdict = ctrl + 4;
-    g.raw_r = a.ref_hv, g.raw_q = a.qry_hv, g.i8ctrl = ctrl, g.hv_d = a.hv_d, g.same_set = same ? 1u : 0u;
+    g.raw_q = a.qry_hv, g.ref_index = a.ref_index, g.i8ctrl = ctrl, g.hv_d = a.hv_d, g.same_set = same ? 1u : 0u;
     int nt = 4;
     {
       const uint64_t tm = (a.R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
@@ -1633,6 +1687,10 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
       HG_HIP(c, hipGetLastError());
     }
     veto = ctrl + 4;
+    if (ops_given) {  // (nothing to fall back on: the caller reads the verdict)
+      if (speculated) *speculated = -3;
+      return HG_OK;
+    }
     // The previous call on exactly these operands took the i8 path: the f16 fallback chain (five launches that would
     // all return at once) is not queued again.  Should the verdict come back negative after all, the caller reruns
     // the statistics-driven f16 schedule (*speculated == -2).
@@ -1834,6 +1892,27 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     spec_cover = 2;
   }
   if (speculated) *speculated = spec_cover;
+  return HG_OK;
+}
+
+// ---- operands prepared where the rows live (sharded callers) ---------------------------------------------------------
+size_t hg_dist_ops_row_bytes_impl(uint32_t hv_d) { return (size_t)((hv_d + 127) / 128 * 128) + 128; }
+size_t hg_dist_ops_meta_bytes_impl() { return sizeof(I8RowMeta); }
+size_t hg_dist_ops_padded_rows_impl(size_t n) {
+  return std::max(std::max((n + 255) / 256 * 256, (n + 319) / 320 * 320), (n + 191) / 192 * 192);
+}
+hg_status hg_run_dist_prep_ops(hg_ctx *c, const int16_t *d_hv, uint32_t rows, uint32_t hv_d, uint8_t *d_ops, void *d_meta,
+                               uint32_t *d_flag) {
+  if (hv_d > 8192 || hv_d % 8) return hg_fail(c, HG_ERR_UNSUPPORTED, "prepared operands need hv_d <= 8192, hv_d % 8 == 0");
+  const uint32_t kp8 = (hv_d + 127) / 128 * 128, ldk8 = kp8 + 128;
+  HG_HIP(c, hipMemsetAsync(d_flag, 0, sizeof(uint32_t), c->stream));
+  hg_timed tmp(c, HG_T_DIST_PREP);
+  // (ctrl[1] is where the kernel ORs its failure bits: the caller's flag word)
+  hipLaunchKernelGGL(prep_i8_kernel, dim3((rows + 3) / 4), dim3(256), 0, c->stream, d_hv, rows, hv_d, kp8, ldk8,
+                     reinterpret_cast<int8_t *>(d_ops), static_cast<int32_t *>(nullptr), static_cast<int32_t *>(nullptr),
+                     static_cast<uint32_t *>(nullptr), static_cast<I8Outlier *>(nullptr), 0u, d_flag - 1, 0u,
+                     static_cast<I8RowMeta *>(d_meta));
+  HG_HIP(c, hipGetLastError());
   return HG_OK;
 }
 

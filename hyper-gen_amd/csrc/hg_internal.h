@@ -229,7 +229,20 @@ struct hg_dist_args {
   float ani_th;
   int symmetric;
   uint32_t ref_off = 0, qry_off = 0;  // global indices of row 0 / column 0 when the call is a block of a larger matrix
+  // the reference side as prepared byte operands (hg_dist_prep_ops_dev on the GPUs that own the rows, gathered by the caller):
+  // ref_hv is unused then.  ref_ops: hg_dist_ops_padded_rows(R) rows of hg_dist_ops_row_bytes(hv_d); ref_meta: R records of
+  // hg_dist_ops_meta_bytes(); ref_flags: the owners' n_flags failure words; ref_index: optional global index per row
+  const uint8_t *ref_ops = nullptr;
+  const void *ref_meta = nullptr;
+  const uint32_t *ref_flags = nullptr;
+  uint32_t n_flags = 0;
+  const uint32_t *ref_index = nullptr;
 };
+size_t hg_dist_ops_row_bytes_impl(uint32_t hv_d);
+size_t hg_dist_ops_meta_bytes_impl();
+size_t hg_dist_ops_padded_rows_impl(size_t n);
+hg_status hg_run_dist_prep_ops(hg_ctx *c, const int16_t *d_hv, uint32_t rows, uint32_t hv_d, uint8_t *d_ops, void *d_meta,
+                               uint32_t *d_flag);
 // d_verdict (two uint32: code, window length) != nullptr allows the speculative schedule: prepass, on-device
 // exactness verdict (0 = one f32 window covers K; 1 / 2 = windows of 2 048 / 1 024 dims; 3 = neither) and the
 // GEMM launches guarded by it are queued without a host round trip.  *speculated = -1 if the call was not

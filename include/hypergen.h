@@ -219,6 +219,33 @@ hg_status hg_dist_block_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t 
                             size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
                             hg_ani_hit *d_out, size_t cap, size_t *n_out);
 
+/* ---- sharded dist: reference operands prepared where the rows live -----------------------------------
+ * hg_dist_block_dev needs every reference row as i16 (8 KiB at D = 4096) and converts ALL of them to its byte operands
+ * itself: with the references spread over N GPUs that is an exchange of R x D x 2 bytes and an N-fold repeated prepass.
+ * Here the rank that OWNS a row prepares it once -- hg_dist_prep_ops_dev: the centred byte operand (src/hd.rs:29,84-87:
+ * hv = 2 * count - n, so (hv + e) >> 1 fits a byte), 4 KiB + 128 at D = 4096, and a 72-byte control record -- and the
+ * exchange moves those (half the bytes; the reference's i16 rows never travel).  hg_dist_block_ops_dev is
+ * hg_dist_block_dev with the reference side given that way; the query side is still the caller's own i16 rows.
+ *   d_ops   : rows x hg_dist_ops_row_bytes(hv_d) bytes;  d_meta : rows x hg_dist_ops_meta_bytes() bytes (opaque);
+ *   d_flag  : ONE device word per prepared block: 0 = every row fits the byte scheme.  The consumer passes the flag
+ *             words of all blocks it gathered (d_flags, n_flags).
+ *   d_ref_ops (consumer): room for hg_dist_ops_padded_rows(R) rows -- the tiles overhang, the call zeroes the rows behind R.
+ *   d_ref_index: NULL (row i is global reference ref_off + i) or the global index of every row, for a gathered block
+ *             whose rows are not one contiguous range (chunked exchanges); not with `symmetric`.
+ * Returns HG_ERR_INEXACT, with nothing reported, when an owner's flag is set or the call's own query rows do not fit
+ * the scheme (sketches beyond ~6 000 hashes at D = 4096): the caller then gathers the i16 rows and uses
+ * hg_dist_block_dev -- same hits either way.  hv_d <= 8192, hv_d % 8 == 0. */
+size_t hg_dist_ops_row_bytes(uint32_t hv_d);
+size_t hg_dist_ops_meta_bytes(void);
+size_t hg_dist_ops_padded_rows(size_t rows);
+hg_status hg_dist_prep_ops_dev(hg_ctx *ctx, const int16_t *d_hv, size_t rows, uint32_t hv_d, uint8_t *d_ops,
+                               uint8_t *d_meta, uint32_t *d_flag);
+hg_status hg_dist_block_ops_dev(hg_ctx *ctx, const uint8_t *d_ref_ops, const uint8_t *d_ref_meta, const int32_t *d_ref_norm2,
+                                size_t R, size_t ref_off, const uint32_t *d_ref_index, const uint32_t *d_flags,
+                                size_t n_flags, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
+                                size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
+                                hg_ani_hit *d_out, size_t cap, size_t *n_out);
+
 /* Which exact operand path the last hg_dist / hg_dist_dev / hg_dist_block_dev call of this ctx took (all give the same
  * integers): 0 = f16 operands on v_mfma_f32_16x16x32_f16 (exact f32 windows), 1 = centred i8 operands on
  * v_mfma_i32_16x16x64_i8 (sketches of up to ~6 000 hashes at D = 4096; decided on the device), 2 = integer VALU fallback;
