@@ -54,6 +54,8 @@ def parse():
                     help="initialise the process group and run the all-gather / broadcast steps even with ONE rank "
                          "(a one-GPU box then executes the RCCL code path of the N > 1 run)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-chunks", type=int, default=2,
+                    help="row chunks per rank of the dist leg's operand exchange (chunk c + 1 travels under the GEMM of chunk c)")
     return ap.parse_args()
 
 
@@ -618,29 +620,80 @@ def main():
         mine_n2 = (mine.int() ** 2).sum(1).int()
         cap = max(1 << 20, rows * R // 20)
         hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)  # hg_ani_hit = 12 bytes
+        R_all = rows * world
         if coll:
-            ref_all = torch.empty((R // world * world, HV_D), dtype=torch.int16, device=dev)
-            ref_n2 = torch.empty(R // world * world, dtype=torch.int32, device=dev)
+            ref_all = torch.empty((R_all, HV_D), dtype=torch.int16, device=dev)
+            ref_n2 = torch.empty(R_all, dtype=torch.int32, device=dev)
+            # The exchange moves PREPARED operands: every rank converts its own reference rows to centred byte operands +
+            # control records once (hg_dist_prep_ops_dev) and all-gathers those -- 4.3 KB per row instead of 8 KB of i16, and
+            # no rank repeats another rank's prepass.  The rows travel in `chunks` row blocks per rank; the GEMM of chunk c
+            # (all ranks' block c x this rank's query rows, global reference indices through an index map) runs while
+            # chunk c + 1 is in flight.  A veto on any rank (sketches that do not fit the byte scheme) falls back to the
+            # all-gather of the i16 rows for that step.
+            chunks = max(1, min(a.dist_chunks, rows))
+            rb_, mb_ = hg.lib().hg_dist_ops_row_bytes(HV_D), hg.lib().hg_dist_ops_meta_bytes()
+            my_ops = torch.empty((rows, rb_), dtype=torch.uint8, device=dev)
+            my_meta = torch.empty((rows, mb_), dtype=torch.uint8, device=dev)
+            my_flag = torch.zeros(4, dtype=torch.int32, device=dev)  # [0] the flag word (+ padding to 16 bytes)
+            cb = [(c * rows // chunks, (c + 1) * rows // chunks) for c in range(chunks)]  # this rank's row range per chunk
+            wbytes = [(hi - lo) * (4 + mb_) + 16 for lo, hi in cb]                         # norms | records | flag
+            ops_all = [torch.zeros((hg.lib().hg_dist_ops_padded_rows((hi - lo) * world), rb_), dtype=torch.uint8, device=dev) for lo, hi in cb]
+            words_all = [torch.empty(world * w, dtype=torch.uint8, device=dev) for w in wbytes]
+            ref_index = [torch.cat([torch.arange(r * rows + lo, r * rows + hi, dtype=torch.int32) for r in range(world)]).to(dev)
+                         for lo, hi in cb]
         found = 0
+        fallbacks = 0
+
+        def gather_bytes(dst, src):
+            """all-gather of raw bytes (RCCL has no int16 datatype and the payloads are opaque); returns a work handle"""
+            if a.backend == "nccl":
+                return torch.distributed.all_gather_into_tensor(dst.view(-1), src.view(-1), async_op=True)
+            h_dst = torch.empty(dst.numel(), dtype=torch.uint8)  # gloo (testing aid): the same collective on host copies
+            torch.distributed.all_gather_into_tensor(h_dst, src.reshape(-1).cpu())
+            dst.view(-1).copy_(h_dst)
+            return None
+
+        def gather_i16():
+            for w in (gather_bytes(ref_all.view(torch.uint8), mine.view(torch.uint8)), gather_bytes(ref_n2.view(torch.uint8), mine_n2.view(torch.uint8))):
+                if w is not None:
+                    w.wait()
 
         def dstep():
-            nonlocal found
-            if coll:  # the path's one exchange step: all-gather the reference HV matrix (RCCL/xGMI)
-                # as raw bytes: RCCL has no int16 datatype and the payload is opaque to the collective
-                if a.backend == "nccl":
-                    torch.distributed.all_gather_into_tensor(ref_all.view(torch.uint8).view(-1),
-                                                             mine.view(torch.uint8).view(-1))
-                    torch.distributed.all_gather_into_tensor(ref_n2, mine_n2)
-                else:  # gloo (testing aid): the same collective on host copies
-                    h_all, h_n2 = torch.empty(ref_all.shape, dtype=torch.int16), torch.empty(ref_n2.shape, dtype=torch.int32)
-                    torch.distributed.all_gather_into_tensor(h_all.view(torch.uint8).view(-1), mine.cpu().view(torch.uint8).view(-1))
-                    torch.distributed.all_gather_into_tensor(h_n2, mine_n2.cpu())
-                    ref_all.copy_(h_all), ref_n2.copy_(h_n2)
-                r, rn, nr = ref_all, ref_n2, ref_all.shape[0]
-            else:
-                r, rn, nr = mine, mine_n2, rows
-            found, _ = ctx.dist_dev(r.data_ptr(), rn.data_ptr(), nr, mine.data_ptr(), mine_n2.data_ptr(), rows,
-                                    HV_D, KSIZE, False, 85.0, hits.data_ptr(), cap)
+            nonlocal found, fallbacks
+            if not coll:
+                found, _ = ctx.dist_dev(mine.data_ptr(), mine_n2.data_ptr(), rows, mine.data_ptr(), mine_n2.data_ptr(), rows,
+                                        HV_D, KSIZE, False, 85.0, hits.data_ptr(), cap)
+                return
+            ctx.dist_prep_ops_dev(mine.data_ptr(), rows, HV_D, my_ops.data_ptr(), my_meta.data_ptr(), my_flag.data_ptr())
+            works = []
+            for c, (lo, hi) in enumerate(cb):  # every chunk's exchange is queued at once, in order
+                words = torch.cat([mine_n2[lo:hi].view(torch.uint8).view(-1), my_meta[lo:hi].view(-1), my_flag.view(torch.uint8)])
+                works.append((gather_bytes(ops_all[c][: (hi - lo) * world], my_ops[lo:hi]), gather_bytes(words_all[c], words)))
+            total, vetoed = 0, False
+            for c, (lo, hi) in enumerate(cb):
+                for w in works[c]:
+                    if w is not None:
+                        w.wait()  # (the compute stream waits; the host does not)
+                m = hi - lo
+                wv = words_all[c].view(world, wbytes[c])
+                n2_c = wv[:, : 4 * m].contiguous().view(torch.int32).view(-1)
+                meta_c = wv[:, 4 * m: 4 * m + m * mb_].contiguous()
+                flags_c = wv[:, 4 * m + m * mb_: 4 * m + m * mb_ + 4].contiguous().view(torch.int32).view(-1)
+                n, st = ctx.dist_block_ops_dev(ops_all[c].data_ptr(), meta_c.data_ptr(), n2_c.data_ptr(), m * world, 0,
+                                               ref_index[c].data_ptr(), flags_c.data_ptr(), world, mine.data_ptr(), mine_n2.data_ptr(),
+                                               rows, rank * rows, HV_D, KSIZE, False, 85.0, hits.data_ptr() + 12 * total, cap - total)
+                if st == hg.ERR_INEXACT:
+                    vetoed = True
+                    break
+                if st != 0:
+                    raise SystemExit("dist hit buffer too small")
+                total += n
+            if vetoed:  # every rank sees the same flags; a query-side veto is this rank's alone -- either way: the i16 rows
+                fallbacks += 1
+                gather_i16()
+                total, st = ctx.dist_block_dev(ref_all.data_ptr(), ref_n2.data_ptr(), R_all, 0, mine.data_ptr(), mine_n2.data_ptr(), rows,
+                                               rank * rows, HV_D, KSIZE, False, 85.0, hits.data_ptr(), cap)
+            found = total
 
         settle(dstep, SETTLE["dist"])
         for _ in range(max(a.warmup, 1)):
@@ -655,6 +708,19 @@ def main():
         ddt = max_over_ranks(time.perf_counter() - t0, world, dev)
         dtm = ctx.timings()
         ctx.enable_timing(False)
+        if coll:  # the prepared-operand exchange against the i16 exchange: same hit set (outside the timed region)
+            got = hits[: 3 * found].view(-1, 3).clone()
+            gather_i16()
+            n16, st16 = ctx.dist_block_dev(ref_all.data_ptr(), ref_n2.data_ptr(), R_all, 0, mine.data_ptr(), mine_n2.data_ptr(), rows,
+                                           rank * rows, HV_D, KSIZE, False, 85.0, hits.data_ptr(), cap)
+            ref16 = hits[: 3 * n16].view(-1, 3)
+
+            def canon(h):
+                k = h[:, 0].long() * (1 << 32) + h[:, 1].long()
+                return h[torch.argsort(k)]
+            if st16 != 0 or n16 != found or not torch.equal(canon(got), canon(ref16)):
+                raise SystemExit("PARITY GATE FAILED: prepared-operand exchange and i16 exchange disagree (%d vs %d hits)" % (found, n16))
+            dstep()  # (the timed path's hits back in `hits` for the gates below)
         pairs = (rows * world) * rows * world  # all ranks together cover R x Q
         # GEMM time per step: the sum of the bracketed launches of the class (an i8 attempt queues its GEMM and, behind
         # it, the vetoed f16 kernels that return at once -- all of it is the price of one pass)
@@ -674,6 +740,11 @@ def main():
             "unit": "M ANI-pairs/sec", "ms_per_step": ddt / a.steps * 1e3, "scaling": "strong",
             "config": {"workload": "%d ref x %d query clustered synthetic HVs (BASELINE configs[3]), thresholded "
                                    "output" % (rows * world, rows * world), "hits_per_rank": int(found)},
+            "exchange": ({"form": "prepared byte operands + control records, all-gathered in %d row chunks per rank, GEMM of chunk c "
+                                  "under the exchange of chunk c + 1" % chunks,
+                          "bytes_per_rank_per_step": int(rows * (rb_ + mb_ + 4) + 16 * chunks), "i16_form_bytes": int(rows * (2 * HV_D + 4)),
+                          "fallbacks_to_i16": fallbacks, "checked_against_i16_exchange": True,
+                          "note": "unmeasured on more than one physical GPU until an 8-GPU node runs it"} if coll else None),
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": dist_traffic, "traffic_source": dist_traffic_src,
                          "kernel": dist_kernel, "operands": "i8" if path == 1 else "f16",
@@ -886,7 +957,7 @@ def main():
         out["parity_gate"] = {"status": "skipped (no CPU leg: N > 1 or --no-cpu-baseline); hamming / 10k / host-fed self-checks ran"}
     if coll:
         out["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
-                              "steps": "all-gather of the reference HV matrix + norms (dist), query broadcast + hit "
+                              "steps": "chunked all-gather of the prepared reference operands + control records (dist), query broadcast + hit "
                                        "gather (hamming), barrier / max-reduce around every timed region"}
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

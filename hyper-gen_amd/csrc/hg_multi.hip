@@ -101,6 +101,9 @@ struct hg_multi {
     hg_ctx::Buf mine, mine_n2;    // this shard's uploaded reference rows (host entry points)
     hg_ctx::Buf qry, qry_n2;      // this shard's query rows (host entry points)
     hg_ctx::Buf hits;             // per-shard hit list
+    // the exchange of PREPARED operands (dist_core_ops): this shard's own rows as byte operands + control records + flag
+    // word, and what it gathers from all owners
+    hg_ctx::Buf ops_mine, meta_mine, flag_mine, ops_all, meta_all, flags_all;
     hipEvent_t ready = nullptr;   // "this shard's published rows are complete"
   };
   std::vector<Shard> sh;
@@ -254,7 +257,8 @@ extern "C" void hg_multi_destroy(hg_multi *m) {
   for (size_t s = 0; s < m->ctx.size(); ++s) {
     (void)hipSetDevice(m->dev[s]);
     hg_multi::Shard &x = m->sh[s];
-    for (hg_ctx::Buf *b : {&x.ref_all, &x.n2_all, &x.mine, &x.mine_n2, &x.qry, &x.qry_n2, &x.hits})
+    for (hg_ctx::Buf *b : {&x.ref_all, &x.n2_all, &x.mine, &x.mine_n2, &x.qry, &x.qry_n2, &x.hits, &x.ops_mine, &x.meta_mine,
+                           &x.flag_mine, &x.ops_all, &x.meta_all, &x.flags_all})
       if (b->p) (void)hipFree(b->p);
   }
   for (size_t s = 0; s < m->sh.size(); ++s)
@@ -371,6 +375,166 @@ hg_status gather_refs(hg_multi *m, const int16_t *const *d_ref, const int32_t *c
   return HG_OK;
 }
 
+// shard lists back to back into the caller's buffer (hit order is unspecified by contract)
+hg_status merge_hits(hg_multi *m, const std::vector<size_t> &found, hg_status st, hg_ani_hit *out, size_t cap, size_t *n_out) {
+  const int ns = (int)m->ctx.size();
+  size_t total = 0;
+  for (int s = 0; s < ns; ++s) total += found[s];
+  if (n_out) *n_out = total;
+  if (st != HG_OK && st != HG_ERR_CAPACITY) return st;
+  if (total > cap) return mfail(m, HG_ERR_CAPACITY, "hit buffer too small");
+  size_t at = 0;
+  for (int s = 0; s < ns; ++s) {
+    if (!found[s]) continue;
+    hg_ctx *c = m->ctx[s];
+    HG_HIP(c, hipSetDevice(m->dev[s]));
+    HG_HIP(c, hipMemcpyAsync(out + at, m->sh[s].hits.p, found[s] * sizeof(hg_ani_hit), hipMemcpyDeviceToHost, c->stream));
+    at += found[s];
+  }
+  for (int s = 0; s < ns; ++s) {
+    HG_HIP(m->ctx[s], hipSetDevice(m->dev[s]));
+    HG_HIP(m->ctx[s], hipStreamSynchronize(m->ctx[s]->stream));
+  }
+  return HG_OK;
+}
+
+// The exchange of PREPARED operands: every shard converts its own reference rows to centred byte operands + 72-byte
+// control records once (hg_dist_prep_ops_dev), and the peers pull those -- 4.3 KB per row at D = 4096 instead of 8 KB of
+// i16, and no shard repeats another shard's prepass.  In the all-vs-all case a shard additionally pulls the i16 rows of
+// its QUERY range that it does not own itself (under `symmetric` the column ranges are balanced by pair count and do not
+// coincide with the row blocks).  Returns HG_ERR_INEXACT, with nothing reported, when an owner's or a query side's rows
+// do not fit the byte scheme: dist_core then runs the i16 exchange.
+hg_status dist_core_ops(hg_multi *m, const int16_t *const *d_ref, const int32_t *const *d_rn, const int16_t *const *d_qry,
+                        const int32_t *const *d_qn, const DistPlan &pl, uint32_t hv_d, uint32_t ksize, int symmetric,
+                        float ani_th, hg_ani_hit *out, size_t cap, size_t *n_out) {
+  const int ns = (int)m->ctx.size();
+  const size_t rb = hg_dist_ops_row_bytes(hv_d), mb = hg_dist_ops_meta_bytes(), row16 = (size_t)hv_d * sizeof(int16_t);
+  std::vector<size_t> found(ns, 0), caps(ns, 0);
+  const bool rccl_mode = m->gather == HG_GATHER_RCCL && !m->comm.empty();
+  // phase 1 (one thread per shard): workspaces, and the shard's own rows prepared on its stream
+  hg_status st = for_each_shard(m, [&](int s) -> hg_status {
+    hg_ctx *c = m->ctx[s];
+    hg_multi::Shard &x = m->sh[s];
+    const size_t rows = pl.rhi[s] - pl.rlo[s], qn_rows = pl.chi[s] - pl.clo[s];
+    HG_HIP(c, hipSetDevice(m->dev[s]));
+    hg_status e;
+    if ((e = hg_ensure(c, x.ops_mine, rows * rb + 64)) != HG_OK) return e;
+    if ((e = hg_ensure(c, x.meta_mine, rows * mb + 64)) != HG_OK) return e;
+    if ((e = hg_ensure(c, x.flag_mine, 64)) != HG_OK) return e;
+    if (qn_rows || rccl_mode) {
+      if ((e = hg_ensure(c, x.ops_all, hg_dist_ops_padded_rows(pl.R) * rb + 64)) != HG_OK) return e;
+      if ((e = hg_ensure(c, x.meta_all, pl.R * mb + 64)) != HG_OK) return e;
+      if ((e = hg_ensure(c, x.n2_all, pl.R * sizeof(int32_t) + 64)) != HG_OK) return e;
+      if ((e = hg_ensure(c, x.flags_all, (size_t)ns * sizeof(uint32_t) + 64)) != HG_OK) return e;
+    }
+    if (!d_qry && qn_rows) {  // all-vs-all: this shard's query rows, assembled below
+      if ((e = hg_ensure(c, x.qry, qn_rows * row16 + 64)) != HG_OK) return e;
+      if ((e = hg_ensure(c, x.qry_n2, qn_rows * sizeof(int32_t) + 64)) != HG_OK) return e;
+    }
+    const unsigned __int128 pairs = (unsigned __int128)pl.R * qn_rows;
+    caps[s] = (size_t)std::min<unsigned __int128>(pairs, cap);
+    if ((e = hg_ensure(c, x.hits, caps[s] * sizeof(hg_ani_hit) + 64)) != HG_OK) return e;
+    HG_HIP(c, hipMemsetAsync(x.flag_mine.p, 0, 16, c->stream));
+    if (rows)
+      return hg_dist_prep_ops_dev(c, d_ref[s], rows, hv_d, static_cast<uint8_t *>(x.ops_mine.p), static_cast<uint8_t *>(x.meta_mine.p),
+                                  static_cast<uint32_t *>(x.flag_mine.p));
+    return HG_OK;
+  });
+  if (st != HG_OK) return st;
+  // phase 2 (this thread): the exchange, queued on the pullers' streams behind the owners' "ready" events
+  size_t peer_bytes = 0;
+  bool equal = true;
+  for (int t = 1; t < ns; ++t) equal = equal && (pl.rhi[t] - pl.rlo[t]) == (pl.rhi[0] - pl.rlo[0]);
+  if (rccl_mode) {
+    const RcclApi &r = rccl();
+    ncclResult_t e = r.GroupStart();
+    for (int s = 0; s < ns && e == ncclSuccess; ++s) {
+      if (hipSetDevice(m->dev[s]) != hipSuccess) {
+        e = ncclSystemError;
+        break;
+      }
+      hg_multi::Shard &x = m->sh[s];
+      hipStream_t stq = m->ctx[s]->stream;
+      auto *oa = static_cast<uint8_t *>(x.ops_all.p), *ma = static_cast<uint8_t *>(x.meta_all.p);
+      auto *na = static_cast<int32_t *>(x.n2_all.p);
+      auto *fa = static_cast<uint32_t *>(x.flags_all.p);
+      if (equal) {
+        const size_t rows = pl.rhi[s] - pl.rlo[s];
+        e = r.AllGather(x.ops_mine.p, oa, rows * rb, ncclUint8, m->comm[s], stq);
+        if (e == ncclSuccess) e = r.AllGather(x.meta_mine.p, ma, rows * mb, ncclUint8, m->comm[s], stq);
+        if (e == ncclSuccess) e = r.AllGather(d_rn[s], na, rows * sizeof(int32_t), ncclUint8, m->comm[s], stq);
+      } else {
+        for (int t = 0; t < ns && e == ncclSuccess; ++t) {
+          const size_t rows = pl.rhi[t] - pl.rlo[t];
+          if (!rows) continue;
+          e = r.Broadcast(x.ops_mine.p, oa + pl.rlo[t] * rb, rows * rb, ncclUint8, t, m->comm[s], stq);
+          if (e == ncclSuccess) e = r.Broadcast(x.meta_mine.p, ma + pl.rlo[t] * mb, rows * mb, ncclUint8, t, m->comm[s], stq);
+          if (e == ncclSuccess) e = r.Broadcast(d_rn[s], na + pl.rlo[t], rows * sizeof(int32_t), ncclUint8, t, m->comm[s], stq);
+        }
+      }
+      if (e == ncclSuccess) e = r.AllGather(x.flag_mine.p, fa, sizeof(uint32_t), ncclUint8, m->comm[s], stq);
+    }
+    const ncclResult_t e2 = r.GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return mfail(m, HG_ERR_HIP, std::string("RCCL all-gather: ") + r.GetErrorString(e));
+  }
+  for (int s = 0; s < ns; ++s)
+    if (hipSetDevice(m->dev[s]) != hipSuccess || hipEventRecord(m->sh[s].ready, m->ctx[s]->stream) != hipSuccess)
+      return mfail(m, HG_ERR_HIP, "hg_dist_multi: event record failed");
+  for (int s = 0; s < ns; ++s) {
+    const size_t qn_rows = pl.chi[s] - pl.clo[s];
+    if (!qn_rows) continue;
+    hg_ctx *c = m->ctx[s];
+    hg_multi::Shard &x = m->sh[s];
+    HG_HIP(c, hipSetDevice(m->dev[s]));
+    for (int t = 0; t < ns; ++t) {
+      const size_t rows = pl.rhi[t] - pl.rlo[t];
+      if (!rows) continue;
+      if (t != s) HG_HIP(c, hipStreamWaitEvent(c->stream, m->sh[t].ready, 0));
+      if (!rccl_mode) {
+        HG_HIP(c, peer_copy(m, s, static_cast<uint8_t *>(x.ops_all.p) + pl.rlo[t] * rb, t, m->sh[t].ops_mine.p, rows * rb));
+        HG_HIP(c, peer_copy(m, s, static_cast<uint8_t *>(x.meta_all.p) + pl.rlo[t] * mb, t, m->sh[t].meta_mine.p, rows * mb));
+        HG_HIP(c, peer_copy(m, s, static_cast<int32_t *>(x.n2_all.p) + pl.rlo[t], t, d_rn[t], rows * sizeof(int32_t)));
+        HG_HIP(c, peer_copy(m, s, static_cast<uint32_t *>(x.flags_all.p) + t, t, m->sh[t].flag_mine.p, sizeof(uint32_t)));
+        if (m->dev[s] != m->dev[t]) peer_bytes += rows * (rb + mb + 4);
+      }
+      if (!d_qry) {  // all-vs-all: the part of this shard's query range that owner t holds, as i16 rows
+        const size_t lo = std::max(pl.clo[s], pl.rlo[t]), hi = std::min(pl.chi[s], pl.rhi[t]);
+        if (lo < hi) {
+          HG_HIP(c, peer_copy(m, s, static_cast<int16_t *>(x.qry.p) + (lo - pl.clo[s]) * (size_t)hv_d, t,
+                              d_ref[t] + (lo - pl.rlo[t]) * (size_t)hv_d, (hi - lo) * row16));
+          HG_HIP(c, peer_copy(m, s, static_cast<int32_t *>(x.qry_n2.p) + (lo - pl.clo[s]), t, d_rn[t] + (lo - pl.rlo[t]),
+                              (hi - lo) * sizeof(int32_t)));
+          if (m->dev[s] != m->dev[t]) peer_bytes += (hi - lo) * (row16 + 4);
+        }
+      }
+    }
+  }
+  // phase 3 (one thread per shard): (all refs, as gathered operands) x (this shard's query rows)
+  std::vector<hg_status> sst(ns, HG_OK);
+  st = for_each_shard(m, [&](int s) -> hg_status {
+    hg_ctx *c = m->ctx[s];
+    hg_multi::Shard &x = m->sh[s];
+    const size_t qn_rows = pl.chi[s] - pl.clo[s];
+    if (qn_rows == 0) return HG_OK;
+    HG_HIP(c, hipSetDevice(m->dev[s]));
+    const int16_t *q_hv = d_qry ? d_qry[s] : static_cast<const int16_t *>(x.qry.p);
+    const int32_t *q_n2 = d_qry ? d_qn[s] : static_cast<const int32_t *>(x.qry_n2.p);
+    sst[s] = hg_dist_block_ops_dev(c, static_cast<const uint8_t *>(x.ops_all.p), static_cast<const uint8_t *>(x.meta_all.p),
+                                   static_cast<const int32_t *>(x.n2_all.p), pl.R, 0, nullptr,
+                                   static_cast<const uint32_t *>(x.flags_all.p), (size_t)ns, q_hv, q_n2, qn_rows, pl.clo[s], hv_d,
+                                   ksize, symmetric, ani_th, static_cast<hg_ani_hit *>(x.hits.p), caps[s], &found[s]);
+    return sst[s] == HG_ERR_INEXACT ? HG_OK : sst[s];
+  });
+  for (int s = 0; s < ns; ++s)
+    if (sst[s] == HG_ERR_INEXACT) return HG_ERR_INEXACT;  // (an owner's veto is seen by every shard; a query side's by its own)
+  m->gather_report = (rccl_mode ? std::string("rccl ") + (equal ? "ncclAllGather" : "grouped ncclBroadcast") + " over " + std::to_string(ns) + " ranks"
+                                : std::string("peer pulls (hipMemcpyPeerAsync)")) + ", prepared byte operands + control records: " +
+                     std::to_string(pl.R * (rb + mb + 4)) + " B per shard instead of " + std::to_string(pl.R * (row16 + 4)) +
+                     " B of i16 rows, " + std::to_string(peer_bytes) + " B between distinct devices; " + m->peer_report;
+  return merge_hits(m, found, st, out, cap, n_out);
+}
+
 // d_ref / d_rn: shard s's reference rows on its device.  d_qry == nullptr: all-vs-all on the gathered matrix.
 hg_status dist_core(hg_multi *m, const int16_t *const *d_ref, const int32_t *const *d_rn, const int16_t *const *d_qry,
                     const int32_t *const *d_qn, const DistPlan &pl, uint32_t hv_d, uint32_t ksize, int symmetric,
@@ -378,6 +542,14 @@ hg_status dist_core(hg_multi *m, const int16_t *const *d_ref, const int32_t *con
   const int ns = (int)m->ctx.size();
   const size_t row_bytes = (size_t)hv_d * sizeof(int16_t);
   DrainOnExit drain_guard{m};  // every return below leaves all shard streams idle
+  // the exchange of prepared operands first (half the bytes, no repeated prepass); a veto -- sketches that do not fit the
+  // byte scheme -- or the "f16" hook on shard 0 brings the i16 exchange below
+  if (hv_d <= 8192 && hv_d % 8 == 0 && m->ctx[0]->dbg_dist_path != "f16") {
+    const hg_status os = dist_core_ops(m, d_ref, d_rn, d_qry, d_qn, pl, hv_d, ksize, symmetric, ani_th, out, cap, n_out);
+    if (os != HG_ERR_INEXACT) return os;
+    drain(m);
+    if (n_out) *n_out = 0;
+  }
   std::vector<size_t> found(ns, 0), caps(ns, 0);
   std::vector<int16_t *> g_hv(ns, nullptr);
   std::vector<int32_t *> g_n2(ns, nullptr);
@@ -414,25 +586,7 @@ hg_status dist_core(hg_multi *m, const int16_t *const *d_ref, const int32_t *con
     return hg_dist_block_dev(c, g_hv[s], g_n2[s], pl.R, 0, q_hv, q_n2, qn_rows, pl.clo[s], hv_d, ksize, symmetric, ani_th,
                              static_cast<hg_ani_hit *>(m->sh[s].hits.p), caps[s], &found[s]);
   });
-  size_t total = 0;
-  for (int s = 0; s < ns; ++s) total += found[s];
-  if (n_out) *n_out = total;
-  if (st != HG_OK && st != HG_ERR_CAPACITY) return st;
-  if (total > cap) return mfail(m, HG_ERR_CAPACITY, "hit buffer too small");
-  // merge: shard lists back to back (hit order is unspecified by contract)
-  size_t at = 0;
-  for (int s = 0; s < ns; ++s) {
-    if (!found[s]) continue;
-    hg_ctx *c = m->ctx[s];
-    HG_HIP(c, hipSetDevice(m->dev[s]));
-    HG_HIP(c, hipMemcpyAsync(out + at, m->sh[s].hits.p, found[s] * sizeof(hg_ani_hit), hipMemcpyDeviceToHost, c->stream));
-    at += found[s];
-  }
-  for (int s = 0; s < ns; ++s) {
-    HG_HIP(m->ctx[s], hipSetDevice(m->dev[s]));
-    HG_HIP(m->ctx[s], hipStreamSynchronize(m->ctx[s]->stream));
-  }
-  return HG_OK;
+  return merge_hits(m, found, st, out, cap, n_out);
 }
 
 // column ranges of the all-vs-all case: by pair count under `symmetric` (column j pairs with j rows)

@@ -65,6 +65,8 @@ def test_bench_two_ranks_share_one_gpu():
     assert j["n_gpus"] == 2 and j["value"] > 0 and "cpu_baseline" not in j
     assert j["sketch_10k"]["config"]["genomes_per_gpu"] == 25 and j["sketch_10k"]["scaling"] == "strong"
     assert j["dist"]["value"] > 0 and j["dist"]["config"]["hits_per_rank"] > 0
+    ex = j["dist"]["exchange"]  # prepared byte operands, chunked; checked against the i16 exchange inside the run
+    assert ex["checked_against_i16_exchange"] and ex["fallbacks_to_i16"] == 0 and ex["bytes_per_rank_per_step"] < 0.6 * ex["i16_form_bytes"]
     assert j["hamming"]["config"]["hits_merged"] == 300 and j["hamming"]["config"]["refs_per_rank"] == 3001
 
 

@@ -124,6 +124,36 @@ def test_hg_multi_dev_resident_shards_larger(hg):
         assert found > 1000 and np.array_equal(_key(got), _key(want))
 
 
+def test_hg_multi_exchanges_prepared_operands_and_falls_back_to_i16_rows(hg):
+    """the exchange step moves byte operands + control records prepared by the shard that owns the rows (half the bytes of
+    the i16 rows); rows that do not fit the byte scheme -- on an owner's or on a query side -- bring the i16 exchange, and
+    so does the "f16" hook on shard 0: identical hits every way"""
+    import bench
+    dev = torch.device("cuda:0")
+    n = 2400
+    hv = bench.clustered_hvs(n, 0, dev).clone()
+    for case in ("clean", "dirty", "hook"):
+        if case == "dirty":
+            hv[2000, 9] += 1  # mixed parity: no centred byte form for this row
+        n2 = (hv.int() ** 2).sum(1).int()
+        with hg.Context(0) as one, hg.Multi([0, 0, 0]) as m:
+            if case == "hook":
+                hg.lib().hg_ctx_set_debug(m.ctx_handle(0), b"dist_path", b"f16")
+            rows = [900, 700, 800]
+            cuts = [0, 900, 1600, 2400]
+            parts = [(hv[a:b].contiguous(), n2[a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])]
+            for sym in (False, True):
+                out = torch.zeros(3 * 300_000, dtype=torch.int32, device=dev)
+                found, st = one.dist_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, sym, 85.0,
+                                         out.data_ptr(), 300_000)
+                want = out[: 3 * found].cpu().numpy().view(hg.ANI_HIT_DTYPE)
+                got = m.dist_dev([x[0].data_ptr() for x in parts], [x[1].data_ptr() for x in parts], rows, None, None, None,
+                                 D, 21, sym, 85.0, cap=300_000)
+                assert found > 5_000 and np.array_equal(_key(got), _key(want)), (case, sym)
+                rep = m.gather_report()
+                assert ("prepared byte operands" in rep) == (case == "clean"), (case, rep)
+
+
 def test_hg_multi_hamming_search_sharded_refs(hg, orc):
     rng = np.random.default_rng(77)
     HD, R, Q = 2048, 1501, 64
