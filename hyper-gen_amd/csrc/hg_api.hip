@@ -83,7 +83,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort, &c->w_redo, &c->w_pk, &c->w_pktab,
-                         &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2,
+                         &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2, &c->w_cen,
                          &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -1041,9 +1041,16 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   } else {
     c->i8_sig_ref = c->i8_sig_qry = nullptr;
   }
-  // no guarded launch applied (or the f16 chain was not queued behind a trusted i8 attempt that failed after all):
-  // statistics-driven schedule
-  if (h_res[8] != 1u && (spec_cover == -2 || (spec_cover >= 0 && (int)h_res[1] > spec_cover))) {
+  if (h_res[8] == 2u) {  // the centred f16 kernel did the work
+    c->last_dist_path = 3;
+    c->last_kernel[HG_T_DIST] = c->last_kernel_cen;
+    c->cen_sig_ref = d_ref_hv, c->cen_sig_qry = d_qry_hv, c->cen_sig_r = (uint32_t)R, c->cen_sig_q = (uint32_t)Q, c->cen_sig_d = hv_d;
+  } else {
+    c->cen_sig_ref = c->cen_sig_qry = nullptr;
+  }
+  // no guarded launch applied (or the raw f16 chain was not queued behind a trusted i8 / centred attempt that failed after
+  // all): statistics-driven schedule
+  if (h_res[8] == 0u && (spec_cover == -2 || (spec_cover >= 0 && (int)h_res[1] > spec_cover))) {
     HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
     if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;

@@ -42,10 +42,14 @@ struct hg_ctx {
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
+  Buf w_cen;                   // centred f16 path: row / column info words, statistics slots, failure + verdict words
+  std::string last_kernel_cen; // name of the last centred f16 GEMM queued (it is the DIST kernel when its verdict was positive)
+  const void *cen_sig_ref = nullptr, *cen_sig_qry = nullptr;  // operands of the last call that ran on centred f16 operands
+  uint32_t cen_sig_r = 0, cen_sig_q = 0, cen_sig_d = 0;
   int last_ham_path = -1;       // last Hamming search: 0 xor + popcount kernel, 1 +-1 byte GEMM (i8), 2 +-1.0 e2m1 GEMM (FP4)
   std::string last_kernel[HG_T_COUNT];  // name of the last kernel launched per timing class (hg_ctx_last_kernel)
   std::string last_kernel_i8;           // ... of the last i8 operand attempt (it is the DIST kernel when the attempt was valid)
-  int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA, 1 i8 MFMA, 2 integer VALU
+  int last_dist_path = -1;      // operand path of the last thresholded dist call: 0 f16 MFMA (raw values), 1 i8 MFMA, 2 integer VALU, 3 f16 MFMA on centred counts
   const void *i8_sig_ref = nullptr, *i8_sig_qry = nullptr;  // operands of the last call that took the i8 path
   uint32_t i8_sig_r = 0, i8_sig_q = 0, i8_sig_d = 0;
   uint32_t i8_skip = 0;         // calls left that skip the i8 attempt after it was vetoed

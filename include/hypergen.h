@@ -65,7 +65,8 @@ hg_status hg_ctx_sync(hg_ctx *ctx);
 int hg_device_count(void);
 /* development / test hook (no reference counterpart): force an internal code path of THIS ctx.
  * keys: "dist_tile" = "" | "small" | "big" | "wide"      (GEMM tile geometry)
- *       "dist_path" = "" | "f16" | "i8"                    (operand format of the ANI GEMM)
+ *       "dist_path" = "" | "f16" | "i8" | "cen"            (operand format of the ANI GEMM: raw values as f16 only / try byte
+ *                                                           operands / try centred counts as f16 -- also on small problems)
  *       "dist_order" = "" | "plain"                        ("plain": a self-comparison does not run its diagonal tiles first)
  *       "ham_path"  = "" | "popc" | "mfma" | "fp4"         (Hamming search: xor + popcount, +-1 byte GEMM, +-1 e2m1 GEMM)
  *       "kmer_input" = "" | "packed"                       ("packed": batches that arrive as ASCII are 2-bit packed on the
@@ -87,7 +88,7 @@ hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
 hg_status hg_ctx_enable_timing(hg_ctx *ctx, int on);
 hg_status hg_ctx_timings(hg_ctx *ctx, float ms_sum[HG_T_COUNT], uint32_t launches[HG_T_COUNT]);
 /* name of the kernel the last call launched for timing class `cls` (HG_T_KMER, HG_T_DIST), spelled as rocprofv3
- * prints it ("kmer_sample_shared<21, true, false>", "dist_mfma_kernel<false, false, true, true, 5, true, false, false>");
+ * prints it ("kmer_sample_shared<21, true, false>", "dist_mfma_kernel<false, false, true, true, 5, true, false, false, false>");
  * "" if none.  A measurement harness uses it to check that a committed profile belongs to the kernel that ran. */
 const char *hg_ctx_last_kernel(const hg_ctx *ctx, int cls);
 
@@ -247,9 +248,10 @@ hg_status hg_dist_block_ops_dev(hg_ctx *ctx, const uint8_t *d_ref_ops, const uin
                                 hg_ani_hit *d_out, size_t cap, size_t *n_out);
 
 /* Which exact operand path the last hg_dist / hg_dist_dev / hg_dist_block_dev call of this ctx took (all give the same
- * integers): 0 = f16 operands on v_mfma_f32_16x16x32_f16 (exact f32 windows), 1 = centred i8 operands on
- * v_mfma_i32_16x16x64_i8 (sketches of up to ~6 000 hashes at D = 4096; decided on the device), 2 = integer VALU fallback;
- * -1 = none yet. */
+ * integers): 0 = the raw values as f16 operands on v_mfma_f32_16x16x32_f16 (exact f32 windows), 1 = centred i8 operands on
+ * v_mfma_i32_16x16x64_i8 (sketches of up to ~6 000 hashes at D = 4096; decided on the device), 2 = integer VALU fallback,
+ * 3 = the centred counts as f16 operands (one exact f32 window up to ~16 000 hashes per sketch at D = 4096: where byte
+ * operands stop); -1 = none yet. */
 int hg_ctx_last_dist_path(const hg_ctx *ctx);
 
 /* order of dump_ani_file (src/utils.rs:262-269): stable ascending sort by ANI over the

@@ -783,6 +783,47 @@ def test_dist_i8_reach_mid_size_sketches(ctx, orc, n, expect_i8):
     assert (got[sel] > 0).all() and np.abs(got[sel] - want[sel]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("n,expect", [(7000, 3), (12000, 3), (15000, 3), (20000, 0)])
+def test_dist_centred_f16_operands_for_large_sketches(ctx, orc, n, expect):
+    """Sketches beyond the reach of byte operands (~6 000 hashes at D = 4096): the centred counts (x + e) >> 1 as f16 are
+    exact in ONE f32 accumulation window up to ~15 500 hashes (max row sum c^2 ~ n D / 4 <= 2^24), so they take the whole-K kernel
+    (path 3) -- same hits, bit for bit, as the windowed raw-value path and the oracle's ANI; at 20 000 hashes the bound
+    fails on the device and the raw-value chain queued behind runs (path 0).  A row of mixed parity has no centred form."""
+    rng = np.random.default_rng(n)
+    D, R, Q = 4096, 640, 500
+    base = rng.binomial(int(n * 0.6), 0.5, (5, D))
+    r, q = _sketch_like(rng, R, D, n, base), _sketch_like(rng, Q, D, n, base)
+    rn = np.array([orc.hv_norm2(x) for x in r], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
+    key = lambda h: np.sort(h, order=["ref_idx", "qry_idx"])
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    try:
+        ctx.set_debug("dist_path", "cen")  # (small problem: the automatic choice starts at 256^3 pairs x dims)
+        hc = key(ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=60.0))
+        assert ctx.last_dist_path() == expect
+        if expect == 3:
+            assert ctx.last_kernel("dist").endswith(", true>")  # dist_mfma_kernel<..., CEN = true>
+            hc2 = key(ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=60.0))  # (the repeat: raw chain not queued)
+            assert ctx.last_dist_path() == 3 and np.array_equal(hc, hc2)
+            bad = r.copy()
+            bad[17, 100] += 1  # mixed parity
+            bn = np.array([orc.hv_norm2(x) for x in bad], np.int32)
+            hb = key(ctx.dist(bad, bn, q, qn, 21, symmetric=False, ani_th=60.0))
+            assert ctx.last_dist_path() == 0
+            ctx.set_debug("dist_path", "f16")
+            assert np.array_equal(hb, key(ctx.dist(bad, bn, q, qn, 21, symmetric=False, ani_th=60.0)))
+        ctx.set_debug("dist_path", "f16")
+        h16 = key(ctx.dist(r, rn, q, qn, 21, symmetric=False, ani_th=60.0))
+        assert ctx.last_dist_path() == 0
+    finally:
+        ctx.set_debug("dist_path", "")
+    assert hc.size == h16.size > 1000 and np.array_equal(hc, h16)
+    got = np.zeros_like(want)
+    got[hc["ref_idx"], hc["qry_idx"]] = hc["ani"]
+    sel = want >= 60.0 + 1e-4
+    assert (got[sel] > 0).all() and np.abs(got[sel] - want[sel]).max() <= 1e-4
+
+
 def test_dist_i8_vetoed_inputs_fall_back_to_f16(ctx, orc):
     """Inputs the i8 path must refuse on the device -- a row of mixed parity, a residual beyond a byte, more outlier
     dims than extra columns -- still give the f16 result (the f16 kernels queued behind the attempt run)."""
