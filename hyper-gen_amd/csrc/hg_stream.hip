@@ -246,6 +246,12 @@ struct hg_sketch_stream {
       std::thread th;
     } w[N_WORKERS];
     hipStream_t copy = nullptr;
+    // A second copy stream for the genomes' own uploads, used in turn with `copy`: a copy command costs ~7 us of link
+    // idle time whatever it moves (ASCII 5 MB: 50 GB/s; hg_pack2 1.9 MB: 42; hg_pack2s 1.25 MB: 36 -- the bench's
+    // packed_stream legs), and with two queues the command overhead of one runs under the transfer of the other.
+    hipStream_t copy2 = nullptr;
+    hipEvent_t copy2_done = nullptr;  // "everything queued on copy2 for the chunk being handed over"
+    unsigned turn = 0;
     Chunk chunk[N_CHUNKS];
     std::deque<Item> in;
     std::deque<int> free_chunks, full_chunks;
@@ -301,6 +307,8 @@ bool hand_over(hg_sketch_stream *s, Engine &e, int ci) {
   if (!flush_run(s, e, c)) return false;
   if (c.n_jobs) ST_HIP(s, hipMemcpyAsync(c.d_jobs, c.h_jobs, c.n_jobs * sizeof(UnpackJob), hipMemcpyHostToDevice, e.copy));
   if (c.n_sjobs) ST_HIP(s, hipMemcpyAsync(c.d_sjobs, c.h_sjobs, c.n_sjobs * sizeof(SparseJob), hipMemcpyHostToDevice, e.copy));
+  ST_HIP(s, hipEventRecord(e.copy2_done, e.copy2));  // the chunk's uploads on the second stream join the first
+  ST_HIP(s, hipStreamWaitEvent(e.copy, e.copy2_done, 0));
   ST_HIP(s, hipEventRecord(c.uploaded, e.copy));
   std::lock_guard<std::mutex> lk(s->mu);
   e.full_chunks.push_back(ci);
@@ -384,6 +392,7 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
         if (c.pk_bytes + blob + 64 > c.pk_cap) {  // (+ the readable slack behind the last blob) the packed area grows between chunks' uses (nothing of this chunk is in flight
           // unless earlier genomes of it are: wait for their copies before the old block goes away)
           ST_HIP(s, hipStreamSynchronize(e.copy));
+          ST_HIP(s, hipStreamSynchronize(e.copy2));
           uint8_t *nb = nullptr;
           const size_t want = std::max(c.pk_bytes + blob + blob / 8 + 64, (size_t)(CHUNK_BYTES * 3 / 2 + (1u << 20)));  // (a chunk of blobs uploads up to CHUNK_BYTES; sparse ones add their rebuilt bitmaps)
           hipError_t he = hipMalloc(reinterpret_cast<void **>(&nb), want);
@@ -401,7 +410,7 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
           ST_HIP(s, hipHostMalloc(reinterpret_cast<void **>(&c.h_sjobs), CHUNK_GENOMES * sizeof(SparseJob), hipHostMallocDefault));
           ST_HIP(s, hipMalloc(reinterpret_cast<void **>(&c.d_sjobs), CHUNK_GENOMES * sizeof(SparseJob)));
         }
-        ST_HIP(s, hipMemcpyAsync(c.dpk + c.pk_bytes, it.seq, up, hipMemcpyHostToDevice, e.copy));
+        ST_HIP(s, hipMemcpyAsync(c.dpk + c.pk_bytes, it.seq, up, hipMemcpyHostToDevice, (e.turn++ & 1u) ? e.copy2 : e.copy));
         const uint64_t mask_off = c.pk_bytes + (blob - mbytes);
         UnpackJob &jb = c.h_jobs[c.n_jobs++];
         jb.pk_off = c.pk_bytes, jb.out_off = c.bytes, jb.n_bps = it.len, jb.mask_off = mask_off, jb.first_block = c.n_blocks, jb.pad = 0;
@@ -422,7 +431,7 @@ void uploader(hg_sketch_stream *s, Engine *ep) {
           c.run_hi = c.bytes + padded;
         } else {
           if (!flush_run(s, e, c)) return false;
-          ST_HIP(s, hipMemcpyAsync(c.d + c.bytes, it.seq, it.len, hipMemcpyHostToDevice, e.copy));
+          ST_HIP(s, hipMemcpyAsync(c.d + c.bytes, it.seq, it.len, hipMemcpyHostToDevice, (e.turn++ & 1u) ? e.copy2 : e.copy));
         }
       }
       e.t_up_copy += now_s() - tc;
@@ -537,6 +546,7 @@ void destroy(hg_sketch_stream *s) {
     }
     (void)hipSetDevice(e->device);
     if (e->copy) (void)hipStreamSynchronize(e->copy);
+    if (e->copy2) (void)hipStreamSynchronize(e->copy2);
     for (Chunk &c : e->chunk) {
       if (c.d) (void)hipFree(c.d);
       if (c.stage) (void)hipHostFree(c.stage);
@@ -552,6 +562,8 @@ void destroy(hg_sketch_stream *s) {
       if (w.h_res) (void)hipHostFree(w.h_res);
     }
     if (e->copy) (void)hipStreamDestroy(e->copy);
+    if (e->copy2) (void)hipStreamDestroy(e->copy2);
+    if (e->copy2_done) (void)hipEventDestroy(e->copy2_done);
     for (auto &w : e->w)
       if (w.ctx) hg_ctx_destroy(w.ctx);
     delete e;
@@ -585,6 +597,8 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
     if (st == HG_OK) {
       if ((he = hipSetDevice(e->device)) == hipSuccess)
         he = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
+      if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy2, hipStreamNonBlocking);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&e->copy2_done, hipEventDisableTiming);
       for (int k = 0; k < N_CHUNKS && he == hipSuccess; ++k) {
         if ((he = hipMalloc(reinterpret_cast<void **>(&e->chunk[k].d), CHUNK_BYTES + 64)) == hipSuccess)
           e->chunk[k].cap = CHUNK_BYTES + 64, he = hipEventCreateWithFlags(&e->chunk[k].uploaded, hipEventDisableTiming);

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/tools/dist_only.py --reps 4"
+CMD="python3 $ROOT/tools/dist_only.py --reps 4 ${HG_DIST_ARGS:-}"
 export HG_PROFILE_COMMAND="$CMD"
 # kernel-trace + stats pass first (its own run: --pmc passes carry only --kernel-trace)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1 || echo "stats pass failed" >> "$OUT/errors.txt"

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""profiles/README.md for one round, written from the committed summaries themselves (kernel averages from
+<tag>_kernel_stats.csv / <tag>_dist_kernel_stats.csv, the bench line from <tag>_bench_line.json) -- no hand-typed numbers.
+usage: tools/profiles_readme.py <tag>"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+
+
+def table(name, top=14):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return ["(no `%s`)" % name]
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: -int(r["total_ns"]))
+    out = ["| kernel | launches | average ms | fastest ms | slowest ms |", "|---|---|---|---|---|"]
+    for r in rows[:top]:
+        out.append("| `%s` | %s | %.3f | %.3f | %.3f |" % (r["kernel"], r["calls"], float(r["average_ns"]) / 1e6, int(r["min_ns"]) / 1e6,
+                                                           int(r["max_ns"]) / 1e6))
+    return out
+
+
+L = ["# profiles/", "",
+     "Round files are named `rNN_*`; earlier rounds' files stay for comparison.  Every `%s_*.json` carries a `_stamp`: sha256 over the" % tag,
+     "library's sources (`hypergen_amd.source_stamp()`), the kernel names in the file, the profiled command and the commit the summary",
+     "was copied in at; `bench.py` quotes a file's counters only for the same sources and the kernel the library reports it launched.",
+     "**This file is generated** (`tools/profiles_readme.py %s`) from the summaries beside it." % tag, "",
+     "## `%s_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats` of the bench command" % tag, "",
+     "`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --genomes-10k 0",
+     "--hostfed-genomes 0` (`tools/profile_gpu.sh %s`; only the headline shapes are launched, so that per-kernel averages are per shape;" % tag,
+     "profiled passes run at a lower clock than un-profiled ones).", ""]
+L += table(tag + "_kernel_stats.csv")
+L += ["", "## `%s_dist_kernel_stats.csv` -- the dist kernels alone (`tools/profile_dist.sh %sdist`: `python3 tools/dist_only.py --reps 4`, 10 000 x 10 000)" % (tag, tag), ""]
+L += table(tag + "_dist_kernel_stats.csv", 8)
+if os.path.exists(os.path.join(P, tag + "_distf16_kernel_stats.csv")):
+    L += ["", "## `%s_distf16_kernel_stats.csv` -- the same command on large sketches (`--nhash 10000`: centred f16 operands)" % tag, ""]
+    L += table(tag + "_distf16_kernel_stats.csv", 8)
+bl = os.path.join(P, tag + "_bench_line.json")
+if os.path.exists(bl):
+    j = json.load(open(bl))
+    rf = j["roofline"]
+    L += ["", "## `%s_bench_line.json` -- `python bench.py --steps 20 --warmup 3` on the committed sources" % tag, "",
+          "| | |", "|---|---|",
+          "| sketch, packed bases resident | %.0f genomes/s, kernel `%s` %.3f ms / launch = %.4f of the HBM peak (algorithmic L + 2 D bytes) |" % (
+              j["value"], rf["kernel"], rf["launch_ms"], rf["frac"]),
+          "| sketch, ASCII resident | %.0f genomes/s, `%s` %.3f ms |" % (j["ascii_resident"]["value"], j["ascii_resident"]["kernel"], j["ascii_resident"]["launch_ms"])]
+    if "sketch_10k" in j:
+        L.append("| 10 000 genomes on one GPU | %.0f genomes/s |" % j["sketch_10k"]["value"])
+    if "host_fed" in j:
+        hf = j["host_fed"]
+        L.append("| host-fed (PCIe) | ASCII %.0f genomes/s; 2-bit packed stream %.0f (sparse form, %.3f B/base) / %.0f (bitmap form) |" % (
+            hf["value"], hf["packed_stream"]["value"], hf["packed_stream"]["bytes_per_base"], hf["packed_stream"]["bitmap_form"]["value"]))
+    if "dist" in j:
+        d = j["dist"]
+        L.append("| dist 10 000 x 10 000 | %.0f M pairs/s, GEMM %.3f ms = %.3f of the %s peak |" % (
+            d["value"], d["roofline"]["launch_ms"], d["roofline"]["frac"], d["roofline"]["peak_dtype"]))
+    if "hamming" in j:
+        h = j["hamming"]
+        L.append("| Hamming search 50 000 x 10 000 x 16384 | %.0f M pairs/s |" % h["value"])
+L += ["", "## the other files", "",
+      "| file | what | made by |", "|---|---|---|",
+      "| `%s_rocprofv3_kernel_stats_full.csv` | the unfiltered `--stats` table of the bench command | `tools/profile_gpu.sh %s` |" % (tag, tag),
+      "| `%s_pmc.json`, `%s_dist_pmc.json` | per-kernel counter averages per launch from the separate `--pmc` passes (FETCH_SIZE; WRITE_SIZE; SQ_*; GRBM / MFMA / LDS; TCC) + corrected HBM bytes | `tools/summarize_prof.py` |" % (tag, tag),
+      "| `%s_derived.md` | per-kernel derived metrics (instr / cycle, MFMA busy, LDS busy, LDS conflicts, L2 hit, wait split, HBM bytes) | `tools/derive_prof.py %s` |" % (tag, tag),
+      "| `%s_kmer_traffic.json`, `%s_kmer_ascii_traffic.json`, `%s_dist_traffic.json` | the `roofline.traffic` figures `bench.py` reports | idem |" % (tag, tag, tag),
+      "| `%s_kmer_packed_isa.*`, `%s_kmer_isa.*` | static instruction budget of `kmer_sample_shared<21, true, PACKED>` by class, per k-mer | `tools/kmer_isa.py %s [packed]` |" % (tag, tag, tag),
+      "| `r04_dist_persistent_negative.txt` | the persistent-workgroup GEMM variant of round 4: timings against one tile per workgroup and whole-tile `s_memtime` stamps of both | `tools/dist_only.py`, `tools/dist_tile_stamps.py` on `-DHG_DIST_STAMPS` builds |",
+      "| `r03_mfma_ceiling.txt` | what the matrix pipe sustains in the GEMM's loop shape, ingredient by ingredient | `tools/mfma_microbench.hip` |",
+      "| `r01_instruction_rates.txt` | measured issue cost of the integer instructions the k-mer kernel is made of | `tools/gpu_microbench.hip` |"]
+open(os.path.join(P, "README.md"), "w").write("\n".join(L) + "\n")
+print("\n".join(L))

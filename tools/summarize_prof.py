@@ -10,10 +10,12 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("kmer_sample", "sort_unique", "encode_wave_kernel", "encode_finalize_kernel", "encode_kernel", "bucket_count_kernel",
+OURS = ("prep_cen_kernel", "decide_cen_kernel", "kmer_sample", "sort_unique", "encode_wave_kernel", "encode_finalize_kernel", "encode_kernel", "bucket_count_kernel",
         "bucket_scan_kernel", "bucket_scatter_kernel", "bucket_sort_kernel", "bucket_copy_kernel", "dist_mfma", "dist_int",
         "prep_fast_kernel", "prep_i8_kernel", "i8_entries_kernel", "prep_kernel", "decide_kernel", "synth_kernel",
-        "hamming_kernel", "binarize_kernel", "gather_keys_kernel", "permute_hits_kernel", "topk_kernel")
+        "hamming_kernel", "binarize_kernel", "gather_keys_kernel", "permute_hits_kernel", "topk_kernel", "prep_cen_kernel",
+        "decide_cen_kernel", "unpack_meta_kernel", "pack2_kernel", "expand_runs_kernel", "unpack2_kernel", "expand_bits_fp4_kernel",
+        "expand_bits_kernel")
 
 
 def short(name):
@@ -25,6 +27,8 @@ def short(name):
                 return "kmer_sample_grouped" + name.split("kmer_sample_grouped")[1].split("(")[0]
             if "kmer_sample_shared" in name:
                 return "kmer_sample_shared" + name.split("kmer_sample_shared")[1].split("(")[0]
+            if "kmer_sample_long" in name:
+                return "kmer_sample_long" + name.split("kmer_sample_long")[1].split("(")[0]
             if "dist_mfma" in name:
                 return "dist_mfma_kernel" + name.split("dist_mfma_kernel")[1].split("(")[0]
             return k
