@@ -173,3 +173,49 @@ def test_veto_falls_back_to_the_i16_rows(hg, where):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_prepared_operands_random_ragged_shapes(hg, orc, seed):
+    """small and ragged: a handful of rows, hv_d that is not a multiple of 128, one or several owners, planted clamped
+    entries -- against the oracle's ANI matrix"""
+    rng = np.random.default_rng(500 + seed)
+    d = int(rng.choice([64, 200, 1000, 1032, 4096]))
+    R, Q, world = int(rng.integers(1, 400)), int(rng.integers(1, 300)), int(rng.integers(1, 4))
+    n = int(rng.choice([61, 600, 3333]))
+    cnt = rng.binomial(n, 0.5, (R + Q, d))
+    hv = (2 * cnt - n).astype(np.int16)
+    for _ in range(int(rng.integers(0, 12))):  # clamped entries: |count - n / 2| > 127
+        hv[rng.integers(0, R + Q), rng.integers(0, d)] += np.int16(2 * int(rng.choice([-1, 1])) * int(rng.integers(130, 200)))
+    ref, qry = hv[:R], hv[R:]
+    rn = np.array([orc.hv_norm2(x) for x in ref], np.int32)
+    qn = np.array([orc.hv_norm2(x) for x in qry], np.int32)
+    want = orc.ani_matrix(ref, rn, qry, qn, 21)
+    th = float(rng.choice([0.0, 50.0, 70.0]))
+    t_ref, t_rn = torch.from_numpy(ref).cuda(), torch.from_numpy(rn).cuda()
+    t_qry, t_qn = torch.from_numpy(qry).cuda(), torch.from_numpy(qn).cuda()
+    from hypergen_amd import shard
+    bounds = [shard.shard_range(R, r, world) for r in range(world)]
+    rb, mb = hg.lib().hg_dist_ops_row_bytes(d), hg.lib().hg_dist_ops_meta_bytes()
+    with hg.Context(0) as c:
+        parts = []
+        for lo, hi in bounds:
+            ops = torch.empty((max(hi - lo, 1), rb), dtype=torch.uint8, device="cuda")
+            meta = torch.empty((max(hi - lo, 1), mb), dtype=torch.uint8, device="cuda")
+            flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+            c.dist_prep_ops_dev(t_ref[lo:hi].contiguous().data_ptr() if hi > lo else 0, hi - lo, d, ops.data_ptr(), meta.data_ptr(), flag.data_ptr())
+            parts.append((ops[: hi - lo], meta[: hi - lo], flag))
+        ops, meta, flags = gathered(hg, parts)
+        cap = R * Q + 16
+        hits = torch.empty(cap * 3, dtype=torch.int32, device="cuda")
+        found, st = c.dist_block_ops_dev(ops.data_ptr(), meta.data_ptr(), t_rn.data_ptr(), R, 0, 0, flags.data_ptr(), world,
+                                         t_qry.data_ptr(), t_qn.data_ptr(), Q, 0, d, 21, False, th, hits.data_ptr(), cap)
+        if st == hg.ERR_INEXACT:  # a residual beyond a byte / too many entries in one row: the i16 path must agree with the oracle
+            found, st = c.dist_block_dev(t_ref.data_ptr(), t_rn.data_ptr(), R, 0, t_qry.data_ptr(), t_qn.data_ptr(), Q, 0, d, 21, False, th,
+                                         hits.data_ptr(), cap)
+        assert st == 0
+        got = hitset(hits, found)
+    sure = {(i, j) for i, j in zip(*np.nonzero(want >= th + 1e-4))}
+    maybe = {(i, j) for i, j in zip(*np.nonzero(want >= th - 1e-4))}
+    assert sure <= set(got) <= maybe
+    assert all(abs(float(v) - float(want[k])) <= 1e-4 for k, v in got.items())
