@@ -481,14 +481,29 @@ def main():
         for _ in range(reps):
             own.sketch_batch(host_rows, p)
         hdt_ = time.perf_counter() - t0
+        link_form = "2-bit packed by the library's host threads (0.375 B/base)" if own.last_kernel("kmer").endswith("true>") else "ASCII"
+        # the same call with the library told to send ASCII (debug hook "hostfed"): the link-bound rate of round 3
+        own.set_debug("hostfed", "ascii")
+        a_hv, a_n2, _ = own.sketch_batch(host_rows, p)
+        if not (np.array_equal(a_hv, h_hv) and np.array_equal(a_n2, h_n2)):
+            raise SystemExit("PARITY GATE FAILED: host-fed sketches depend on the form sent over the link")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            own.sketch_batch(host_rows, p)
+        adt_ = time.perf_counter() - t0
         own.close()
-        gbs = HF * reps * (L_GENOME + 1) / hdt_ / 1e9
-        out["host_fed"] = {"value": HF * reps / hdt_, "unit": "genomes/sec", "pcie_gbs": gbs, "pcie_peak_gbs": 63.0,
-                           "frac_of_pcie": gbs / 63.0,
+        gbs = HF * reps * (L_GENOME + 1) / adt_ / 1e9
+        out["host_fed"] = {"value": HF * reps / hdt_, "unit": "genomes/sec", "link_form": link_form,
+                           "host_threads": min(16, len(os.sched_getaffinity(0))),
+                           "ascii_link": {"value": HF * reps / adt_, "unit": "genomes/sec", "pcie_gbs": gbs, "pcie_peak_gbs": 63.0,
+                                          "frac_of_pcie": gbs / 63.0},
                            "config": {"workload": "%d of the step's genomes from pinned host memory through "
-                                                  "hg_sketch_batch (upload overlapped with the kernels), results "
-                                                  "back on the host; rank 0 only" % HF}}
-        log("host-fed: %.0f genomes/s = %.1f GB/s of sequence over PCIe" % (out["host_fed"]["value"], gbs))
+                                                  "hg_sketch_batch (the library 2-bit packs each sub-batch on its host threads "
+                                                  "while the previous one uploads; kernels overlap both), results "
+                                                  "back on the host; rank 0 only.  ascii_link: the same call with the bases "
+                                                  "sent as ASCII" % HF}}
+        log("host-fed: %.0f genomes/s (%s); %.0f genomes/s = %.1f GB/s of sequence over PCIe as ASCII" % (
+            out["host_fed"]["value"], link_form, HF * reps / adt_, gbs))
         # the same genomes as hg_pack2 blobs (3 bits per base) through the streaming entry points: what the CLI's
         # readers do when the link is what limits.  Packing is host work of the caller's reader threads and is
         # reported beside the rate, not inside it.
@@ -596,20 +611,28 @@ def main():
         if not np.array_equal(got_n, want_nh):
             raise SystemExit("PARITY GATE FAILED: per-call hash counts differ from the batch's")
         dt_s = min(run_threads(call_sample) for _ in range(2))
+        pc_form = "2-bit packed by the calling threads" if pc_ctx[0].last_kernel("kmer").endswith("true>") else "ASCII"
         run_threads(call_sketch)
         dt_k = min(run_threads(call_sketch) for _ in range(2))
         for c in pc_ctx:
+            c.set_debug("hostfed", "ascii")
+        run_threads(call_sample)
+        if not np.array_equal(got_n, want_nh):
+            raise SystemExit("PARITY GATE FAILED: per-call hash counts differ from the batch's")
+        dt_a = min(run_threads(call_sample) for _ in range(2))
+        for c in pc_ctx:
             c.close()
-        out["per_call"] = {"value": HF / dt_s, "unit": "genomes/sec", "threads": PT,
-                           "pcie_gbs": HF * (L_GENOME + 1) / dt_s / 1e9,
+        out["per_call"] = {"value": HF / dt_s, "unit": "genomes/sec", "threads": PT, "link_form": pc_form,
                            "sketch_one": {"value": HF / dt_k, "unit": "genomes/sec"},
+                           "ascii_link": {"value": HF / dt_a, "unit": "genomes/sec", "pcie_gbs": HF * (L_GENOME + 1) / dt_a / 1e9},
                            "config": {"workload": "%d of the step's genomes from pinned host memory, ONE synchronous "
                                                   "hg_kmer_hash_sample call per genome (hash list back on the host) "
                                                   "from %d host threads with one hg_ctx each on this GPU -- the "
                                                   "reference's rayon pattern, src/sketch_cuda.rs:79-96; sketch_one = "
-                                                  "hg_sketch_batch with n = 1 in the same pattern; rank 0 only" % (HF, PT)}}
-        log("per_call: %.0f genomes/s through hg_kmer_hash_sample on %d threads (%.1f GB/s), %.0f through hg_sketch_batch(n=1)" % (
-            HF / dt_s, PT, out["per_call"]["pcie_gbs"], HF / dt_k))
+                                                  "hg_sketch_batch with n = 1 in the same pattern; ascii_link = "
+                                                  "hg_kmer_hash_sample with the bases sent as ASCII; rank 0 only" % (HF, PT)}}
+        log("per_call: %.0f genomes/s through hg_kmer_hash_sample on %d threads (%s), %.0f through hg_sketch_batch(n=1); %.0f as ASCII (%.1f GB/s)" % (
+            HF / dt_s, PT, pc_form, HF / dt_k, HF / dt_a, out["per_call"]["ascii_link"]["pcie_gbs"]))
         del host, blobs
 
     # ---------------- dist: R x Q ANI matrix, thresholded ------------------------------------------

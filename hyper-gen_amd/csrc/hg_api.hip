@@ -13,6 +13,9 @@
 #include <vector>
 
 #include <chrono>
+#include <functional>
+#include <memory>
+#include <sched.h>
 
 #include "hg_host.h"
 
@@ -135,6 +138,7 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   else if (k == "dist_path") c->dbg_dist_path = v;
   else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;
+  else if (k == "hostfed") c->dbg_hostfed = v;  // hg_sketch_batch / hg_kmer_hash_sample: "ascii" never 2-bit pack on the host, "packed" always
   else if (k == "kmer_input") c->dbg_kmer_input = v;  // "packed": ASCII batches are 2-bit packed on the device first and take the packed kernels
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;
@@ -784,6 +788,110 @@ extern "C" void hg_pinned_free(void *p) {
 constexpr uint64_t HG_STAGE_BYTES = 64ull << 20;
 constexpr uint64_t HG_PACK_BYTES = HG_STAGE_BYTES + (2ull << 20);  // a sub-batch of genomes < 1 MiB each fits
 
+// Host threads the library may use for its own host-side work on a call (2-bit packing of a host-fed batch): the cores
+// this process may run on, at most 16 -- the reference's default `-t` (src/utils.rs:54-56).
+static unsigned host_threads() {
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n ? n : 1u, (unsigned)CPU_COUNT(&set));
+  return std::max(1u, std::min(n, 16u));
+}
+
+// Host-fed calls in flight in this process (hg_sketch_batch / hg_kmer_hash_sample, any context): the reference's pattern is
+// one call per genome from a pool of host threads (src/sketch_cuda.rs:79-96), and then the calls share ONE link.
+static std::atomic<int> g_hostfed_calls{0};
+namespace {
+struct HostfedCall {
+  int others;
+  HostfedCall() : others(g_hostfed_calls.fetch_add(1)) {}
+  ~HostfedCall() { g_hostfed_calls.fetch_sub(1); }
+};
+}  // namespace
+static bool host_pinned(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the runtime)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+// Whether ONE genome handed over by a host-fed call goes over the link 2-bit packed (packed by the calling thread into the
+// context's page-locked staging buffer: ~0.07 ms per Mbp) instead of as ASCII: yes when the link is what the call would
+// wait for -- 3 or more other host-fed calls in flight -- or when the source is pageable memory, which the runtime would
+// stage through its own pinned buffers anyway.  Hook: "hostfed" = "ascii" never, "packed" always.
+static bool pack_single(const hg_ctx *c, const void *seq, uint64_t n_bps, int others) {
+  if (c->dbg_hostfed == "ascii" || hg_pack2_size(n_bps) > HG_PACK_BYTES) return false;
+  if (c->dbg_hostfed == "packed") return true;
+  return n_bps >= (256u << 10) && (others >= 3 || !host_pinned(seq));
+}
+
+// A few worker threads that live for one call: run(n, fn) executes fn(i) for i in [0, n) on all of them (the caller's
+// thread takes part) and returns when every index is done.
+namespace {
+class CallPool {
+ public:
+  explicit CallPool(unsigned threads) {
+    for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
+  }
+  ~CallPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  template <class F>
+  void run(size_t n, F &&fn) {
+    if (!n) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = [&fn](size_t i) { fn(i); };
+      n_ = n, next_ = 0, done_ = 0, ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return done_ == n_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      size_t i;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (next_ >= n_) return;
+        i = next_++;
+      }
+      fn_(i);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (++done_ == n_) cv_done_.notify_all();
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  std::function<void(size_t)> fn_;
+  size_t n_ = 0, next_ = 0, done_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
 extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
                                      const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
                                      uint32_t *nhash_out) {
@@ -793,19 +901,51 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
   if (n == 0) return HG_OK;
   if (!seqs || !lens || !hv_out || !norm2_out || !nhash_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   HG_HIP(c, hipSetDevice(c->device));
+  // The link is what limits this entry point (50 GB/s = 10 k genomes/s of 5 Mbp as ASCII): a batch that is worth it goes
+  // over as 2-bit packed bases -- hg_pack2 blobs, 0.375 bytes per base, packed by a few host threads of this call into the
+  // page-locked staging buffers while the previous sub-batch uploads -- and is sketched by the packed-input kernels
+  // (bit-identical results).  Needs cores: with fewer than 4 usable ones the ASCII path stays.  Hook: "hostfed" = "ascii".
+  // A call that hands over little (the n = 1 of the one-call-per-genome pattern) packs on its own thread, when
+  // pack_single() says the link is contended.
+  HostfedCall in_flight;
+  unsigned P = host_threads();
+  uint64_t all_bytes = 0;
+  for (size_t g = 0; g < n; ++g) all_bytes += lens[g];
+  bool want_pack = (P >= 4 && all_bytes >= (32ull << 20) && c->dbg_hostfed != "ascii") || (n > 1 && c->dbg_hostfed == "packed");
+  if (want_pack) P = std::max(1u, P / (unsigned)(1 + in_flight.others));
+  else if (n == 1 && pack_single(c, seqs[0], lens[0], in_flight.others)) want_pack = true, P = 1;
+  const uint64_t stage_bytes = want_pack ? 2 * HG_STAGE_BYTES : HG_STAGE_BYTES;  // (packed: 48 MB per upload)
   // device layout: 16-byte aligned starts, 64 bytes of slack; sub-batch boundaries by bytes
-  std::vector<uint64_t> offs(n), l64(n);
+  std::vector<uint64_t> offs(n), l64(n), boffs(n);
   std::vector<size_t> cut{0};
   uint64_t total = 0, in_chunk = 0;
   for (size_t g = 0; g < n; ++g) {
     if (lens[g] && !seqs[g]) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
-    if (in_chunk >= HG_STAGE_BYTES) cut.push_back(g), in_chunk = 0;
+    if (in_chunk >= stage_bytes) cut.push_back(g), in_chunk = 0;
     offs[g] = total, l64[g] = lens[g];
     const uint64_t padded = (lens[g] + 15) & ~(uint64_t)15;
     total += padded, in_chunk += padded;
   }
   cut.push_back(n);
   const size_t n_chunks = cut.size() - 1;
+  // packed sub-batches: blob g of sub-batch k at the sub-batch's own start in the device buffer (its ASCII region is
+  // larger than its blobs) + the sum of the blob sizes in front of it; a sub-batch whose blobs outgrow a staging buffer
+  // (one huge genome) stays ASCII
+  std::vector<uint8_t> sub_packed(n_chunks, 0);
+  std::vector<uint64_t> sub_pk_bytes(n_chunks, 0);
+  if (want_pack) {
+    for (size_t k = 0; k < n_chunks; ++k) {
+      uint64_t at = 0;
+      for (size_t g = cut[k]; g < cut[k + 1]; ++g) boffs[g] = offs[cut[k]] + at, at += hg_pack2_size(lens[g]);
+      sub_pk_bytes[k] = at;
+      sub_packed[k] = at <= HG_PACK_BYTES && at > 0;
+    }
+  }
+  std::unique_ptr<CallPool> pool;
+  if (want_pack) pool.reset(new CallPool(P));
+  // packing has to outrun the link to be worth it from page-locked sources (ASCII goes at ~50 GB/s from those): the
+  // uploader times its first packed sub-batch and leaves the rest as ASCII when the host is too slow for that
+  const bool src_pinned = want_pack && n > 1 && host_pinned(seqs[0]);
   if ((s = hg_ensure(c, c->w_seq, total + 64)) != HG_OK) return s;
   const size_t hv_bytes = n * (size_t)p->hv_d * sizeof(int16_t);
   if ((s = hg_ensure(c, c->w_hv, hv_bytes + n * 8 + 64)) != HG_OK) return s;
@@ -829,7 +969,35 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
     for (size_t k = first_chunk; k < n_chunks; ++k) {
       const size_t g0 = cut[k], g1 = cut[k + 1];
       const uint64_t span = offs[g1 - 1] + ((l64[g1 - 1] + 15) & ~(uint64_t)15) - offs[g0];
-      if (g1 - g0 >= 16 && span / (g1 - g0) < ((uint64_t)1 << 20) && span <= HG_PACK_BYTES) {
+      if (sub_packed[k]) {
+        // 2-bit pack the sub-batch into page-locked staging (all host threads of the call), then ONE upload
+        const int b = (int)(k & 1);
+        if (!c->pack_buf[b]) {
+          e = hipHostMalloc(&c->pack_buf[b], HG_PACK_BYTES, hipHostMallocDefault);
+          if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pack_ev[b], hipEventDisableTiming);
+        }
+        if (e == hipSuccess && c->pack_used[b]) e = hipEventSynchronize(c->pack_ev[b]);
+        if (e == hipSuccess) {
+          auto *pin = static_cast<uint8_t *>(c->pack_buf[b]);
+          // pieces of 1 Mbase, so that the threads finish together whatever the genome sizes
+          constexpr uint64_t PIECE = 1ull << 20;
+          std::vector<std::pair<size_t, uint64_t>> pieces;
+          for (size_t g = g0; g < g1; ++g)
+            for (uint64_t b = 0; b < lens[g]; b += PIECE) pieces.emplace_back(g, b);
+          const auto t0 = std::chrono::steady_clock::now();
+          pool->run(pieces.size(), [&](size_t i) {
+            const size_t g = pieces[i].first;
+            const uint64_t b = pieces[i].second;
+            hg_pack2_piece(seqs[g], lens[g], p->norm_mode, pin + (boffs[g] - boffs[g0]), b, std::min<uint64_t>(lens[g], b + PIECE));
+          });
+          const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          if (src_pinned && k == first_chunk && (double)span < 55e9 * sec && c->dbg_hostfed != "packed")
+            for (size_t j = k + 1; j < n_chunks; ++j) sub_packed[j] = 0;
+          if (e == hipSuccess) e = hipMemcpyAsync(d_seq + boffs[g0], pin, sub_pk_bytes[k], hipMemcpyHostToDevice, c->copy_stream);
+          if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], c->copy_stream);
+          c->pack_used[b] = true;
+        }
+      } else if (g1 - g0 >= 16 && span / (g1 - g0) < ((uint64_t)1 << 20) && span <= HG_PACK_BYTES) {
         // many small genomes: pack them into pinned memory (device layout) and upload once -- a
         // hipMemcpyAsync per 2 kbp genome costs more than the genome
         const int b = (int)(k & 1);
@@ -877,8 +1045,12 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
       s = hg_fail(c, HG_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
       break;
     }
-    s = hg_sketch_batch_dev(c, d_seq, offs.data() + g0, l64.data() + g0, m, p, d_hv + g0 * (size_t)p->hv_d, d_n2 + g0,
-                            d_nh + g0);
+    if (sub_packed[k])
+      s = hg_sketch_batch_dev_packed(c, d_seq, boffs.data() + g0, l64.data() + g0, m, p, d_hv + g0 * (size_t)p->hv_d, d_n2 + g0,
+                                     d_nh + g0);
+    else
+      s = hg_sketch_batch_dev(c, d_seq, offs.data() + g0, l64.data() + g0, m, p, d_hv + g0 * (size_t)p->hv_d, d_n2 + g0,
+                              d_nh + g0);
     if (s != HG_OK) break;
     e = hipMemcpyAsync(hv_out + g0 * (size_t)p->hv_d, d_hv + g0 * (size_t)p->hv_d, m * (size_t)p->hv_d * sizeof(int16_t),
                        hipMemcpyDeviceToHost, c->stream);
@@ -911,14 +1083,29 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   const std::vector<uint64_t> offs{0}, l64{n_bps};
   hg_status s = hg_ensure(c, c->w_seq, n_bps + 64);
   if (s != HG_OK) return s;
-  HG_HIP(c, hipMemcpyAsync(c->w_seq.p, seq, n_bps, hipMemcpyHostToDevice, c->stream));
+  // over the link as ASCII, or 2-bit packed by this thread when the link is shared with other calls (pack_single())
+  HostfedCall in_flight;
+  const bool packed = pack_single(c, seq, n_bps, in_flight.others);
+  if (packed) {
+    if (!c->pack_buf[0]) {
+      HG_HIP(c, hipHostMalloc(&c->pack_buf[0], HG_PACK_BYTES, hipHostMallocDefault));
+      HG_HIP(c, hipEventCreateWithFlags(&c->pack_ev[0], hipEventDisableTiming));
+    }
+    if (c->pack_used[0]) HG_HIP(c, hipEventSynchronize(c->pack_ev[0]));
+    if (hg_pack2(seq, n_bps, norm_mode, static_cast<uint8_t *>(c->pack_buf[0])) != HG_OK) return hg_fail(c, HG_ERR_INVALID, "hg_pack2");
+    HG_HIP(c, hipMemcpyAsync(c->w_seq.p, c->pack_buf[0], hg_pack2_size(n_bps), hipMemcpyHostToDevice, c->stream));
+    HG_HIP(c, hipEventRecord(c->pack_ev[0], c->stream));
+    c->pack_used[0] = true;
+  } else {
+    HG_HIP(c, hipMemcpyAsync(c->w_seq.p, seq, n_bps, hipMemcpyHostToDevice, c->stream));
+  }
   // capacity heuristic wants "scaled"; derive it from the threshold (threshold = MAX / scaled)
   uint64_t scaled = threshold ? UINT64_MAX / threshold : UINT64_MAX;
   if (scaled < 1) scaled = 1;
   BatchPlan pl;
   uint32_t *d_nd = nullptr;
   s = sample_batch(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), 1, ksize, threshold, scaled,
-                   seed, canonical != 0, norm_mode, pl, &d_nd);
+                   seed, canonical != 0, norm_mode, pl, &d_nd, packed);
   if (s != HG_OK) return s;
   uint32_t nd = 0;
   HG_HIP(c, hipMemcpyAsync(&nd, d_nd, sizeof nd, hipMemcpyDeviceToHost, c->stream));

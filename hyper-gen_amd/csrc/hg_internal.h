@@ -89,7 +89,7 @@ struct hg_ctx {
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // development / test hooks (hg_ctx_set_debug); never read from the environment
-  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input;
+  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input, dbg_hostfed;
   int dbg_sort_buckets = 0;
   // pinned host scratch
   void *h_pin = nullptr;
@@ -139,6 +139,9 @@ struct hg_genome_meta {
   uint32_t item_first;  // index of the genome's first work item
   uint64_t mask_off;    // packed input: byte offset of the genome's not-a-base bitmap in d_seq (hg_pack2: seq_off + padded code bytes)
 };
+// hg_formats.cpp: bases [b0, b1) of one genome into their place in its hg_pack2 blob (b0 % 64 == 0; b1 % 64 == 0 or
+// b1 == n_bps) -- the unit of work of the host threads that pack a host-fed batch
+void hg_pack2_piece(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t b0, size_t b1);
 // hg_sketch_batch_dev_packed with the bitmaps at explicit offsets (the streaming path: a genome that came over the link as
 // codes + run table has its bitmap rebuilt behind the table, not directly behind the codes)
 hg_status hg_sketch_batch_dev_packed_masks(hg_ctx *c, const uint8_t *d_blobs, const uint64_t *code_offs, const uint64_t *mask_offs,

@@ -71,6 +71,8 @@ int hg_device_count(void);
  *       "ham_path"  = "" | "popc" | "mfma" | "fp4"         (Hamming search: xor + popcount, +-1 byte GEMM, +-1 e2m1 GEMM)
  *       "kmer_input" = "" | "packed"                       ("packed": batches that arrive as ASCII are 2-bit packed on the
  *                                                           device first and take the packed-input kernels)
+ *       "hostfed" = "" | "ascii" | "packed"                (what hg_sketch_batch / hg_kmer_hash_sample send over the link:
+ *                                                           the library's choice / always ASCII / always 2-bit packed on the host)
  *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
  * Nothing in the library reads environment variables. */
 hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
@@ -160,7 +162,15 @@ hg_status hg_sketch_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t 
 hg_status hg_sketch_batch_dev_packed(hg_ctx *ctx, const uint8_t *d_blobs, const uint64_t *offsets,
                                      const uint64_t *n_bps, size_t n, const hg_sketch_params *p,
                                      int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash);
-/* host buffers in, host results out (one H2D of the sequences, one D2H of the HVs) */
+/* host buffers in, host results out.  The sequences cross the link in sub-batches that upload while the previous one is
+ * sketched.  What crosses is the library's choice and never changes a result bit: a batch of >= 32 MB on a host with >= 4
+ * usable cores is 2-bit packed by up to 16 host threads of the call (hg_pack2 blobs, 0.375 bytes per base, in pieces of
+ * 1 Mbase into page-locked staging; the packed-input kernels sketch them) -- 2.3x the ASCII rate on the measured box,
+ * where host DRAM (114 GB/s of packing reads) then limits instead of PCIe; the first sub-batch is timed and the rest goes
+ * as ASCII when the host packs slower than the link carries.  A call with n = 1 packs on the calling thread when the
+ * source is pageable memory or when >= 3 other host-fed calls of the process are in flight (the reference's
+ * one-call-per-genome pattern from a thread pool, src/sketch_cuda.rs:79-96: the calls share one link).  Debug key
+ * "hostfed" = "ascii" | "packed" pins the choice.  The same rule applies to hg_kmer_hash_sample. */
 hg_status hg_sketch_batch(hg_ctx *ctx, const uint8_t *const *seqs, const size_t *lens,
                           size_t n, const hg_sketch_params *p, int16_t *hv_out,
                           int32_t *norm2_out, uint32_t *nhash_out);

@@ -151,3 +151,97 @@ def test_packed_1000x5mbp_equals_ascii_and_takes_three_eighths_of_the_memory(hg,
     for g in (3, 777):
         w_hv, w_n2, w_nh = orc.sketch_genome(orc.synth_genome(g, L))
         assert int(res[1][2][g]) == w_nh and int(res[1][1][g]) == w_n2 and np.array_equal(res[1][0][g].cpu().numpy(), w_hv)
+
+
+# ---- host-fed entry points: the library 2-bit packs on the host when the link is what limits ------------------------------------
+# (hg_sketch_batch: batches >= 32 MB on hosts with >= 4 usable cores; one-genome calls: pageable sources or >= 3 other calls in
+# flight; hook "hostfed" = "ascii" / "packed" pins the choice).  Results must not depend on the form that crossed the link.
+
+def _host_genomes(rng, n, lo, hi):
+    return [genome(rng, int(rng.integers(lo, hi))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_hostfed_batch_packed_on_the_host_equals_ascii(hg, orc, pinned):
+    """~300 MB in 3 sub-batches (128 MB of ASCII each when packed), ragged lengths, one empty and one shorter-than-k genome"""
+    rng = np.random.default_rng(77)
+    seqs = _host_genomes(rng, 70, 3_000_000, 5_500_000) + [np.zeros(0, np.uint8), genome(rng, 11)] + _host_genomes(rng, 40, 200, 90_000)
+    if pinned:
+        keep = [torch.from_numpy(s.copy()).pin_memory() if s.size else torch.zeros(0, dtype=torch.uint8) for s in seqs]
+        seqs = [k.numpy() for k in keep]
+    p = hg.default_params(hv_d=1024)
+    res = {}
+    for mode in ("ascii", "packed", ""):
+        c = hg.Context(0)
+        if mode:
+            c.set_debug("hostfed", mode)
+        res[mode] = c.sketch_batch(seqs, p)
+        if mode == "packed":
+            assert c.last_kernel("kmer").endswith("true>")
+        if mode == "ascii":
+            assert not c.last_kernel("kmer").endswith("true>")
+        c.close()
+    for mode in ("packed", ""):
+        for a, b in zip(res["ascii"], res[mode]):
+            assert np.array_equal(a, b), mode
+    for i in (0, 69, 71, 80):
+        w_hv, w_n2, w_nh = orc.sketch_genome(seqs[i], 21, 1500, 123, True, hv_d=1024)
+        assert res[""][2][i] == w_nh and res[""][1][i] == w_n2 and np.array_equal(res[""][0][i], w_hv), i
+
+
+@pytest.mark.parametrize("norm", [0, 1])
+def test_hostfed_single_genome_calls_packed_on_the_host(hg, orc, norm):
+    rng = np.random.default_rng(5 + norm)
+    for n in (0, 20, 21, 1000, 300_000, 2_000_003):
+        s = genome(rng, n, junk=0.01)
+        if n > 100:
+            s[rng.choice(n, n // 50, replace=False)] = ord("U")
+        got = {}
+        for mode in ("ascii", "packed", ""):  # "" = the library's choice: a pageable source >= 256 KB goes packed
+            c = hg.Context(0)
+            if mode:
+                c.set_debug("hostfed", mode)
+            got[mode] = (np.sort(c.kmer_hash_sample(s, 21, 40, 123, True, norm)), c.last_kernel("kmer"))
+            if n >= 21:
+                assert got[mode][1].endswith("true>") == (mode == "packed" or (mode == "" and n >= 256 * 1024)), (mode, n, got[mode][1])
+            p = hg.default_params(scaled=40, hv_d=512)
+            p.norm_mode = norm
+            got[mode] += c.sketch_batch([s], p)
+            c.close()
+        want = np.sort(orc.kmer_hash_sample(s, 21, 40, 123, True, norm)) if n <= 300_000 else got["ascii"][0]
+        for mode in ("ascii", "packed", ""):
+            assert np.array_equal(got[mode][0], want), (mode, n)
+            for a, b in zip(got[mode][2:], got["ascii"][2:]):
+                assert np.array_equal(a, b), (mode, n)
+
+
+def test_hostfed_concurrent_single_genome_calls(hg, orc):
+    """the reference's pattern (one call per genome from a pool of threads, src/sketch_cuda.rs:79-96) from pinned memory: with
+    the calls sharing the link the library packs on the calling threads; every result equals the lone ASCII call's"""
+    import threading
+    rng = np.random.default_rng(9)
+    keep = [torch.from_numpy(genome(rng, int(rng.integers(400_000, 1_500_000)))).pin_memory() for _ in range(48)]
+    seqs = [k.numpy() for k in keep]
+    solo = hg.Context(0)
+    solo.set_debug("hostfed", "ascii")
+    want = [np.sort(solo.kmer_hash_sample(s, 21, 200)) for s in seqs]
+    solo.close()
+    T = 8
+    ctxs = [hg.Context(0) for _ in range(T)]
+    got, used_packed, bad = [None] * len(seqs), [0] * T, []
+
+    def w(t):
+        try:
+            for g in range(t, len(seqs), T):
+                got[g] = np.sort(ctxs[t].kmer_hash_sample(seqs[g], 21, 200))
+                used_packed[t] += ctxs[t].last_kernel("kmer").endswith("true>")
+        except Exception as e:  # pragma: no cover
+            bad.append(repr(e))
+    ths = [threading.Thread(target=w, args=(t,)) for t in range(T)]
+    [x.start() for x in ths]
+    [x.join() for x in ths]
+    assert not bad, bad
+    for g in range(len(seqs)):
+        assert np.array_equal(got[g], want[g]), g
+    for c in ctxs:
+        c.close()

@@ -53,8 +53,13 @@ if os.path.exists(bl):
         L.append("| 10 000 genomes on one GPU | %.0f genomes/s |" % j["sketch_10k"]["value"])
     if "host_fed" in j:
         hf = j["host_fed"]
-        L.append("| host-fed (PCIe) | ASCII %.0f genomes/s; 2-bit packed stream %.0f (sparse form, %.3f B/base) / %.0f (bitmap form) |" % (
-            hf["value"], hf["packed_stream"]["value"], hf["packed_stream"]["bytes_per_base"], hf["packed_stream"]["bitmap_form"]["value"]))
+        L.append("| host-fed (PCIe) | hg_sketch_batch %.0f genomes/s (%s; %.0f as ASCII); 2-bit packed stream %.0f (sparse form, %.3f B/base) / %.0f (bitmap form) |" % (
+            hf["value"], hf.get("link_form", "ASCII"), hf.get("ascii_link", hf)["value"], hf["packed_stream"]["value"],
+            hf["packed_stream"]["bytes_per_base"], hf["packed_stream"]["bitmap_form"]["value"]))
+    if "per_call" in j:
+        pc = j["per_call"]
+        L.append("| one call per genome, %d host threads | hg_kmer_hash_sample %.0f genomes/s (%s; %.0f as ASCII), hg_sketch_batch(n=1) %.0f |" % (
+            pc["threads"], pc["value"], pc.get("link_form", "ASCII"), pc.get("ascii_link", pc)["value"], pc["sketch_one"]["value"]))
     if "dist" in j:
         d = j["dist"]
         L.append("| dist 10 000 x 10 000 | %.0f M pairs/s, GEMM %.3f ms = %.3f of the %s peak |" % (
