@@ -825,73 +825,6 @@ static bool pack_single(const hg_ctx *c, const void *seq, uint64_t n_bps, int ot
   return n_bps >= (256u << 10) && (others >= 3 || !host_pinned(seq));
 }
 
-// A few worker threads that live for one call: run(n, fn) executes fn(i) for i in [0, n) on all of them (the caller's
-// thread takes part) and returns when every index is done.
-namespace {
-class CallPool {
- public:
-  explicit CallPool(unsigned threads) {
-    for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
-  }
-  ~CallPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto &t : th_) t.join();
-  }
-  template <class F>
-  void run(size_t n, F &&fn) {
-    if (!n) return;
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = [&fn](size_t i) { fn(i); };
-      n_ = n, next_ = 0, done_ = 0, ++gen_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [&] { return done_ == n_; });
-    fn_ = nullptr;
-  }
-
- private:
-  void work() {
-    for (;;) {
-      size_t i;
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (next_ >= n_) return;
-        i = next_++;
-      }
-      fn_(i);
-      std::lock_guard<std::mutex> lk(mu_);
-      if (++done_ == n_) cv_done_.notify_all();
-    }
-  }
-  void worker() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
-      }
-      work();
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex mu_;
-  std::condition_variable cv_, cv_done_;
-  std::function<void(size_t)> fn_;
-  size_t n_ = 0, next_ = 0, done_ = 0;
-  uint64_t gen_ = 0;
-  bool stop_ = false;
-};
-}  // namespace
-
 extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
                                      const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
                                      uint32_t *nhash_out) {
@@ -942,7 +875,7 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
     }
   }
   std::unique_ptr<CallPool> pool;
-  if (want_pack) pool.reset(new CallPool(P));
+  if (want_pack) pool.reset(new CallPool(P));  // (takes the threads it can get)
   // packing has to outrun the link to be worth it from page-locked sources (ASCII goes at ~50 GB/s from those): the
   // uploader times its first packed sub-batch and leaves the rest as ASCII when the host is too slow for that
   const bool src_pinned = want_pack && n > 1 && host_pinned(seqs[0]);

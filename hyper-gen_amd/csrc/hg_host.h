@@ -1,7 +1,12 @@
 // Host-only seams between hg_formats.cpp (no HIP) and hg_api.hip.
 #pragma once
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "../../include/hypergen.h"
 
@@ -10,3 +15,76 @@ typedef bool (*hg_grow_fn)(uint8_t *&buf, size_t &cap, size_t need, size_t keep,
 
 hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, size_t *pcap, size_t *n_bps,
                              hg_grow_fn grow, void *user);
+
+// hg_formats.cpp: bases [b0, b1) of one genome into their place in its hg_pack2 blob (b0 % 64 == 0; b1 % 64 == 0 or
+// b1 == n_bps; `out` must not overlap `seq`) -- the unit of work of the host threads that pack a host-fed batch
+void hg_pack2_piece(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t b0, size_t b1);
+
+// A few worker threads that live for one call: run(n, fn) executes fn(i) for i in [0, n) on all of them (the caller's
+// thread takes part) and returns when every index is done.
+class CallPool {
+ public:
+  explicit CallPool(unsigned threads) {
+    try {
+      for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
+    } catch (...) {  // no more threads to be had: the pool works with the ones it got (the caller's thread at least)
+    }
+  }
+  ~CallPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  template <class F>
+  void run(size_t n, F &&fn) {
+    if (!n) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = [&fn](size_t i) { fn(i); };
+      n_ = n, next_ = 0, done_ = 0, ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return done_ == n_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      size_t i;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (next_ >= n_) return;
+        i = next_++;
+      }
+      fn_(i);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (++done_ == n_) cv_done_.notify_all();
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  std::function<void(size_t)> fn_;
+  size_t n_ = 0, next_ = 0, done_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+

@@ -139,9 +139,6 @@ struct hg_genome_meta {
   uint32_t item_first;  // index of the genome's first work item
   uint64_t mask_off;    // packed input: byte offset of the genome's not-a-base bitmap in d_seq (hg_pack2: seq_off + padded code bytes)
 };
-// hg_formats.cpp: bases [b0, b1) of one genome into their place in its hg_pack2 blob (b0 % 64 == 0; b1 % 64 == 0 or
-// b1 == n_bps) -- the unit of work of the host threads that pack a host-fed batch
-void hg_pack2_piece(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t b0, size_t b1);
 // hg_sketch_batch_dev_packed with the bitmaps at explicit offsets (the streaming path: a genome that came over the link as
 // codes + run table has its bitmap rebuilt behind the table, not directly behind the codes)
 hg_status hg_sketch_batch_dev_packed_masks(hg_ctx *c, const uint8_t *d_blobs, const uint64_t *code_offs, const uint64_t *mask_offs,
