@@ -90,6 +90,10 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
                          &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (auto &t : c->tile_tabs) {
+    if (t.dev.p) (void)hipFree(t.dev.p);
+    if (t.uploaded) (void)hipEventDestroy(t.uploaded);
+  }
   for (auto &t : c->t_pending) {
     if (t.own_e0) (void)hipEventDestroy(t.e0);
     (void)hipEventDestroy(t.e1);

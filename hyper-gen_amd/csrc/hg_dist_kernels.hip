@@ -578,6 +578,12 @@ constexpr uint32_t ST = 8;       // super-tile edge, in tiles
 static inline uint32_t dist_grid(uint32_t tiles_m, uint32_t tiles_n) {
   return ((tiles_m + ST - 1) / ST) * ((tiles_n + ST - 1) / ST) * ST * ST;
 }
+// Slot -> tile table of a launch (see the kernel's tile order): the tiles that have work -- inside the matrix, not entirely
+// on / below the diagonal of a symmetric comparison -- in the XCD-aware super-tile walk, cut into 8 runs of equal length
+// (+-1), run x walked by the workgroups b with b % 8 == x; with `diag` the tiles that straddle the diagonal (two per tile
+// row) come first, dealt round the XCDs.  Returns the grid size and sets g.tile_tab / g.diag_first; on any failure (or
+// for shapes beyond 65 535 tiles a side, or under the "legacy" order hook) the kernel's own blockIdx mapping stays.
+static uint32_t dist_tile_table(hg_ctx *c, struct GemmArgs &g, uint32_t bm, uint32_t bn, bool diag);
 // Tile geometries (waves are 2 (M) x NWN (N), each wave owns WTM x NT MFMA tiles of 16 x 16):
 //   small: 128 x 128, 4 waves, 72 KiB LDS, 2 workgroups / CU  -- small problems, little padding
 //   big  : 256 x 256, 8 waves, 144 KiB LDS, 1 workgroup / CU  -- half the LDS and L2 bytes per flop
@@ -651,8 +657,93 @@ struct GemmArgs {
   const uint32_t *i8ctrl;          // [0] entries reserved, [1] flags of the prepass
   uint32_t hv_d, same_set;
   uint32_t diag_first;             // leading workgroup slots that take the tiles on the diagonal (0: plain order)
+  const uint32_t *tile_tab;        // slot -> tile (tm | tn << 16, ~0u: no tile) built by the host (dist_tile_table); nullptr:
+                                   // the workgroup derives its tile from blockIdx as described at the top of the kernel
   int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
 };
+
+static uint32_t dist_tile_table(hg_ctx *c, GemmArgs &g, uint32_t bm, uint32_t bn, bool diag) {
+  const uint32_t legacy_diag = diag ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
+  auto legacy = [&]() {
+    g.tile_tab = nullptr, g.diag_first = legacy_diag;
+    return legacy_diag + dist_grid(g.tiles_m, g.tiles_n);
+  };
+  if (c->dbg_dist_order == "legacy" || g.tiles_m > 0xFFFFu || g.tiles_n > 0xFFFEu || (uint64_t)g.tiles_m * g.tiles_n > (1u << 24)) return legacy();
+  const uint32_t flags = (diag ? 1u : 0u) | (g.symmetric ? 2u : 0u);
+  hg_ctx::TileTab *hit = nullptr, *lru = &c->tile_tabs[0];
+  for (auto &t : c->tile_tabs) {
+    if (t.n_slots && t.tiles_m == g.tiles_m && t.tiles_n == g.tiles_n && t.bm == bm && t.bn == bn && t.flags == flags &&
+        (!g.symmetric || t.ref_off - t.qry_off == (uint64_t)g.ref_off - (uint64_t)g.qry_off))  // (the triangle test sees only the difference)
+      hit = &t;
+    if (t.used < lru->used) lru = &t;
+  }
+  if (!hit) {
+    hg_ctx::TileTab &t = *lru;
+    // an evicted table: its device copy is rewritten in stream order behind the launches that read it; its host copy
+    // once the old upload has passed
+    if (!t.uploaded && hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      t.uploaded = nullptr;
+      return legacy();
+    }
+    if (t.used) (void)hipEventSynchronize(t.uploaded);
+    t.n_slots = 0;
+    try {
+      std::vector<uint32_t> dg, walk;
+      auto has_work = [&](uint32_t tm, uint32_t tn) {
+        return !(g.symmetric && (uint64_t)tm * bm + g.ref_off >= (uint64_t)tn * bn + g.qry_off + bn);
+      };
+      auto on_diag = [&](uint32_t tm, uint32_t tn) { return diag && (tn == tm * bm / bn || tn == (tm * bm + bm - 1) / bn); };
+      if (diag)
+        for (uint32_t second = 0; second < 2; ++second)  // the rows' first diagonal tiles, the dense ones, go round the XCDs first
+          for (uint32_t tm = 0; tm < g.tiles_m; ++tm) {
+            const uint32_t tn0 = tm * bm / bn, tn1 = (tm * bm + bm - 1) / bn, tn = second ? tn1 : tn0;
+            if ((second && tn1 == tn0) || tn >= g.tiles_n || !has_work(tm, tn)) continue;
+            dg.push_back(tm | tn << 16);
+          }
+      const uint32_t sup_m = (g.tiles_m + ST - 1) / ST, sup_n = (g.tiles_n + ST - 1) / ST;
+      for (uint32_t sup = 0; sup < sup_m * sup_n; ++sup)
+        for (uint32_t within = 0; within < ST * ST; ++within) {
+          const uint32_t tm = (sup / sup_n) * ST + within / ST, tn = (sup % sup_n) * ST + within % ST;
+          if (tm >= g.tiles_m || tn >= g.tiles_n || on_diag(tm, tn) || !has_work(tm, tn)) continue;
+          walk.push_back(tm | tn << 16);
+        }
+      // the queue of XCD x: its share of the diagonal tiles, then one contiguous run of the walk
+      std::vector<uint32_t> queue[8];
+      for (size_t i = 0; i < dg.size(); ++i) queue[i % 8].push_back(dg[i]);
+      const size_t total = dg.size() + walk.size(), q = total / 8, r = total % 8;
+      size_t w = 0;
+      for (size_t x = 0; x < 8; ++x)
+        for (const size_t mine = q + (x < r ? 1 : 0); queue[x].size() < mine && w < walk.size();) queue[x].push_back(walk[w++]);
+      for (size_t x = 0; w < walk.size(); x = (x + 1) % 8) queue[x].push_back(walk[w++]);  // (tiny grids only: a share smaller than its diagonal tiles)
+      size_t rows = 0;
+      for (auto &qu : queue) rows = std::max(rows, qu.size());
+      t.host.assign(std::max<size_t>(rows, 1) * 8, ~0u);
+      for (size_t x = 0; x < 8; ++x)
+        for (size_t j = 0; j < queue[x].size(); ++j) t.host[8 * j + x] = queue[x][j];
+    } catch (const std::bad_alloc &) {
+      t.n_slots = 0;
+      return legacy();
+    }
+    if (hg_ensure(c, t.dev, t.host.size() * sizeof(uint32_t)) != HG_OK) {
+      t.n_slots = 0;
+      return legacy();
+    }
+    // (ordered on the ctx's stream like every other workspace write: a launch that still reads the evicted table is ahead of it)
+    if (hipMemcpyAsync(t.dev.p, t.host.data(), t.host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      t.n_slots = 0;
+      return legacy();
+    }
+    (void)hipEventRecord(t.uploaded, c->stream);
+    t.tiles_m = g.tiles_m, t.tiles_n = g.tiles_n, t.bm = bm, t.bn = bn, t.flags = flags, t.ref_off = g.ref_off, t.qry_off = g.qry_off;
+    t.n_slots = (uint32_t)t.host.size();
+    hit = &t;
+  }
+  hit->used = ++c->tile_tab_clock;
+  g.tile_tab = static_cast<const uint32_t *>(hit->dev.p), g.diag_first = 0;
+  return hit->n_slots;
+}
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only,
 // 64 no outlier corrections in phase 2
@@ -678,7 +769,7 @@ __device__ unsigned long long g_dist_stamps[16][2][8][6];
 __device__ unsigned long long g_dist_tile_stamps[16][8][10];
 __device__ unsigned long long g_dist_tile_real[2048][2];  // s_memrealtime (100 MHz) at points 1 and 2: with the stamps of
                                                           // g_dist_tile_stamps' wave 0 this gives the shader clock of the main loop
-__device__ unsigned long long g_dist_tile_all[2048][5];  // per workgroup: entry, main loop done, tile done, candidates evaluated, XCC id
+__device__ unsigned long long g_dist_tile_all[2048][5];  // per workgroup: entry, main loop done, tile done, candidates evaluated, XCC id | HW_ID << 8
 #define HG_TSTAMP(pt)                                                                                      \
   if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528)                                    \
     g_dist_tile_stamps[blockIdx.x - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();            \
@@ -731,7 +822,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
 #ifdef HG_DIST_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 2048)
     g_dist_tile_all[blockIdx.x][3] = 0, g_dist_tile_all[blockIdx.x][1] = 0, g_dist_tile_all[blockIdx.x][2] = 0,
-    g_dist_tile_all[blockIdx.x][4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // hwreg(HW_REG_XCC_ID, 0, 4)
+    g_dist_tile_all[blockIdx.x][4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) |  // hwreg(HW_REG_XCC_ID, 0, 4)
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);  // HW_REG_HW_ID
 #endif
   if (g.veto && (CEN ? g.veto[0] == 1u : g.veto[0] != 0u)) return;  // uniform: a kernel queued before this one did the work (1: the i8 one, 2: the centred f16 one)
   if (I8 && !HAM) {
@@ -769,7 +861,15 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // The host may therefore put the tiles that straddle the diagonal in front (g.diag_first workgroup slots, two per tile
   // row, a multiple of 8 so that the XCD of the remaining workgroups is unchanged): longest jobs first.
   uint32_t tm, tn;
-  if (blockIdx.x < g.diag_first) {
+  if (g.tile_tab) {
+    // the host's table: exactly the tiles that have work, every XCD the same number of them (+-1) in the order described
+    // above, the diagonal ones in front.  Slots that return at once -- the super-tile grid's padding, the diagonal tiles'
+    // places in the walk, the lower triangle of a symmetric comparison -- made some CUs run six tiles and others four
+    // where five each were due: the hardware deals workgroup i to XCD i % 8 whatever it turns out to do.
+    const uint32_t t = g.tile_tab[blockIdx.x];
+    if (t == ~0u) return;
+    tm = t & 0xFFFFu, tn = t >> 16;
+  } else if (blockIdx.x < g.diag_first) {
     // slot s: tile row s % (diag_first / 2), its first (s < diag_first / 2) or second diagonal tile -- diag_first / 2 is a
     // multiple of 8, so the rows' first tiles, the dense ones, go round the XCDs (with two adjacent slots per row they
     // all fell to the even XCDs: 223 k against 126 k candidates per XCD)
@@ -1638,7 +1738,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
     else if (c->dbg_dist_tile == "wide") nt = 5;
   }
   g.tiles_m = (R + 255) / 256, g.tiles_n = (Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
-  const uint32_t n_tiles = dist_grid(g.tiles_m, g.tiles_n);
+  const uint32_t n_tiles = dist_tile_table(c, g, 256, (uint32_t)nt * 64, false);
   const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
   auto launch = [&](auto kern, const std::string &name, int threads) -> hipError_t {
     c->last_kernel[HG_T_DIST] = name;
@@ -1766,8 +1866,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
     // (the same matrix on both sides at the same global offset: hits cluster on the diagonal -- those tiles first)
-    g.diag_first = (same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
-    const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
+    const uint32_t n_tiles = dist_tile_table(c, g, 256, (uint32_t)nt * 64, same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain");
     const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
     const void *fp = nt == 5 ? reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 5, true>)
                              : reinterpret_cast<const void *>(&dist_mfma_kernel<false, false, true, true, 4, true>);
@@ -1863,8 +1962,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
       else if (c->dbg_dist_tile == "wide") nt = 5;
     }
     g.tiles_m = (a.R + 255) / 256, g.tiles_n = (a.Q + (uint32_t)nt * 64 - 1) / ((uint32_t)nt * 64);
-    g.diag_first = (same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
-    const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
+    const uint32_t n_tiles = dist_tile_table(c, g, 256, (uint32_t)nt * 64, same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain");
     const size_t lds = nt == 5 ? dist_lds_bytes<true, 5, true>() : dist_lds_bytes<true, 4, true>();
     auto launch_cen = [&](auto kern, const std::string &name, int threads) -> hipError_t {
       const void *fp = reinterpret_cast<const void *>(kern);
@@ -2038,8 +2136,7 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const uint32_t bm = big ? 256 : 128, bn = big ? (uint32_t)nt * 64 : 128;
   g.tiles_m = (a.R + bm - 1) / bm, g.tiles_n = (a.Q + bn - 1) / bn;
   // (thresholded self-comparison: the tiles on the diagonal first, as on the i8 path)
-  g.diag_first = (!full && same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain") ? 2 * ((g.tiles_m + 7) / 8 * 8) : 0u;
-  const uint32_t n_tiles = g.diag_first + dist_grid(g.tiles_m, g.tiles_n);
+  const uint32_t n_tiles = dist_tile_table(c, g, bm, bn, !full && same && a.ref_off == a.qry_off && c->dbg_dist_order != "plain");
   auto launch = [&](auto kern, const std::string &name, int threads, size_t lds) -> hipError_t {
     if (!guard || v_lo == 0) c->last_kernel[HG_T_DIST] = name;  // (a guarded second launch covers verdicts 1..2 only)
     const void *fp = reinterpret_cast<const void *>(kern);

@@ -43,6 +43,15 @@ struct hg_ctx {
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
   Buf w_cen;                   // centred f16 path: row / column info words, statistics slots, failure + verdict words
+  // slot -> tile tables of the dist / Hamming GEMM launches (hg_dist_kernels.hip: dist_tile_table), a few shapes kept
+  struct TileTab {
+    uint32_t tiles_m = 0, tiles_n = 0, bm = 0, bn = 0, flags = 0, n_slots = 0;
+    uint64_t ref_off = 0, qry_off = 0, used = 0;
+    Buf dev;
+    std::vector<uint32_t> host;  // (kept: the upload reads it asynchronously)
+    hipEvent_t uploaded = nullptr;  // behind the upload: the host copy may be rewritten once it has passed
+  } tile_tabs[8];
+  uint64_t tile_tab_clock = 0;
   std::string last_kernel_cen; // name of the last centred f16 GEMM queued (it is the DIST kernel when its verdict was positive)
   const void *cen_sig_ref = nullptr, *cen_sig_qry = nullptr;  // operands of the last call that ran on centred f16 operands
   uint32_t cen_sig_r = 0, cen_sig_q = 0, cen_sig_d = 0;

@@ -67,7 +67,9 @@ int hg_device_count(void);
  * keys: "dist_tile" = "" | "small" | "big" | "wide"      (GEMM tile geometry)
  *       "dist_path" = "" | "f16" | "i8" | "cen"            (operand format of the ANI GEMM: raw values as f16 only / try byte
  *                                                           operands / try centred counts as f16 -- also on small problems)
- *       "dist_order" = "" | "plain"                        ("plain": a self-comparison does not run its diagonal tiles first)
+ *       "dist_order" = "" | "plain" | "legacy"             ("plain": a self-comparison does not run its diagonal tiles first;
+ *                                                           "legacy": workgroups derive their tile from blockIdx instead of
+ *                                                           reading the host's balanced slot -> tile table)
  *       "ham_path"  = "" | "popc" | "mfma" | "fp4"         (Hamming search: xor + popcount, +-1 byte GEMM, +-1 e2m1 GEMM)
  *       "kmer_input" = "" | "packed"                       ("packed": batches that arrive as ASCII are 2-bit packed on the
  *                                                           device first and take the packed-input kernels)

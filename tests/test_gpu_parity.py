@@ -653,8 +653,9 @@ def test_dist_i8_operand_path_equals_f16_and_oracle(ctx, orc, same):
 
 @pytest.mark.parametrize("path", ["i8", "f16"])
 def test_dist_tile_orders_and_epilogue_paths_agree(ctx, orc, path):
-    """A self-comparison runs its diagonal tiles first (hg_ctx_set_debug "dist_order" = "plain" turns that off): the
-    same hits either way, symmetric or not, on a size with ragged last tiles.  The HVs are clustered in blocks of 150 so
+    """A self-comparison runs its diagonal tiles first (hg_ctx_set_debug "dist_order" = "plain" turns that off; "legacy"
+    = the kernel's own blockIdx -> tile mapping instead of the host's balanced slot table): the
+    same hits every way, symmetric or not, on a size with ragged last tiles.  The HVs are clustered in blocks of 150 so
     that diagonal tiles carry dense blocks (candidate lists that overflow in the middle of a tile: the slab path with
     its cooperative flushes) while the others see scattered candidates or none (the lane-mask path, one list per tile,
     and the early exit); a low and a high threshold move tiles between the three."""
@@ -672,9 +673,11 @@ def test_dist_tile_orders_and_epilogue_paths_agree(ctx, orc, path):
             for sym in (False, True):
                 ctx.set_debug("dist_order", "plain")
                 a = key(ctx.dist(hv, rn, hv, rn, 21, symmetric=sym, ani_th=th))
+                ctx.set_debug("dist_order", "legacy")  # the workgroups derive their tiles from blockIdx (no host table)
+                l = key(ctx.dist(hv, rn, hv, rn, 21, symmetric=sym, ani_th=th))
                 ctx.set_debug("dist_order", "")
                 b = key(ctx.dist(hv, rn, hv, rn, 21, symmetric=sym, ani_th=th))
-                assert a.size == b.size > 10000 and np.array_equal(a, b), (th, sym)
+                assert a.size == b.size > 10000 and np.array_equal(a, b) and np.array_equal(l, b), (th, sym)
                 got = np.zeros((400, R), np.float32)
                 m = b["ref_idx"] < 400
                 got[b["ref_idx"][m], b["qry_idx"][m]] = b["ani"][m]
