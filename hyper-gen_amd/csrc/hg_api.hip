@@ -499,10 +499,20 @@ hg_status pack_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *seq_offs, 
   return HG_OK;
 }
 
+// One-genome callers that want the sorted hash list on the host (hg_kmer_hash_sample): the distinct count and the first
+// max_hashes hashes ride back with the counter copy sample_batch synchronises on anyway -- one synchronisation per call
+// instead of three.  valid is set when the list the LDS sort produced is final (no overflow, no second sort pass).
+struct SampleFetch {
+  size_t max_hashes = 0;
+  const uint64_t *h_hashes = nullptr;  // in the ctx's page-locked scratch: consume before the next call on the ctx
+  uint32_t nd = 0;
+  bool valid = false;
+};
+
 hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
                        size_t n, uint32_t ksize, uint64_t threshold, uint64_t scaled_for_cap, uint64_t seed,
                        bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out, bool packed = false,
-                       const uint64_t *mask_offs = nullptr) {
+                       const uint64_t *mask_offs = nullptr, SampleFetch *fetch = nullptr) {
   if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
   std::vector<uint64_t> hook_offs;
   if (!packed && c->dbg_kmer_input == "packed") {
@@ -547,7 +557,11 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     if ((s = hg_ensure(c, c->w_cnt, 2 * n * sizeof(uint32_t) + 16)) != HG_OK) return s;
     const size_t pin_meta = (n * sizeof(hg_genome_meta) + 63) & ~(size_t)63;
     const size_t pin_items = (n_items * sizeof(uint32_t) + 63) & ~(size_t)63;
-    if ((s = hg_ensure_pinned(c, n * sizeof(uint32_t) + 64 + (reuse ? 0 : pin_meta + pin_items))) != HG_OK) return s;
+    // (the fetch block lies behind the plan's staging area whether this call uses that or not)
+    const size_t fetch_off = ((n * sizeof(uint32_t) + 63) & ~(size_t)63) + pin_meta + pin_items;
+    const size_t fetch_n = (fetch && n == 1) ? std::min<size_t>({fetch->max_hashes, pl.meta[0].hit_cap, (size_t)1 << 16}) : 0;
+    if ((s = hg_ensure_pinned(c, n * sizeof(uint32_t) + 64 + (reuse ? 0 : pin_meta + pin_items) +
+                                     (fetch && n == 1 ? fetch_off + 64 + fetch_n * 8 : 0))) != HG_OK) return s;
     auto *d_meta = static_cast<hg_genome_meta *>(c->w_gmeta.p);
     auto *d_items = static_cast<uint32_t *>(c->w_items.p);
     auto *d_hits = static_cast<uint64_t *>(c->w_hits.p);
@@ -581,6 +595,13 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
     }
     // overflow check on the raw counters (they keep counting past the capacity)
     HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    uint8_t *h_fetch = static_cast<uint8_t *>(c->h_pin) + fetch_off;
+    if (fetch && n == 1) {
+      fetch->valid = false;
+      HG_HIP(c, hipMemcpyAsync(h_fetch, d_nd, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      if (fetch_n)
+        HG_HIP(c, hipMemcpyAsync(h_fetch + 64, d_hits + pl.meta[0].hit_off, fetch_n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
     HG_HIP(c, hipStreamSynchronize(c->stream));
     bool overflow = false;
     want.assign(n, 0);
@@ -639,6 +660,15 @@ hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets,
       }
       c->plan_max_hits = pl.max_hits;
       *d_ndistinct_out = d_nd;
+      if (fetch && n == 1) {
+        // the copies above saw the final list iff the first sort pass covered the set
+        const uint32_t cnt = std::min(h_cnt[0], pl.meta[0].hit_cap);
+        if (cnt <= hg_sort_lds_keys(sort_cap) && cnt <= HG_SORT_LDS_MAX_KEYS) {  // (then nothing above touched the scratch either)
+          uint32_t nd;
+          std::memcpy(&nd, h_fetch, sizeof nd);
+          if (nd <= fetch_n) fetch->valid = true, fetch->nd = nd, fetch->h_hashes = reinterpret_cast<const uint64_t *>(h_fetch + 64);
+        }
+      }
       return HG_OK;
     }
     c->plan_valid = false;
@@ -1041,9 +1071,16 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   if (scaled < 1) scaled = 1;
   BatchPlan pl;
   uint32_t *d_nd = nullptr;
+  SampleFetch fetch;
+  fetch.max_hashes = out_hashes ? cap : 0;
   s = sample_batch(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), 1, ksize, threshold, scaled,
-                   seed, canonical != 0, norm_mode, pl, &d_nd, packed);
+                   seed, canonical != 0, norm_mode, pl, &d_nd, packed, nullptr, &fetch);
   if (s != HG_OK) return s;
+  if (fetch.valid) {  // count and hashes came back with sample_batch's own synchronisation
+    *n_out = fetch.nd;
+    if (fetch.nd) std::memcpy(out_hashes, fetch.h_hashes, fetch.nd * sizeof(uint64_t));
+    return HG_OK;
+  }
   uint32_t nd = 0;
   HG_HIP(c, hipMemcpyAsync(&nd, d_nd, sizeof nd, hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));
