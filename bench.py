@@ -611,7 +611,8 @@ def main():
         if not np.array_equal(got_n, want_nh):
             raise SystemExit("PARITY GATE FAILED: per-call hash counts differ from the batch's")
         dt_s = min(run_threads(call_sample) for _ in range(2))
-        pc_form = "2-bit packed by the calling threads" if pc_ctx[0].last_kernel("kmer").endswith("true>") else "ASCII"
+        n_pk = sum(c.last_kernel("kmer").endswith("true>") for c in pc_ctx)
+        pc_form = "the library's measured choice: %d of the %d threads' last calls went 2-bit packed by the calling thread, the others ASCII" % (n_pk, PT)
         run_threads(call_sketch)
         dt_k = min(run_threads(call_sketch) for _ in range(2))
         for c in pc_ctx:

@@ -849,14 +849,74 @@ static bool host_pinned(const void *p) {
   }
   return a.type == hipMemoryTypeHost;
 }
-// Whether ONE genome handed over by a host-fed call goes over the link 2-bit packed (packed by the calling thread into the
-// context's page-locked staging buffer: ~0.07 ms per Mbp) instead of as ASCII: yes when the link is what the call would
-// wait for -- 3 or more other host-fed calls in flight -- or when the source is pageable memory, which the runtime would
-// stage through its own pinned buffers anyway.  Hook: "hostfed" = "ascii" never, "packed" always.
-static bool pack_single(const hg_ctx *c, const void *seq, uint64_t n_bps, int others) {
-  if (c->dbg_hostfed == "ascii" || hg_pack2_size(n_bps) > HG_PACK_BYTES) return false;
-  if (c->dbg_hostfed == "packed") return true;
-  return n_bps >= (256u << 10) && (others >= 3 || !host_pinned(seq));
+// Whether ONE genome handed over by a host-fed call goes over the link 2-bit packed (by the calling thread into the
+// context's page-locked staging buffer) instead of as ASCII.
+//  * pageable source (>= 256 KB): packed -- the runtime would stage it through its own pinned buffers anyway;
+//  * page-locked source, fewer than 3 other host-fed calls in flight: ASCII (a lone 5 Mbp call takes 0.18 ms as ASCII,
+//    0.33 ms packed);
+//  * page-locked source, the link shared by K >= 4 calls (the reference's one-call-per-genome pattern from a thread
+//    pool): packed as long as the host keeps up.  With K calls sharing a link of L bytes/s a call waits n K / L for its
+//    ASCII, or n / r + 0.375 n K / L packed at r bytes/s: packing pays while r > L / (0.625 K).  r is what the calling
+//    threads really achieve TOGETHER (16 of them are bound by host DRAM: 7 GB/s each on a quiet box of the pool -- 17 k
+//    genomes/s against 10 k --, 4 GB/s on one whose memory was busy -- 8.6 k against 10 k), so it is measured in the
+//    packed calls themselves (decayed mean, kept per range of K: r falls as K grows); when it falls short, the next calls
+//    of that range go as ASCII -- 256 of them, doubling each time packing fails again, up to 16 384 -- and then packing is
+//    tried afresh.
+// Hook: "hostfed" = "ascii" never, "packed" always.
+namespace {
+constexpr double HG_LINK_BYTES_PER_S = 50e9;  // what ASCII uploads from page-locked memory reach on Gen5 x16 (bench.py host_fed.ascii_link)
+struct PackState {
+  std::atomic<uint64_t> rate{0};       // decayed mean of the bytes/s one calling thread packed at, contended packed calls
+  std::atomic<uint32_t> samples{0};    // ... and how many calls it has seen since packing was (re)started
+  std::atomic<int32_t> ascii_left{0};  // > 0: contended calls still to go as ASCII before packing is tried again
+  std::atomic<uint32_t> backoff{256};
+};
+PackState g_pack[6];  // by calls in flight: 4-5, 6-7, 8-11, 12-15, 16-23, 24 and more
+inline PackState &pack_state(int sharing) {
+  return g_pack[sharing < 6 ? 0 : sharing < 8 ? 1 : sharing < 12 ? 2 : sharing < 16 ? 3 : sharing < 24 ? 4 : 5];
+}
+struct SingleChoice {
+  bool packed = false, measured = false;
+  int sharing = 1;  // calls in flight, this one included
+};
+// after a measured call packed its genome: n bytes in sec seconds
+void pack_measured(const SingleChoice &ch, uint64_t n, double sec) {
+  if (!ch.measured || sec <= 0) return;
+  PackState &st = pack_state(ch.sharing);
+  const uint64_t rate = (uint64_t)((double)n / sec), old = st.rate.load(std::memory_order_relaxed);
+  const uint64_t now = old ? old - old / 8 + rate / 8 : rate;  // (racing updates lose a sample at worst)
+  st.rate.store(now, std::memory_order_relaxed);
+  const uint32_t seen = st.samples.fetch_add(1, std::memory_order_relaxed) + 1;
+  if (seen >= 8 && (double)now * 0.625 * ch.sharing < 0.9 * HG_LINK_BYTES_PER_S) {
+    const uint32_t b = st.backoff.load(std::memory_order_relaxed);
+    st.ascii_left.store((int32_t)b, std::memory_order_relaxed);
+    st.backoff.store(std::min<uint32_t>(2 * b, 16384u), std::memory_order_relaxed);
+    st.samples.store(0, std::memory_order_relaxed), st.rate.store(0, std::memory_order_relaxed);
+  } else if (seen == 1024) {
+    st.backoff.store(256, std::memory_order_relaxed);  // (a long run of packing that paid)
+  }
+}
+}  // namespace
+static SingleChoice pack_single(const hg_ctx *c, const void *seq, uint64_t n_bps, int others) {
+  SingleChoice r;
+  r.sharing = others + 1;
+  if (c->dbg_hostfed == "ascii" || hg_pack2_size(n_bps) > HG_PACK_BYTES) return r;
+  r.packed = true;
+  if (c->dbg_hostfed == "packed") return r;
+  r.packed = false;
+  if (n_bps < (256u << 10)) return r;
+  if (!host_pinned(seq)) {
+    r.packed = true;
+    return r;
+  }
+  if (others < 3) return r;
+  PackState &st = pack_state(r.sharing);
+  if (st.ascii_left.load(std::memory_order_relaxed) > 0) {
+    st.ascii_left.fetch_sub(1, std::memory_order_relaxed);
+    return r;
+  }
+  r.packed = r.measured = true;
+  return r;
 }
 
 extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
@@ -880,7 +940,11 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
   for (size_t g = 0; g < n; ++g) all_bytes += lens[g];
   bool want_pack = (P >= 4 && all_bytes >= (32ull << 20) && c->dbg_hostfed != "ascii") || (n > 1 && c->dbg_hostfed == "packed");
   if (want_pack) P = std::max(1u, P / (unsigned)(1 + in_flight.others));
-  else if (n == 1 && pack_single(c, seqs[0], lens[0], in_flight.others)) want_pack = true, P = 1;
+  SingleChoice single;
+  if (!want_pack && n == 1) {
+    single = pack_single(c, seqs[0], lens[0], in_flight.others);
+    if (single.packed) want_pack = true, P = 1;
+  }
   const uint64_t stage_bytes = want_pack ? 2 * HG_STAGE_BYTES : HG_STAGE_BYTES;  // (packed: 48 MB per upload)
   // device layout: 16-byte aligned starts, 64 bytes of slack; sub-batch boundaries by bytes
   std::vector<uint64_t> offs(n), l64(n), boffs(n);
@@ -960,6 +1024,7 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
           const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           if (src_pinned && k == first_chunk && (double)span < 55e9 * sec && c->dbg_hostfed != "packed")
             for (size_t j = k + 1; j < n_chunks; ++j) sub_packed[j] = 0;
+          if (n == 1) pack_measured(single, lens[0], sec);
           if (e == hipSuccess) e = hipMemcpyAsync(d_seq + boffs[g0], pin, sub_pk_bytes[k], hipMemcpyHostToDevice, c->copy_stream);
           if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], c->copy_stream);
           c->pack_used[b] = true;
@@ -1052,14 +1117,17 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   if (s != HG_OK) return s;
   // over the link as ASCII, or 2-bit packed by this thread when the link is shared with other calls (pack_single())
   HostfedCall in_flight;
-  const bool packed = pack_single(c, seq, n_bps, in_flight.others);
+  const SingleChoice single = pack_single(c, seq, n_bps, in_flight.others);
+  const bool packed = single.packed;
   if (packed) {
     if (!c->pack_buf[0]) {
       HG_HIP(c, hipHostMalloc(&c->pack_buf[0], HG_PACK_BYTES, hipHostMallocDefault));
       HG_HIP(c, hipEventCreateWithFlags(&c->pack_ev[0], hipEventDisableTiming));
     }
     if (c->pack_used[0]) HG_HIP(c, hipEventSynchronize(c->pack_ev[0]));
+    const auto tp0 = std::chrono::steady_clock::now();
     if (hg_pack2(seq, n_bps, norm_mode, static_cast<uint8_t *>(c->pack_buf[0])) != HG_OK) return hg_fail(c, HG_ERR_INVALID, "hg_pack2");
+    pack_measured(single, n_bps, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
     HG_HIP(c, hipMemcpyAsync(c->w_seq.p, c->pack_buf[0], hg_pack2_size(n_bps), hipMemcpyHostToDevice, c->stream));
     HG_HIP(c, hipEventRecord(c->pack_ev[0], c->stream));
     c->pack_used[0] = true;

@@ -170,8 +170,10 @@ hg_status hg_sketch_batch_dev_packed(hg_ctx *ctx, const uint8_t *d_blobs, const 
  * 1 Mbase into page-locked staging; the packed-input kernels sketch them) -- 2.3x the ASCII rate on the measured box,
  * where host DRAM (114 GB/s of packing reads) then limits instead of PCIe; the first sub-batch is timed and the rest goes
  * as ASCII when the host packs slower than the link carries.  A call with n = 1 packs on the calling thread when the
- * source is pageable memory or when >= 3 other host-fed calls of the process are in flight (the reference's
- * one-call-per-genome pattern from a thread pool, src/sketch_cuda.rs:79-96: the calls share one link).  Debug key
+ * source is pageable memory, or when >= 3 other host-fed calls of the process are in flight (the reference's
+ * one-call-per-genome pattern from a thread pool, src/sketch_cuda.rs:79-96: the calls share one link) and the calling
+ * threads together pack fast enough for that to pay -- their rate is measured in the packed calls; when it falls short
+ * (a host whose memory is busy) the following calls go as ASCII for a while before packing is tried again.  Debug key
  * "hostfed" = "ascii" | "packed" pins the choice.  The same rule applies to hg_kmer_hash_sample. */
 hg_status hg_sketch_batch(hg_ctx *ctx, const uint8_t *const *seqs, const size_t *lens,
                           size_t n, const hg_sketch_params *p, int16_t *hv_out,
