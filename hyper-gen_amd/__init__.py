@@ -76,7 +76,7 @@ EXPORTS = [
     "hg_sort_ani_hits_dev", "hg_sort_ani_hits_staged", "hg_topk_per_query_dev", "hg_ctx_last_dist_path",
     "hg_ctx_last_hamming_path", "hg_read_fastx_pinned", "hg_pinned_free",
     "hg_sketch_stream_open", "hg_sketch_stream_push", "hg_sketch_stream_pop", "hg_sketch_stream_finish",
-    "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node",
+    "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node", "hg_bind_thread_to_numa_node",
     "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
     "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
     "hg_sketch_batch_dev_packed", "hg_pack2_batch_dev", "hg_pack2_dev",
@@ -166,6 +166,7 @@ def lib():
         "hg_read_fastx_pinned": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]),
         "hg_pinned_free": (None, [vp]),
         "hg_device_numa_node": (C.c_int, [C.c_int]),
+        "hg_bind_thread_to_numa_node": (C.c_int, [C.c_int, C.c_uint]),
         "hg_sketch_stream_open": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(SketchParams), C.POINTER(vp)]),
         "hg_sketch_stream_push": (C.c_int, [vp, vp, sz, C.c_uint64]),
         "hg_sketch_stream_pop": (C.c_int, [vp, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),

@@ -919,6 +919,23 @@ static SingleChoice pack_single(const hg_ctx *c, const void *seq, uint64_t n_bps
   return r;
 }
 
+// Page-locked staging buffer b of the context with room for `need` bytes, free to be rewritten (the upload that last read
+// it has passed).  Sized by need -- locking pages costs ~0.25 ms per MB, and a pool of one-call-per-genome contexts
+// should not pin 66 MB each for 2 MB blobs.
+static hipError_t pack_buf_for(hg_ctx *c, int b, size_t need) {
+  hipError_t e = hipSuccess;
+  if (c->pack_used[b]) e = hipEventSynchronize(c->pack_ev[b]);
+  if (e != hipSuccess) return e;
+  if (!c->pack_ev[b] && (e = hipEventCreateWithFlags(&c->pack_ev[b], hipEventDisableTiming)) != hipSuccess) return e;
+  if (c->pack_cap[b] >= need) return hipSuccess;
+  if (c->pack_buf[b]) (void)hipHostFree(c->pack_buf[b]);
+  c->pack_buf[b] = nullptr, c->pack_cap[b] = 0, c->pack_used[b] = false;
+  const size_t want = (need + need / 4 + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  if ((e = hipHostMalloc(&c->pack_buf[b], want, hipHostMallocDefault)) != hipSuccess) return e;
+  c->pack_cap[b] = want;
+  return hipSuccess;
+}
+
 extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, const size_t *lens, size_t n,
                                      const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
                                      uint32_t *nhash_out) {
@@ -973,7 +990,15 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
     }
   }
   std::unique_ptr<CallPool> pool;
-  if (want_pack) pool.reset(new CallPool(P));  // (takes the threads it can get)
+  // The pool's threads run on the NUMA node the sequences lie on (page-locked memory from the HIP runtime: the device's node,
+  // like the staging buffers they write; packing from the other socket is ~1.5x slower), the uploader thread too.
+  int pack_node = -1;
+  if (want_pack && P > 1) {
+    for (size_t g = 0; g < n && pack_node < 0; ++g)
+      if (lens[g]) pack_node = hg_numa_node_of(seqs[g]);
+    if (pack_node < 0) pack_node = hg_device_numa_node(c->device);
+  }
+  if (want_pack) pool.reset(new CallPool(P, pack_node));  // (takes the threads it can get)
   // packing has to outrun the link to be worth it from page-locked sources (ASCII goes at ~50 GB/s from those): the
   // uploader times its first packed sub-batch and leaves the rest as ASCII when the host is too slow for that
   const bool src_pinned = want_pack && n > 1 && host_pinned(seqs[0]);
@@ -984,8 +1009,12 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
   auto *d_hv = static_cast<int16_t *>(c->w_hv.p);
   auto *d_n2 = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->w_hv.p) + ((hv_bytes + 15) & ~(size_t)15));
   auto *d_nh = reinterpret_cast<uint32_t *>(d_n2 + n);
-  if (!c->copy_stream) HG_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  while (c->copy_events.size() < n_chunks) {
+  // one sub-batch (the n = 1 of a one-call-per-genome pool above all): its upload goes on the context's own stream, in
+  // front of its kernels -- no second stream, no event to wait for
+  const bool one_stream = n_chunks == 1;
+  if (!one_stream && !c->copy_stream) HG_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  const hipStream_t up_stream = one_stream ? c->stream : c->copy_stream;
+  while (!one_stream && c->copy_events.size() < n_chunks) {
     hipEvent_t e;
     HG_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->copy_events.push_back(e);
@@ -997,17 +1026,14 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
   hipError_t copy_err = hipSuccess;
   auto upload = [&](size_t first_chunk) {
     hipError_t e = hipSetDevice(c->device);
+    if (n_chunks > 1) (void)hg_bind_thread_to_numa_node(pack_node, P);  // (the helper thread only, never the caller's)
     for (size_t k = first_chunk; k < n_chunks; ++k) {
       const size_t g0 = cut[k], g1 = cut[k + 1];
       const uint64_t span = offs[g1 - 1] + ((l64[g1 - 1] + 15) & ~(uint64_t)15) - offs[g0];
       if (sub_packed[k]) {
         // 2-bit pack the sub-batch into page-locked staging (all host threads of the call), then ONE upload
         const int b = (int)(k & 1);
-        if (!c->pack_buf[b]) {
-          e = hipHostMalloc(&c->pack_buf[b], HG_PACK_BYTES, hipHostMallocDefault);
-          if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pack_ev[b], hipEventDisableTiming);
-        }
-        if (e == hipSuccess && c->pack_used[b]) e = hipEventSynchronize(c->pack_ev[b]);
+        if (e == hipSuccess) e = pack_buf_for(c, b, n == 1 ? sub_pk_bytes[k] : HG_PACK_BYTES);
         if (e == hipSuccess) {
           auto *pin = static_cast<uint8_t *>(c->pack_buf[b]);
           // pieces of 1 Mbase, so that the threads finish together whatever the genome sizes
@@ -1025,32 +1051,28 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
           if (src_pinned && k == first_chunk && (double)span < 55e9 * sec && c->dbg_hostfed != "packed")
             for (size_t j = k + 1; j < n_chunks; ++j) sub_packed[j] = 0;
           if (n == 1) pack_measured(single, lens[0], sec);
-          if (e == hipSuccess) e = hipMemcpyAsync(d_seq + boffs[g0], pin, sub_pk_bytes[k], hipMemcpyHostToDevice, c->copy_stream);
-          if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], c->copy_stream);
+          if (e == hipSuccess) e = hipMemcpyAsync(d_seq + boffs[g0], pin, sub_pk_bytes[k], hipMemcpyHostToDevice, up_stream);
+          if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], up_stream);
           c->pack_used[b] = true;
         }
       } else if (g1 - g0 >= 16 && span / (g1 - g0) < ((uint64_t)1 << 20) && span <= HG_PACK_BYTES) {
         // many small genomes: pack them into pinned memory (device layout) and upload once -- a
         // hipMemcpyAsync per 2 kbp genome costs more than the genome
         const int b = (int)(k & 1);
-        if (!c->pack_buf[b]) {
-          e = hipHostMalloc(&c->pack_buf[b], HG_PACK_BYTES, hipHostMallocDefault);
-          if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pack_ev[b], hipEventDisableTiming);
-        }
-        if (e == hipSuccess && c->pack_used[b]) e = hipEventSynchronize(c->pack_ev[b]);
+        if (e == hipSuccess) e = pack_buf_for(c, b, HG_PACK_BYTES);
         if (e == hipSuccess) {
           auto *pin = static_cast<uint8_t *>(c->pack_buf[b]);
           for (size_t g = g0; g < g1; ++g)
             if (lens[g]) std::memcpy(pin + (offs[g] - offs[g0]), seqs[g], lens[g]);
-          e = hipMemcpyAsync(d_seq + offs[g0], pin, span, hipMemcpyHostToDevice, c->copy_stream);
-          if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], c->copy_stream);
+          e = hipMemcpyAsync(d_seq + offs[g0], pin, span, hipMemcpyHostToDevice, up_stream);
+          if (e == hipSuccess) e = hipEventRecord(c->pack_ev[b], up_stream);
           c->pack_used[b] = true;
         }
       } else {
         for (size_t g = g0; g < g1 && e == hipSuccess; ++g)
-          if (lens[g]) e = hipMemcpyAsync(d_seq + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, c->copy_stream);
+          if (lens[g]) e = hipMemcpyAsync(d_seq + offs[g], seqs[g], lens[g], hipMemcpyHostToDevice, up_stream);
       }
-      if (e == hipSuccess) e = hipEventRecord(c->copy_events[k], c->copy_stream);
+      if (e == hipSuccess && !one_stream) e = hipEventRecord(c->copy_events[k], up_stream);
       std::lock_guard<std::mutex> lk(mu);
       if (e != hipSuccess) copy_err = e;
       queued = e == hipSuccess ? k + 1 : n_chunks;  // on error release the consumer, which then reports it
@@ -1072,7 +1094,7 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
       }
     }
     const size_t g0 = cut[k], m = cut[k + 1] - g0;
-    hipError_t e = hipStreamWaitEvent(c->stream, c->copy_events[k], 0);
+    hipError_t e = one_stream ? hipSuccess : hipStreamWaitEvent(c->stream, c->copy_events[k], 0);
     if (e != hipSuccess) {
       s = hg_fail(c, HG_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
       break;
@@ -1089,7 +1111,7 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
     if (e != hipSuccess) s = hg_fail(c, HG_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
   }
   if (uploader.joinable()) uploader.join();
-  (void)hipStreamSynchronize(c->copy_stream);
+  if (!one_stream) (void)hipStreamSynchronize(c->copy_stream);
   if (s != HG_OK) {
     (void)hipStreamSynchronize(c->stream);
     return s;
@@ -1120,13 +1142,9 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   const SingleChoice single = pack_single(c, seq, n_bps, in_flight.others);
   const bool packed = single.packed;
   if (packed) {
-    if (!c->pack_buf[0]) {
-      HG_HIP(c, hipHostMalloc(&c->pack_buf[0], HG_PACK_BYTES, hipHostMallocDefault));
-      HG_HIP(c, hipEventCreateWithFlags(&c->pack_ev[0], hipEventDisableTiming));
-    }
-    if (c->pack_used[0]) HG_HIP(c, hipEventSynchronize(c->pack_ev[0]));
+    HG_HIP(c, pack_buf_for(c, 0, hg_pack2_size(n_bps)));
     const auto tp0 = std::chrono::steady_clock::now();
-    if (hg_pack2(seq, n_bps, norm_mode, static_cast<uint8_t *>(c->pack_buf[0])) != HG_OK) return hg_fail(c, HG_ERR_INVALID, "hg_pack2");
+    hg_pack2_piece(seq, n_bps, norm_mode, static_cast<uint8_t *>(c->pack_buf[0]), 0, n_bps);  // (the whole genome as one piece)
     pack_measured(single, n_bps, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
     HG_HIP(c, hipMemcpyAsync(c->w_seq.p, c->pack_buf[0], hg_pack2_size(n_bps), hipMemcpyHostToDevice, c->stream));
     HG_HIP(c, hipEventRecord(c->pack_ev[0], c->stream));

@@ -7,6 +7,8 @@
 // reference-produced .sketch file exists in this environment, so byte compatibility with the
 // Rust binary is UNPINNED ("parity status").
 #include <fcntl.h>
+#include <sched.h>
+#include <sys/syscall.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -267,6 +269,13 @@ __attribute__((target("avx2"))) size_t pack2_avx2(const uint8_t *seq, size_t n, 
 // AVX-512 (BW + VBMI) form of the same: one 128-entry table look-up classifies and encodes 64 bases (entry = the 2-bit code,
 // or 0x80 for a byte that is not a base; bytes >= 0x80 carry their own sign bit), two multiply-adds gather 4 codes per
 // dword, vpmovdb narrows them to 16 code bytes; the sign bits are the 64 mask bits.  ~2.5x the AVX2 loop per core.
+#ifndef HG_PACK_NT
+#define HG_PACK_NT 1  /* 0: ordinary stores also for streamed output (A/B) */
+#endif
+// STREAM: the output is not read by this core again (it goes to the device by DMA) -- non-temporal stores, so that the
+// destination lines are not fetched from memory before they are overwritten (codes 16-byte, mask 8-byte aligned; the
+// caller fences).  16 threads packing a host-fed batch are bound by host memory traffic, of which that fetch was a sixth.
+template <bool STREAM>
 __attribute__((target("avx512f,avx512bw,avx512vbmi"))) size_t pack2_avx512(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes,
                                                                           uint8_t *mask) {
   alignas(64) uint8_t lut[128];
@@ -287,8 +296,13 @@ __attribute__((target("avx512f,avx512bw,avx512vbmi"))) size_t pack2_avx512(const
     const __m128i b = _mm512_cvtepi32_epi8(q);
     const uint64_t m = (uint64_t)bad;
     // the stores stay behind the loads also when codes == seq (16 + 8 bytes written per 64 read)
-    _mm_storeu_si128(reinterpret_cast<__m128i *>(codes + (i >> 2)), b);
-    std::memcpy(mask + (i >> 3), &m, 8);
+    if (STREAM && HG_PACK_NT) {
+      _mm_stream_si128(reinterpret_cast<__m128i *>(codes + (i >> 2)), b);
+      _mm_stream_si64(reinterpret_cast<long long *>(mask + (i >> 3)), (long long)m);
+    } else {
+      _mm_storeu_si128(reinterpret_cast<__m128i *>(codes + (i >> 2)), b);
+      std::memcpy(mask + (i >> 3), &m, 8);
+    }
   }
   return i;
 }
@@ -299,12 +313,20 @@ extern "C" size_t hg_pack2_size(size_t n_bps) { return al16((n_bps + 3) / 4) + a
 
 namespace {
 // bases [0, n) of `seq` -> codes / mask, both pointing at the bytes of base 0 (n a multiple of 32, or the tail)
-inline void pack2_span(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes, uint8_t *mask) {
+// (stream: see pack2_avx512 -- only when codes is 16-byte and mask 8-byte aligned and neither overlaps seq)
+inline void pack2_span(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes, uint8_t *mask, bool stream = false) {
   size_t done = 0;
 #if defined(__x86_64__)
   static const int isa = (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi")) ? 2
                          : __builtin_cpu_supports("avx2") ? 1 : 0;
-  if (isa == 2) done = pack2_avx512(seq, n, u2t, codes, mask);
+  if (isa == 2) {
+    if (stream && !((uintptr_t)codes & 15) && !((uintptr_t)mask & 7)) {
+      done = pack2_avx512<true>(seq, n, u2t, codes, mask);
+      _mm_sfence();
+    } else {
+      done = pack2_avx512<false>(seq, n, u2t, codes, mask);
+    }
+  }
   if (isa >= 1) done += pack2_avx2(seq + done, n - done, u2t, codes + (done >> 2), mask + (done >> 3));
 #endif
   pack2_scalar(seq, done, n, u2t, codes, mask);
@@ -408,12 +430,49 @@ extern "C" hg_status hg_pack2(const uint8_t *seq, size_t n_bps, uint32_t norm_mo
 void hg_pack2_piece(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t b0, size_t b1) {
   const size_t cb = al16((n_bps + 3) / 4);
   uint8_t *mask = out + cb;
-  pack2_span(seq + b0, b1 - b0, norm_mode == HG_NORM_U2T, out + (b0 >> 2), mask + (b0 >> 3));
+  pack2_span(seq + b0, b1 - b0, norm_mode == HG_NORM_U2T, out + (b0 >> 2), mask + (b0 >> 3), true);
   if (b1 == n_bps) {
     const size_t mb = al16((n_bps + 7) / 8), used = (n_bps + 3) / 4, mused = (n_bps + 7) / 8;
     if (cb > used) std::memset(out + used, 0, cb - used);
     if (mb > mused) std::memset(mask + mused, 0, mb - mused);
   }
+}
+
+// ---- NUMA placement of host threads ----------------------------------------------------------------------------------
+extern "C" int hg_bind_thread_to_numa_node(int node, unsigned threads_sharing) {
+  if (node < 0) return 0;
+  char path[96];
+  std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = std::fopen(path, "r");
+  if (!f) return 0;
+  char line[4096] = {0};
+  const bool ok = std::fgets(line, sizeof line, f) != nullptr;
+  std::fclose(f);
+  if (!ok) return 0;
+  cpu_set_t allowed, set;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return 0;
+  CPU_ZERO(&set);
+  unsigned cpus = 0;
+  for (char *q = line; *q;) {  // "0-63,128-191"
+    char *end = nullptr;
+    const long lo = std::strtol(q, &end, 10);
+    if (end == q) break;
+    long hi = lo;
+    if (*end == '-') hi = std::strtol(end + 1, &end, 10);
+    for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &set), ++cpus;
+    if (*end != ',') break;
+    q = end + 1;
+  }
+  if (!cpus || cpus < threads_sharing) return 0;
+  return sched_setaffinity(0, sizeof set, &set) == 0 ? 1 : 0;
+}
+// NUMA node of the page that holds p (-1: unknown -- not mapped yet, or no such system call)
+int hg_numa_node_of(const void *p) {
+  void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095);
+  int status = -1;
+  const long r = syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0);  // (nodes == NULL: query only)
+  return r == 0 && status >= 0 ? status : -1;
 }
 
 // ---- FASTA -----------------------------------------------------------------------------------------------

@@ -20,13 +20,21 @@ hg_status hg_read_fastx_impl(const char *path, uint32_t mode, uint8_t **pbuf, si
 // b1 == n_bps; `out` must not overlap `seq`) -- the unit of work of the host threads that pack a host-fed batch
 void hg_pack2_piece(const uint8_t *seq, size_t n_bps, uint32_t norm_mode, uint8_t *out, size_t b0, size_t b1);
 
+// hg_formats.cpp: NUMA node of the page that holds p (-1 unknown)
+int hg_numa_node_of(const void *p);
+
 // A few worker threads that live for one call: run(n, fn) executes fn(i) for i in [0, n) on all of them (the caller's
 // thread takes part) and returns when every index is done.
 class CallPool {
  public:
-  explicit CallPool(unsigned threads) {
+  // node >= 0: the workers bind themselves to that NUMA node's CPUs (the caller's own thread is left where it is)
+  explicit CallPool(unsigned threads, int node = -1) {
     try {
-      for (unsigned t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
+      for (unsigned t = 1; t < threads; ++t)
+        th_.emplace_back([this, node, threads] {
+          (void)hg_bind_thread_to_numa_node(node, threads);
+          worker();
+        });
     } catch (...) {  // no more threads to be had: the pool works with the ones it got (the caller's thread at least)
     }
   }

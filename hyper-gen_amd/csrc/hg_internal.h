@@ -91,6 +91,7 @@ struct hg_ctx {
   // two pinned staging buffers for sub-batches of many small genomes (one packed upload instead of one
   // hipMemcpyAsync per genome); pack_ev[i] marks the last upload that read pack_buf[i]
   void *pack_buf[2] = {nullptr, nullptr};
+  size_t pack_cap[2] = {0, 0};  // (sized by need: 2 MB for the 5 Mbp genome of a one-genome call, 66 MB for a batch's sub-batches)
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   bool pack_used[2] = {false, false};
   // rows [pad_rows, padded rows) of the f16 operand copies are known to be zero (dist tiles hang over)

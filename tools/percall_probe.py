@@ -9,6 +9,7 @@ import hypergen_amd as hg
 L = 5_000_000
 HF = 128
 PASSES = int(os.environ.get("HG_PROBE_PASSES", "7"))
+BIND = os.environ.get("HG_PROBE_BIND", "0") == "1"  # the calling threads bound to the device's NUMA node
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 stride = (L + 1 + 15) // 16 * 16
@@ -20,7 +21,7 @@ for g in range(HF):
 rows = [host[g].numpy() for g in range(HF)]
 thr = (2**64 - 1) // 1500
 MODES = ("ascii", "packed", "")
-for PT in (1, 4, 8, 16, 32):
+for PT in (8, 16, 32) if BIND else (1, 4, 8, 16, 32):
     cs = {m: [hg.Context(0) for _ in range(PT)] for m in MODES}
     outs = [np.zeros(8192, np.uint64) for _ in range(PT)]
     for m in MODES:
@@ -34,6 +35,8 @@ for PT in (1, 4, 8, 16, 32):
             def w(t):
                 n = hg.C.c_size_t(0)
                 c = cs[m][t]
+                if BIND:
+                    hg.lib().hg_bind_thread_to_numa_node(hg.lib().hg_device_numa_node(0), PT)
                 for g in range(t, HF, PT):
                     c._ck(hg.lib().hg_kmer_hash_sample(c._h, hg._ptr(rows[g]), rows[g].size, 21, hg.C.c_uint64(thr), hg.C.c_uint64(123), 1, 0,
                                                        hg._ptr(outs[t]), 8192, hg.C.byref(n)))
