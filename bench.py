@@ -476,21 +476,26 @@ def main():
         h_hv, h_n2, h_nh = own.sketch_batch(host_rows, p)
         if not (np.array_equal(h_hv, hv[:HF].cpu().numpy()) and np.array_equal(h_n2, n2[:HF].cpu().numpy())):
             raise SystemExit("PARITY GATE FAILED: host-fed sketches differ from the HBM-resident ones")
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            own.sketch_batch(host_rows, p)
-        hdt_ = time.perf_counter() - t0
+        def median_pass(passes=5):
+            """one hg_sketch_batch call over the HF genomes per pass; the median pass (the host is shared: a pass that meets
+            another tenant's memory traffic takes up to twice as long)"""
+            ts = []
+            for _ in range(passes):
+                t0 = time.perf_counter()
+                own.sketch_batch(host_rows, p)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return ts[len(ts) // 2]
+
+        reps = 1
+        hdt_ = median_pass()
         link_form = "2-bit packed by the library's host threads (0.375 B/base)" if own.last_kernel("kmer").endswith("true>") else "ASCII"
         # the same call with the library told to send ASCII (debug hook "hostfed"): the link-bound rate of round 3
         own.set_debug("hostfed", "ascii")
         a_hv, a_n2, _ = own.sketch_batch(host_rows, p)
         if not (np.array_equal(a_hv, h_hv) and np.array_equal(a_n2, h_n2)):
             raise SystemExit("PARITY GATE FAILED: host-fed sketches depend on the form sent over the link")
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            own.sketch_batch(host_rows, p)
-        adt_ = time.perf_counter() - t0
+        adt_ = median_pass(3)
         own.close()
         gbs = HF * reps * (L_GENOME + 1) / adt_ / 1e9
         out["host_fed"] = {"value": HF * reps / hdt_, "unit": "genomes/sec", "link_form": link_form,
@@ -500,8 +505,8 @@ def main():
                            "config": {"workload": "%d of the step's genomes from pinned host memory through "
                                                   "hg_sketch_batch (the library 2-bit packs each sub-batch on its host threads "
                                                   "while the previous one uploads; kernels overlap both), results "
-                                                  "back on the host; rank 0 only.  ascii_link: the same call with the bases "
-                                                  "sent as ASCII" % HF}}
+                                                  "back on the host; the median of 5 calls; rank 0 only.  ascii_link: the same call with the bases "
+                                                  "sent as ASCII (median of 3)" % HF}}
         log("host-fed: %.0f genomes/s (%s); %.0f genomes/s = %.1f GB/s of sequence over PCIe as ASCII" % (
             out["host_fed"]["value"], link_form, HF * reps / adt_, gbs))
         # the same genomes as hg_pack2 blobs (3 bits per base) through the streaming entry points: what the CLI's
@@ -528,11 +533,13 @@ def main():
             t.join()
         ref_hv, ref_n2 = hv[:HF].cpu().numpy(), n2[:HF].cpu().numpy()
 
+        stream_reps = 3
+
         def stream_pass(sparse):
-            """the HF genomes through push_packed(_sparse) / pop, best of `reps` passes; returns (seconds, bytes over the link)"""
+            """the HF genomes through push_packed(_sparse) / pop, best of `stream_reps` passes; returns (seconds, bytes over the link)"""
             with hg.SketchStream((local,), p) as st:
                 best = None
-                for rep in range(reps + 1):
+                for rep in range(stream_reps + 1):
                     t0 = time.perf_counter()
                     for g in range(HF):
                         if sparse and sblobs[g] is not None:
@@ -563,7 +570,7 @@ def main():
                                    "0.25 B per base over the link) from pinned memory through "
                                    "hg_sketch_stream_push_packed_sparse / pop -- the device rebuilds the bitmap and the blobs go "
                                    "to the packed-input kernels as they arrive --, best of %d passes; packing time not "
-                                   "included.  bitmap_form: the same through hg_pack2 blobs (0.375 B per base)" % (HF, reps)}}
+                                   "included.  bitmap_form: the same through hg_pack2 blobs (0.375 B per base)" % (HF, stream_reps)}}
         log("host-fed, 2-bit packed stream: %.0f genomes/s sparse (%.1f GB/s over PCIe), %.0f genomes/s bitmap form (%.1f GB/s); "
             "host packing %.2f ms per genome and thread" % (HF / best, pk_bytes / best / 1e9, HF / best_b, bytes_b / best_b / 1e9, pack_ms))
         # ---- per_call: the literal drop-in of the reference's inner seam (src/sketch_cuda.rs:79-96,120-166) ------
