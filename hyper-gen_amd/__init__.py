@@ -76,7 +76,7 @@ EXPORTS = [
     "hg_sort_ani_hits_dev", "hg_sort_ani_hits_staged", "hg_topk_per_query_dev", "hg_ctx_last_dist_path",
     "hg_ctx_last_hamming_path", "hg_read_fastx_pinned", "hg_pinned_free",
     "hg_sketch_stream_open", "hg_sketch_stream_push", "hg_sketch_stream_pop", "hg_sketch_stream_finish",
-    "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node", "hg_bind_thread_to_numa_node",
+    "hg_sketch_stream_last_error", "hg_sketch_stream_close", "hg_sketch_stream_stats", "hg_device_numa_node", "hg_bind_thread_to_numa_node", "hg_dist_tile_order",
     "hg_sketch_stream_push_packed", "hg_pack2_size", "hg_pack2", "hg_unpack2_dev",
     "hg_sketch_stream_try_push", "hg_sketch_stream_max_pending",
     "hg_sketch_batch_dev_packed", "hg_pack2_batch_dev", "hg_pack2_dev",
@@ -167,6 +167,8 @@ def lib():
         "hg_pinned_free": (None, [vp]),
         "hg_device_numa_node": (C.c_int, [C.c_int]),
         "hg_bind_thread_to_numa_node": (C.c_int, [C.c_int, C.c_uint]),
+        "hg_dist_tile_order": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
         "hg_sketch_stream_open": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(SketchParams), C.POINTER(vp)]),
         "hg_sketch_stream_push": (C.c_int, [vp, vp, sz, C.c_uint64]),
         "hg_sketch_stream_pop": (C.c_int, [vp, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
@@ -238,6 +240,21 @@ def lib():
 
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if isinstance(a, np.ndarray) else C.c_void_p(int(a))
+
+
+def dist_tile_order(tiles_m, tiles_n, tile_rows=256, tile_cols=320, diagonal_first=False, symmetric=False, ref_off=0, qry_off=0):
+    """hg_dist_tile_order: the slot -> tile table of a launch as a uint32 array (tm | tn << 16, 0xFFFFFFFF = no tile)"""
+    n = C.c_size_t(0)
+    st = lib().hg_dist_tile_order(tiles_m, tiles_n, tile_rows, tile_cols, int(diagonal_first), int(symmetric), ref_off, qry_off,
+                                  None, 0, C.byref(n))
+    if st not in (OK, ERR_CAPACITY):
+        raise HgError(st, "hg_dist_tile_order")
+    out = np.zeros(max(n.value, 1), np.uint32)
+    st = lib().hg_dist_tile_order(tiles_m, tiles_n, tile_rows, tile_cols, int(diagonal_first), int(symmetric), ref_off, qry_off,
+                                  C.c_void_p(out.ctypes.data), out.size, C.byref(n))
+    if st != OK:
+        raise HgError(st, "hg_dist_tile_order")
+    return out[: n.value]
 
 
 def default_params(**kw):

@@ -408,6 +408,16 @@ hg_status hg_read_fastx_into(const char *path, uint32_t mode, uint8_t **buf, siz
  * device like every compute entry point. */
 hg_status hg_read_fastx_pinned(const char *path, uint32_t mode, uint8_t **buf, size_t *cap, size_t *n_bps);
 void hg_pinned_free(void *p);
+/* The order in which a dist / Hamming launch with tiles_m x tiles_n tiles of tile_rows x tile_cols walks its tiles (host
+ * code only, no device needed; for inspection and for the tests): workgroup slot b runs tile out[b] = tm | tn << 16, or
+ * no tile where out[b] == 0xFFFFFFFF.  The hardware deals slot b to XCD b % 8, so the slots b = x, x + 8, ... are XCD
+ * x's queue: every tile that has work (with `symmetric`: not entirely on or below the diagonal of the global
+ * enumeration, row 0 = ref_off, column 0 = qry_off) exactly once; the XCDs' tile counts differ by at most one; each
+ * queue walks 8 x 8 super-tiles in halves of 4 x 8 tiles (the tiles resident on an XCD share 4 + 8 operand blocks through
+ * its L2); with diagonal_first the tiles that straddle the diagonal (a database compared with itself has its hits
+ * there) lead the queues.  *n_slots = the launch's grid size; HG_ERR_CAPACITY (with *n_slots set) if cap is too small. */
+hg_status hg_dist_tile_order(uint32_t tiles_m, uint32_t tiles_n, uint32_t tile_rows, uint32_t tile_cols, int diagonal_first,
+                             int symmetric, uint64_t ref_off, uint64_t qry_off, uint32_t *out, size_t cap, size_t *n_slots);
 /* NUMA node of a device (-1 unknown): host threads that fill page-locked buffers for it should run there */
 int hg_device_numa_node(int device_id);
 /* Restricts the CALLING thread to the CPUs of a NUMA node (the ones it may already run on), unless the node has fewer of
