@@ -10,6 +10,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+for kv in os.environ.get("HG_DEBUG", "").split(","):  # e.g. HG_DEBUG=dist_defer=off,dist_order=legacy
+    if "=" in kv:
+        ctx.set_debug(*kv.split("=", 1))
 hv = bench.clustered_hvs(n, 0, dev)
 n2 = (hv.int() ** 2).sum(1).int()
 cap = 1 << 23
@@ -29,6 +32,19 @@ for th in (101.0, 85.0):
     sh = (hw >> 12) & 1
     se = (hw >> 13) & 7
     print("th %.0f kernel %s: %d tiles stamped, tile mean %.0f ticks" % (th, ctx.last_kernel("dist"), idx.size, (al[idx, 2] - al[idx, 0]).mean()))
+    dur = al[idx, 2] - al[idx, 0]
+    print("  tile duration: min %d  median %d  p90 %d  p99 %d  max %d; slots 0..39 (first diagonal tiles) median %d max %d; 40..79 median %d" % (
+        dur.min(), np.median(dur), np.percentile(dur, 90), np.percentile(dur, 99), dur.max(),
+        np.median(al[:40, 2] - al[:40, 0]), (al[:40, 2] - al[:40, 0]).max(), np.median(al[40:80, 2] - al[40:80, 0])))
+    spans = []
+    for x in range(8):
+        m = idx[xcc[idx] == x]
+        key = se[m] * 100 + sh[m] * 16 + cu[m]
+        for k in np.unique(key):
+            w = m[key == k]
+            spans.append(al[w, 2].max() - al[w, 0].min())  # (one CU, one counter)
+    spans = np.array(spans)
+    print("  per CU, first tile's entry -> last tile's end: min %d  median %d  p90 %d  max %d" % (spans.min(), np.median(spans), np.percentile(spans, 90), spans.max()))
     for x in range(8):
         m = idx[xcc[idx] == x]
         t0 = al[m, 0].min()
