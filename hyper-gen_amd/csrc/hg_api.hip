@@ -86,7 +86,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   hg_ctx::Buf *bufs[] = {&c->w_items, &c->w_gmeta, &c->w_hits, &c->w_cnt, &c->w_seq, &c->w_hv, &c->w_hits2, &c->w_lsort, &c->w_redo, &c->w_pk, &c->w_pktab,
-                         &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2, &c->w_cen, &c->w_cand,
+                         &c->w_misc, &c->w_f16a, &c->w_f16b, &c->w_stats, &c->w_ani, &c->w_hv2, &c->w_cen,
                          &c->w_n2a, &c->w_n2b, &c->w_sorthits, &c->w_i8a, &c->w_i8b, &c->w_i8misc};
   for (auto *b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -142,7 +142,6 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   else if (k == "dist_path") c->dbg_dist_path = v;
   else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;
-  else if (k == "dist_defer") c->dbg_dist_defer = v;  // "off": the tiles of an i8 dist launch evaluate their own candidates
   else if (k == "hostfed") c->dbg_hostfed = v;  // hg_sketch_batch / hg_kmer_hash_sample: "ascii" never 2-bit pack on the host, "packed" always
   else if (k == "kmer_input") c->dbg_kmer_input = v;  // "packed": ASCII batches are 2-bit packed on the device first and take the packed kernels
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
@@ -1249,17 +1248,6 @@ extern "C" hg_status hg_dist_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32
                            d_out, cap, n_out);
 }
 
-// After a dist call's result words are back: did the i8 launch defer more candidates than its arrays hold (word 14)?  Then
-// some were dropped and the hit list is incomplete: the caller repeats the call with the tiles evaluating their own
-// candidates (dist_defer_off), and the next call gets arrays of the size this one needed.
-static bool dist_cands_overflowed(hg_ctx *c, const uint32_t *h_res) {
-  if (!c->cand_cap_used) return false;
-  c->cand_last = h_res[14];
-  if (h_res[14] <= c->cand_cap_used) return false;
-  c->cand_want = (uint64_t)h_res[14] + h_res[14] / 4;
-  return true;
-}
-
 extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R,
                                        size_t ref_off, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
                                        size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
@@ -1291,14 +1279,6 @@ extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const
   if ((s = hg_run_dist(c, a, d_count + 1, &spec_cover)) != HG_OK) return s;
   const uint32_t *h_res = nullptr;
   if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
-  if (dist_cands_overflowed(c, h_res)) {
-    HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
-    c->dist_defer_off = true;
-    s = hg_run_dist(c, a, d_count + 1, &spec_cover);
-    c->dist_defer_off = false;
-    if (s != HG_OK) return s;
-    if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
-  }
   const bool i8_tried = h_res[9] != 0;  // the i8 prepass wrote its K-step count
   if (i8_tried && h_res[8] != 1u) c->i8_skip = 16;  // vetoed on the device: f16 ran; do not probe again for a while
   if (h_res[8] == 1u) {
@@ -1376,14 +1356,6 @@ extern "C" hg_status hg_dist_block_ops_dev(hg_ctx *c, const uint8_t *d_ref_ops, 
   if ((s = hg_run_dist(c, a, d_count + 1, &spec)) != HG_OK) return s;
   const uint32_t *h_res = nullptr;
   if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
-  if (dist_cands_overflowed(c, h_res)) {
-    HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
-    c->dist_defer_off = true;
-    s = hg_run_dist(c, a, d_count + 1, &spec);
-    c->dist_defer_off = false;
-    if (s != HG_OK) return s;
-    if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
-  }
   const bool valid = h_res[8] == 1u;
   const uint32_t found = h_res[0];
   c->i8_sig_ref = c->i8_sig_qry = nullptr;

@@ -657,13 +657,6 @@ struct GemmArgs {
   const uint32_t *i8ctrl;          // [0] entries reserved, [1] flags of the prepass
   uint32_t hv_d, same_set;
   uint32_t diag_first;             // leading workgroup slots that take the tiles on the diagonal (0: plain order)
-  // Deferred evaluation (thresholded i8 launches; nullptr: every tile evaluates its own candidates): a tile only APPENDS the
-  // pairs that pass its pre-filter -- {row, column, G} of the call's own enumeration -- to these arrays (one reservation per
-  // tile / per flush on cand_count) and dist_cand_kernel, queued behind the GEMM, does the exact arithmetic for all of them
-  // at once.  A count beyond cand_cap means candidates were dropped: the host repeats the call without deferral.
-  uint32_t *cand_count, *cand_i, *cand_j;
-  int32_t *cand_g;
-  uint32_t cand_cap;
   const uint32_t *tile_tab;        // slot -> tile (tm | tn << 16, ~0u: no tile) built by the host (dist_tile_table); nullptr:
                                    // the workgroup derives its tile from blockIdx as described at the top of the kernel
   int32_t ham_thr;                 // HAM: candidates are G >= ham_thr
@@ -1416,34 +1409,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     staged = 0;
     __syncthreads();  // the lists may be refilled only after every wave has read them
   };
-  // Deferred evaluation: the lists go to the call's candidate arrays as they are (global row / column instead of the tile's)
-  // -- no arithmetic, no global loads, and ONE barrier-separated step instead of three.
-  const bool defer = I8 && !HAM && !FULL && g.cand_count != nullptr;  // workgroup-uniform
-  auto cand_out = [&](const uint2 *cl, uint32_t n, uint32_t base) __attribute__((always_inline)) {
-    for (uint32_t e = tid; e < n; e += THREADS) {
-      const uint2 c2 = cl[e];
-      const uint32_t pos = base + e;
-      if (pos < g.cand_cap) g.cand_i[pos] = row0 + (c2.x >> 16), g.cand_j[pos] = col0 + (c2.x & 0xffffu), g.cand_g[pos] = (int32_t)c2.y;
-    }
-  };
-  auto flush_defer = [&]() __attribute__((always_inline)) {
-    if (lane == 0) s_len[wave] = staged;
-    __syncthreads();
-    uint32_t total = 0;
-#pragma unroll
-    for (uint32_t l = 0; l < NW_; ++l) total += s_len[l];
-    if (tid == 0) s_cnt[NW_] = total ? atomicAdd(g.cand_count, total) : 0u;
-    __syncthreads();
-    uint32_t off = s_cnt[NW_];
-    const uint2 *all = reinterpret_cast<const uint2 *>(sAB);
-    for (uint32_t l = 0; l < NW_; ++l) {
-      const uint32_t n_list = s_len[l];
-      cand_out(all + l * CAND_CAP, n_list, off);
-      off += n_list;
-    }
-    staged = 0;
-    __syncthreads();  // the lists may be refilled only after every wave has read them
-  };
   // Phase 0: `d >= ur(row) + tq(column)` with the thresholds staged at kernel entry: the lane's NT column thresholds are
   // fetched here, the four row thresholds of a slab with one 16-byte read per slab (all 4 * WTM of them kept in
   // registers from the top push the i8 kernels into scratch).
@@ -1535,9 +1500,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         all_cands += v;
       }
       if (lane_cands != 0u) off += atomicAdd(&s_fill[wave], lane_cands);
-      // (deferred evaluation: the tile's range of the candidate arrays is requested NOW -- the answer is needed after the
-      // append, which hides the round trip)
-      if (defer && tid == 0) s_len[NW_] = atomicAdd(g.cand_count, all_cands);
       uint2 *const cand = reinterpret_cast<uint2 *>(sAB);
       // A lane has ~2 candidates among its 160 accumulators, at positions only it knows, and registers cannot be
       // indexed per lane: slab by slab the lane's 4 * NT accumulators bounce through LDS (NT 16-byte stores into the
@@ -1574,13 +1536,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
         }
       });
       staged = wave_u == 0 ? all_cands : 0u;
-      if (defer) {  // one list, its range reserved above: out it goes
-        __syncthreads();
-        cand_out(reinterpret_cast<const uint2 *>(sAB), all_cands, s_len[NW_]);
-        HG_TSTAMP(4)
-        HG_TSTAMP(5)
-        return;
-      }
     }
   } else {
   // (compile-time m, r, n: the accumulator registers must be indexed statically whatever the optimiser thinks of the
@@ -1642,79 +1597,13 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       __syncthreads();
       const bool any_full = s_len[NW_ + m % 3] != 0u;
       if (wave == 0 && lane == 0) s_len[NW_ + (m + 2) % 3] = 0u;
-      if (any_full) {
-        if (defer) flush_defer();
-        else flush_all(std::integral_constant<uint32_t, (HG_P2_U < 2 ? HG_P2_U : 2)>{});  // (the accumulators are live: two batches in flight)
-      }
+      if (any_full) flush_all(std::integral_constant<uint32_t, (HG_P2_U < 2 ? HG_P2_U : 2)>{});  // (the accumulators are live: two batches in flight)
     }
   });
   }
   HG_TSTAMP(4)
-  if (defer) flush_defer();
-  else flush_all(std::integral_constant<uint32_t, HG_P2_U>{});  // end of the tile
+  flush_all(std::integral_constant<uint32_t, HG_P2_U>{});  // end of the tile
   HG_TSTAMP(5)
-  }
-}
-
-// ---- deferred evaluation of the i8 launches' candidates ---------------------------------------------------------------
-// What phase 2 does inside a tile, for ALL candidates of a launch at once: G = sum a_r a_q becomes the exact dot product
-// through the clamped entries of row i / column j and the parity terms, the reference's float32 ANI decides, hits are
-// compacted per workgroup of 1 024 candidates and appended with ONE reservation.  The tiles' own phase 2 was latency --
-// a dependent global load per batch, a reservation round trip per flush, with one workgroup per CU and nothing to overlap
-// them with -- and a dense diagonal tile (26 000 candidates) took 2.9 tile times: five tiles per CU became six rounds.
-// Here 32 waves per CU hide those latencies behind each other.
-constexpr int CAND_THREADS = 1024;
-__global__ __launch_bounds__(CAND_THREADS) void dist_cand_kernel(GemmArgs g) {
-  __shared__ uint32_t s_w[CAND_THREADS / 64 + 1];
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t n = min(g.cand_count[0], g.cand_cap);
-  for (uint32_t base = blockIdx.x * CAND_THREADS; base < n; base += gridDim.x * CAND_THREADS) {  // workgroup-uniform
-    const uint32_t e = base + tid;
-    const bool valid = e < n;
-    uint32_t i = 0, j = 0;
-    float ani = 0.f;
-    if (valid) {
-      i = g.cand_i[e], j = g.cand_j[e];
-      int32_t G = g.cand_g[e];
-      const int32_t ir = g.info_r[i], iq = g.info_q[j], er = ir & 1, eq = iq & 1;
-      const uint32_t cr = ((uint32_t)g.slot_r[i] >> 14) & 255u, cq = ((uint32_t)g.slot_q[j] >> 14) & 255u;  // count (8) | sum |b| (14)
-      if (cr) {  // b_i[d] * c_j[d], c = the true centred count of column j
-        const uint32_t f = g.first_r[i];
-        for (uint32_t t = 0; t < cr; ++t) {
-          const I8Outlier o = g.ents[f + t];
-          G += (int32_t)o.b * (((int32_t)g.raw_q[(size_t)j * g.hv_d + o.d] + eq) >> 1);
-        }
-      }
-      if (cq) {  // a_i[d] * b_j[d], a = the clamped byte of row i (its operand)
-        const uint32_t f = g.first_q[j];
-        for (uint32_t t = 0; t < cq; ++t) {
-          const I8Outlier o = g.ents[f + t];
-          G += (int32_t)o.b * (int32_t)reinterpret_cast<const int8_t *>(g.A)[(size_t)i * g.ldk * 2 + o.d];
-        }
-      }
-      const int32_t dot = 4 * G - eq * (ir - er) - er * (iq - eq) + (er & eq) * (int32_t)g.hv_d;
-      ani = ani_from_dot(dot, g.nr[i], g.nq[j], g.kf);
-    }
-    const bool hit = valid && ani >= g.ani_th;
-    const unsigned long long bal = __ballot(hit);
-    if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t total = 0;
-#pragma unroll
-      for (int w = 0; w < CAND_THREADS / 64; ++w) {
-        const uint32_t v = s_w[w];
-        s_w[w] = total, total += v;
-      }
-      s_w[CAND_THREADS / 64] = total ? atomicAdd(g.hit_count, total) : 0u;
-    }
-    __syncthreads();
-    if (hit) {
-      const uint32_t pos = s_w[CAND_THREADS / 64] + s_w[wave] +
-                           __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      if (pos < g.hit_cap) g.hits[pos] = hg_ani_hit{g.ref_index ? g.ref_index[i] : i + g.ref_off, j + g.qry_off, ani};
-    }
-    __syncthreads();  // (s_w is rewritten by the next trip)
   }
 }
 
@@ -1989,21 +1878,6 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     g.info_r = info_r, g.info_q = info_q, g.slot_r = slot_r, g.slot_q = slot_q, g.ents = list;
     g.first_r = first_r, g.first_q = first_q, g.ent_cap = ent_cap, g.i8verdict = ctrl + 4;
     g.raw_q = a.qry_hv, g.ref_index = a.ref_index, g.i8ctrl = ctrl, g.hv_d = a.hv_d, g.same_set = same ? 1u : 0u;
-    // Deferred evaluation of the candidates (see dist_cand_kernel): room for twice the caller's hit capacity, 1 M at least,
-    // 16 M at most (192 MB), or what the previous call that overflowed asked for; d_verdict[13] (word 14 of the caller's
-    // result block) counts them.  Hook: "dist_defer" = "off".
-    uint32_t cand_cap = 0;
-    if (!c->dist_defer_off && c->dbg_dist_defer != "off" && a.hit_cap) {
-      const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(std::max<uint64_t>(2ull * a.hit_cap, 1u << 20), 1u << 24), c->cand_want);
-      cand_cap = (uint32_t)std::min<uint64_t>({want, (uint64_t)a.R * a.Q, 0xFFFFFFF0ull});
-      if (hg_ensure(c, c->w_cand, (size_t)cand_cap * 12 + 64) != HG_OK) cand_cap = 0;  // (no room: the tiles evaluate their own)
-    }
-    if (cand_cap) {
-      g.cand_count = d_verdict + 13, g.cand_cap = cand_cap;
-      g.cand_i = static_cast<uint32_t *>(c->w_cand.p), g.cand_j = g.cand_i + cand_cap;
-      g.cand_g = reinterpret_cast<int32_t *>(g.cand_j + cand_cap);
-    }
-    c->cand_cap_used = cand_cap;
     int nt = 4;
     {
       const uint64_t tm = (a.R + 255) / 256, ncu = (uint64_t)std::max(c->n_cu, 1);
@@ -2032,13 +1906,6 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
         hipLaunchKernelGGL((dist_mfma_kernel<false, false, true, true, 4, true>), dim3(n_tiles), dim3(TileCfg<true, 4>::THREADS), lds,
                            c->stream, g);
       HG_HIP(c, hipGetLastError());
-      if (cand_cap) {
-        // grid: the candidates of the previous call on this context + a quarter (the kernel strides, so any count is covered)
-        const uint64_t est = c->cand_last ? (uint64_t)c->cand_last + c->cand_last / 4 : (uint64_t)cand_cap / 4;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((est + CAND_THREADS - 1) / CAND_THREADS, 256), 16384);
-        hipLaunchKernelGGL(dist_cand_kernel, dim3(blocks), dim3(CAND_THREADS), 0, c->stream, g);
-        HG_HIP(c, hipGetLastError());
-      }
     }
     veto = ctrl + 4;
     if (ops_given) {  // (nothing to fall back on: the caller reads the verdict)

@@ -42,10 +42,6 @@ struct hg_ctx {
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
-  Buf w_cand;                  // i8 dist launches: the candidates the tiles defer to dist_cand_kernel (row, column, G arrays)
-  uint32_t cand_cap_used = 0, cand_last = 0;  // capacity given to the last launch (0: not deferred), candidates it produced
-  uint64_t cand_want = 0;      // capacity to give the next launch after one that overflowed
-  bool dist_defer_off = false; // the repeat of a call whose candidates overflowed: the tiles evaluate their own
   Buf w_cen;                   // centred f16 path: row / column info words, statistics slots, failure + verdict words
   // slot -> tile tables of the dist / Hamming GEMM launches (hg_dist_kernels.hip: dist_tile_table), a few shapes kept
   struct TileTab {
@@ -103,7 +99,7 @@ struct hg_ctx {
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // development / test hooks (hg_ctx_set_debug); never read from the environment
-  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input, dbg_hostfed, dbg_dist_defer;
+  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input, dbg_hostfed;
   int dbg_sort_buckets = 0;
   // pinned host scratch
   void *h_pin = nullptr;

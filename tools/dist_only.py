@@ -24,7 +24,7 @@ n2 = (hv.int() ** 2).sum(1).int()
 cap = max(1 << 20, a.n * a.n // 20)
 hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
 ctx.enable_timing(True)
-# HG_DIST_VARIANTS = comma list of "<tile>[:<path>[:<order>[:<defer>]]]" (hg_ctx_set_debug keys dist_tile / dist_path / dist_order / dist_defer), e.g. ",:f16,wide:i8,::legacy,:::off"
+# HG_DIST_VARIANTS = comma list of "<tile>[:<path>[:<order>]]" (hg_ctx_set_debug keys dist_tile / dist_path / dist_order), e.g. ",:f16,wide:i8,::legacy"
 variants = os.environ.get("HG_DIST_VARIANTS", "").split(",")
 res = {v: [] for v in variants}
 for r in range(a.reps + 1):
@@ -32,7 +32,6 @@ for r in range(a.reps + 1):
         ctx.set_debug("dist_tile", v.split(":")[0])
         ctx.set_debug("dist_path", v.split(":")[1] if ":" in v else "")
         ctx.set_debug("dist_order", v.split(":")[2] if v.count(":") > 1 else "")  # "" | "plain" | "legacy"
-        ctx.set_debug("dist_defer", v.split(":")[3] if v.count(":") > 2 else "")  # "" | "off"
         ctx.timings()
         found, _ = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), a.n, hv.data_ptr(), n2.data_ptr(), a.n, 4096, 21, False,
                                 a.th, hits.data_ptr(), cap)
