@@ -1439,10 +1439,11 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   constexpr uint32_t BNC_LANE = 80, BNC_WAVE = 64 * BNC_LANE;  // bytes of a lane's / a wave's bounce buffer (append loop)
   static_assert(NT * 16 <= (int)BNC_LANE, "a lane's slab fits its bounce buffer");
   constexpr uint32_t SLAB_BITS = (1u << (4 * NT)) - 1u;
-  bool by_lane = false;  // workgroup-uniform
+  bool by_lane = false, have_masks = false;  // workgroup-uniform
   uint32_t notpass[LANE_MASKS ? WTM : 1], lane_cands = 0, wave_cands = 0;  // (wave_cands: lane w holds wave w's count)
   if constexpr (LANE_MASKS) {
     if (!(g.symmetric && row0 + g.ref_off + (uint32_t)BM - 1u >= col0 + g.qry_off)) {
+      have_masks = true;
       uint32_t lane_total = 0;
       dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -1486,21 +1487,6 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       by_lane = __ballot(wave_cands > CAND_CAP) == 0 && all_c * 8u <= (uint32_t)dist_lds_main_bytes<BIG, NT, GLDS>() - (THREADS / 64) * BNC_WAVE;
     }
   }
-  if (by_lane) {
-    if constexpr (LANE_MASKS) {
-      // ONE list for the workgroup (the per-wave regions are contiguous): wave w's candidates start behind those of
-      // the waves below it -- every wave knows all counts --, and one LDS atomic per lane reserves the run that takes
-      // the lane's candidates.  Fewer half-empty batches for phase 2 than eight lists, and flush_all sees list 0 only.
-      const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
-      uint32_t off = 0, all_cands = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < (uint32_t)(THREADS / 64); ++w) {
-        const uint32_t v = __builtin_amdgcn_readlane(wave_cands, w);
-        off += w < wave_u ? v : 0u;
-        all_cands += v;
-      }
-      if (lane_cands != 0u) off += atomicAdd(&s_fill[wave], lane_cands);
-      uint2 *const cand = reinterpret_cast<uint2 *>(sAB);
       // A lane has ~2 candidates among its 160 accumulators, at positions only it knows, and registers cannot be
       // indexed per lane: slab by slab the lane's 4 * NT accumulators bounce through LDS (NT 16-byte stores into the
       // lane's own 80 bytes -- a stride that keeps 16 lanes on 64 different banks), and a loop over the set bits of the
@@ -1508,9 +1494,13 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       // predicated append per element, 160 exec-mask regions per lane -- took 8 000 cycles per tile for ~1 000
       // candidates: in-kernel stamps.)  The bounce buffers sit at the top of the stage area, the list grows from its
       // bottom; a wave's LDS operations execute in order, so no barrier is involved.
+  auto append_slabs = [&](uint32_t off, uint32_t m_lo, uint32_t m_hi, uint32_t wave_u) __attribute__((always_inline)) {
+    if constexpr (LANE_MASKS) {
+      uint2 *const cand = reinterpret_cast<uint2 *>(sAB);
       char *const bnc = reinterpret_cast<char *>(sAB) + dist_lds_main_bytes<BIG, NT, GLDS>() - (THREADS / 64 - wave_u) * BNC_WAVE + lane * BNC_LANE;
       dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
         constexpr int m = decltype(mc)::value;
+        if ((uint32_t)m < m_lo || (uint32_t)m >= m_hi) return;  // (constants in the one-list path)
         uint32_t rest = ~notpass[m] & SLAB_BITS;
         if (__ballot(rest != 0u) == 0) return;  // wave-uniform
 #pragma unroll
@@ -1535,7 +1525,75 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
           ++off;
         }
       });
+    }
+  };
+  if (by_lane) {
+    if constexpr (LANE_MASKS) {
+      // ONE list for the workgroup (the per-wave regions are contiguous): wave w's candidates start behind those of
+      // the waves below it -- every wave knows all counts --, and one LDS atomic per lane reserves the run that takes
+      // the lane's candidates.  Fewer half-empty batches for phase 2 than eight lists, and flush_all sees list 0 only.
+      const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+      uint32_t off = 0, all_cands = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)(THREADS / 64); ++w) {
+        const uint32_t v = __builtin_amdgcn_readlane(wave_cands, w);
+        off += w < wave_u ? v : 0u;
+        all_cands += v;
+      }
+      if (lane_cands != 0u) off += atomicAdd(&s_fill[wave], lane_cands);
+      append_slabs(off, 0u, (uint32_t)WTM, wave_u);
       staged = wave_u == 0 ? all_cands : 0u;
+    }
+  } else if (have_masks && !CHUNKED && !HG_EXP(256)) {  // (the windowed kernel's second accumulator set leaves no registers for it)
+    if constexpr (LANE_MASKS) {
+      // GROUPS OF SLABS (a tile with more candidates than the one list holds: the dense diagonal blocks of a database compared
+      // with itself): the same masks, the same append, the same cooperative phase 2 -- for as many whole 16-row slabs at a
+      // time as the list takes (one slab of all waves always fits).  The slab path below empties the per-wave lists after
+      // nearly every slab of such a tile, because ONE wave's list fills up while the others' stay empty (a 100 x 100 block
+      // of hits lies in two waves' columns): 8 flushes of 3 000 candidates instead of 2-3 of 10 000, each with its
+      // reservation round trip and its barriers -- a dense tile took 308 k ticks against 134 k for a normal one, and the
+      // CUs that hold one ended a tile time after the others (profiles/r04_dist_defer_neutral.txt).
+      constexpr uint32_t NWV = THREADS / 64;
+      constexpr uint32_t TOTM_BYTES = 4u * NWV * WTM;
+      constexpr uint32_t LIST_ROOM = ((uint32_t)dist_lds_main_bytes<BIG, NT, GLDS>() - NWV * BNC_WAVE - TOTM_BYTES) / 8u;
+      static_assert(LIST_ROOM >= NWV * 4u * NT * 64u, "one slab of all waves fits the list");
+      uint32_t *const s_totm = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sAB) + dist_lds_main_bytes<BIG, NT, GLDS>() - NWV * BNC_WAVE - TOTM_BYTES);  // [wave][slab]
+      const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+      for (int m = 0; m < WTM; ++m) {
+        uint32_t c = (uint32_t)__popc(~notpass[m] & SLAB_BITS);
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) s_totm[wave_u * WTM + m] = c;
+      }
+      __syncthreads();
+      // (nothing of the table is kept in registers: the 160 accumulators and the masks are live across the flushes below)
+      uint32_t m0 = 0;  // workgroup-uniform
+      while (m0 < (uint32_t)WTM) {
+        uint32_t m1 = m0, gtot = 0, goff = 0, lane_g = 0;
+#pragma unroll
+        for (int m = 0; m < WTM; ++m) {
+          if ((uint32_t)m != m1 || (uint32_t)m < m0) continue;  // uniform
+          uint32_t t = 0, bl = 0;  // candidates of slab m in all waves / in the waves below this one
+          for (uint32_t w = 0; w < NWV; ++w) {
+            const uint32_t v = s_totm[w * WTM + m];
+            t += v, bl += w < wave_u ? v : 0u;
+          }
+          if (gtot + t > LIST_ROOM) continue;
+          gtot += t, goff += bl, lane_g += (uint32_t)__popc(~notpass[m] & SLAB_BITS), m1 = (uint32_t)m + 1u;
+        }
+        if (gtot != 0u) {
+          if (lane == 0) s_fill[wave] = 0u;  // (this wave's LDS operations execute in order: the reset is in front of its lanes' atomics)
+          uint32_t off = goff;
+          if (lane_g != 0u) off += atomicAdd(&s_fill[wave], lane_g);
+          append_slabs(off, m0, m1, wave_u);
+          staged = wave_u == 0 ? gtot : 0u;
+          flush_all(std::integral_constant<uint32_t, (HG_P2_U < 2 ? HG_P2_U : 2)>{});  // (the accumulators are live: two batches in flight)
+        }
+        m0 = m1;
+      }
+      HG_TSTAMP(4)
+      HG_TSTAMP(5)
+      return;
     }
   } else {
   // (compile-time m, r, n: the accumulator registers must be indexed statically whatever the optimiser thinks of the
