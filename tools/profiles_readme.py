@@ -77,6 +77,7 @@ L += ["", "## the other files", "",
       "| `r04_dist_tile_table.txt` | per-CU timelines of one dist launch (which CU ran which workgroups, from whole-tile stamps + `HW_ID`) with the blockIdx mapping and with the host-built slot -> tile table, and the timings of both | `tools/dist_cu_timeline.py` on a `-DHG_DIST_STAMPS` build, `tools/dist_only.py` |",
       "| `r04_hostfed_probe.txt` | the one-call-per-genome pattern by number of calling threads and link form (ASCII / packed / the library's choice), and its ingredients alone (host packing, resident calls, uploads) | `tools/percall_probe.py`, `tools/percall_ingredients.py` |",
       "| `r04_dist_defer_neutral.txt` | deferred candidate evaluation (tiles append candidates, a second kernel evaluates them): kernel times, per-CU spans and tile durations against in-tile evaluation | `tools/dist_only.py`, `tools/dist_cu_timeline.py` |",
+      "| `r04_dist_half_slots_negative.txt` | half tiles at the end of the XCDs' queues: timings against whole tiles, per-CU spans | `tools/dist_only.py`, `tools/dist_cu_timeline.py` |",
       "| `r04_dist_persistent_negative.txt` | the persistent-workgroup GEMM variant of round 4: timings against one tile per workgroup and whole-tile `s_memtime` stamps of both | `tools/dist_only.py`, `tools/dist_tile_stamps.py` on `-DHG_DIST_STAMPS` builds |",
       "| `r03_mfma_ceiling.txt` | what the matrix pipe sustains in the GEMM's loop shape, ingredient by ingredient | `tools/mfma_microbench.hip` |",
       "| `r01_instruction_rates.txt` | measured issue cost of the integer instructions the k-mer kernel is made of | `tools/gpu_microbench.hip` |"]
