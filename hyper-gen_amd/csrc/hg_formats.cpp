@@ -317,7 +317,10 @@ namespace {
 inline void pack2_span(const uint8_t *seq, size_t n, bool u2t, uint8_t *codes, uint8_t *mask, bool stream = false) {
   size_t done = 0;
 #if defined(__x86_64__)
-  static const int isa = (__builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi")) ? 2
+#ifndef HG_PACK_AVX512
+#define HG_PACK_AVX512 1  /* 0: the AVX2 loop also where AVX-512 VBMI exists (A/B) */
+#endif
+  static const int isa = (HG_PACK_AVX512 && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi")) ? 2
                          : __builtin_cpu_supports("avx2") ? 1 : 0;
   if (isa == 2) {
     if (stream && !((uintptr_t)codes & 15) && !((uintptr_t)mask & 7)) {
