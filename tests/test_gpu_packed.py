@@ -245,3 +245,23 @@ def test_hostfed_concurrent_single_genome_calls(hg, orc):
         assert np.array_equal(got[g], want[g]), g
     for c in ctxs:
         c.close()
+
+
+def test_hostfed_small_batches_forced_packed(hg, orc):
+    """the "hostfed" = "packed" hook on batches far below the size the library would pack on its own: a few tiny genomes, an
+    empty one among them, one sub-batch"""
+    rng = np.random.default_rng(31)
+    seqs = [genome(rng, n) for n in (1000, 0, 20, 21, 70_000, 3, 2500)]
+    p = hg.default_params(scaled=20, hv_d=512)
+    res = {}
+    for mode in ("ascii", "packed"):
+        c = hg.Context(0)
+        c.set_debug("hostfed", mode)
+        res[mode] = c.sketch_batch(seqs, p)
+        assert c.last_kernel("kmer").endswith("true>") == (mode == "packed")
+        c.close()
+    for a, b in zip(res["ascii"], res["packed"]):
+        assert np.array_equal(a, b)
+    for i in (0, 4, 6):
+        w_hv, w_n2, w_nh = orc.sketch_genome(seqs[i], 21, 20, 123, True, hv_d=512)
+        assert res["packed"][2][i] == w_nh and res["packed"][1][i] == w_n2 and np.array_equal(res["packed"][0][i], w_hv)

@@ -928,3 +928,32 @@ def test_ani_golden_through_the_dist_kernels(hg, ctx, orc):
             for i in sel:
                 if cases[i]["ani"] >= th + 1e-4:
                     assert abs(got[(i, i)] - cases[i]["ani"]) <= 1e-4
+
+
+def test_hamming_tile_orders_agree(ctx, orc):
+    """a search of several tiles a side (6 x 5 at 256 x 256, 6 x 5 at 256 x 320): the host's slot -> tile table and the
+    kernel's own blockIdx mapping report the same pairs, and they are the oracle's"""
+    import torch
+    rng = np.random.default_rng(99)
+    R, Q, d = 1500, 1300, 1024
+    r = rng.integers(-40, 40, (R, d)).astype(np.int16)
+    q = np.vstack([r[:400] + (rng.random((400, d)) < 0.02) * 90, rng.integers(-40, 40, (Q - 400, d))]).astype(np.int16)
+    dev = torch.device("cuda:0")
+    wr, wq = orc.binarize(r), orc.binarize(q)
+    br, bq = torch.from_numpy(wr.view(np.int32)).to(dev), torch.from_numpy(wq.view(np.int32)).to(dev)
+    want = orc.hamming_matrix(wr, wq)
+    max_dist = 300
+    exp = {(i, j, int(want[i, j])) for i, j in zip(*np.nonzero(want <= max_dist))}
+    assert 300 < len(exp) < 5000
+    hits = torch.empty(3 * 20000, dtype=torch.int32, device=dev)
+    try:
+        for order in ("", "legacy"):
+            for tile in ("big", "wide"):
+                ctx.set_debug("dist_order", order)
+                ctx.set_debug("dist_tile", tile)
+                n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, max_dist, hits.data_ptr(), 20000)
+                got = hits.cpu().numpy().view(np.uint32)[: 3 * n].reshape(-1, 3)
+                assert st == 0 and {(int(a), int(b), int(c)) for a, b, c in got} == exp, (order, tile)
+    finally:
+        ctx.set_debug("dist_order", "")
+        ctx.set_debug("dist_tile", "")
