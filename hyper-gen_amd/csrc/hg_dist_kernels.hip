@@ -1364,6 +1364,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
   // hits in every tile all 8 waves of all 256 workgroups arrive together at the end of a round, and one atomic per
   // wave kept every CU waiting ~25 us per round), and the batches of all lists dealt round-robin to the waves.
   uint32_t *s_len = s_cnt + NW_ + 1;  // the list lengths + three "some list is nearly full" flags (slot m % 3)
+#ifndef HG_GROUP_U
+#define HG_GROUP_U 2  /* ... in the flushes of the slab-group path, where the accumulators are live (A/B: 3, 4) */
+#endif
 #ifndef HG_P2_U
 #define HG_P2_U 4  /* batches a wave keeps in flight in the last phase 2 of a tile (A/B: 1 = one at a time) */
 #endif
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
           if (lane_g != 0u) off += atomicAdd(&s_fill[wave], lane_g);
           append_slabs(off, m0, m1, wave_u);
           staged = wave_u == 0 ? gtot : 0u;
-          flush_all(std::integral_constant<uint32_t, (HG_P2_U < 2 ? HG_P2_U : 2)>{});  // (the accumulators are live: two batches in flight)
+          flush_all(std::integral_constant<uint32_t, HG_GROUP_U>{});
         }
         m0 = m1;
       }
