@@ -1779,6 +1779,7 @@ hg_status hg_run_hamming_mfma(hg_ctx *c, const uint32_t *d_ref_bits, uint32_t R,
   if ((s = hg_ensure(c, c->w_i8a, (size_t)Rp * ldkb)) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_i8b, (size_t)Qp * ldkb)) != HG_OK) return s;
   auto *a8 = static_cast<uint8_t *>(c->w_i8a.p), *b8 = static_cast<uint8_t *>(c->w_i8b.p);
+  c->i8_pad[0].ptr = c->i8_pad[1].ptr = nullptr;  // (the dist path's zero rows in these buffers are overwritten below)
   c->i8_sig_ref = c->i8_sig_qry = nullptr;  // the dist path's operand copies are gone
   if (Rp > R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)R * ldkb, 0, (size_t)(Rp - R) * ldkb, c->stream));
   if (Qp > Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)Q * ldkb, 0, (size_t)(Qp - Q) * ldkb, c->stream));
@@ -1908,8 +1909,22 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     auto *first_r = reinterpret_cast<uint32_t *>(mb + o_fr), *first_q = same ? first_r : reinterpret_cast<uint32_t *>(mb + o_fq);
     auto *list = reinterpret_cast<I8Outlier *>(mb + o_list);
     uint32_t *ctrl = d_verdict + 3;  // words 4.. of the caller's result block (zeroed by the caller, read back with the hit count)
-    if (Rp > a.R) HG_HIP(c, hipMemsetAsync(a8 + (size_t)a.R * ldk8, 0, (size_t)(Rp - a.R) * ldk8, c->stream));
-    if (!same && Qp > a.Q) HG_HIP(c, hipMemsetAsync(b8 + (size_t)a.Q * ldk8, 0, (size_t)(Qp - a.Q) * ldk8, c->stream));
+    // The rows behind R / Q (the LDS-DMA reads whole tiles) must be zero.  The context's own operand copies keep them from
+    // call to call -- the prepass writes rows below R only --, so a repeat of the same geometry needs no memset (one or two
+    // 1 MB commands in front of the prepass of every call otherwise); a caller's buffer (prepared operands) is zeroed always.
+    auto pad_rows = [&](int side, int8_t *base, uint32_t n, uint32_t np, bool own) -> hipError_t {
+      hg_ctx::I8Pad &k = c->i8_pad[side];
+      if (own && k.ptr == base && k.rows == n && k.padded == np && k.pitch == ldk8) return hipSuccess;
+      k.ptr = nullptr;
+      if (np > n) {
+        const hipError_t e = hipMemsetAsync(base + (size_t)n * ldk8, 0, (size_t)(np - n) * ldk8, c->stream);
+        if (e != hipSuccess) return e;
+      }
+      if (own) k.ptr = base, k.rows = n, k.padded = np, k.pitch = ldk8;
+      return hipSuccess;
+    };
+    HG_HIP(c, pad_rows(0, a8, a.R, Rp, !ops_given));
+    if (!same) HG_HIP(c, pad_rows(1, b8, a.Q, Qp, true));
     {
       hg_timed tmp(c, HG_T_DIST_PREP);
       if (ops_given)

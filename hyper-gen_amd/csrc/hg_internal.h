@@ -42,6 +42,10 @@ struct hg_ctx {
   Buf w_hv2;      // staged second HV matrix (host dist)
   Buf w_n2a, w_n2b;
   Buf w_i8a, w_i8b, w_i8misc;  // i8 operand copies (+ extra columns), row info / outlier list / column maps
+  struct I8Pad {               // which zero padding rows w_i8a / w_i8b hold since the last dist call (hg_run_dist)
+    const void *ptr = nullptr;
+    uint32_t rows = 0, padded = 0, pitch = 0;
+  } i8_pad[2];
   Buf w_cen;                   // centred f16 path: row / column info words, statistics slots, failure + verdict words
   // slot -> tile tables of the dist / Hamming GEMM launches (hg_dist_kernels.hip: dist_tile_table), a few shapes kept
   struct TileTab {
