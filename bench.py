@@ -47,6 +47,10 @@ def parse():
                     help="TOTAL genomes of the configs[2] leg, sharded over the ranks (0 = skip)")
     ap.add_argument("--hostfed-genomes", type=int, default=256, help="genomes of the host-fed (PCIe) leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the draft-assembly and many-small-genomes legs")
+    ap.add_argument("--small-genomes", type=int, default=100000, help="genomes of the many-small-genomes leg (50 kbp each)")
+    ap.add_argument("--cli", action="store_true", help="also run tools/cli_dist_bench.py (end-to-end hyper-gen dist / search at "
+                                                        "--dist-n sketches) and report its split as `cli`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank logic on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses device 0")
@@ -76,10 +80,12 @@ def max_over_ranks(x, world, dev):
     return float(t.item())
 
 
-def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100):
+def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100, salt=0):
     """Synthetic i16 HVs with the statistics of real sketches: hv = 2*count - n where count is
     Binomial(n, 1/2); members of a cluster share the counts of shared_frac*n hashes, so
-    within-cluster ANI is ~96-97 % and cross-cluster ANI ~0 (about 1 % of pairs pass ani_th=85)."""
+    within-cluster ANI is ~96-97 % and cross-cluster ANI ~0 (about 1 % of pairs pass ani_th=85).
+    salt != 0: OTHER members of the same clusters (same shared counts, fresh private ones) -- a second,
+    distinct set with the hit structure of the first (the two-set legs)."""
     import torch  # (tests import this helper without going through main())
     ns = int(n * shared_frac)
     ids = torch.arange(first_row, first_row + rows, device=dev)
@@ -94,11 +100,47 @@ def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100):
         m = cl == c
         k = int(m.sum())
         g2 = torch.Generator(device=dev)
-        g2.manual_seed(0x48480000 + int(c) * 7919 + first_row)
+        g2.manual_seed(0x48480000 + int(c) * 7919 + first_row + 104729 * salt)
         fresh = torch.round((n - ns) / 2 + ((n - ns) ** 0.5) / 2 * torch.randn((k, HV_D), generator=g2, device=dev))
         out[m] = (2 * (shared[None, :] + fresh) - n).to(torch.int16)
     del half
     return out
+
+
+def draftify(seq, n, stride, L, seed=0x5EED):
+    """Rewrites the n clean single-contig synthetic genomes in `seq` (genome g at g*stride: 'N' + L bases, the
+    read_merge_seq layout of src/fastx_reader.rs:6-29) IN PLACE into what a draft assembly looks like to the sketch path:
+      * 200 contigs: 199 further record starts, i.e. an 'N' at 199 random positions (one per FASTA header);
+      * ~30 % soft-masked: whole 1 kbp blocks lower-cased (RepeatMasker-style runs);
+      * 0.05 % IUPAC ambiguity codes (RYKMSWBDHV and n) at random positions;
+      * one 50 kbp tandem repeat of a 171-base unit at a random place.
+    Deterministic (torch generator on the buffer's device); the same bytes go to the CPU oracle for the gate."""
+    import torch
+    dev = seq.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    view = seq[: n * stride].view(n, stride)
+    iupac = torch.tensor(list(b"RYKMSWBDHVn"), dtype=torch.uint8, device=dev)
+    CH = 50  # genomes per pass (bounds the scratch)
+    for g0 in range(0, n, CH):
+        m = min(CH, n - g0)
+        body = view[g0: g0 + m, 1: 1 + L]
+        rows = torch.arange(m, device=dev)[:, None]
+        # tandem repeat first (the masks below then apply to it like to everything else)
+        start = torch.randint(0, L - 50_000, (m,), generator=g, device=dev)
+        unit = torch.gather(body, 1, start[:, None] + torch.arange(171, device=dev)[None, :])
+        idx = start[:, None] + torch.arange(50_000, device=dev)[None, :]
+        body[rows, idx] = unit[:, torch.arange(50_000, device=dev) % 171]
+        nblk = (L + 999) // 1000
+        soft = torch.rand((m, nblk), generator=g, device=dev) < 0.30
+        soft = soft.repeat_interleave(1000, dim=1)[:, :L]
+        body |= soft.to(torch.uint8) * 0x20
+        del soft
+        k = int(L * 0.0005)
+        pos = torch.randint(0, L, (m, k), generator=g, device=dev)
+        body[rows, pos] = iupac[torch.randint(0, iupac.numel(), (m, k), generator=g, device=dev)]
+        brk = torch.randint(0, L, (m, 199), generator=g, device=dev)
+        body[rows, brk] = ord("N")
 
 
 def newest_profile(suffix):
@@ -413,6 +455,97 @@ def main():
                            "config": {"workload": "the same %d genomes resident as ASCII (1 B per base, %.1f GB), "
                                                   "hg_sketch_batch_dev; sketches identical to the headline's" % (N, N * stride / 1e9)}},
     }
+
+    # ---------------- the inputs real users have (never `value`) ----------------------------------------------------
+    # Every timed leg above runs on clean, single-contig, iid-uniform genomes.  (a) `draft_assemblies`: the SAME N genomes
+    # rewritten as draft assemblies (draftify: 200 contigs, 30 % soft-masked, 0.05 % IUPAC codes, a 50 kbp tandem repeat) --
+    # every tile that holds a non-base takes the kernel's validity-window path, the repeat's k-mers pile up in the hit
+    # staging; (b) `many_small`: 100 000 genomes of 50 kbp in one batch (plasmids / viral genomes: the per-genome costs --
+    # work-item table, one sort and one encode workgroup per genome -- instead of the per-base ones).  Both in the two
+    # resident forms, identical sketches required, three sampled genomes against the CPU oracle.
+    if not a.no_realistic and world == 1:
+        def time_leg(fn, n_gen, reps):
+            settle(fn, 5)
+            ctx.enable_timing(True)
+            ctx.timings()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t0
+            tml = ctx.timings()
+            ctx.enable_timing(False)
+            return {"value": n_gen * reps / dtl, "unit": "genomes/sec", "steps": reps, "ms_per_step": dtl / reps * 1e3,
+                    "kernel": ctx.last_kernel("kmer"), "kernel_ms_per_step": {k: v[0] / reps for k, v in tml.items() if v[1]}}
+
+        def gate(name, buf, st_, length, hv_t, n2_t, nh_t, picks, scaled=SCALED):
+            if a.no_cpu_baseline:
+                return "skipped (--no-cpu-baseline)"
+            from oracle import oracle as orc
+            for g in picks:
+                host = buf[g * st_: g * st_ + length + 1].cpu().numpy()
+                w_hv, w_n2, w_nh = orc.sketch_genome(host, scaled=scaled)
+                if not (int(nh_t[g]) == w_nh and int(n2_t[g]) == w_n2 and np.array_equal(hv_t[g].cpu().numpy(), w_hv)):
+                    raise SystemExit("PARITY GATE FAILED: %s, genome %d differs from the CPU oracle" % (name, g))
+            return "genomes %s == CPU oracle (hash count, HV, norm)" % (list(picks),)
+
+        reps_r = max(2, min(a.steps, 10))
+        seq_r = seq.clone()
+        draftify(seq_r, N, stride, L_GENOME)
+        blobs_r = torch.empty_like(blobs)
+        ctx.pack2_batch_dev(seq_r.data_ptr(), offs, lens, blobs_r.data_ptr(), boffs)
+        hv_r, n2_r, nh_r = torch.empty_like(hv), torch.empty_like(n2), torch.empty_like(nh)
+        hv_q, n2_q, nh_q = torch.empty_like(hv), torch.empty_like(n2), torch.empty_like(nh)
+        r_pk = time_leg(lambda: ctx.sketch_batch_dev_packed(blobs_r.data_ptr(), boffs, lens, p, hv_r.data_ptr(), n2_r.data_ptr(),
+                                                            nh_r.data_ptr()), N, reps_r)
+        r_as = time_leg(lambda: ctx.sketch_batch_dev(seq_r.data_ptr(), offs, lens, p, hv_q.data_ptr(), n2_q.data_ptr(),
+                                                     nh_q.data_ptr()), N, reps_r)
+        if not (torch.equal(hv_r, hv_q) and torch.equal(n2_r, n2_q) and torch.equal(nh_r, nh_q)):
+            raise SystemExit("PARITY GATE FAILED: draft assemblies, packed and ASCII-resident sketches differ")
+        r_pk["vs_clean"] = r_pk["value"] / value
+        r_as["vs_clean"] = r_as["value"] / (N * world * steps_a / dt_a)
+        out["realistic"] = {"draft_assemblies": dict(
+            r_pk, ascii_resident=r_as, nhash_mean=float(nh_r.float().mean().item()),
+            parity=gate("draft assemblies", seq_r, stride, L_GENOME, hv_r, n2_r, nh_r, (0, N // 2, N - 1)),
+            config={"workload": "the headline's %d genomes as draft assemblies: 200 contigs each (an 'N' per record start, "
+                                "src/fastx_reader.rs:6-29), ~30 %% soft-masked in 1 kbp runs, 0.05 %% IUPAC codes, one 50 kbp tandem "
+                                "repeat of a 171-base unit; resident as hg_pack2 blobs (ascii_resident: as ASCII)" % N})}
+        log("realistic, draft assemblies: %.0f genomes/s packed (%.2f of clean; kmer %.2f ms), %.0f ASCII (%.2f of clean; kmer %.2f ms)" % (
+            r_pk["value"], r_pk["vs_clean"], r_pk["kernel_ms_per_step"].get("kmer", 0.0), r_as["value"], r_as["vs_clean"],
+            r_as["kernel_ms_per_step"].get("kmer", 0.0)))
+        del seq_r, blobs_r, hv_r, n2_r, nh_r, hv_q, n2_q, nh_q
+        if a.small_genomes:
+            NS, LS = a.small_genomes, 50_000
+            st_s = (LS + 1 + 15) // 16 * 16
+            seq_s = torch.empty(NS * st_s + 64, dtype=torch.uint8, device=dev)
+            ctx.synth_genomes_dev(0, NS, LS, st_s, seq_s.data_ptr())
+            offs_s, lens_s = np.arange(NS, dtype=np.uint64) * st_s, np.full(NS, LS + 1, np.uint64)
+            bsz_s = hg.lib().hg_pack2_size(LS + 1)
+            boffs_s = np.arange(NS, dtype=np.uint64) * bsz_s
+            blobs_s = torch.empty(NS * bsz_s + 64, dtype=torch.uint8, device=dev)
+            ctx.pack2_batch_dev(seq_s.data_ptr(), offs_s, lens_s, blobs_s.data_ptr(), boffs_s)
+            hv_s = torch.empty((NS, HV_D), dtype=torch.int16, device=dev)
+            n2_s, nh_s = torch.empty(NS, dtype=torch.int32, device=dev), torch.empty(NS, dtype=torch.int32, device=dev)
+            hv_t, n2_t, nh_t = torch.empty_like(hv_s), torch.empty_like(n2_s), torch.empty_like(nh_s)
+            s_pk = time_leg(lambda: ctx.sketch_batch_dev_packed(blobs_s.data_ptr(), boffs_s, lens_s, p, hv_s.data_ptr(), n2_s.data_ptr(),
+                                                                nh_s.data_ptr()), NS, reps_r)
+            s_as = time_leg(lambda: ctx.sketch_batch_dev(seq_s.data_ptr(), offs_s, lens_s, p, hv_t.data_ptr(), n2_t.data_ptr(),
+                                                         nh_t.data_ptr()), NS, reps_r)
+            if not (torch.equal(hv_s, hv_t) and torch.equal(n2_s, n2_t) and torch.equal(nh_s, nh_t)):
+                raise SystemExit("PARITY GATE FAILED: many small genomes, packed and ASCII-resident sketches differ")
+            for r_ in (s_pk, s_as):
+                r_["mbases_per_sec"] = r_["value"] * LS / 1e6
+            s_pk["vs_clean_per_base"] = s_pk["mbases_per_sec"] / (value * L_GENOME / 1e6)
+            out["realistic"]["many_small"] = dict(
+                s_pk, ascii_resident=s_as, nhash_mean=float(nh_s.float().mean().item()),
+                parity=gate("many small genomes", seq_s, st_s, LS, hv_s, n2_s, nh_s, (0, NS // 2, NS - 1)),
+                config={"workload": "%d synthetic genomes of %d bp in one batch (%.1f GB as ASCII), k=21 scaled=1500 D=4096; "
+                                    "resident as hg_pack2 blobs (ascii_resident: as ASCII)" % (NS, LS, NS * st_s / 1e9)})
+            log("realistic, %d x %d bp: %.0f genomes/s packed = %.0f Mbase/s (%.2f of the clean per-base rate), %.0f ASCII; kernels %s" % (
+                NS, LS, s_pk["value"], s_pk["mbases_per_sec"], s_pk["vs_clean_per_base"], s_as["value"],
+                {k: round(v, 2) for k, v in s_pk["kernel_ms_per_step"].items()}))
+            del seq_s, blobs_s, hv_s, n2_s, nh_s, hv_t, n2_t, nh_t
 
     # ---------------- configs[2]: 10 000 genomes TOTAL, sharded over the ranks -------------------------------
     # (the headline above is weak-scaled at 1 000 genomes per GPU; this leg is the fixed-size job BASELINE.json
@@ -800,6 +933,61 @@ def main():
         }
         log("dist: %.0f M pairs/s, gemm %.3f ms/launch = %.1f TFLOP/s, hits/rank %d" % (
             out["dist"]["value"], gemm_ms, ach, found))
+        # ---- the same matrix size measured the two other ways a user reaches it (N = 1; never the dist `value`) -----------
+        # `dist` above passes ONE buffer as references and queries (the same 10 000 HVs on both sides): the
+        # library recognises that, prepares the operands once and both GEMM operands are one matrix.
+        #   two_sets : R and Q are DIFFERENT members of the same clusters in different buffers (`hyper-gen dist -r A -q B`):
+        #              both prepasses, two operand matrices, the same ~1.3 M hits;
+        #   symmetric: one set with symmetric = 1, the reference's path_r == path_q case (src/dist.rs:13,243-265):
+        #              R (R - 1) / 2 pairs, tiles below the diagonal never start.
+        if not coll and world == 1:
+            other = clustered_hvs(rows, 0, dev, salt=1)
+            other_n2 = (other.int() ** 2).sum(1).int()
+
+            def variant(qv, qn, sym, pairs_v, what):
+                got = 0
+
+                def vstep():
+                    nonlocal got
+                    got, _ = ctx.dist_dev(mine.data_ptr(), mine_n2.data_ptr(), rows, qv.data_ptr(), qn.data_ptr(), rows, HV_D, KSIZE,
+                                          sym, 85.0, hits.data_ptr(), cap)
+                settle(vstep, 100)
+                ctx.enable_timing(True)
+                ctx.timings()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    vstep()
+                torch.cuda.synchronize()
+                vdt = time.perf_counter() - t0
+                vtm = ctx.timings()
+                ctx.enable_timing(False)
+                vg = vtm["dist"][0] / max(a.steps, 1)
+                vpath = ctx.last_dist_path()
+                vpeak = MFMA_F16_PEAK_TFLOPS * (2.0 if vpath == 1 else 1.0)
+                vach = 2.0 * HV_D * pairs_v / (vg * 1e-3) / 1e12
+                return {"value": pairs_v * a.steps / vdt / 1e6, "unit": "M ANI-pairs/sec", "ms_per_step": vdt / a.steps * 1e3,
+                        "pairs": pairs_v, "hits": int(got), "gemm_ms": vg, "prep_ms": vtm["dist_prep"][0] / max(a.steps, 1),
+                        "tflops": vach, "frac_of_peak": vach / vpeak, "operands": "i8" if vpath == 1 else "f16",
+                        "kernel": ctx.last_kernel("dist"), "config": {"workload": what}}
+
+            out["dist"]["two_sets"] = variant(other, other_n2, False, rows * rows,
+                                              "%d refs x %d queries in DIFFERENT buffers: the queries are other members of the references' "
+                                              "clusters (clustered_hvs(salt=1)), thresholded at 85" % (rows, rows))
+            # (gate: the two-set hits against a CPU block, outside the timed region)
+            two_hits = hits[: 3 * out["dist"]["two_sets"]["hits"]].clone()
+            out["dist"]["symmetric"] = variant(mine, mine_n2, True, rows * (rows - 1) // 2,
+                                               "the %d HVs against themselves with symmetric = 1 (i < j only; src/dist.rs:243-265)" % rows)
+            out["dist"]["two_sets"]["vs_same_set_gemm"] = out["dist"]["two_sets"]["gemm_ms"] / gemm_ms
+            log("dist two_sets: %.0f M pairs/s, gemm %.3f ms (%.2f x the same-set kernel), prep %.3f ms, hits %d; symmetric: %.0f M pairs/s, gemm %.3f ms, hits %d" % (
+                out["dist"]["two_sets"]["value"], out["dist"]["two_sets"]["gemm_ms"], out["dist"]["two_sets"]["vs_same_set_gemm"],
+                out["dist"]["two_sets"]["prep_ms"], out["dist"]["two_sets"]["hits"], out["dist"]["symmetric"]["value"],
+                out["dist"]["symmetric"]["gemm_ms"], out["dist"]["symmetric"]["hits"]))
+            if out["dist"]["symmetric"]["hits"] * 2 + rows != int(found):  # every i < j hit twice + the diagonal
+                raise SystemExit("PARITY GATE FAILED: symmetric hits %d x 2 + %d != same-set hits %d" % (out["dist"]["symmetric"]["hits"], rows, found))
+            dstep()  # the same-set leg's hits back in `hits` for the gates below
+        else:
+            other = None
         # the same call on the 10 000 REAL sketches of the sketch_10k leg (N = 1 only: they are all on this GPU): clusters
         # of 100 genomes at 0 - 9.9 % substitutions, so ani_th = 85 keeps about the within-cluster pairs
         if real_hv is not None:
@@ -943,6 +1131,21 @@ def main():
             100 * out["hamming"]["roofline"]["frac"], merged.size))
         del rb, qb, hh
 
+    # ---------------- end to end through the CLI (--cli; rank 0, N = 1) ----------------------------------------------
+    # `hyper-gen dist` / `search` as a user starts them (src/dist.rs:11-63, src/utils.rs:260-308): .sketch files in, TSV
+    # out, process start and HIP bring-up included -- a child process (tools/cli_dist_bench.py), never a re-exec.
+    if a.cli and rank == 0 and world == 1 and a.dist_n:
+        import subprocess
+        torch.cuda.synchronize()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_dist_bench.py"), "--n", str(a.dist_n)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise SystemExit("cli leg failed: " + r.stderr.decode()[-2000:])
+        out["cli"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        log("cli: dist -r A -q A %.2f s, dist -r A -q B %.2f s, search %.2f s (wall, %d sketches)" % (
+            out["cli"]["dist_symmetric"]["wall_s"], out["cli"]["dist_two_files"]["wall_s"],
+            [v for k, v in out["cli"].items() if k.startswith("search")][0]["wall_s"], a.dist_n))
+
     # ---------------- CPU baseline (rank 0, single-GPU runs only) ----------------------------------
     # The same leg is the run's parity gate ("parity gates must pass before any number is
     # reported"): the oracle's outputs, which it produces anyway, are compared with this run's GPU results
@@ -979,6 +1182,17 @@ def main():
             if err > 1e-4 or herr > 1e-4 or hr.size < n_cpu_hits:
                 raise SystemExit("PARITY GATE FAILED: ANI block max |gpu - cpu| = %g, hits %g, %d < %d" % (err, herr, hr.size, n_cpu_hits))
             gate.update(ani_block="%d x %d" % (br, bq), ani_max_abs_err=err, ani_hits_checked=int(hr.size), ani_hits_max_abs_err=herr)
+            if other is not None:  # ... and the two-set leg's hits against a 512 x 2 048 CPU block of (refs x other set)
+                tb = orc.ani_matrix(mine[:512].cpu().numpy(), mine_n2[:512].cpu().numpy(), other[:2048].cpu().numpy(),
+                                    other_n2[:2048].cpu().numpy(), KSIZE)
+                th_ = two_hits.view(-1, 3)
+                sel = (th_[:, 0] < 512) & (th_[:, 1] < 2048)
+                hr, hq = th_[sel, 0].long().cpu().numpy(), th_[sel, 1].long().cpu().numpy()
+                ha = th_[sel, 2].contiguous().view(torch.float32).cpu().numpy()
+                terr = float(np.abs(ha - tb[hr, hq]).max()) if hr.size else 0.0
+                if terr > 1e-4 or hr.size < int((tb >= 85.0 + 1e-4).sum()) or hr.size > int((tb >= 85.0 - 1e-4).sum()):
+                    raise SystemExit("PARITY GATE FAILED: two-set dist: max |gpu - cpu| = %g, %d hits" % (terr, hr.size))
+                gate.update(ani_two_sets_block="512 x 2048", ani_two_sets_hits_checked=int(hr.size), ani_two_sets_hits_max_abs_err=terr)
             if real_hv is not None:  # ... and the real sketches: a 512 x 2 048 CPU block against the timed run's hits
                 r_hv, r_n2 = real_hv
                 rb = orc.ani_matrix(r_hv[:512].cpu().numpy(), r_n2[:512].cpu().numpy(), r_hv[:2048].cpu().numpy(),

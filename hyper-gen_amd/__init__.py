@@ -82,6 +82,8 @@ EXPORTS = [
     "hg_sketch_batch_dev_packed", "hg_pack2_batch_dev", "hg_pack2_dev",
     "hg_pack2s_size", "hg_pack2s", "hg_sketch_stream_push_packed_sparse",
     "hg_dist_ops_row_bytes", "hg_dist_ops_meta_bytes", "hg_dist_ops_padded_rows", "hg_dist_prep_ops_dev", "hg_dist_block_ops_dev",
+    "hg_hv_packed_bytes_naive", "hg_hv_pack_naive", "hg_hv_unpack_naive", "hg_hv_payload_layout", "hg_hv_unpack_batch_dev",
+    "hg_sketch_file_read_image", "hg_sketch_file_image", "hg_sketch_file_payload_offset",
 ]
 
 
@@ -230,6 +232,14 @@ def lib():
         "hg_ctx_timings": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
         "hg_synth_genomes_dev": (C.c_int, [vp, C.c_uint64, sz, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, vp]),
+        "hg_hv_packed_bytes_naive": (sz, [C.c_uint32, C.c_uint32]),
+        "hg_hv_pack_naive": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "hg_hv_unpack_naive": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "hg_hv_payload_layout": (C.c_int, [C.c_uint32, C.c_uint32, sz]),
+        "hg_hv_unpack_batch_dev": (C.c_int, [vp, vp, sz, vp, vp, vp, sz, C.c_uint32, vp]),
+        "hg_sketch_file_read_image": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "hg_sketch_file_image": (vp, [vp, C.POINTER(sz)]),
+        "hg_sketch_file_payload_offset": (C.c_uint64, [vp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here == the ABI lost a symbol
@@ -485,6 +495,14 @@ class Context:
         self._ck(st, allow=(ERR_CAPACITY,))
         return n.value, st
 
+    def hv_unpack_batch_dev(self, d_payloads, payloads_bytes, offsets, quant_bits, layouts, hv_d, d_hv):
+        """decompress_file_sketch on the device: payload i at d_payloads + offsets[i] -> row i of d_hv (n x hv_d int16)"""
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        quant_bits = np.ascontiguousarray(quant_bits, np.uint8)
+        lay = None if layouts is None else np.ascontiguousarray(layouts, np.uint8)
+        self._ck(lib().hg_hv_unpack_batch_dev(self._h, d_payloads, payloads_bytes, _ptr(offsets), _ptr(quant_bits),
+                                              None if lay is None else _ptr(lay), offsets.size, hv_d, d_hv))
+
     def last_dist_path(self):
         """0 = f16 MFMA, 1 = i8 MFMA, 2 = integer VALU (all exact), -1 = no thresholded dist call yet."""
         return int(lib().hg_ctx_last_dist_path(self._h))
@@ -649,6 +667,56 @@ def hv_unpack(packed, hv_d, q):
     if st != OK:
         raise HgError(st, "hg_hv_unpack")
     return hv
+
+
+PAYLOAD_BITPACKER8X, PAYLOAD_NAIVE = 0, 1
+
+
+def hv_pack_naive(hv, q=None):
+    """the payload layout of hosts without AVX2 (src/hd.rs:158-166): (q, bytes)"""
+    hv = np.ascontiguousarray(hv, np.int16)
+    q = hv_quant_bits(hv) if q is None else q
+    out = np.zeros(lib().hg_hv_packed_bytes_naive(hv.size, q), np.uint8)
+    st = lib().hg_hv_pack_naive(_ptr(hv), hv.size, q, _ptr(out))
+    if st != OK:
+        raise HgError(st, "hg_hv_pack_naive")
+    return q, out
+
+
+def hv_unpack_naive(packed, hv_d, q):
+    packed = np.ascontiguousarray(packed).view(np.uint8)
+    hv = np.zeros(hv_d, np.int16)
+    st = lib().hg_hv_unpack_naive(_ptr(packed), hv_d, q, _ptr(hv))
+    if st != OK:
+        raise HgError(st, "hg_hv_unpack_naive")
+    return hv
+
+
+def hv_payload_layout(hv_d, q, payload_bytes):
+    return int(lib().hg_hv_payload_layout(hv_d, q, payload_bytes))
+
+
+def read_sketch_file_image(path):
+    """(image bytes as a numpy array, records) -- the records carry `payload_off` / `payload_bytes` instead of `hv`"""
+    h = C.c_void_p()
+    st = lib().hg_sketch_file_read_image(os.fsencode(path), C.byref(h))
+    if st != OK:
+        raise HgError(st, "hg_sketch_file_read_image(%s)" % path)
+    try:
+        nb = C.c_size_t(0)
+        base = lib().hg_sketch_file_image(h, C.byref(nb))
+        img = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(nb.value,)).copy() if nb.value else np.zeros(0, np.uint8)
+        out = []
+        for i in range(lib().hg_sketch_file_count(h)):
+            r = lib().hg_sketch_file_get(h, i).contents
+            assert not r.hv
+            out.append(dict(ksize=r.ksize, scaled=r.scaled, canonical=bool(r.canonical), seed=r.seed,
+                            hv_d=r.hv_d, hv_quant_bits=r.hv_quant_bits, hv_norm_2=r.hv_norm_2,
+                            file_str=r.file_str.decode(), payload_off=int(lib().hg_sketch_file_payload_offset(h, i)),
+                            payload_bytes=int(r.hv_len) * 2))
+        return img, out
+    finally:
+        lib().hg_sketch_file_free(h)
 
 
 def sort_ani_hits(hits, Q, symmetric=False):

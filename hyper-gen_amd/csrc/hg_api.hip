@@ -276,7 +276,11 @@ hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const
       seen = true;
       break;
     }
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
     if ((spins & 0x3ff) == 0x3ff &&
         std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(800))
       break;
@@ -986,7 +990,11 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
       uint64_t at = 0;
       for (size_t g = cut[k]; g < cut[k + 1]; ++g) boffs[g] = offs[cut[k]] + at, at += hg_pack2_size(lens[g]);
       sub_pk_bytes[k] = at;
-      sub_packed[k] = at <= HG_PACK_BYTES && at > 0;
+      // ... and one whose blobs outgrow its own ASCII region (hg_pack2_size is 32 for 1..16 bases, their padded ASCII 16:
+      // a sub-batch of very short sequences) stays ASCII too -- its blobs would run into the next sub-batch's region, or,
+      // for the last one, past the end of the buffer
+      const uint64_t span = offs[cut[k + 1] - 1] + ((lens[cut[k + 1] - 1] + 15) & ~(uint64_t)15) - offs[cut[k]];
+      sub_packed[k] = at <= HG_PACK_BYTES && at <= span && at > 0;
     }
   }
   std::unique_ptr<CallPool> pool;

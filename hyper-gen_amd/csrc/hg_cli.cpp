@@ -66,6 +66,7 @@ void debugf(const char *fmt, ...) {
 
 struct Cli {
   std::string mode, path = "1", path_r = "1", path_q = "1", out, method = "t1ha2", device = "cpu";
+  bool pack_naive = false;  // --pack_layout naive: the payload layout of reference hosts without AVX2 (src/hd.rs:158-166)
   unsigned threads = 16, ksize = 21, top_n = 1;
   bool canonical = true;
   unsigned long long seed = 123, scaled = 1500, hv_d = 4096;
@@ -87,7 +88,9 @@ Cli parse(int argc, char **argv) {
                 "  hyper-gen search -r {ref_sketch} -q {query_sketch} -o {top_hits_per_query} [-n top_n]\n\n"
                 "options: -p --path, -r --path_r, -q --path_q, -o --out, -t --thread [16], -m --sketch_method,\n"
                 "         -C --canonical [true], -k --ksize [21], -S --seed [123], -s --scaled [1500], -d --hv_d [4096],\n"
-                "         -Q --quant_scale [1.0], -a --ani_th [85.0], -D --device [cpu]\n");
+                "         -Q --quant_scale [1.0], -a --ani_th [85.0], -D --device [cpu]\n"
+                "extensions: -n --top_n [1] (search), --pack_layout avx2|naive [avx2] (sketch: the payload layout of\n"
+                "         reference hosts with / without AVX2; dist and search read both)\n");
     std::exit(0);
   }
   if (c.mode != "sketch" && c.mode != "dist" && c.mode != "search") die("unknown subcommand '" + c.mode + "'");
@@ -95,7 +98,7 @@ Cli parse(int argc, char **argv) {
   static const std::map<std::string, char> longs = {
       {"path", 'p'}, {"path_r", 'r'}, {"path_q", 'q'}, {"out", 'o'}, {"thread", 't'}, {"sketch_method", 'm'},
       {"canonical", 'C'}, {"ksize", 'k'}, {"seed", 'S'}, {"scaled", 's'}, {"hv_d", 'd'}, {"quant_scale", 'Q'},
-      {"ani_th", 'a'}, {"device", 'D'}, {"top_n", 'n'}};
+      {"ani_th", 'a'}, {"device", 'D'}, {"top_n", 'n'}, {"pack_layout", 'L'}};
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i], val;
     char key = 0;
@@ -143,6 +146,11 @@ Cli parse(int argc, char **argv) {
       case 'a': c.ani_th = std::strtof(val.c_str(), nullptr); break;
       case 'D': c.device = val; break;
       case 'n': c.top_n = (unsigned)u(1u << 20); break;  // search only (extension: the reference's search is a stub)
+      case 'L':  // sketch only (extension): which of the reference's two payload layouts to write
+        if (val == "naive") c.pack_naive = true;
+        else if (val == "avx2" || val == "bitpacker8x") c.pack_naive = false;
+        else die("invalid value '" + val + "' for '--pack_layout' (avx2 | naive)");
+        break;
       default: die("unexpected argument '" + a + "'");
     }
   }
@@ -302,14 +310,15 @@ int run_sketch(const Cli &c) {
     cv_space.notify_all();
     const double ts1 = now_s();
     const uint32_t q = hg_hv_quant_bits(hv.data(), (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
-    payload[f].resize((hg_hv_packed_bytes((uint32_t)c.hv_d, q) + 1) / 2);  // (the i16 view of the bytes, src/hd.rs:155-157)
-    if (hg_hv_pack(hv.data(), (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[f].data())) != HG_OK) die("pack");
+    const size_t pk_bytes = c.pack_naive ? hg_hv_packed_bytes_naive((uint32_t)c.hv_d, q) : hg_hv_packed_bytes((uint32_t)c.hv_d, q);
+    payload[f].resize((pk_bytes + 1) / 2);  // (the i16 view of the bytes, src/hd.rs:155-157)
+    if ((c.pack_naive ? hg_hv_pack_naive : hg_hv_pack)(hv.data(), (uint32_t)c.hv_d, q, reinterpret_cast<uint8_t *>(payload[f].data())) != HG_OK) die("pack");
     hg_file_sketch &r = recs[f];
     std::memset(&r, 0, sizeof r);
     r.ksize = (uint8_t)c.ksize, r.canonical = c.canonical, r.hv_quant_bits = (uint8_t)q, r.hv_norm_2 = n2;
     r.scaled = c.scaled, r.seed = c.seed, r.hv_d = c.hv_d;
     r.file_str = files[f].c_str();
-    r.hv = payload[f].data(), r.hv_len = hg_hv_packed_bytes((uint32_t)c.hv_d, q) / 2;  // align_to::<i16>().1: whole i16s
+    r.hv = payload[f].data(), r.hv_len = pk_bytes / 2;  // align_to::<i16>().1: whole i16s
     t_wait += ts1 - tw0, t_pack += now_s() - ts1;
   }
   for (auto &t : readers) t.join();
@@ -338,49 +347,87 @@ int run_sketch(const Cli &c) {
   return 0;
 }
 
+// A loaded .sketch file: the records (names, norms, widths) on the host, the bit-packed payloads still inside the file
+// image.  decompress_file_sketch (src/hd.rs:171-180) happens on the device: the image's payload bytes go over the link as
+// they are (4.6 KB per sketch at 9 bits against 8 KB of int16) and hg_hv_unpack_batch_dev decodes them into the matrix
+// the dist kernels read -- no host unpack threads, no second copy of the matrix in host memory.
 struct Loaded {
   hg_sketch_file *f = nullptr;
-  std::vector<int16_t> hv;
   std::vector<int32_t> n2;
+  std::vector<uint64_t> off;     // payload offsets in the image
+  std::vector<uint8_t> q, lay;   // quantisation bits, payload layout (BitPacker8x / the non-AVX2 one) per record
   size_t n = 0;
   uint64_t hv_d = 0;
   uint8_t ksize = 0;
 };
 
-void load(const std::string &path, Loaded &L, unsigned threads) {
+void load(const std::string &path, Loaded &L) {
   logline("INFO", "Loading sketch from " + path);
-  if (hg_sketch_file_read(path.c_str(), &L.f) != HG_OK) die("Opening sketch file failed!");
+  if (hg_sketch_file_read_image(path.c_str(), &L.f) != HG_OK) die("Opening sketch file failed!");
   L.n = hg_sketch_file_count(L.f);
   if (L.n == 0) die("empty sketch file " + path);
   const hg_file_sketch *r0 = hg_sketch_file_get(L.f, 0);
   L.hv_d = r0->hv_d, L.ksize = r0->ksize;
   // validate before sizing anything from the file's own numbers
   if (L.hv_d == 0 || L.hv_d > 65536) die("unsupported HV dimension in " + path);
+  L.n2.resize(L.n), L.off.resize(L.n), L.q.resize(L.n), L.lay.resize(L.n);
   for (size_t i = 0; i < L.n; ++i) {
     const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
     if (r->hv_quant_bits < 1 || r->hv_quant_bits > 16) die("corrupt sketch record (quantisation bits) in " + path);
+    if (r->hv_d != L.hv_d) die("sketches of one file use different HV dimensions");
+    // which of the reference's two payload layouts this is follows from its length (they never coincide)
+    const int lay = hg_hv_payload_layout((uint32_t)L.hv_d, r->hv_quant_bits, (size_t)r->hv_len * 2);
+    if (lay < 0) die("corrupt sketch payload in " + path);
+    L.n2[i] = r->hv_norm_2, L.off[i] = hg_sketch_file_payload_offset(L.f, i), L.q[i] = r->hv_quant_bits, L.lay[i] = (uint8_t)lay;
   }
+}
+
+// The sketches of a file on the devices: shard s (hg_shard_range) gets the slice of the file image that holds its
+// records, decodes it there and keeps the int16 rows and the norms (what hg_dist_multi_dev takes).
+struct DevSet {
+  std::vector<const int16_t *> hv;
+  std::vector<const int32_t *> n2;
+  std::vector<size_t> rows;
+};
+void to_devices(hg_multi *m, const Loaded &L, DevSet &D) {
   char buf[96];
   std::snprintf(buf, sizeof buf, "Decompressing sketch with HV dim=%llu", (unsigned long long)L.hv_d);
   logline("INFO", buf);
-  L.hv.resize(L.n * L.hv_d), L.n2.resize(L.n);
-  // decompress_file_sketch is a rayon loop in the reference (src/hd.rs:171-180): -t threads here
-  std::atomic<size_t> next{0};
-  auto work = [&] {
-    for (size_t i; (i = next.fetch_add(1)) < L.n;) {
-      const hg_file_sketch *r = hg_sketch_file_get(L.f, i);
-      if (r->hv_d != L.hv_d) die("sketches of one file use different HV dimensions");
-      if (r->hv_len != hg_hv_packed_bytes((uint32_t)L.hv_d, r->hv_quant_bits) / 2) die("corrupt sketch payload in " + path);
-      if (hg_hv_unpack(reinterpret_cast<const uint8_t *>(r->hv), (uint32_t)L.hv_d, r->hv_quant_bits,
-                       L.hv.data() + i * L.hv_d) != HG_OK)
-        die("unpack failed");
-      L.n2[i] = r->hv_norm_2;
-    }
+  const int ns = hg_multi_size(m);
+  D.hv.assign(ns, nullptr), D.n2.assign(ns, nullptr), D.rows.assign(ns, 0);
+  size_t img_bytes = 0;
+  const uint8_t *img = hg_sketch_file_image(L.f, &img_bytes);
+  auto work = [&](int s) {
+    size_t lo = 0, hi = 0;
+    hg_shard_range(L.n, s, ns, &lo, &hi);
+    if (hi == lo) return;
+    hg_ctx *ctx = hg_multi_ctx(m, s);
+    const uint64_t b0 = L.off[lo], b1 = L.off[hi - 1] + 2 * hg_sketch_file_get(L.f, hi - 1)->hv_len;
+    if (b1 > img_bytes || b0 > b1) die("corrupt sketch payload");
+    std::vector<uint64_t> rel(hi - lo);
+    for (size_t i = lo; i < hi; ++i) rel[i - lo] = L.off[i] - b0;
+    void *d_img = nullptr, *d_hv = nullptr, *d_n2 = nullptr;
+    ck(ctx, hg_dev_alloc(ctx, b1 - b0, &d_img), "alloc");
+    ck(ctx, hg_dev_alloc(ctx, (hi - lo) * L.hv_d * sizeof(int16_t), &d_hv), "alloc");
+    ck(ctx, hg_dev_alloc(ctx, (hi - lo) * sizeof(int32_t), &d_n2), "alloc");
+    ck(ctx, hg_copy_h2d(ctx, d_img, img + b0, b1 - b0), "upload");
+    ck(ctx, hg_copy_h2d(ctx, d_n2, L.n2.data() + lo, (hi - lo) * sizeof(int32_t)), "upload");
+    ck(ctx, hg_hv_unpack_batch_dev(ctx, static_cast<const uint8_t *>(d_img), b1 - b0, rel.data(), L.q.data() + lo, L.lay.data() + lo,
+                                   hi - lo, (uint32_t)L.hv_d, static_cast<int16_t *>(d_hv)), "unpack");
+    ck(ctx, hg_dev_free(ctx, d_img), "free");
+    D.hv[s] = static_cast<const int16_t *>(d_hv), D.n2[s] = static_cast<const int32_t *>(d_n2), D.rows[s] = hi - lo;
   };
   std::vector<std::thread> th;
-  for (unsigned t = 1; t < std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, L.n / 64)); ++t) th.emplace_back(work);
-  work();
+  for (int s = 1; s < ns; ++s) th.emplace_back(work, s);
+  work(0);
   for (auto &t : th) t.join();
+}
+void release(hg_multi *m, DevSet &D) {
+  for (size_t s = 0; s < D.hv.size(); ++s) {
+    hg_ctx *ctx = hg_multi_ctx(m, (int)s);
+    if (D.hv[s]) (void)hg_dev_free(ctx, const_cast<int16_t *>(D.hv[s]));
+    if (D.n2[s]) (void)hg_dev_free(ctx, const_cast<int32_t *>(D.n2[s]));
+  }
 }
 
 int run_dist(const Cli &c) {
@@ -396,13 +443,18 @@ int run_dist(const Cli &c) {
     multi = open_all_devices();
     debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
   });
-  load(c.path_r, R, c.threads);
-  if (!sym) load(c.path_q, Qs, c.threads);
-  debugf("sketch files loaded and decompressed in %.1f ms", (now_s() - tp) * 1e3);
+  load(c.path_r, R);
+  if (!sym) load(c.path_q, Qs);
+  debugf("sketch files loaded in %.1f ms", (now_s() - tp) * 1e3);
   opener.join();
   const Loaded &Q = sym ? R : Qs;
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
   if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
+  tp = now_s();
+  DevSet dR, dQ;
+  to_devices(multi, R, dR);
+  if (!sym) to_devices(multi, Qs, dQ);
+  debugf("payloads uploaded and decompressed on the device(s) in %.1f ms", (now_s() - tp) * 1e3);
   logline("INFO", "Computing ANI..");
   tp = now_s();
   const size_t total = sym ? R.n * (Q.n - 1) / 2 : R.n * Q.n;
@@ -410,8 +462,9 @@ int run_dist(const Cli &c) {
   size_t found = 0;
   for (;;) {
     // reference rows are all-gathered over xGMI, query rows stay on their shard's GPU
-    hg_status s = hg_dist_multi(multi, R.hv.data(), R.n2.data(), R.n, Q.hv.data(), Q.n2.data(), Q.n, (uint32_t)R.hv_d,
-                                R.ksize, sym, c.ani_th, hits.data(), hits.size(), &found);
+    hg_status s = hg_dist_multi_dev(multi, dR.hv.data(), dR.n2.data(), dR.rows.data(), sym ? nullptr : dQ.hv.data(),
+                                    sym ? nullptr : dQ.n2.data(), sym ? nullptr : dQ.rows.data(), (uint32_t)R.hv_d, R.ksize, sym,
+                                    c.ani_th, hits.data(), hits.size(), &found);
     if (s == HG_ERR_CAPACITY) {
       hits.resize(found);
       continue;
@@ -420,6 +473,7 @@ int run_dist(const Cli &c) {
     break;
   }
   hits.resize(found);
+  release(multi, dR), release(multi, dQ);
   debugf("ANI matrix (%zu hits) in %.1f ms", found, (now_s() - tp) * 1e3);
   tp = now_s();
   // dump_ani_file's order (src/utils.rs:262-269), produced on the device: two stable radix passes instead of a
@@ -487,18 +541,30 @@ int run_search(const Cli &c) {
   const auto t0 = std::chrono::steady_clock::now();
   Loaded R, Q;
   hg_multi *multi = nullptr;
-  std::thread opener([&] { multi = open_all_devices(); });  // the HIP runtime comes up while the files are read
-  load(c.path_r, R, c.threads);
-  load(c.path_q, Q, c.threads);
+  double tp = now_s();
+  std::thread opener([&] {  // the HIP runtime comes up while the files are read
+    const double td = now_s();
+    multi = open_all_devices();
+    debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
+  });
+  load(c.path_r, R);
+  load(c.path_q, Q);
+  debugf("sketch files loaded in %.1f ms", (now_s() - tp) * 1e3);
   opener.join();
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
   if (R.hv_d != Q.hv_d) die("Ref and query sketches use different HV dimensions!");
+  tp = now_s();
+  DevSet dR, dQ;
+  to_devices(multi, R, dR);
+  to_devices(multi, Q, dQ);
+  debugf("payloads uploaded and decompressed on the device(s) in %.1f ms", (now_s() - tp) * 1e3);
   logline("INFO", "Searching..");
+  tp = now_s();
   std::vector<hg_ani_hit> hits(std::max<size_t>(1024, R.n * Q.n / 16));
   size_t found = 0;
   for (;;) {
-    hg_status s = hg_dist_multi(multi, R.hv.data(), R.n2.data(), R.n, Q.hv.data(), Q.n2.data(), Q.n, (uint32_t)R.hv_d,
-                                R.ksize, 0, c.ani_th, hits.data(), hits.size(), &found);
+    hg_status s = hg_dist_multi_dev(multi, dR.hv.data(), dR.n2.data(), dR.rows.data(), dQ.hv.data(), dQ.n2.data(), dQ.rows.data(),
+                                    (uint32_t)R.hv_d, R.ksize, 0, c.ani_th, hits.data(), hits.size(), &found);
     if (s == HG_ERR_CAPACITY) {
       hits.resize(found);
       continue;
@@ -506,6 +572,9 @@ int run_search(const Cli &c) {
     ckm(multi, s, "search");
     break;
   }
+  release(multi, dR), release(multi, dQ);
+  debugf("ANI matrix (%zu hits) in %.1f ms", found, (now_s() - tp) * 1e3);
+  tp = now_s();
   hg_ctx *ctx = hg_multi_ctx(multi, 0);
   const uint32_t k = std::max(1u, c.top_n);
   void *d_hits = nullptr, *d_out = nullptr, *d_cnt = nullptr;
@@ -520,6 +589,8 @@ int run_search(const Cli &c) {
   ck(ctx, hg_copy_d2h(ctx, best.data(), d_out, best.size() * sizeof(hg_ani_hit)), "download");
   ck(ctx, hg_copy_d2h(ctx, cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t)), "download");
   hg_dev_free(ctx, d_hits), hg_dev_free(ctx, d_out), hg_dev_free(ctx, d_cnt);
+  debugf("top-%u per query in %.1f ms", k, (now_s() - tp) * 1e3);
+  tp = now_s();
   std::string tsv;
   char line[64];
   size_t reported = 0;
@@ -536,6 +607,7 @@ int run_search(const Cli &c) {
   FILE *f = std::fopen(c.out.c_str(), "wb");
   if (!f || (tsv.size() && std::fwrite(tsv.data(), 1, tsv.size(), f) != tsv.size())) die("Dump search file failed!");
   std::fclose(f);
+  debugf("TSV formatted and written (%.1f MB) in %.1f ms", tsv.size() / 1e6, (now_s() - tp) * 1e3);
   char buf[256];
   std::snprintf(buf, sizeof buf, "Searched %zu queries against %zu references: %zu results (top %u, ANI >= %.1f) took %.3fs",
                 Q.n, R.n, reported, k, c.ani_th, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

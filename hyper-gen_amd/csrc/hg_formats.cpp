@@ -107,11 +107,64 @@ extern "C" hg_status hg_hv_unpack(const uint8_t *packed, uint32_t hv_d, uint32_t
   return HG_OK;
 }
 
+// ---- the non-AVX2 layout (src/hd.rs:158-166, 213-231) ------------------------------------------------------------------
+// A plain LSB-first bit stream of the values' low q bits in 16-bit words, (q*hv_d + 16) / 16 of them.  Written here
+// through a 64-bit shift register, a value at a time (the oracle follows the reference's bit-by-bit loops).
+extern "C" size_t hg_hv_packed_bytes_naive(uint32_t hv_d, uint32_t q) { return 2 * (((size_t)q * hv_d + 16) / 16); }
+
+extern "C" hg_status hg_hv_pack_naive(const int16_t *hv, uint32_t hv_d, uint32_t q, uint8_t *packed) {
+  if (!hv || !packed || q < 1 || q > 16) return HG_ERR_INVALID;
+  const size_t words = hg_hv_packed_bytes_naive(hv_d, q) / 2;
+  const uint32_t mask = (1u << q) - 1u;
+  uint64_t reg = 0;
+  uint32_t have = 0;
+  size_t w = 0;
+  auto put16 = [&](uint16_t v) {
+    packed[2 * w] = (uint8_t)v, packed[2 * w + 1] = (uint8_t)(v >> 8);  // i16 little endian, as bincode stores them
+    ++w;
+  };
+  for (uint32_t d = 0; d < hv_d; ++d) {
+    reg |= (uint64_t)((uint32_t)(uint16_t)hv[d] & mask) << have;
+    for (have += q; have >= 16; have -= 16, reg >>= 16) put16((uint16_t)reg);
+  }
+  if (have) put16((uint16_t)reg);
+  while (w < words) put16(0);
+  return HG_OK;
+}
+
+extern "C" hg_status hg_hv_unpack_naive(const uint8_t *packed, uint32_t hv_d, uint32_t q, int16_t *hv) {
+  if (!hv || !packed || q < 1 || q > 16) return HG_ERR_INVALID;
+  const uint32_t mask = (1u << q) - 1u;
+  // `1 << (q-1)` and `1 << q` as the reference's i16 expressions evaluate in a release build (shift amounts modulo 16)
+  const int16_t half = (int16_t)(uint16_t)(1u << ((q - 1) & 15)), full = (int16_t)(uint16_t)(1u << (q & 15));
+  uint64_t reg = 0;
+  uint32_t have = 0;
+  size_t w = 0;
+  for (uint32_t d = 0; d < hv_d; ++d) {
+    for (; have < q; have += 16, ++w) reg |= (uint64_t)((uint32_t)packed[2 * w] | ((uint32_t)packed[2 * w + 1] << 8)) << have;
+    int16_t v = (int16_t)(uint16_t)((uint32_t)reg & mask);
+    reg >>= q, have -= q;
+    if (v > half) v = (int16_t)((uint16_t)v - (uint16_t)full);  // strictly greater: src/hd.rs:221-227
+    hv[d] = v;
+  }
+  return HG_OK;
+}
+
+extern "C" int hg_hv_payload_layout(uint32_t hv_d, uint32_t q, size_t payload_bytes) {
+  if (q < 1 || q > 16) return -1;
+  // (the i16 view of the BitPacker8x bytes drops an odd last byte: src/hd.rs:155-157 `align_to::<i16>().1`)
+  if (payload_bytes == hg_hv_packed_bytes(hv_d, q) / 2 * 2) return HG_PAYLOAD_BITPACKER8X;
+  if (payload_bytes == hg_hv_packed_bytes_naive(hv_d, q)) return HG_PAYLOAD_NAIVE;
+  return -1;
+}
+
 // ---- .sketch: bincode 1.x default config = little endian, fixed-width ints, u64 lengths --------------
 struct hg_sketch_file {
   std::vector<hg_file_sketch> recs;
   std::vector<std::string> names;
-  std::vector<std::vector<int16_t>> payloads;
+  std::vector<std::vector<int16_t>> payloads;  // hg_sketch_file_read
+  std::vector<uint8_t> image;                  // hg_sketch_file_read_image: the file as read ...
+  std::vector<uint64_t> payload_off;           // ... and where record i's payload starts in it
 };
 
 namespace {
@@ -156,29 +209,58 @@ extern "C" hg_status hg_sketch_file_write(const char *path, const hg_file_sketch
   return (std::fclose(f) == 0 && ok) ? HG_OK : HG_ERR_IO;
 }
 
-extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out) {
+namespace {
+// the whole file in one buffer (fstat + read: no 64 KiB fread loop, no vector growth)
+hg_status slurp(const char *path, std::vector<uint8_t> &buf) {
+  const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return HG_ERR_IO;
+  struct stat st;
+  if (::fstat(fd, &st) != 0 || st.st_size < 0) {
+    ::close(fd);
+    return HG_ERR_IO;
+  }
+  try {
+    buf.resize((size_t)st.st_size);
+  } catch (const std::bad_alloc &) {
+    ::close(fd);
+    return HG_ERR_OOM;
+  }
+  size_t have = 0;
+  while (have < buf.size()) {
+    const ssize_t got = ::read(fd, buf.data() + have, buf.size() - have);
+    if (got < 0 && errno == EINTR) continue;
+    if (got <= 0) break;
+    have += (size_t)got;
+  }
+  ::close(fd);
+  buf.resize(have);
+  return HG_OK;
+}
+
+// copy_payloads = false: the records' hv stay NULL, the payloads are addressed through image + payload_off
+// (hg_sketch_file_image / hg_sketch_file_payload_offset: what goes to hg_hv_unpack_batch_dev)
+hg_status read_sketch_file(const char *path, hg_sketch_file **out, bool copy_payloads) {
   if (!path || !out) return HG_ERR_INVALID;
   *out = nullptr;
-  FILE *f = std::fopen(path, "rb");
-  if (!f) return HG_ERR_IO;
-  std::vector<uint8_t> buf;
-  uint8_t tmp[1 << 16];
-  size_t got;
-  while ((got = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
-  std::fclose(f);
-  const uint8_t *p = buf.data(), *end = p + buf.size();
-  uint64_t n = 0;
-  if (!get(p, end, n)) return HG_ERR_IO;
   hg_sketch_file *sf = new (std::nothrow) hg_sketch_file();
   if (!sf) return HG_ERR_OOM;
+  hg_status rs = slurp(path, sf->image);
+  if (rs != HG_OK) {
+    delete sf;
+    return rs;
+  }
+  const std::vector<uint8_t> &buf = sf->image;
+  const uint8_t *p = buf.data(), *end = p + buf.size();
+  uint64_t n = 0;
   // a record is at least 47 bytes (31 fixed + two u64 lengths): a count the file cannot hold is corruption,
   // not an allocation request (a hostile count must not reach resize())
-  if (n > (buf.size() - 8) / 47) {
+  if (!get(p, end, n) || n > (buf.size() - 8) / 47) {
     delete sf;
     return HG_ERR_IO;
   }
   try {
-  sf->recs.resize(n), sf->names.resize(n), sf->payloads.resize(n);
+  sf->recs.resize(n), sf->names.resize(n), sf->payload_off.resize(n);
+  if (copy_payloads) sf->payloads.resize(n);
   for (uint64_t i = 0; i < n; ++i) {
     hg_file_sketch &r = sf->recs[i];
     std::memset(&r, 0, sizeof r);
@@ -195,8 +277,11 @@ extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out)
       delete sf;
       return HG_ERR_IO;
     }
-    sf->payloads[i].resize(hl);
-    if (hl) std::memcpy(sf->payloads[i].data(), p, hl * 2);
+    sf->payload_off[i] = (uint64_t)(p - buf.data());
+    if (copy_payloads) {
+      sf->payloads[i].resize(hl);
+      if (hl) std::memcpy(sf->payloads[i].data(), p, hl * 2);
+    }
     p += hl * 2;
     r.hv_len = hl;
   }
@@ -206,10 +291,22 @@ extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out)
   }
   for (uint64_t i = 0; i < n; ++i) {  // pointers only after the vectors stopped moving
     sf->recs[i].file_str = sf->names[i].c_str();
-    sf->recs[i].hv = sf->payloads[i].data();
+    sf->recs[i].hv = copy_payloads ? sf->payloads[i].data() : nullptr;
   }
+  if (copy_payloads) std::vector<uint8_t>().swap(sf->image);  // (the copies are the payloads now)
   *out = sf;
   return HG_OK;
+}
+}  // namespace
+
+extern "C" hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out) { return read_sketch_file(path, out, true); }
+extern "C" hg_status hg_sketch_file_read_image(const char *path, hg_sketch_file **out) { return read_sketch_file(path, out, false); }
+extern "C" const uint8_t *hg_sketch_file_image(const hg_sketch_file *f, size_t *bytes) {
+  if (bytes) *bytes = f ? f->image.size() : 0;
+  return (f && !f->image.empty()) ? f->image.data() : nullptr;
+}
+extern "C" uint64_t hg_sketch_file_payload_offset(const hg_sketch_file *f, size_t i) {
+  return (f && i < f->payload_off.size()) ? f->payload_off[i] : 0;
 }
 
 extern "C" size_t hg_sketch_file_count(const hg_sketch_file *f) { return f ? f->recs.size() : 0; }

@@ -295,6 +295,31 @@ uint32_t hg_hv_quant_bits(const int16_t *hv, uint32_t hv_d);
 size_t hg_hv_packed_bytes(uint32_t hv_d, uint32_t quant_bits);
 hg_status hg_hv_pack(const int16_t *hv, uint32_t hv_d, uint32_t quant_bits, uint8_t *packed);
 hg_status hg_hv_unpack(const uint8_t *packed, uint32_t hv_d, uint32_t quant_bits, int16_t *hv);
+/* The OTHER payload layout: what the reference writes and reads on a host WITHOUT AVX2 (src/hd.rs:158-166, 213-231).
+ * (quant_bits * hv_d + 16) / 16 int16 words -- always one word more than the bits need when that product is a multiple
+ * of 16 -- holding the low quant_bits bits of every value LSB first, NO offset added.  Decoding follows the reference
+ * to the letter: `if v > (1 << (q-1)) { v - (1 << q) }` in i16 -- strictly greater, so -2^(q-1) (low bits 100..0) comes
+ * back as +2^(q-1), and at quant_bits = 16 (`1 << 15` = -32768, `1 << 16` wraps to 1) every value but -32768 comes back
+ * one lower: the reference's naive round trip is lossy exactly there, and so is this one.
+ * The two layouts never have the same payload length (the naive one is longer by at least one word), which is how
+ * hg_hv_payload_layout -- and through it `hyper-gen dist` / `search` -- tells them apart: HG_PAYLOAD_BITPACKER8X,
+ * HG_PAYLOAD_NAIVE, or -1 for a length that is neither.  `hyper-gen sketch` writes the naive layout only behind
+ * `--pack_layout naive` (an extension flag; the default is what the reference writes on every AVX2 host). */
+enum { HG_PAYLOAD_BITPACKER8X = 0, HG_PAYLOAD_NAIVE = 1 };
+size_t hg_hv_packed_bytes_naive(uint32_t hv_d, uint32_t quant_bits);
+hg_status hg_hv_pack_naive(const int16_t *hv, uint32_t hv_d, uint32_t quant_bits, uint8_t *packed);
+hg_status hg_hv_unpack_naive(const uint8_t *packed, uint32_t hv_d, uint32_t quant_bits, int16_t *hv);
+int hg_hv_payload_layout(uint32_t hv_d, uint32_t quant_bits, size_t payload_bytes);
+/* decompress_file_sketch (src/hd.rs:171-180: one rayon task per sketch) on the device: n payloads, payload i at
+ * d_payloads + offsets[i] (byte offsets of any alignment into a device buffer of payloads_bytes bytes -- e.g. the image of
+ * a .sketch file, see hg_sketch_file_payload_offset; host array) in layout layouts[i] with quant_bits[i] (host arrays;
+ * layouts == NULL: all BitPacker8x), decoded to row i of the n x hv_d int16 matrix d_hv -- the same integers as
+ * hg_hv_unpack / hg_hv_unpack_naive, rows and dimensions behind the last whole block included.  The payloads are 4.6 KB
+ * per sketch at quant_bits = 9 against 8 KB of int16: `hyper-gen dist` uploads the file's payload bytes as they are and
+ * decodes them here instead of unpacking on host threads and uploading the matrix.  Stream-ordered; the host arrays are
+ * consumed before the call returns.  (hg_hv_unpack_kernel) */
+hg_status hg_hv_unpack_batch_dev(hg_ctx *ctx, const uint8_t *d_payloads, size_t payloads_bytes, const uint64_t *offsets,
+                                 const uint8_t *quant_bits, const uint8_t *layouts, size_t n, uint32_t hv_d, int16_t *d_hv);
 
 /* ---- .sketch files (host side; src/types.rs:224-235, src/utils.rs:234-258) ------------ */
 typedef struct {
@@ -315,6 +340,12 @@ typedef struct hg_sketch_file hg_sketch_file; /* owns the records of a loaded fi
 
 hg_status hg_sketch_file_write(const char *path, const hg_file_sketch *recs, size_t n);
 hg_status hg_sketch_file_read(const char *path, hg_sketch_file **out);
+/* The same parse without the payload copies: the records' `hv` are NULL (hv_len is set), the file's bytes stay in one
+ * buffer (hg_sketch_file_image) and record i's payload starts at hg_sketch_file_payload_offset(f, i) in it -- upload the
+ * image once and decode on the device with hg_hv_unpack_batch_dev (what `hyper-gen dist` / `search` do). */
+hg_status hg_sketch_file_read_image(const char *path, hg_sketch_file **out);
+const uint8_t *hg_sketch_file_image(const hg_sketch_file *f, size_t *bytes);
+uint64_t hg_sketch_file_payload_offset(const hg_sketch_file *f, size_t i);
 size_t hg_sketch_file_count(const hg_sketch_file *f);
 const hg_file_sketch *hg_sketch_file_get(const hg_sketch_file *f, size_t i);
 void hg_sketch_file_free(hg_sketch_file *f);

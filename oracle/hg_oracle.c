@@ -413,6 +413,36 @@ void orc_unpack_hv(const uint8_t *packed, size_t hv_d, unsigned q, int16_t *hv) 
   for (size_t d = hv_d / 256 * 256; d < hv_d; d++) hv[d] = (int16_t)(0u - (uint16_t)offset);
 }
 
+/* The OTHER layout: what the reference writes / reads on a host WITHOUT AVX2 (src/hd.rs:158-166 and :213-231).  Restated bit
+ * by bit in the reference's own loop order, in i16 arithmetic with Rust's release-mode semantics (wrapping; a shift amount
+ * is taken modulo the type's width):
+ *   pack  : (q*hv_d + 16) / 16 i16 words, zero-initialised (one word more than the bits need when q*hv_d is a multiple of 16);
+ *           bit i of the stream = bit (i % q) of hv[i / q] -- the low q bits of the two's-complement VALUE, no offset added --
+ *           stored at bit (i % 16) of word i / 16;
+ *   unpack: the same bits OR-ed back, and at the end of every element `if v > (1 << (q-1)) { v - (1 << q) }` -- strictly
+ *           greater, so the one value whose low q bits are exactly 100..0 (-2^(q-1)) comes back as +2^(q-1): the reference's
+ *           naive round trip is not lossless for it.  q = 16: `1 << 15` is -32768 as i16 and `1 << 16` wraps to 1, so every
+ *           element but -32768 comes back one lower.  Both are reproduced here (the layout is defined by what the reference
+ *           does), and documented in include/hypergen.h. */
+size_t orc_packed_words_naive(size_t hv_d, unsigned q) { return ((size_t)q * hv_d + 16) / 16; }
+void orc_pack_hv_naive(const int16_t *hv, size_t hv_d, unsigned q, int16_t *out) {
+  memset(out, 0, orc_packed_words_naive(hv_d, q) * sizeof(int16_t));
+  for (size_t i = 0; i < (size_t)q * hv_d; i++) {
+    const int16_t bit = (int16_t)((hv[i / q] >> (i % q)) & 1); /* arithmetic shift of the i16 value */
+    out[i / 16] = (int16_t)((uint16_t)out[i / 16] | (uint16_t)((uint16_t)bit << (i % 16)));
+  }
+}
+void orc_unpack_hv_naive(const int16_t *packed, size_t hv_d, unsigned q, int16_t *hv) {
+  const int16_t half = (int16_t)(uint16_t)(1u << ((q - 1) & 15)); /* `1 << (q-1)` in i16 */
+  const int16_t full = (int16_t)(uint16_t)(1u << (q & 15));       /* `1 << q` in i16: the amount wraps at 16 */
+  memset(hv, 0, hv_d * sizeof(int16_t));
+  for (size_t i = 0; i < (size_t)q * hv_d; i++) {
+    const uint16_t bit = (uint16_t)((packed[i / 16] >> (i % 16)) & 1);
+    hv[i / q] = (int16_t)((uint16_t)hv[i / q] | (uint16_t)(bit << (i % q)));
+    if ((i + 1) % q == 0 && hv[i / q] > half) hv[i / q] = (int16_t)((uint16_t)hv[i / q] - (uint16_t)full);
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* ANI                                                                        */
 /* ------------------------------------------------------------------------- */

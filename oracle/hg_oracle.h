@@ -84,6 +84,12 @@ void orc_pack_hv(const int16_t *hv, size_t hv_d, unsigned quant_bits,
 void orc_unpack_hv(const uint8_t *packed, size_t hv_d, unsigned quant_bits,
                    int16_t *hv);
 
+/* the layout of hosts WITHOUT AVX2 (src/hd.rs:158-166, 213-231): (q*hv_d + 16) / 16 i16 words, the low q bits of each
+ * value LSB first, no offset; the decode's strict `>` and its q = 16 shifts are the reference's (see hg_oracle.c). */
+size_t orc_packed_words_naive(size_t hv_d, unsigned quant_bits);
+void orc_pack_hv_naive(const int16_t *hv, size_t hv_d, unsigned quant_bits, int16_t *out);
+void orc_unpack_hv_naive(const int16_t *packed, size_t hv_d, unsigned quant_bits, int16_t *hv);
+
 /* ---- ANI ------------------------------------------------------------------- */
 
 /* i32 dot (src/dist.rs:147-151), wrapping. */

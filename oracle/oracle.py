@@ -57,6 +57,12 @@ def lib():
         L.orc_pack_hv.argtypes = [i16p, C.c_size_t, C.c_uint, u8p]
         L.orc_unpack_hv.restype = None
         L.orc_unpack_hv.argtypes = [u8p, C.c_size_t, C.c_uint, i16p]
+        L.orc_packed_words_naive.restype = C.c_size_t
+        L.orc_packed_words_naive.argtypes = [C.c_size_t, C.c_uint]
+        L.orc_pack_hv_naive.restype = None
+        L.orc_pack_hv_naive.argtypes = [i16p, C.c_size_t, C.c_uint, i16p]
+        L.orc_unpack_hv_naive.restype = None
+        L.orc_unpack_hv_naive.argtypes = [i16p, C.c_size_t, C.c_uint, i16p]
         L.orc_hv_dot.restype = C.c_int32
         L.orc_hv_dot.argtypes = [i16p, i16p, C.c_size_t]
         L.orc_ani_from_dot.restype = C.c_float
@@ -222,6 +228,22 @@ def unpack_hv(packed, hv_d, q):
     packed = np.ascontiguousarray(packed, dtype=np.uint8)
     hv = np.zeros(hv_d, np.int16)
     lib().orc_unpack_hv(_p(packed, C.c_uint8), hv_d, q, _p(hv, C.c_int16))
+    return hv
+
+
+def pack_hv_naive(hv, q=None):
+    """the non-AVX2 layout (src/hd.rs:158-166): returns (q, i16 words)"""
+    hv = np.ascontiguousarray(hv, dtype=np.int16)
+    q = quant_bits(hv) if q is None else q
+    out = np.zeros(int(lib().orc_packed_words_naive(hv.size, q)), np.int16)
+    lib().orc_pack_hv_naive(_p(hv, C.c_int16), hv.size, q, _p(out, C.c_int16))
+    return q, out
+
+
+def unpack_hv_naive(packed, hv_d, q):
+    packed = np.ascontiguousarray(packed, dtype=np.int16)
+    hv = np.zeros(hv_d, np.int16)
+    lib().orc_unpack_hv_naive(_p(packed, C.c_int16), hv_d, q, _p(hv, C.c_int16))
     return hv
 
 

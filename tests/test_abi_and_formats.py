@@ -95,6 +95,49 @@ def test_pack_matches_oracle(hg, orc):
             assert (hg.hv_unpack(packed, d, q) == orc.unpack_hv(opacked, d, q)).all(), (q, d)
 
 
+def test_naive_payload_layout_matches_oracle_and_is_told_apart(hg, orc):
+    """the non-AVX2 payload layout (src/hd.rs:158-166, 213-231): product == oracle byte for byte and value for value (the
+    reference's lossy corners included), and the two layouts are told apart by their lengths"""
+    rng = np.random.default_rng(21)
+    for q in range(6, 17):
+        for d in (256, 1000, 4096, 4104, 24):
+            lim = 1 << (q - 1)
+            hv = rng.integers(-lim, lim, d).astype(np.int16)
+            hv[:3] = [-lim, lim - 1, 0]
+            _, got = hg.hv_pack_naive(hv, q)
+            _, want = orc.pack_hv_naive(hv, q)
+            assert got.size == hg.lib().hg_hv_packed_bytes_naive(d, q) and np.array_equal(got, want.view(np.uint8)), (q, d)
+            assert np.array_equal(hg.hv_unpack_naive(got, d, q), orc.unpack_hv_naive(want, d, q)), (q, d)
+            bp = hg.lib().hg_hv_packed_bytes(d, q) // 2 * 2  # (the i16 view of the BitPacker8x bytes)
+            assert hg.hv_payload_layout(d, q, got.size) == hg.PAYLOAD_NAIVE
+            assert hg.hv_payload_layout(d, q, bp) == hg.PAYLOAD_BITPACKER8X
+            assert hg.hv_payload_layout(d, q, bp + 1) == -1 and hg.hv_payload_layout(d, 0, bp) == -1
+    # a value wider than q bits is cut to its low q bits, like the reference's `(hv >> k) & 1` loop
+    hv = np.array([300, -300] * 8, np.int16)
+    assert np.array_equal(hg.hv_pack_naive(hv, 6)[1], orc.pack_hv_naive(hv, 6)[1].view(np.uint8))
+
+
+def test_sketch_file_image_reader(hg, tmp_path):
+    """hg_sketch_file_read_image: the same records without payload copies; payload i sits at its offset in the image"""
+    rng = np.random.default_rng(22)
+    recs = []
+    for i in range(7):
+        hv = rng.integers(-200, 200, 512).astype(np.int16)
+        q, pk = (hg.hv_pack_naive if i == 3 else hg.hv_pack)(hv)
+        recs.append(dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=512, hv_quant_bits=q, hv_norm_2=i,
+                         file_str="p" * i + "/g%d.fna" % i, hv=pk.view(np.int16)))
+    path = str(tmp_path / "x.sketch")
+    hg.write_sketch_file(path, recs)
+    img, meta = hg.read_sketch_file_image(path)
+    full = hg.read_sketch_file(path)
+    assert img.tobytes() == open(path, "rb").read() and len(meta) == len(full) == 7
+    for m, f, r in zip(meta, full, recs):
+        assert m["file_str"] == f["file_str"] and m["hv_norm_2"] == f["hv_norm_2"] and m["payload_bytes"] == f["hv"].size * 2
+        assert img[m["payload_off"]: m["payload_off"] + m["payload_bytes"]].tobytes() == f["hv"].tobytes() == r["hv"].tobytes()
+    assert hg.hv_payload_layout(512, meta[3]["hv_quant_bits"], meta[3]["payload_bytes"]) == hg.PAYLOAD_NAIVE
+    assert hg.hv_payload_layout(512, meta[2]["hv_quant_bits"], meta[2]["payload_bytes"]) == hg.PAYLOAD_BITPACKER8X
+
+
 def test_sketch_file_layout_and_roundtrip(hg, tmp_path):
     hv = (np.arange(1536) - 700).astype(np.int16)
     recs = [dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=4096, hv_quant_bits=6, hv_norm_2=-5,

@@ -197,3 +197,94 @@ def test_cli_hv_d_not_a_multiple_of_256_follows_the_reference(tmp_path, orc):
     for i in range(3):
         for j in range(i + 1, 3):
             assert abs(got[(files[i], files[j])] - want[i, j]) <= 1e-3 + 1e-4
+
+
+def test_device_unpack_matches_the_host_decoders(orc):
+    """hg_hv_unpack_batch_dev (decompress_file_sketch on the device, src/hd.rs:171-232): both payload layouts, every width,
+    payloads at odd byte offsets (they sit behind path strings in a file image), hv_d with a partial last block -- the same
+    integers as the oracle's decoders, the reference's lossy corners (q = 16, -2^(q-1) in the naive layout) included."""
+    import torch
+    import hypergen_amd as hg
+    rng = np.random.default_rng(41)
+    dev = torch.device("cuda:0")
+    with hg.Context(0) as ctx:
+        for hv_d in (4096, 1000, 256, 16384):
+            blobs, offs, qs, lays, want = [], [], [], [], []
+            pos = 0
+            for i in range(64):
+                q = 6 + i % 11
+                lim = 1 << (q - 1)
+                hv = rng.integers(-lim, lim, hv_d).astype(np.int16)
+                hv[:2] = [-lim, lim - 1]
+                naive = i % 3 == 1
+                if naive:
+                    _, w = orc.pack_hv_naive(hv, q)
+                    payload = w.view(np.uint8)
+                    want.append(orc.unpack_hv_naive(w, hv_d, q))
+                else:
+                    _, payload = orc.pack_hv(hv, q)
+                    payload = payload[: payload.size // 2 * 2]  # the i16 view the file stores (src/hd.rs:155-157)
+                    want.append(orc.unpack_hv(np.concatenate([payload, np.zeros(1, np.uint8)]), hv_d, q))
+                pad = rng.integers(0, 5)  # any alignment
+                blobs += [np.full(pad, 0xEE, np.uint8), payload]
+                pos += pad
+                offs.append(pos), qs.append(q), lays.append(hg.PAYLOAD_NAIVE if naive else hg.PAYLOAD_BITPACKER8X)
+                pos += payload.size
+            img = torch.from_numpy(np.concatenate(blobs)).to(dev)
+            out = torch.full((64, hv_d), 12345, dtype=torch.int16, device=dev)
+            ctx.hv_unpack_batch_dev(img.data_ptr(), img.numel(), offs, qs, lays, hv_d, out.data_ptr())
+            got = out.cpu().numpy()
+            for i in range(64):
+                assert np.array_equal(got[i], want[i]), (hv_d, i, qs[i], lays[i])
+            # a payload that reaches past the buffer is refused, not read
+            with pytest.raises(hg.HgError):
+                ctx.hv_unpack_batch_dev(img.data_ptr(), offs[-1] + 8, offs, qs, lays, hv_d, out.data_ptr())
+
+
+def test_cli_reads_and_writes_the_non_avx2_payload_layout(tmp_path, orc):
+    """`hyper-gen sketch --pack_layout naive` writes what a reference host without AVX2 writes (src/hd.rs:158-166); dist and
+    search read either layout (told apart by the payload length), also mixed in one file.  The naive decode is the
+    reference's: a sketch holding the value -2^(q-1) comes back with +2^(q-1) there."""
+    import hypergen_amd as hg
+    d = tmp_path / "fa"
+    d.mkdir()
+    names = ["a.fna", "b.fna", "c.fna", "d.fna"]
+    for i, n in enumerate(names):
+        write_fasta(str(d / n), orc.synth_genome(i * 7, 200_000)[1:], n)
+    out_a, out_n = str(tmp_path / "avx2.sketch"), str(tmp_path / "naive.sketch")
+    for out, extra in ((out_a, []), (out_n, ["--pack_layout", "naive"])):
+        r = subprocess.run([hg.CLI_PATH, "sketch", "-p", str(d), "-o", out, "-s", "100"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    ra, rn = hg.read_sketch_file(out_a), hg.read_sketch_file(out_n)
+    hvs = []
+    for x, y in zip(ra, rn):
+        q = x["hv_quant_bits"]
+        hv = hg.hv_unpack(x["hv"].view(np.uint8), 4096, q)
+        hvs.append(hv)
+        assert y["hv_quant_bits"] == q and y["hv_norm_2"] == x["hv_norm_2"] and y["hv"].size == (q * 4096 + 16) // 16
+        assert np.array_equal(y["hv"], orc.pack_hv_naive(hv, q)[1])
+    # dist on the naive file == the oracle's ANI of what the reference's naive decoder returns for these payloads
+    dec = np.stack([orc.unpack_hv_naive(y["hv"], 4096, y["hv_quant_bits"]) for y in rn])
+    n2 = np.array([y["hv_norm_2"] for y in rn], np.int32)
+    want = orc.ani_matrix(dec, n2, dec, n2, 21)
+    mixed = str(tmp_path / "mixed.sketch")
+    hg.write_sketch_file(mixed, [ra[0], rn[1], ra[2], rn[3]])
+    for sk in (out_n, mixed):
+        tsv = str(tmp_path / "o.tsv")
+        r = subprocess.run([hg.CLI_PATH, "dist", "-r", sk, "-q", out_a, "-o", tsv, "-a", "0"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = [l.split("\t") for l in open(tsv).read().splitlines()]
+        assert len(rows) == 16
+        idx = {str(d / n): i for i, n in enumerate(names)}
+        for a, b, v in rows:
+            i, j = idx[a], idx[b]
+            ref_row = dec[i] if (sk == out_n or i in (1, 3)) else hvs[i]
+            w = orc.ani_matrix(ref_row[None], n2[i: i + 1], hvs[j][None], n2[j: j + 1], 21)[0, 0]
+            assert abs(float(v) - w) <= 1e-3 + 1e-4, (sk, a, b)
+    assert want.shape == (4, 4)
+    # a payload of neither length is refused
+    bad = dict(ra[0])
+    bad["hv"] = ra[0]["hv"][:-3]
+    hg.write_sketch_file(mixed, [bad])
+    r = subprocess.run([hg.CLI_PATH, "dist", "-r", mixed, "-q", out_a, "-o", str(tmp_path / "x.tsv")], capture_output=True, text=True)
+    assert r.returncode != 0 and "corrupt sketch payload" in r.stderr

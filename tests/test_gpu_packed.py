@@ -265,3 +265,25 @@ def test_hostfed_small_batches_forced_packed(hg, orc):
     for i in (0, 4, 6):
         w_hv, w_n2, w_nh = orc.sketch_genome(seqs[i], 21, 20, 123, True, hv_d=512)
         assert res["packed"][2][i] == w_nh and res["packed"][1][i] == w_n2 and np.array_equal(res["packed"][0][i], w_hv)
+
+
+def test_hostfed_forced_packed_with_very_short_sequences(hg, orc):
+    """hg_pack2_size is 32 bytes for 1..16 bases while their padded ASCII is 16: a sub-batch dominated by such sequences has
+    blobs larger than its own ASCII region of the device buffer.  Such a sub-batch must stay ASCII (its blobs would overwrite
+    the next sub-batch's region or run past the buffer); one whose blobs fit goes packed as asked.  Results equal either way."""
+    rng = np.random.default_rng(32)
+    p = hg.default_params(ksize=5, scaled=1, hv_d=256)
+    tiny = [genome(rng, int(n)) for n in rng.integers(1, 17, 3000)]
+    for seqs, packs in ((tiny, False), (tiny + [genome(rng, 200_000)], True), ([genome(rng, 9)], False)):
+        res = {}
+        for mode in ("ascii", "packed"):
+            c = hg.Context(0)
+            c.set_debug("hostfed", mode)
+            res[mode] = c.sketch_batch(seqs, p)
+            assert c.last_kernel("kmer").endswith("true>") == (mode == "packed" and packs), (mode, len(seqs))
+            c.close()
+        for a, b in zip(res["ascii"], res["packed"]):
+            assert np.array_equal(a, b)
+        for i in (0, len(seqs) // 2, len(seqs) - 1):
+            w_hv, w_n2, w_nh = orc.sketch_genome(seqs[i], 5, 1, 123, True, hv_d=256)
+            assert res["packed"][2][i] == w_nh and res["packed"][1][i] == w_n2 and np.array_equal(res["packed"][0][i], w_hv)

@@ -193,6 +193,39 @@ def test_pack_follows_the_crate_definition_incl_q16_and_partial_blocks(orc):
             assert (back[whole:] == np.int16(-off if q < 16 else -32768)).all()  # 0 as i16 - offset (src/hd.rs:206-212)
 
 
+def _naive_model(hv, q):
+    """third statement of the non-AVX2 layout (src/hd.rs:158-166), on Python integers: the stream is the concatenation of
+    the values' low q bits, LSB first; 16 stream bits per i16 word, (q*d + 16) // 16 words"""
+    bits = []
+    for x in hv:
+        bits += [((int(x) & 0xFFFF) >> k) & 1 for k in range(q)]
+    words = [0] * ((q * len(hv) + 16) // 16)
+    for i, b in enumerate(bits):
+        words[i // 16] |= b << (i % 16)
+    return np.array(words, np.uint16).view(np.int16)
+
+
+def test_naive_layout_follows_the_reference_loops(orc):
+    """the payload of hosts without AVX2 (src/hd.rs:158-166, 213-231): oracle against the bit-level model, and the
+    reference's decode quirks -- strict `>` (the value -2^(q-1) comes back as +2^(q-1)) and the i16 shifts at q = 16"""
+    rng = np.random.default_rng(12)
+    for q in range(6, 17):
+        for d in (16, 256, 100, 1000, 4096):
+            lim = 1 << (q - 1)
+            hv = rng.integers(-lim, lim, d).astype(np.int16)
+            hv[:3] = [-lim, lim - 1, -1]
+            _, words = orc.pack_hv_naive(hv, q)
+            assert words.size == (q * d + 16) // 16 and np.array_equal(words, _naive_model(hv, q)), (q, d)
+            back = orc.unpack_hv_naive(words, d, q)
+            if q < 16:
+                want = hv.astype(np.int32)
+                want[want == -lim] = lim  # low bits 100..0: `v > 1 << (q-1)` is false, the value stays +2^(q-1)
+                assert np.array_equal(back, want.astype(np.int16)), (q, d)
+            else:  # `1 << 15` = -32768, `1 << 16` wraps to 1: v > -32768 -> v - 1
+                want = np.where(hv == -32768, hv, (hv.astype(np.int32) - 1).astype(np.int16))
+                assert np.array_equal(back, want), d
+
+
 def test_ani_golden(orc):
     for c in golden("g4_ani.json"):
         got = orc.ani_from_dot(c["dot"], c["nr"], c["nq"], c["k"])

@@ -1,7 +1,17 @@
 #!/usr/bin/env python3
-"""End-to-end `hyper-gen dist` on a synthetic .sketch file of N clustered sketches (development aid; GPU)."""
+"""End-to-end `hyper-gen dist` / `hyper-gen search` on synthetic .sketch files of N clustered sketches (GPU).
+
+Three runs of the CLI binary, as a user would start them (src/dist.rs:11-63, src/utils.rs:260-308):
+  dist -r A -q A     the reference's path_r == path_q case: symmetric, i < j
+  dist -r A -q B     two different files (B = other members of A's clusters)
+  search -r A -q B   top-n references per query
+Each run twice (the second from a warm page cache); the stage split comes from the CLI's own RUST_LOG=debug lines.
+Prints a human-readable report and, last, ONE JSON line (`--json PATH` also writes it there): bench.py's `cli` object.
+"""
 import argparse
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -15,35 +25,90 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import hypergen_amd as hg  # noqa: E402
 import bench  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=10000)
-ap.add_argument("--threads", type=int, default=16)
-a = ap.parse_args()
-exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hyper-gen_amd", "hyper-gen")
-d = tempfile.mkdtemp(prefix="hgdist_", dir="/tmp")
-try:
-    hv = bench.clustered_hvs(a.n, 0, torch.device("cuda:0")).cpu().numpy()
+STAGES = (("load_ms", r"sketch files loaded in ([\d.]+) ms"),
+          ("upload_unpack_ms", r"payloads uploaded and decompressed on the device\(s\) in ([\d.]+) ms"),
+          ("devices_ms", r"devices opened in ([\d.]+) ms"),
+          ("ani_matrix_ms", r"ANI matrix \(\d+ hits\) in ([\d.]+) ms"),
+          ("order_ms", r"hits ordered in ([\d.]+) ms"),
+          ("topk_ms", r"top-\d+ per query in ([\d.]+) ms"),
+          ("format_ms", r"TSV formatted \([\d.]+ MB\) in ([\d.]+) ms"),
+          ("write_ms", r"TSV written in ([\d.]+) ms"),
+          ("format_write_ms", r"TSV formatted and written \([\d.]+ MB\) in ([\d.]+) ms"))
+
+
+def write_db(path, hv, first):
     n2 = (hv.astype(np.int64) ** 2).sum(1).astype(np.int32)
     recs = []
-    t0 = time.time()
-    for i in range(a.n):
+    for i in range(hv.shape[0]):
         q, packed = hg.hv_pack(hv[i])
-        recs.append(dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=4096, hv_quant_bits=q,
-                         hv_norm_2=int(n2[i]), file_str="/data/genomes/cluster%04d/genome_%06d.fna" % (i // 100, i),
+        recs.append(dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=hv.shape[1], hv_quant_bits=q,
+                         hv_norm_2=int(n2[i]), file_str="/data/genomes/cluster%04d/genome_%06d.fna" % (i // 100, first + i),
                          hv=packed.view(np.int16)))
-    sk = os.path.join(d, "db.sketch")
-    hg.write_sketch_file(sk, recs)
-    print("wrote %d sketches (%.1f MB) in %.1f s" % (a.n, os.path.getsize(sk) / 1e6, time.time() - t0))
+    hg.write_sketch_file(path, recs)
+
+
+def run_cli(exe, args, out, threads, log):
+    best = None
     for rep in range(2):
-        out = os.path.join(d, "ani.tsv")
         t0 = time.time()
-        o = subprocess.run([exe, "dist", "-r", sk, "-q", sk, "-o", out, "-t", str(a.threads)], check=True,
-                           stdout=subprocess.PIPE, stderr=None if rep else subprocess.DEVNULL,
-                           env=dict(os.environ, RUST_LOG="debug")).stdout.decode()
+        o = subprocess.run([exe] + args + ["-o", out, "-t", str(threads)], check=True, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, env=dict(os.environ, RUST_LOG="debug")).stdout.decode()
         dt = time.time() - t0
-        if rep:
-            print("\n".join(l.split(" - ", 1)[1] for l in o.splitlines() if " - " in l))
-        lines = sum(1 for _ in open(out))
-        print("hyper-gen dist %d x %d: %.2f s, %d TSV lines (%.1f MB)" % (a.n, a.n, dt, lines, os.path.getsize(out) / 1e6))
-finally:
-    shutil.rmtree(d, ignore_errors=True)
+        if best is None or dt < best[0]:
+            best = (dt, o)
+    dt, o = best
+    res = {"wall_s": dt, "tsv_lines": sum(1 for _ in open(out)), "tsv_mb": os.path.getsize(out) / 1e6}
+    for key, pat in STAGES:
+        m = re.search(pat, o)
+        if m:
+            res[key] = float(m.group(1))
+    m = re.search(r"took ([\d.]+)s", o)
+    if m:
+        res["reported_s"] = float(m.group(1))
+    log("    " + "\n    ".join(l.split(" - ", 1)[1] for l in o.splitlines() if " - " in l))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--top", type=int, default=5)
+    ap.add_argument("--json", default="")
+    a = ap.parse_args()
+
+    def log(m):
+        print(m, flush=True)
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hyper-gen_amd", "hyper-gen")
+    d = tempfile.mkdtemp(prefix="hgdist_", dir="/tmp")
+    out = {"n": a.n, "threads": a.threads}
+    try:
+        dev = torch.device("cuda:0")
+        t0 = time.time()
+        ska, skb = os.path.join(d, "a.sketch"), os.path.join(d, "b.sketch")
+        write_db(ska, bench.clustered_hvs(a.n, 0, dev).cpu().numpy(), 0)
+        write_db(skb, bench.clustered_hvs(a.n, 0, dev, salt=1).cpu().numpy(), a.n)
+        out["sketch_file_mb"] = os.path.getsize(ska) / 1e6
+        log("wrote 2 x %d sketches (%.1f MB each) in %.1f s" % (a.n, out["sketch_file_mb"], time.time() - t0))
+        tsv = os.path.join(d, "ani.tsv")
+        for name, args in (("dist_symmetric", ["dist", "-r", ska, "-q", ska]),
+                           ("dist_two_files", ["dist", "-r", ska, "-q", skb]),
+                           ("search_top%d" % a.top, ["search", "-r", ska, "-q", skb, "-n", str(a.top)])):
+            log("hyper-gen %s  (%d x %d, -t %d; the faster of two runs)" % (" ".join(os.path.basename(x) for x in args), a.n, a.n, a.threads))
+            r = run_cli(exe, args, tsv, a.threads, log)
+            pairs = a.n * (a.n - 1) // 2 if name == "dist_symmetric" else a.n * a.n
+            r["pairs"] = pairs
+            r["m_pairs_per_s_end_to_end"] = pairs / r["wall_s"] / 1e6
+            out[name] = r
+            log("  => %.2f s wall, %d TSV lines (%.1f MB), %.0f M pairs/s end to end" % (r["wall_s"], r["tsv_lines"], r["tsv_mb"], r["m_pairs_per_s_end_to_end"]))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    line = json.dumps(out)
+    if a.json:
+        with open(a.json, "w") as f:
+            f.write(line + "\n")
+    print(line)
+
+
+if __name__ == "__main__":
+    main()
