@@ -768,7 +768,7 @@ static uint32_t dist_tile_table(hg_ctx *c, GemmArgs &g, uint32_t bm, uint32_t bn
 }
 // development builds only (-DHG_DIST_EXPERIMENT=<bits>, results are wrong): timing with parts of the kernel
 // compiled out -- 1 no in-loop DMA, 2 no fragment reads / MFMAs, 4 no epilogue, 8 reads but no MFMAs, 16 no in-loop barrier, 32 fragments read in the first step only,
-// 64 no outlier corrections in phase 2
+// 64 no outlier corrections in phase 2, 512 every tile streams the operand rows of tile (0, 0) -- and only their first 2 KiB, over and over: all L2 hits (what the L2 misses cost)
 #ifdef HG_DIST_EXPERIMENT
 #define HG_EXP(bit) ((HG_DIST_EXPERIMENT & (bit)) != 0)
 #else
@@ -1009,8 +1009,8 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
       if (i < PB) vB[i] = off;
       if (i < PA) vA[i] = off;
     }
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)row0 * g.ldk), 0, 0x7fffffff, 0x00020000);
-    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)col0 * g.ldk), 0, 0x7fffffff, 0x00020000);
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.A + (size_t)(HG_EXP(512) ? 0u : row0) * g.ldk), 0, 0x7fffffff, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(g.B + (size_t)(HG_EXP(512) ? 0u : col0) * g.ldk), 0, 0x7fffffff, 0x00020000);
   }
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
 #define HG_DMA(stage, k0)                                                                                   \
@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
     _Float16 *wbase = sAB + (stage) * STAGE_ELEMS + wave * 64 * 8; /* this wave's 1 KiB of instruction 0 */ \
     _Pragma("unroll") for (int i = 0; i < (PA > PB ? PA : PB); ++i) {                                       \
       if (i < PA)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (k0) * 2, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(wbase + i * LT * 8), 16, vA[i < PA ? i : 0], (HG_EXP(512) ? (k0) & 1023u : (k0)) * 2, 0, 0); \
       if (i < PB)                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (k0) * 2, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(wbase + TILE_ELEMS + i * LT * 8), 16, vB[i < PB ? i : 0], (HG_EXP(512) ? (k0) & 1023u : (k0)) * 2, 0, 0); \
     }                                                                                                       \
   }                                                                                                         \
   }
