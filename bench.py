@@ -441,8 +441,11 @@ def main():
                      "kernel": kmer_kernel, "launch_ms": kmer_avg_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "input_bytes_per_launch": int(N * blob_sz),
+                     "moved_bytes_per_launch": int(N * (blob_sz + 2 * HV_D)),
+                     "frac_of_hbm_peak_moved": N * (blob_sz + 2 * HV_D) / (kmer_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "algorithmic bytes = SURVEY 8(d)'s L + 2 D per genome (one byte per base in, i16 HV out) whatever "
-                             "the resident form; the packed blobs the kernel actually reads are input_bytes_per_launch. "
+                             "the resident form; the packed blobs the kernel actually reads are input_bytes_per_launch, and frac_of_hbm_peak_moved prices "
+                             "what really crosses HBM (blobs in, HVs out: 2.6x less than the algorithmic bytes). "
                              "Nominally a scan, so priced against HBM; the true binder is integer VALU issue (%s static VALU "
                              "instructions per k-mer, 25 of them the 64-bit multiply-adds of t1ha2; see valu_issue)" % (
                                  ("%.1f" % isa_valu) if isa_valu else "~65"),

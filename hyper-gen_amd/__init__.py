@@ -192,7 +192,7 @@ def lib():
                                             C.c_float, vp, sz, C.POINTER(sz)]),
         "hg_pack2s_size": (sz, [sz, sz]),
         "hg_pack2s": (C.c_int, [vp, sz, C.c_uint32, vp, sz, C.POINTER(sz)]),
-        "hg_sketch_stream_push_packed_sparse": (C.c_int, [vp, vp, sz, C.c_uint64]),
+        "hg_sketch_stream_push_packed_sparse": (C.c_int, [vp, vp, sz, sz, C.c_uint64]),
         "hg_sketch_stream_finish": (C.c_int, [vp]),
         "hg_sketch_stream_last_error": (C.c_char_p, [vp]),
         "hg_sketch_stream_close": (None, [vp]),
@@ -863,8 +863,12 @@ class SketchStream:
         self._push(a, n_bps, tag, 1)
 
     def push_packed_sparse(self, blob, n_bps, tag):
-        """a hg_pack2s blob (pack2s()): codes + run table"""
+        """a hg_pack2s blob (pack2s()): codes + run table.  The buffer must hold the whole blob (checked here: the
+        non-blocking C entry point takes the caller's word for the size; the library validates the table's contents)."""
         a = np.ascontiguousarray(blob, np.uint8)
+        tab = (((n_bps + 3) // 4) + 15) & ~15
+        if n_bps and (a.size < tab + 8 or a.size < lib().hg_pack2s_size(n_bps, int(a[tab: tab + 4].view("<u4")[0]))):
+            raise HgError(ERR_INVALID, "push_packed_sparse: the buffer is shorter than the blob it claims to hold")
         self._push(a, n_bps, tag, 2)
 
     def finish(self):

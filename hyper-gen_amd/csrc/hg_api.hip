@@ -1056,7 +1056,9 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
             hg_pack2_piece(seqs[g], lens[g], p->norm_mode, pin + (boffs[g] - boffs[g0]), b, std::min<uint64_t>(lens[g], b + PIECE));
           });
           const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-          if (src_pinned && k == first_chunk && (double)span < 55e9 * sec && c->dbg_hostfed != "packed")
+          // (page-locked sources go at ~55 GB/s as ASCII; pageable ones through the runtime's bounce buffer at ~12 GB/s: a
+          // host whose cores are capped by a cgroup quota -- host_threads() cannot see one -- may pack slower than even that)
+          if (n > 1 && k == first_chunk && (double)span < (src_pinned ? 55e9 : 12e9) * sec && c->dbg_hostfed != "packed")
             for (size_t j = k + 1; j < n_chunks; ++j) sub_packed[j] = 0;
           if (n == 1) pack_measured(single, lens[0], sec);
           if (e == hipSuccess) e = hipMemcpyAsync(d_seq + boffs[g0], pin, sub_pk_bytes[k], hipMemcpyHostToDevice, up_stream);

@@ -629,7 +629,7 @@ extern "C" hg_status hg_sketch_stream_open(const int *device_ids, int n_devices,
   return HG_OK;
 }
 
-static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, int kind, bool wait);
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, int kind, bool wait, size_t given_bytes = ~(size_t)0);
 
 extern "C" hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag) {
   return push_item(s, seq, len, tag, KIND_ASCII, true);
@@ -639,8 +639,8 @@ extern "C" hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uin
   return push_item(s, blob, n_bps, tag, KIND_PACK2, true);
 }
 
-extern "C" hg_status hg_sketch_stream_push_packed_sparse(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag) {
-  return push_item(s, blob, n_bps, tag, KIND_PACK2S, true);
+extern "C" hg_status hg_sketch_stream_push_packed_sparse(hg_sketch_stream *s, const uint8_t *blob, size_t blob_bytes, size_t n_bps, uint64_t tag) {
+  return push_item(s, blob, n_bps, tag, KIND_PACK2S, true, blob_bytes);
 }
 
 extern "C" hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_t *data, size_t n_bps, uint64_t tag, int packed) {
@@ -650,15 +650,27 @@ extern "C" hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_
 
 extern "C" size_t hg_sketch_stream_max_pending(const hg_sketch_stream *s) { return s ? s->max_pending : 0; }
 
-static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, int kind, bool wait) {
+static hg_status push_item(hg_sketch_stream *s, const uint8_t *seq, size_t len, uint64_t tag, int kind, bool wait, size_t given_bytes) {
   if (!s || (len && !seq)) return HG_ERR_INVALID;
   size_t blob_bytes = 0;
-  if (kind == KIND_PACK2S && len) {  // the blob says how long its run table is
+  if (kind == KIND_PACK2S && len) {  // the blob says how long its run table is -- nothing of it is believed unchecked:
+    // the count is read only if the caller's buffer reaches that far, the blob must fit the buffer, and the table has to be
+    // what expand_runs_kernel's binary search assumes (ascending, disjoint, non-empty runs inside the sequence)
     if (len >= ((size_t)1 << 32)) return HG_ERR_UNSUPPORTED;
+    const size_t tab_off = (((len + 3) / 4) + 15) & ~(size_t)15;
+    if (given_bytes < tab_off + 8) return HG_ERR_INVALID;
     uint32_t n_runs;
-    std::memcpy(&n_runs, seq + ((((len + 3) / 4) + 15) & ~(size_t)15), 4);
+    std::memcpy(&n_runs, seq + tab_off, 4);
     if ((size_t)n_runs > len) return HG_ERR_INVALID;
     blob_bytes = hg_pack2s_size(len, n_runs);
+    if (blob_bytes > given_bytes) return HG_ERR_INVALID;
+    uint64_t prev_end = 0;
+    for (uint32_t r = 0; r < n_runs; ++r) {
+      uint32_t st_len[2];
+      std::memcpy(st_len, seq + tab_off + 8 + (size_t)8 * r, 8);
+      if (st_len[1] == 0 || (r && st_len[0] < prev_end) || (uint64_t)st_len[0] + st_len[1] > len) return HG_ERR_INVALID;
+      prev_end = (uint64_t)st_len[0] + st_len[1];
+    }
   }
   std::unique_lock<std::mutex> lk(s->mu);
   if (s->finishing) return HG_ERR_INVALID;

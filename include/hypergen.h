@@ -374,10 +374,13 @@ hg_status hg_sketch_stream_push(hg_sketch_stream *s, const uint8_t *seq, size_t 
  * packed with the stream's norm_mode. */
 hg_status hg_sketch_stream_push_packed(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
 /* ... or as a hg_pack2s blob: the codes plus a TABLE of the not-a-base runs instead of the bitmap -- 0.25 bytes per base
- * over the link for an ordinary assembly; the device rebuilds the bitmap.  Results are bit-identical. */
-hg_status hg_sketch_stream_push_packed_sparse(hg_sketch_stream *s, const uint8_t *blob, size_t n_bps, uint64_t tag);
-/* non-blocking push of any form (packed: 0 = ASCII, 1 = `data` is a hg_pack2 blob, 2 = a hg_pack2s blob);
- * HG_ERR_CAPACITY = would block */
+ * over the link for an ordinary assembly; the device rebuilds the bitmap.  Results are bit-identical.  blob_bytes = the
+ * size of the caller's buffer: the run count is read and hg_pack2s_size(n_bps, n_runs) bytes are uploaded only if they lie
+ * inside it, and a table whose runs are not ascending, disjoint, non-empty and inside the sequence is refused
+ * (HG_ERR_INVALID) before anything reaches the device. */
+hg_status hg_sketch_stream_push_packed_sparse(hg_sketch_stream *s, const uint8_t *blob, size_t blob_bytes, size_t n_bps, uint64_t tag);
+/* non-blocking push of any form (packed: 0 = ASCII, 1 = `data` is a hg_pack2 blob, 2 = a hg_pack2s blob -- its run table
+ * is validated like above, the buffer's size is the caller's word); HG_ERR_CAPACITY = would block */
 hg_status hg_sketch_stream_try_push(hg_sketch_stream *s, const uint8_t *data, size_t n_bps, uint64_t tag, int packed);
 size_t hg_sketch_stream_max_pending(const hg_sketch_stream *s);
 hg_status hg_sketch_stream_pop(hg_sketch_stream *s, uint64_t *tag, int16_t *hv_out, int32_t *norm2_out,

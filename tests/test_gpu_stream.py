@@ -188,6 +188,48 @@ def test_stream_sparse_packed_equals_ascii(hg, orc, norm):
     assert nh[6] == w_nh and n2[6] == w_n2 and np.array_equal(hv[6], w_hv)
 
 
+def test_sparse_blobs_are_validated_before_they_reach_the_device(hg, orc):
+    """hg_pack2s blobs carry their own run count and table: a short buffer, a count that would read past it, and a table
+    that is not ascending / disjoint / inside the sequence are refused on the host (the device's binary search over the
+    table assumes all of that); the stream stays usable"""
+    import ctypes as C
+    rng = np.random.default_rng(71)
+    g = _dirty(orc, 3, 200_000, rng)
+    blob = hg.pack2s(g)
+    assert blob is not None
+    tab = (((g.size + 3) // 4) + 15) & ~15
+    n_runs = int(blob[tab: tab + 4].view("<u4")[0])
+    assert n_runs >= 3
+    p = hg.default_params(scaled=100)
+    with hg.Context(0) as ctx:
+        hv, n2, nh = ctx.sketch_batch([g], p)
+    with hg.SketchStream((0,), p) as st:
+        with pytest.raises(hg.HgError):
+            st.push_packed_sparse(blob[: tab + 16], g.size, 0)  # the wrapper's size check
+        bad = []
+        b1 = blob.copy()  # runs swapped: not ascending
+        b1[tab + 8: tab + 16], b1[tab + 16: tab + 24] = blob[tab + 16: tab + 24].copy(), blob[tab + 8: tab + 16].copy()
+        bad.append(b1)
+        b2 = blob.copy()  # a run that reaches past the sequence
+        b2[tab + 8 + 8 * (n_runs - 1): tab + 16 + 8 * (n_runs - 1)].view("<u4")[:] = [g.size - 2, 5]
+        bad.append(b2)
+        b3 = blob.copy()  # an empty run
+        b3[tab + 12: tab + 16].view("<u4")[:] = 0
+        bad.append(b3)
+        for i, b in enumerate(bad):
+            with pytest.raises(hg.HgError) as ei:
+                st.push_packed_sparse(b, g.size, 10 + i)
+            assert ei.value.status == hg.ERR_INVALID
+        # the sized C entry point: the buffer's true size is part of the call
+        L = hg.lib()
+        assert L.hg_sketch_stream_push_packed_sparse(st._h, hg._ptr(blob), tab + 4, g.size, C.c_uint64(77)) == hg.ERR_INVALID
+        assert L.hg_sketch_stream_push_packed_sparse(st._h, hg._ptr(blob), blob.size - 1, g.size, C.c_uint64(77)) == hg.ERR_INVALID
+        st.push_packed_sparse(blob, g.size, 5)
+        st.finish()
+        out = _drain(st, 1)
+        assert out[5][1] == n2[0] and out[5][2] == nh[0] and np.array_equal(out[5][0], hv[0])
+
+
 def test_read_fastx_pinned_pack_flag(hg, orc, tmp_path):
     seq = _dirty(orc, 9, 200_000, np.random.default_rng(2))
     f = tmp_path / "g.fna"
