@@ -430,6 +430,96 @@ void release(hg_multi *m, DevSet &D) {
   }
 }
 
+// "{:.3}" of an ANI (0 <= ani <= 100, src/utils.rs:277-282) without snprintf: ani * 1000 is exact in a double (24-bit
+// significand times a 10-bit integer), so rounding that product to the nearest integer, ties to even (rint under the
+// default rounding mode), is the correctly rounded decimal -- what Rust's exact-mode float formatting and glibc's %.3f
+// both print.  Ties exist (ani = odd / 16: about one f32 in 16 000 near 96) and round-half-up would print 400 of the 1.1e9
+// floats in [0, 100] differently: checked exhaustively against 128-bit integer arithmetic.  Writes "\t<int>.<3 digits>\n".
+inline size_t put_ani(char *o, float ani) {
+  const uint64_t v = (uint64_t)__builtin_rint((double)ani * 1000.0);
+  uint64_t ip = v / 1000;
+  const uint32_t fp = (uint32_t)(v % 1000);
+  char tmp[24];
+  size_t n = 0;
+  do tmp[n++] = (char)('0' + ip % 10), ip /= 10;
+  while (ip);
+  size_t k = 0;
+  o[k++] = '\t';
+  while (n) o[k++] = tmp[--n];
+  o[k++] = '.', o[k++] = (char)('0' + fp / 100), o[k++] = (char)('0' + fp / 10 % 10), o[k++] = (char)('0' + fp % 10), o[k++] = '\n';
+  return k;
+}
+
+// An uninitialised array of hits (a std::vector would zero -- and so touch -- every page of a capacity-sized buffer of
+// which a comparison fills one part in sixteen)
+struct HitBuf {
+  hg_ani_hit *p = nullptr;
+  size_t n = 0;
+  ~HitBuf() { std::free(p); }
+  void resize(size_t m) {
+    std::free(p);
+    p = static_cast<hg_ani_hit *>(std::malloc(std::max<size_t>(m, 1) * sizeof(hg_ani_hit)));
+    if (!p) die("out of memory");
+    n = m;
+  }
+};
+
+// All pairs with ANI >= ani_th of (R x Q) -- or of R against itself, i < j, when Q == nullptr --, on the host.  `order`:
+// in dump_ani_file's order (src/utils.rs:262-269).  With one device the hits stay there until they are ordered (dist ->
+// radix passes -> one download); with several, the shards' lists meet on the host and go through device 0 for the order.
+// d_keep != nullptr: the list is wanted on device 0 (for hg_topk_per_query_dev), not on the host: *d_keep receives it
+// (hg_dev_free it) and `hits` stays empty.
+size_t all_hits(hg_multi *multi, const Loaded &R, const DevSet &dR, const Loaded *Q, const DevSet *dQ, float ani_th, bool order,
+                HitBuf &hits, void **d_keep = nullptr) {
+  const bool sym = Q == nullptr;
+  const size_t qn = sym ? R.n : Q->n, total = sym ? R.n * (R.n - 1) / 2 : R.n * qn;
+  size_t cap = std::max<size_t>(1024, total / 16), found = 0;
+  if (hg_multi_size(multi) == 1) {
+    hg_ctx *ctx = hg_multi_ctx(multi, 0);
+    void *d_hits = nullptr;
+    for (;;) {
+      ck(ctx, hg_dev_alloc(ctx, cap * sizeof(hg_ani_hit), &d_hits), "alloc");
+      const hg_status s = hg_dist_dev(ctx, dR.hv[0], dR.n2[0], R.n, sym ? dR.hv[0] : dQ->hv[0], sym ? dR.n2[0] : dQ->n2[0], qn,
+                                      (uint32_t)R.hv_d, R.ksize, sym, ani_th, static_cast<hg_ani_hit *>(d_hits), cap, &found);
+      if (s != HG_ERR_CAPACITY) {
+        ck(ctx, s, "dist");
+        break;
+      }
+      ck(ctx, hg_dev_free(ctx, d_hits), "free");
+      cap = found;
+    }
+    if (order) ck(ctx, hg_sort_ani_hits_dev(ctx, static_cast<hg_ani_hit *>(d_hits), found, qn), "sort");
+    if (d_keep) {
+      *d_keep = d_hits;
+      return found;
+    }
+    hits.resize(found);
+    if (found) ck(ctx, hg_copy_d2h(ctx, hits.p, d_hits, found * sizeof(hg_ani_hit)), "download");
+    ck(ctx, hg_dev_free(ctx, d_hits), "free");
+    return found;
+  }
+  for (;;) {
+    hits.resize(cap);
+    // reference rows are all-gathered over xGMI, query rows stay on their shard's GPU (SURVEY.md 8e)
+    const hg_status s = hg_dist_multi_dev(multi, dR.hv.data(), dR.n2.data(), dR.rows.data(), sym ? nullptr : dQ->hv.data(),
+                                          sym ? nullptr : dQ->n2.data(), sym ? nullptr : dQ->rows.data(), (uint32_t)R.hv_d, R.ksize,
+                                          sym, ani_th, hits.p, cap, &found);
+    if (s != HG_ERR_CAPACITY) {
+      ckm(multi, s, "dist");
+      break;
+    }
+    cap = found;
+  }
+  hits.n = found;
+  hg_ctx *ctx0 = hg_multi_ctx(multi, 0);
+  if (order) ck(ctx0, hg_sort_ani_hits_staged(ctx0, hits.p, found, qn), "sort");
+  if (d_keep) {
+    ck(ctx0, hg_dev_alloc(ctx0, std::max<size_t>(found, 1) * sizeof(hg_ani_hit), d_keep), "alloc");
+    if (found) ck(ctx0, hg_copy_h2d(ctx0, *d_keep, hits.p, found * sizeof(hg_ani_hit)), "upload");
+  }
+  return found;
+}
+
 int run_dist(const Cli &c) {
   if (c.path_r == "1" || c.path_q == "1" || c.out.empty())
     die("the following required arguments were not provided: --path_r --path_q --out");
@@ -458,45 +548,38 @@ int run_dist(const Cli &c) {
   logline("INFO", "Computing ANI..");
   tp = now_s();
   const size_t total = sym ? R.n * (Q.n - 1) / 2 : R.n * Q.n;
-  std::vector<hg_ani_hit> hits(std::max<size_t>(1024, total / 16));
-  size_t found = 0;
-  for (;;) {
-    // reference rows are all-gathered over xGMI, query rows stay on their shard's GPU (SURVEY.md 8e)
-    hg_status s = hg_dist_multi_dev(multi, dR.hv.data(), dR.n2.data(), dR.rows.data(), sym ? nullptr : dQ.hv.data(),
-                                    sym ? nullptr : dQ.n2.data(), sym ? nullptr : dQ.rows.data(), (uint32_t)R.hv_d, R.ksize, sym,
-                                    c.ani_th, hits.data(), hits.size(), &found);
-    if (s == HG_ERR_CAPACITY) {
-      hits.resize(found);
-      continue;
-    }
-    ckm(multi, s, "dist");
-    break;
-  }
-  hits.resize(found);
+  HitBuf hits;
+  // (ordered on the device: dump_ani_file's order, src/utils.rs:262-269 -- two stable radix passes instead of a comparison
+  // sort of up to 10^6..10^8 triples on one host core)
+  const size_t found = all_hits(multi, R, dR, sym ? nullptr : &Qs, sym ? nullptr : &dQ, c.ani_th, true, hits);
   release(multi, dR), release(multi, dQ);
-  debugf("ANI matrix (%zu hits) in %.1f ms", found, (now_s() - tp) * 1e3);
+  debugf("ANI matrix (%zu hits), ordered, on the host in %.1f ms", found, (now_s() - tp) * 1e3);
   tp = now_s();
-  // dump_ani_file's order (src/utils.rs:262-269), produced on the device: two stable radix passes instead of a
-  // comparison sort of up to 10^6..10^8 triples on one host core
-  ck(hg_multi_ctx(multi, 0), hg_sort_ani_hits_staged(hg_multi_ctx(multi, 0), hits.data(), hits.size(), Q.n), "sort");
-  debugf("hits ordered in %.1f ms", (now_s() - tp) * 1e3);
-  tp = now_s();
-  // "{}\t{}\t{:.3}\n" (src/utils.rs:277-282), formatted by -t threads over contiguous ranges of the ordered hits
-  const size_t FT = std::max<size_t>(1, std::min<size_t>(c.threads, hits.size() / 4096 + 1));
+  // "{}\t{}\t{:.3}\n" (src/utils.rs:277-282), formatted by -t threads over contiguous ranges of the ordered hits: the
+  // paths' lengths are looked up once per file, a line is two memcpy and put_ani
+  const size_t FT = std::max<size_t>(1, std::min<size_t>(c.threads, found / 4096 + 1));
   std::vector<std::string> part(FT);
   {
+    std::vector<uint32_t> len_r(R.n), len_q(Q.n);
+    for (size_t i = 0; i < R.n; ++i) len_r[i] = (uint32_t)std::strlen(hg_sketch_file_get(R.f, i)->file_str);
+    for (size_t i = 0; i < Q.n; ++i) len_q[i] = (uint32_t)std::strlen(hg_sketch_file_get(Q.f, i)->file_str);
     auto fmt = [&](size_t t) {
-      const size_t lo = hits.size() * t / FT, hi = hits.size() * (t + 1) / FT;
+      const size_t lo = found * t / FT, hi = found * (t + 1) / FT;
+      size_t need = 0;
+      for (size_t i = lo; i < hi; ++i) need += (size_t)len_r[hits.p[i].ref_idx] + len_q[hits.p[i].qry_idx] + 10;
       std::string &o = part[t];
-      o.reserve((hi - lo) * 96);
-      char line[64];
+      o.resize(need);
+      char *w = &o[0];
       for (size_t i = lo; i < hi; ++i) {
-        const hg_ani_hit &h = hits[i];
-        o += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
-        o += '\t';
-        o += hg_sketch_file_get(Q.f, h.qry_idx)->file_str;
-        o.append(line, (size_t)std::snprintf(line, sizeof line, "\t%.3f\n", (double)h.ani));
+        const hg_ani_hit &h = hits.p[i];
+        std::memcpy(w, hg_sketch_file_get(R.f, h.ref_idx)->file_str, len_r[h.ref_idx]);
+        w += len_r[h.ref_idx];
+        *w++ = '\t';
+        std::memcpy(w, hg_sketch_file_get(Q.f, h.qry_idx)->file_str, len_q[h.qry_idx]);
+        w += len_q[h.qry_idx];
+        w += put_ani(w, h.ani);
       }
+      o.resize((size_t)(w - &o[0]));
     };
     std::vector<std::thread> th;
     for (size_t t = 1; t < FT; ++t) th.emplace_back(fmt, t);
@@ -560,28 +643,16 @@ int run_search(const Cli &c) {
   debugf("payloads uploaded and decompressed on the device(s) in %.1f ms", (now_s() - tp) * 1e3);
   logline("INFO", "Searching..");
   tp = now_s();
-  std::vector<hg_ani_hit> hits(std::max<size_t>(1024, R.n * Q.n / 16));
-  size_t found = 0;
-  for (;;) {
-    hg_status s = hg_dist_multi_dev(multi, dR.hv.data(), dR.n2.data(), dR.rows.data(), dQ.hv.data(), dQ.n2.data(), dQ.rows.data(),
-                                    (uint32_t)R.hv_d, R.ksize, 0, c.ani_th, hits.data(), hits.size(), &found);
-    if (s == HG_ERR_CAPACITY) {
-      hits.resize(found);
-      continue;
-    }
-    ckm(multi, s, "search");
-    break;
-  }
+  HitBuf hits;
+  void *d_hits = nullptr, *d_out = nullptr, *d_cnt = nullptr;
+  const size_t found = all_hits(multi, R, dR, &Q, &dQ, c.ani_th, false, hits, &d_hits);
   release(multi, dR), release(multi, dQ);
   debugf("ANI matrix (%zu hits) in %.1f ms", found, (now_s() - tp) * 1e3);
   tp = now_s();
   hg_ctx *ctx = hg_multi_ctx(multi, 0);
   const uint32_t k = std::max(1u, c.top_n);
-  void *d_hits = nullptr, *d_out = nullptr, *d_cnt = nullptr;
-  ck(ctx, hg_dev_alloc(ctx, std::max<size_t>(found, 1) * sizeof(hg_ani_hit), &d_hits), "alloc");
   ck(ctx, hg_dev_alloc(ctx, Q.n * (size_t)k * sizeof(hg_ani_hit), &d_out), "alloc");
   ck(ctx, hg_dev_alloc(ctx, Q.n * sizeof(uint32_t), &d_cnt), "alloc");
-  if (found) ck(ctx, hg_copy_h2d(ctx, d_hits, hits.data(), found * sizeof(hg_ani_hit)), "upload");
   ck(ctx, hg_topk_per_query_dev(ctx, static_cast<hg_ani_hit *>(d_hits), found, Q.n, k, static_cast<hg_ani_hit *>(d_out),
                                 static_cast<uint32_t *>(d_cnt)), "top-k");
   std::vector<hg_ani_hit> best(Q.n * (size_t)k);
@@ -592,7 +663,7 @@ int run_search(const Cli &c) {
   debugf("top-%u per query in %.1f ms", k, (now_s() - tp) * 1e3);
   tp = now_s();
   std::string tsv;
-  char line[64];
+  char line[32];
   size_t reported = 0;
   for (size_t q = 0; q < Q.n; ++q)
     for (uint32_t r = 0; r < cnt[q]; ++r) {
@@ -600,8 +671,7 @@ int run_search(const Cli &c) {
       tsv += hg_sketch_file_get(Q.f, q)->file_str;
       tsv += '\t';
       tsv += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
-      std::snprintf(line, sizeof line, "\t%.3f\n", (double)h.ani);
-      tsv += line;
+      tsv.append(line, put_ani(line, h.ani));
       ++reported;
     }
   FILE *f = std::fopen(c.out.c_str(), "wb");

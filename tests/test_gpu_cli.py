@@ -288,3 +288,39 @@ def test_cli_reads_and_writes_the_non_avx2_payload_layout(tmp_path, orc):
     hg.write_sketch_file(mixed, [bad])
     r = subprocess.run([hg.CLI_PATH, "dist", "-r", mixed, "-q", out_a, "-o", str(tmp_path / "x.tsv")], capture_output=True, text=True)
     assert r.returncode != 0 and "corrupt sketch payload" in r.stderr
+
+
+def test_cli_dist_tsv_is_the_library_hits_in_dump_order_with_exact_formatting(tmp_path):
+    """`hyper-gen dist` on two different files: the TSV must be, byte for byte, the library's own hits (hg_dist) in
+    dump_ani_file's order (hg_sort_ani_hits) printed as "{}\\t{}\\t{:.3}" -- the CLI formats without printf (ties at the third
+    decimal round to even, as Rust's and glibc's exact formatting do), decodes the payloads on the device and, with one
+    device, orders the hits there before they leave it"""
+    import torch
+    import bench
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    n = 700
+    a = bench.clustered_hvs(n, 0, dev, n=900).cpu().numpy()
+    b = bench.clustered_hvs(n, 0, dev, n=900, salt=1).cpu().numpy()
+    a[5] = a[4]  # identical rows: ANI exactly 100 and ties in the order
+    paths = []
+    for name, hv in (("a", a), ("b", b)):
+        recs = []
+        for i in range(n):
+            q, pk = hg.hv_pack(hv[i])
+            recs.append(dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=4096, hv_quant_bits=q,
+                             hv_norm_2=int((hv[i].astype(np.int64) ** 2).sum()), file_str="/d/%s/%s%04d.fna" % (name, "x" * (i % 3), i),
+                             hv=pk.view(np.int16)))
+        p = str(tmp_path / (name + ".sketch"))
+        hg.write_sketch_file(p, recs)
+        paths.append((p, [r["file_str"] for r in recs], np.array([r["hv_norm_2"] for r in recs], np.int32)))
+    with hg.Context(0) as ctx:
+        for (pr, nr, n2r), (pq, nq, n2q), hv_r, hv_q, sym in ((paths[0], paths[1], a, b, False), (paths[0], paths[0], a, a, True)):
+            tsv = str(tmp_path / "o.tsv")
+            r = subprocess.run([hg.CLI_PATH, "dist", "-r", pr, "-q", pq, "-o", tsv, "-a", "80"], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            hits = ctx.dist(hv_r, n2r, hv_q, n2q, 21, symmetric=sym, ani_th=80.0)
+            hits = hg.sort_ani_hits(hits, n, symmetric=sym)
+            want = "".join("%s\t%s\t%.3f\n" % (nr[h["ref_idx"]], nq[h["qry_idx"]], float(h["ani"])) for h in hits)
+            got = open(tsv).read()
+            assert len(hits) > 3000 and got == want, (sym, len(hits))
