@@ -86,3 +86,45 @@ def test_topk_empty_and_tiny(hits_10k):
     got = out.cpu().numpy().view(hg.ANI_HIT_DTYPE).reshape(5, 2)
     assert cnt.tolist() == [0, 2, 0, 0, 1]
     assert [tuple(x) for x in got[1].tolist()] == [(1, 1, 95.0), (2, 1, 95.0)] and got[4][0]["ref_idx"] == 9
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 1023, 1024, 4095, 4096, 4097, 8193, 70_001, 300_000])
+def test_device_order_on_synthetic_lists(n):
+    """the hand-written radix passes against the host order on lists built to stress them: lengths around the wave /
+    quarter / tile borders, few distinct ANI values (long runs of ties, i.e. stability), reference indices up to 2^32 - 2
+    and a query count whose enumeration key needs more than 32 bits"""
+    import hypergen_amd as hg
+    rng = np.random.default_rng(n)
+    Q = 3_000_000
+    h = np.zeros(n, hg.ANI_HIT_DTYPE)
+    h["ref_idx"] = rng.integers(0, 2**32 - 2, n, dtype=np.uint64).astype(np.uint32)
+    h["ref_idx"][: n // 3] = rng.integers(0, 50, n // 3)
+    h["qry_idx"] = rng.integers(0, Q, n)
+    h["ani"] = rng.choice(np.array([85.0, 85.00001, 90.5, 99.999, 100.0, 0.0], np.float32), n)
+    want = hg.sort_ani_hits(h, Q)
+    dev = torch.device("cuda:0")
+    with hg.Context(0) as ctx:
+        work = torch.from_numpy(h.view(np.int32).copy()).to(dev)
+        ctx.sort_ani_hits_dev(work.data_ptr(), n, Q)
+        torch.cuda.synchronize()
+        got = work.cpu().numpy().view(hg.ANI_HIT_DTYPE).reshape(-1)
+        assert np.array_equal(got, want)
+        # top-k on the same list (query indices below a small Q so that every query has many hits)
+        h2 = h.copy()
+        Q2, k = 37, 5
+        h2["qry_idx"] = rng.integers(0, Q2, n)
+        h2["ref_idx"] = rng.permutation(n).astype(np.uint32)  # distinct, so the expected order is total
+        th = torch.from_numpy(h2.view(np.int32).copy()).to(dev)
+        out = torch.empty((Q2 * k, 3), dtype=torch.int32, device=dev)
+        cnt = torch.empty(Q2, dtype=torch.int32, device=dev)
+        ctx.topk_per_query_dev(th.data_ptr(), n, Q2, k, out.data_ptr(), cnt.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(hg.ANI_HIT_DTYPE).reshape(Q2, k)
+        c = cnt.cpu().numpy()
+        order = np.lexsort((h2["ref_idx"], -h2["ani"].astype(np.float64), h2["qry_idx"]))
+        s = h2[order]
+        per_q = np.bincount(h2["qry_idx"], minlength=Q2)
+        starts = np.concatenate([[0], np.cumsum(per_q)[:-1]])
+        for q in range(Q2):
+            m = min(per_q[q], k)
+            assert c[q] == m and np.array_equal(got[q, :m], s[starts[q]: starts[q] + m]), q
