@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--hostfed-genomes", type=int, default=256, help="genomes of the host-fed (PCIe) leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realistic", action="store_true", help="skip the draft-assembly and many-small-genomes legs")
+    ap.add_argument("--no-dist-variants", action="store_true", help="skip dist.two_sets / dist.symmetric (profiling runs: their "
+                                                                     "launches would enter the dist kernel's per-launch averages)")
     ap.add_argument("--small-genomes", type=int, default=100000, help="genomes of the many-small-genomes leg (50 kbp each)")
     ap.add_argument("--cli", action="store_true", help="also run tools/cli_dist_bench.py (end-to-end hyper-gen dist / search at "
                                                         "--dist-n sketches) and report its split as `cli`")
@@ -943,7 +945,7 @@ def main():
         #              both prepasses, two operand matrices, the same ~1.3 M hits;
         #   symmetric: one set with symmetric = 1, the reference's path_r == path_q case (src/dist.rs:13,243-265):
         #              R (R - 1) / 2 pairs, tiles below the diagonal never start.
-        if not coll and world == 1:
+        if not coll and world == 1 and not a.no_dist_variants:
             other = clustered_hvs(rows, 0, dev, salt=1)
             other_n2 = (other.int() ** 2).sum(1).int()
 

@@ -15,7 +15,7 @@ OURS = ("prep_cen_kernel", "decide_cen_kernel", "kmer_sample", "sort_unique", "e
         "prep_fast_kernel", "prep_i8_kernel", "i8_entries_kernel", "prep_kernel", "decide_kernel", "synth_kernel",
         "hamming_kernel", "binarize_kernel", "gather_keys_kernel", "permute_hits_kernel", "topk_kernel", "prep_cen_kernel",
         "decide_cen_kernel", "unpack_meta_kernel", "pack2_kernel", "expand_runs_kernel", "unpack2_kernel", "expand_bits_fp4_kernel",
-        "expand_bits_kernel")
+        "expand_bits_kernel", "radix_hist_kernel", "radix_scan_kernel", "radix_scatter_kernel", "hg_hv_unpack_kernel")
 
 
 def short(name):
