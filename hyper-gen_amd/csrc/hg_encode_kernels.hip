@@ -108,6 +108,30 @@ __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
     if (tid == 0) ndistinct[g] = n;
     return;
   }
+  if (USE_LDS && n <= 64) {
+    // A handful of hashes (plasmids, viral genomes, the 50 kbp genomes of bench.py's `many_small` leg: 33 hashes each): one
+    // wave orders them in registers -- a 64-lane bitonic network over shuffles, no LDS, no barrier -- while the other waves
+    // leave.  (Through the workgroup-wide network with its barrier per pass, 100 000 such genomes took 0.96 ms; the k-mer
+    // kernel of the same batch 9.3 ms.)
+    if (tid >= 64) return;  // whole waves
+    uint64_t key = tid < n ? region[tid] : ~0ull;  // hashes are < threshold < ~0
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j) << 32) |
+                               (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j);
+        const bool lower = (tid & j) == 0, asc = (tid & k) == 0;
+        const bool take_min = lower == asc;
+        key = (take_min == (other < key)) ? other : key;
+      }
+    const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(key >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)key, 1);
+    const bool keep = tid < n && (tid == 0 || key != prev);
+    const unsigned long long kb = __ballot(keep);
+    if (keep) region[__popcll(kb & ((1ull << tid) - 1ull))] = key;  // (every key was read before the first one is written)
+    if (tid == 0) ndistinct[g] = (uint32_t)__popcll(kb);
+    return;
+  }
   if (in_lds) {
     bool sorted = false;  // workgroup-uniform
     if (USE_LDS && bucket_mul != 0 && n >= (uint32_t)SORT_WG && lds_keys <= SORT_BUCKET_MAX_KEYS) {

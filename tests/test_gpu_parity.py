@@ -554,6 +554,30 @@ def test_sketch_batch_of_many_small_genomes_is_packed_for_upload(ctx, orc, hg):
             assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (rep, i)
 
 
+def test_tiny_hash_sets_sorted_by_one_wave(ctx, orc, hg):
+    """Hash sets of 2..64 raw hits are ordered and de-duplicated by one wave in registers (no LDS network): every count in
+    that range, the counts just above it (65..70: the workgroup's network again), duplicates -- a unit repeated so that the
+    same hashes come several times --, and the sets' HVs; checked for EVERY genome of the batch"""
+    rng = np.random.default_rng(4242)
+    p = hg.default_params(scaled=30)
+    gs = []
+    for n in list(range(700, 2400, 17)) + [100, 21, 22, 40]:  # ~1 hash per 30 bases: 1 .. 80 raw hits
+        g = rand_seq(rng, n)
+        if n % 3 == 0:  # a third of the genomes: their first 300 bases three more times (duplicate hashes)
+            g = np.concatenate([g, g[:300], g[:300], g[:300]])
+        gs.append(g)
+    hv, n2, nh = ctx.sketch_batch(gs, p)
+    sizes = set()
+    for i, g in enumerate(gs):
+        want = orc.kmer_hash_sample(g, 21, 30)
+        got = ctx.kmer_hash_sample(g, 21, 30)
+        assert got.size == want.size and (got == want).all(), i
+        w_hv, w_n2, w_nh = orc.sketch_genome(g, scaled=30)
+        assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), i
+        sizes.add(int(w_nh))
+    assert min(sizes) <= 2 and max(sizes) >= 66 and len(sizes) >= 40
+
+
 def test_hash_sets_with_repeats_take_the_sort_fallback(ctx, orc):
     """The LDS sort's counting-sort fast path buckets the sampled hashes by value (0.8 keys per bucket for uniform
     hashes); equal hashes share a bucket, so a genome with a segment repeated 40 times piles 40 keys into ~100 buckets:
