@@ -29,6 +29,10 @@ STAGES = (("load_ms", r"sketch files loaded in ([\d.]+) ms"),
           ("upload_unpack_ms", r"payloads uploaded and decompressed on the device\(s\) in ([\d.]+) ms"),
           ("devices_ms", r"devices opened in ([\d.]+) ms"),
           ("ani_matrix_ms", r"ANI matrix \(\d+ hits\) in ([\d.]+) ms"),
+          ("ani_ordered_on_host_ms", r"ANI matrix \(\d+ hits\), ordered, on the host in ([\d.]+) ms"),
+          ("dist_device_ms", r"dist on the device ([\d.]+) ms"),
+          ("order_device_ms", r"dist on the device [\d.]+ ms, order ([\d.]+) ms"),
+          ("download_ms", r"order [\d.]+ ms, download ([\d.]+) ms"),
           ("order_ms", r"hits ordered in ([\d.]+) ms"),
           ("topk_ms", r"top-\d+ per query in ([\d.]+) ms"),
           ("format_ms", r"TSV formatted \([\d.]+ MB\) in ([\d.]+) ms"),

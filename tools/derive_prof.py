@@ -49,6 +49,17 @@ if pmcf:
     shutil.copy(os.path.join(srcf, tag + "distf16_kernel_stats.csv"), os.path.join(out, tag + "_distf16_kernel_stats.csv"))
 
 
+# round 5: the same dist command with R and Q in different buffers (--sets two) and with symmetric = 1 (--sets sym)
+extra = {}
+for suffix, what in (("dist2", "two distinct sets"), ("distsym", "symmetric = 1")):
+    sx = os.path.join(ROOT, "gpurun_out", "prof_" + tag + suffix)
+    if os.path.exists(os.path.join(sx, tag + suffix + "_pmc.json")):
+        px = stamped(json.load(open(os.path.join(sx, tag + suffix + "_pmc.json"))))
+        json.dump(px, open(os.path.join(out, tag + "_" + suffix + "_pmc.json"), "w"), indent=1, sort_keys=True)
+        shutil.copy(os.path.join(sx, tag + suffix + "_kernel_stats.csv"), os.path.join(out, tag + "_" + suffix + "_kernel_stats.csv"))
+        extra[what] = px
+
+
 def row(name, d):
     cyc = d["GRBM_GUI_ACTIVE"] / 8.0
     wave = d.get("SQ_WAVE_CYCLES", 0.0)
@@ -95,7 +106,11 @@ for name, d in sorted(((k, v) for k, v in pmcd.items() if not k.startswith("_"))
         lines.append(row(name + " (dist_only run)", d))
 for name, d in sorted(((k, v) for k, v in pmcf.items() if not k.startswith("_")), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
     if "GRBM_GUI_ACTIVE" in d and (d.get("SQ_INSTS_MFMA", 0) > 0 or "prep_cen" in name):
-        lines.append(row(name + " (dist_only run, 10 000 hashes per sketch)", d))
+        lines.append(row(name + " (dist_only run, large sketches: %s)" % (pmcf["_stamp"].get("command", "").split("dist_only.py")[-1].strip() or "?"), d))
+for what, px in extra.items():
+    for name, d in sorted(((k, v) for k, v in px.items() if not k.startswith("_")), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+        if "GRBM_GUI_ACTIVE" in d and (d.get("SQ_INSTS_MFMA", 0) > 0 or "prep_i8" in name):
+            lines.append(row(name + " (dist_only run, %s)" % what, d))
 open(os.path.join(out, tag + "_derived.md"), "w").write("\n".join(lines) + "\n")
 
 # the headline kernel: the packed-input instantiation when the bench ran it (its ASCII-resident twin runs in the same

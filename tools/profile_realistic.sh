@@ -17,7 +17,8 @@ import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["TotalDurationNs"]), r["Name"].split("(")[0][:90], int(r["Calls"]), float(r["AverageNs"])))
+        name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        rows.append((int(r["TotalDurationNs"]), name.split("(")[0][:90], int(r["Calls"]), float(r["AverageNs"])))
 tot = sum(r[0] for r in rows) or 1
 for t, name, calls, avg in sorted(rows, reverse=True)[:8]:
     print("   %5.1f %%  %-90s calls %4d  avg %10.1f us" % (100.0 * t / tot, name, calls, avg / 1e3))
