@@ -38,8 +38,13 @@ L += table(tag + "_kernel_stats.csv")
 L += ["", "## `%s_dist_kernel_stats.csv` -- the dist kernels alone (`tools/profile_dist.sh %sdist`: `python3 tools/dist_only.py --reps 4`, 10 000 x 10 000)" % (tag, tag), ""]
 L += table(tag + "_dist_kernel_stats.csv", 8)
 if os.path.exists(os.path.join(P, tag + "_distf16_kernel_stats.csv")):
-    L += ["", "## `%s_distf16_kernel_stats.csv` -- the same command on large sketches (`--nhash 10000`: centred f16 operands)" % tag, ""]
-    L += table(tag + "_distf16_kernel_stats.csv", 8)
+    L += ["", "## `%s_distf16_kernel_stats.csv` -- the same command on large sketches (`--nhash 6666` from round 5 on, `--nhash 10000` before: centred f16 operands)" % tag, ""]
+    L += table(tag + "_distf16_kernel_stats.csv", 4)
+for suffix, what in (("dist2", "R and Q in DIFFERENT buffers (`--sets two`: other members of the same clusters, both prepasses)"),
+                     ("distsym", "one set with `symmetric = 1` (`--sets sym`: R (R - 1) / 2 pairs)")):
+    if os.path.exists(os.path.join(P, tag + "_" + suffix + "_kernel_stats.csv")):
+        L += ["", "## `%s_%s_kernel_stats.csv` -- the same command, %s" % (tag, suffix, what), ""]
+        L += table(tag + "_" + suffix + "_kernel_stats.csv", 2)
 bl = os.path.join(P, tag + "_bench_line.json")
 if os.path.exists(bl):
     j = json.load(open(bl))
@@ -64,9 +69,28 @@ if os.path.exists(bl):
         d = j["dist"]
         L.append("| dist 10 000 x 10 000 | %.0f M pairs/s, GEMM %.3f ms = %.3f of the %s peak |" % (
             d["value"], d["roofline"]["launch_ms"], d["roofline"]["frac"], d["roofline"]["peak_dtype"]))
+        for key, name in (("two_sets", "two distinct sets"), ("symmetric", "symmetric = 1")):
+            if key in d:
+                L.append("| dist, %s | %.0f M pairs/s, GEMM %.3f ms = %.3f of the peak, prepass %.3f ms, %d hits |" % (
+                    name, d[key]["value"], d[key]["gemm_ms"], d[key]["frac_of_peak"], d[key]["prep_ms"], d[key]["hits"]))
     if "hamming" in j:
         h = j["hamming"]
-        L.append("| Hamming search 50 000 x 10 000 x 16384 | %.0f M pairs/s |" % h["value"])
+        L.append("| Hamming search 50 000 x 10 000 x 16384 | %.0f M pairs/s, kernel %.3f ms = %.3f of the %s peak |" % (
+            h["value"], h["kernel_ms"], h["roofline"]["frac"], h["roofline"].get("peak_dtype", "")))
+    if "realistic" in j:
+        r = j["realistic"]
+        da = r["draft_assemblies"]
+        L.append("| draft assemblies (200 contigs, soft-masked, IUPAC, tandem repeat) | %.0f genomes/s packed = %.3f of clean, %.0f ASCII |" % (
+            da["value"], da["vs_clean"], da["ascii_resident"]["value"]))
+        if "many_small" in r:
+            ms = r["many_small"]
+            L.append("| 100 000 genomes of 50 kbp | %.0f genomes/s = %.0f Mbase/s (%.2f of the clean per-base rate); kernels %s |" % (
+                ms["value"], ms["mbases_per_sec"], ms["vs_clean_per_base"], {k: round(v, 2) for k, v in ms["kernel_ms_per_step"].items()}))
+    if "cli" in j:
+        c = j["cli"]
+        L.append("| `hyper-gen dist -r A -q A` / `-r A -q B` / `search`, 10 000 sketches, end to end | %.2f / %.2f / %.2f s wall (%.3f / %.3f / %.3f s as the tool reports) |" % (
+            c["dist_symmetric"]["wall_s"], c["dist_two_files"]["wall_s"], [v for k, v in c.items() if k.startswith("search")][0]["wall_s"],
+            c["dist_symmetric"].get("reported_s", 0), c["dist_two_files"].get("reported_s", 0), [v for k, v in c.items() if k.startswith("search")][0].get("reported_s", 0)))
 L += ["", "## the other files", "",
       "| file | what | made by |", "|---|---|---|",
       "| `%s_rocprofv3_kernel_stats_full.csv` | the unfiltered `--stats` table of the bench command | `tools/profile_gpu.sh %s` |" % (tag, tag),
@@ -74,6 +98,10 @@ L += ["", "## the other files", "",
       "| `%s_derived.md` | per-kernel derived metrics (instr / cycle, MFMA busy, LDS busy, LDS conflicts, L2 hit, wait split, HBM bytes) | `tools/derive_prof.py %s` |" % (tag, tag),
       "| `%s_kmer_traffic.json`, `%s_kmer_ascii_traffic.json`, `%s_dist_traffic.json` | the `roofline.traffic` figures `bench.py` reports | idem |" % (tag, tag, tag),
       "| `%s_kmer_packed_isa.*`, `%s_kmer_isa.*` | static instruction budget of `kmer_sample_shared<21, true, PACKED>` by class, per k-mer | `tools/kmer_isa.py %s [packed]` |" % (tag, tag, tag),
+      "| `r05_gemm_bounds.md` (+ `r05_l2_bound.txt`, `r05_mfma_shape.txt`, `r05_mfma_loop.txt`, `r05_epilogue_bounds.txt`) | what bounds the three GEMM kernels: the all-L2-hits build, MFMA shapes and operand values, the loop's ingredients, the uneven loader split, the epilogue's removable work | `tools/dist_only.py` on `-DHG_DIST_EXPERIMENT` builds, `tools/mfma_shape_microbench.hip`, `tools/mfma_microbench.hip` |",
+      "| `r05_realistic_kernel_stats.txt` | `rocprofv3 --kernel-trace --stats` of the clean / draft-assembly / many-small-genomes sketch step, both resident forms | `tools/profile_realistic.sh r05` |",
+      "| `r05_cli_dist.txt` | `hyper-gen dist` / `search` end to end with the tool's own stage timings, at the start and at the end of round 5 | `tools/cli_dist_bench.py` |",
+      "| `design_r04_full.md` | DESIGN.md as it stood at the end of round 4 (every round-1..4 narrative) | -- |",
       "| `r04_dist_tile_table.txt` | per-CU timelines of one dist launch (which CU ran which workgroups, from whole-tile stamps + `HW_ID`) with the blockIdx mapping and with the host-built slot -> tile table, and the timings of both | `tools/dist_cu_timeline.py` on a `-DHG_DIST_STAMPS` build, `tools/dist_only.py` |",
       "| `r04_hostfed_probe.txt` | the one-call-per-genome pattern by number of calling threads and link form (ASCII / packed / the library's choice), and its ingredients alone (host packing, resident calls, uploads) | `tools/percall_probe.py`, `tools/percall_ingredients.py` |",
       "| `r04_dist_defer_neutral.txt` | deferred candidate evaluation (tiles append candidates, a second kernel evaluates them): kernel times, per-CU spans and tile durations against in-tile evaluation | `tools/dist_only.py`, `tools/dist_cu_timeline.py` |",
