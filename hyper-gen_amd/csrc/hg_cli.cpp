@@ -70,6 +70,7 @@ void debugf(const char *fmt, ...) {
 struct Cli {
   std::string mode, path = "1", path_r = "1", path_q = "1", out, method = "t1ha2", device = "cpu";
   bool pack_naive = false;  // --pack_layout naive: the payload layout of reference hosts without AVX2 (src/hd.rs:158-166)
+  unsigned shards = 0;      // --shards N (dist / search; testing aid): N shards dealt round the visible devices instead of one each
   unsigned threads = 16, ksize = 21, top_n = 1;
   bool canonical = true;
   unsigned long long seed = 123, scaled = 1500, hv_d = 4096;
@@ -93,7 +94,8 @@ Cli parse(int argc, char **argv) {
                 "         -C --canonical [true], -k --ksize [21], -S --seed [123], -s --scaled [1500], -d --hv_d [4096],\n"
                 "         -Q --quant_scale [1.0], -a --ani_th [85.0], -D --device [cpu]\n"
                 "extensions: -n --top_n [1] (search), --pack_layout avx2|naive [avx2] (sketch: the payload layout of\n"
-                "         reference hosts with / without AVX2; dist and search read both)\n");
+                "         reference hosts with / without AVX2; dist and search read both), --shards N (dist / search: N\n"
+                "         shards dealt round the visible GPUs; default one per GPU)\n");
     std::exit(0);
   }
   if (c.mode != "sketch" && c.mode != "dist" && c.mode != "search") die("unknown subcommand '" + c.mode + "'");
@@ -101,7 +103,7 @@ Cli parse(int argc, char **argv) {
   static const std::map<std::string, char> longs = {
       {"path", 'p'}, {"path_r", 'r'}, {"path_q", 'q'}, {"out", 'o'}, {"thread", 't'}, {"sketch_method", 'm'},
       {"canonical", 'C'}, {"ksize", 'k'}, {"seed", 'S'}, {"scaled", 's'}, {"hv_d", 'd'}, {"quant_scale", 'Q'},
-      {"ani_th", 'a'}, {"device", 'D'}, {"top_n", 'n'}, {"pack_layout", 'L'}};
+      {"ani_th", 'a'}, {"device", 'D'}, {"top_n", 'n'}, {"pack_layout", 'L'}, {"shards", 'G'}};
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i], val;
     char key = 0;
@@ -149,6 +151,7 @@ Cli parse(int argc, char **argv) {
       case 'a': c.ani_th = std::strtof(val.c_str(), nullptr); break;
       case 'D': c.device = val; break;
       case 'n': c.top_n = (unsigned)u(1u << 20); break;  // search only (extension: the reference's search is a stub)
+      case 'G': c.shards = (unsigned)u(64); break;  // dist / search only (testing aid: the several-GPU path on fewer GPUs)
       case 'L':  // sketch only (extension): which of the reference's two payload layouts to write
         if (val == "naive") c.pack_naive = true;
         else if (val == "avx2" || val == "bitpacker8x") c.pack_naive = false;
@@ -169,13 +172,15 @@ void ckm(hg_multi *m, hg_status s, const char *what) {
 
 // every GPU the process can see (HIP_VISIBLE_DEVICES narrows it); the reference opens device 0 only
 // (src/sketch_cuda.rs:52)
-hg_multi *open_all_devices() {
+hg_multi *open_all_devices(unsigned shards = 0) {
   const int n = hg_device_count();
   if (n <= 0) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
-  std::vector<int> ids(n);
-  for (int i = 0; i < n; ++i) ids[i] = i;
+  // (--shards N: N shards dealt round the devices -- repeated ids run several shards on one GPU, which is how the
+  // several-GPU code path is exercised on a one-GPU box)
+  std::vector<int> ids(shards ? shards : (unsigned)n);
+  for (size_t i = 0; i < ids.size(); ++i) ids[i] = (int)(i % (size_t)n);
   hg_multi *m = nullptr;
-  if (hg_multi_create(ids.data(), n, &m) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
+  if (hg_multi_create(ids.data(), (int)ids.size(), &m) != HG_OK) die(std::string("no MI355X device: ") + hg_last_error(nullptr));
   return m;
 }
 
@@ -539,7 +544,7 @@ int run_dist(const Cli &c) {
   hg_multi *multi = nullptr;
   std::thread opener([&] {  // the HIP runtime comes up (~0.2 s) while the sketch files are read and decompressed
     const double td = now_s();
-    multi = open_all_devices();
+    multi = open_all_devices(c.shards);
     debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
   });
   load(c.path_r, R);
@@ -656,7 +661,7 @@ int run_search(const Cli &c) {
   double tp = now_s();
   std::thread opener([&] {  // the HIP runtime comes up while the files are read
     const double td = now_s();
-    multi = open_all_devices();
+    multi = open_all_devices(c.shards);
     debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
   });
   load(c.path_r, R);

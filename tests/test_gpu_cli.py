@@ -316,11 +316,24 @@ def test_cli_dist_tsv_is_the_library_hits_in_dump_order_with_exact_formatting(tm
         paths.append((p, [r["file_str"] for r in recs], np.array([r["hv_norm_2"] for r in recs], np.int32)))
     with hg.Context(0) as ctx:
         for (pr, nr, n2r), (pq, nq, n2q), hv_r, hv_q, sym in ((paths[0], paths[1], a, b, False), (paths[0], paths[0], a, a, True)):
-            tsv = str(tmp_path / "o.tsv")
-            r = subprocess.run([hg.CLI_PATH, "dist", "-r", pr, "-q", pq, "-o", tsv, "-a", "80"], capture_output=True, text=True)
-            assert r.returncode == 0, r.stderr
             hits = ctx.dist(hv_r, n2r, hv_q, n2q, 21, symmetric=sym, ani_th=80.0)
             hits = hg.sort_ani_hits(hits, n, symmetric=sym)
             want = "".join("%s\t%s\t%.3f\n" % (nr[h["ref_idx"]], nq[h["qry_idx"]], float(h["ani"])) for h in hits)
-            got = open(tsv).read()
-            assert len(hits) > 3000 and got == want, (sym, len(hits))
+            # one shard per visible GPU (the hits never touch the host unordered), and three shards dealt round the GPUs: the
+            # several-GPU path (row blocks decoded per shard, peer pulls, per-shard hit lists merged and ordered through
+            # device 0) on however many GPUs the box has
+            for extra in ([], ["--shards", "3"]):
+                tsv = str(tmp_path / "o.tsv")
+                r = subprocess.run([hg.CLI_PATH, "dist", "-r", pr, "-q", pq, "-o", tsv, "-a", "80"] + extra, capture_output=True, text=True)
+                assert r.returncode == 0, r.stderr
+                got = open(tsv).read()
+                assert len(hits) > 3000 and got == want, (sym, extra, len(hits))
+        # search: top 3 references per query, the same through one shard and through two
+        outs = []
+        for extra in ([], ["--shards", "2"]):
+            tsv = str(tmp_path / "s.tsv")
+            r = subprocess.run([hg.CLI_PATH, "search", "-r", paths[0][0], "-q", paths[1][0], "-o", tsv, "-a", "80", "-n", "3"] + extra,
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            outs.append(open(tsv).read())
+        assert outs[0] == outs[1] and outs[0].count("\n") >= n
