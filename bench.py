@@ -109,7 +109,7 @@ def clustered_hvs(rows, first_row, dev, n=3333, shared_frac=0.5, cluster=100, sa
     return out
 
 
-def draftify(seq, n, stride, L, seed=0x5EED):
+def draftify(seq, n, stride, L, seed=0x5EED, repeat_len=50_000):
     """Rewrites the n clean single-contig synthetic genomes in `seq` (genome g at g*stride: 'N' + L bases, the
     read_merge_seq layout of src/fastx_reader.rs:6-29) IN PLACE into what a draft assembly looks like to the sketch path:
       * 200 contigs: 199 further record starts, i.e. an 'N' at 199 random positions (one per FASTA header);
@@ -129,10 +129,10 @@ def draftify(seq, n, stride, L, seed=0x5EED):
         body = view[g0: g0 + m, 1: 1 + L]
         rows = torch.arange(m, device=dev)[:, None]
         # tandem repeat first (the masks below then apply to it like to everything else)
-        start = torch.randint(0, L - 50_000, (m,), generator=g, device=dev)
+        start = torch.randint(0, L - repeat_len, (m,), generator=g, device=dev)
         unit = torch.gather(body, 1, start[:, None] + torch.arange(171, device=dev)[None, :])
-        idx = start[:, None] + torch.arange(50_000, device=dev)[None, :]
-        body[rows, idx] = unit[:, torch.arange(50_000, device=dev) % 171]
+        idx = start[:, None] + torch.arange(repeat_len, device=dev)[None, :]
+        body[rows, idx] = unit[:, torch.arange(repeat_len, device=dev) % 171]
         nblk = (L + 999) // 1000
         soft = torch.rand((m, nblk), generator=g, device=dev) < 0.30
         soft = soft.repeat_interleave(1000, dim=1)[:, :L]

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--leg", default="draft", choices=("clean", "draft", "small"))
 ap.add_argument("--form", default="packed", choices=("packed", "ascii"))
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--repeat", type=int, default=50_000, help="length of the draft leg's tandem repeat (171-base unit)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
@@ -27,7 +28,7 @@ stride = (L + 1 + 15) // 16 * 16
 seq = torch.empty(N * stride + 64, dtype=torch.uint8, device=dev)
 ctx.synth_genomes_dev(0, N, L, stride, seq.data_ptr())
 if a.leg == "draft":
-    bench.draftify(seq, N, stride, L)
+    bench.draftify(seq, N, stride, L, repeat_len=a.repeat)
 offs, lens = np.arange(N, dtype=np.uint64) * stride, np.full(N, L + 1, np.uint64)
 bsz = hg.lib().hg_pack2_size(L + 1)
 boffs = np.arange(N, dtype=np.uint64) * bsz
