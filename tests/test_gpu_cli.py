@@ -103,6 +103,13 @@ def test_cli_reference_fixture(tmp_path):
     tsv = str(tmp_path / "t.tsv")
     r = subprocess.run([hg.CLI_PATH, "dist", "-r", out, "-q", out, "-o", tsv], capture_output=True, text=True)
     assert r.returncode == 0 and open(tsv).read() == ""  # one record, symmetric -> zero pairs
+    # more shards than sketches (shards without rows), and the one record against a copy of the file: ANI of two zero vectors
+    out2 = str(tmp_path / "t2.sketch")
+    hg.write_sketch_file(out2, rec)
+    for extra in ([], ["--shards", "3"]):
+        r = subprocess.run([hg.CLI_PATH, "dist", "-r", out, "-q", out2, "-o", tsv, "-a", "0"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(tsv).read() == "%s\t%s\t0.000\n" % (rec[0]["file_str"], rec[0]["file_str"])  # 0 / 0 -> NaN -> 0 (src/dist.rs:156-157)
 
 
 def test_cli_search_topn_and_cpu_mode_reader(tmp_path, orc):
