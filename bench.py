@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--no-dist-variants", action="store_true", help="skip dist.two_sets / dist.symmetric (profiling runs: their "
                                                                      "launches would enter the dist kernel's per-launch averages)")
     ap.add_argument("--small-genomes", type=int, default=100000, help="genomes of the many-small-genomes leg (50 kbp each)")
-    ap.add_argument("--cli", action="store_true", help="also run tools/cli_dist_bench.py (end-to-end hyper-gen dist / search at "
-                                                        "--dist-n sketches) and report its split as `cli`")
+    ap.add_argument("--no-cli", action="store_true", help="skip the `cli` object (tools/cli_dist_bench.py as a child process: end-to-end "
+                                                           "hyper-gen dist / search at --dist-n sketches; N = 1 only, ~8 s)")
+    ap.add_argument("--cli", action="store_true", help=argparse.SUPPRESS)  # (the leg is on by default since round 5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank logic on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses device 0")
@@ -1139,17 +1140,21 @@ def main():
     # ---------------- end to end through the CLI (--cli; rank 0, N = 1) ----------------------------------------------
     # `hyper-gen dist` / `search` as a user starts them (src/dist.rs:11-63, src/utils.rs:260-308): .sketch files in, TSV
     # out, process start and HIP bring-up included -- a child process (tools/cli_dist_bench.py), never a re-exec.
-    if a.cli and rank == 0 and world == 1 and a.dist_n:
+    if not a.no_cli and rank == 0 and world == 1 and a.dist_n:
         import subprocess
         torch.cuda.synchronize()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_dist_bench.py"), "--n", str(a.dist_n)],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        if r.returncode != 0:
-            raise SystemExit("cli leg failed: " + r.stderr.decode()[-2000:])
-        out["cli"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        log("cli: dist -r A -q A %.2f s, dist -r A -q B %.2f s, search %.2f s (wall, %d sketches)" % (
-            out["cli"]["dist_symmetric"]["wall_s"], out["cli"]["dist_two_files"]["wall_s"],
-            [v for k, v in out["cli"].items() if k.startswith("search")][0]["wall_s"], a.dist_n))
+        try:  # (a measurement beside the line, never a reason to lose the line)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_dist_bench.py"), "--n", str(a.dist_n)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr.decode()[-1500:])
+            out["cli"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            log("cli: dist -r A -q A %.2f s, dist -r A -q B %.2f s, search %.2f s (wall, %d sketches)" % (
+                out["cli"]["dist_symmetric"]["wall_s"], out["cli"]["dist_two_files"]["wall_s"],
+                [v for k, v in out["cli"].items() if k.startswith("search")][0]["wall_s"], a.dist_n))
+        except Exception as e:  # pragma: no cover
+            out["cli"] = {"error": repr(e)[:2000]}
+            log("cli leg failed: %r" % (e,))
 
     # ---------------- CPU baseline (rank 0, single-GPU runs only) ----------------------------------
     # The same leg is the run's parity gate ("parity gates must pass before any number is

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--genomes", "16", "--dist-n", "1024", "--hamming-refs", "4096", "--cpu-seconds", "0.5"],
+                        "--genomes", "16", "--dist-n", "1024", "--hamming-refs", "4096", "--cpu-seconds", "0.5", "--small-genomes", "3000"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -30,6 +30,19 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert j["dist"]["roofline"]["bound"] == "mfma" and j["dist"]["value"] > 0
     assert j["hamming"]["value"] > 0
+    # round 5: the same matrix with two distinct sets and with symmetric = 1; the inputs real users have; the CLI end to end
+    d = j["dist"]
+    assert d["two_sets"]["hits"] > 0 and d["two_sets"]["gemm_ms"] > 0 and d["symmetric"]["pairs"] == 1024 * 1023 // 2
+    assert d["symmetric"]["hits"] * 2 + 1024 == d["config"]["hits_per_rank"]
+    r = j["realistic"]
+    assert r["draft_assemblies"]["value"] > 0 and r["draft_assemblies"]["ascii_resident"]["value"] > 0
+    assert "CPU oracle" in r["draft_assemblies"]["parity"] and "CPU oracle" in r["many_small"]["parity"]
+    assert r["many_small"]["value"] > 0 and 20 < r["many_small"]["nhash_mean"] < 50
+    c = j["cli"]
+    assert "error" not in c, c
+    assert c["dist_symmetric"]["tsv_lines"] == d["symmetric"]["hits"] and c["dist_two_files"]["tsv_lines"] == d["two_sets"]["hits"]
+    assert c["dist_two_files"]["wall_s"] > 0 and any(k.startswith("search") for k in c)
+    assert j["parity_gate"]["status"] == "passed" and j["parity_gate"]["ani_two_sets_hits_checked"] > 0
 
 
 TWO_RANK_ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--genomes", "24", "--genomes-10k", "50", "--dist-n", "2048",
