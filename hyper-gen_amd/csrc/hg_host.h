@@ -1,4 +1,4 @@
-// Host-only seams between hg_formats.cpp (no HIP) and hg_api.hip.
+// Host-only seams between hg_formats.cpp (no HIP) and the hg_api*.hip translation units.
 #pragma once
 #include <condition_variable>
 #include <cstddef>
