@@ -165,11 +165,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K *__restrict_
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
     // (a wave's LDS operations execute in program order: every lane of a digit's group reads the count before the
-    // group's first lane moves it on)
-    const uint32_t seen = s_cnt[wave][d];
+    // group's first lane moves it on.  The lanes talk to each other through these words, so the accesses are relaxed
+    // atomics -- plain ds_read / ds_write, but never cached in a register from one round to the next)
+    const uint32_t seen = __hip_atomic_load(&s_cnt[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     rank[r] = seen + (uint32_t)__popcll(peers & lt);
     __builtin_amdgcn_wave_barrier();
-    if (valid && (peers & lt) == 0ull) s_cnt[wave][d] = seen + (uint32_t)__popcll(peers);
+    if (valid && (peers & lt) == 0ull)
+      __hip_atomic_store(&s_cnt[wave][d], seen + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();

@@ -409,3 +409,40 @@ def test_config4_hamming_search_50k_refs_fullsize(orc):
         assert a.shape == b.shape and bool((a == b).all())
     finally:
         ctx.close()
+
+
+def test_device_decode_of_a_10k_sketch_file_image(orc, tmp_path):
+    """configs[3]'s input side at full size: 10 000 sketches written as a .sketch file (47 MB), read back as an image,
+    uploaded as it is and decoded by hg_hv_unpack_batch_dev -- every row equals the matrix that went in; every 16th record is
+    in the reference's non-AVX2 layout (which cannot represent -2^(q-1): those rows are compared with the oracle's decoder)"""
+    import bench
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    n = 10_000
+    hv = bench.clustered_hvs(n, 0, dev).cpu().numpy()
+    recs = []
+    for i in range(n):
+        if i % 16 == 7:
+            q, pk = hg.hv_pack_naive(hv[i])
+        else:
+            q, pk = hg.hv_pack(hv[i])
+        recs.append(dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=4096, hv_quant_bits=q, hv_norm_2=i,
+                         file_str="/g/%s%d.fna" % ("y" * (i % 5), i), hv=pk.view(np.int16)))
+    path = str(tmp_path / "db.sketch")
+    hg.write_sketch_file(path, recs)
+    img, meta = hg.read_sketch_file_image(path)
+    assert len(meta) == n and img.size > 40_000_000
+    lay = [hg.hv_payload_layout(4096, m["hv_quant_bits"], m["payload_bytes"]) for m in meta]
+    assert lay.count(hg.PAYLOAD_NAIVE) == n // 16 and min(lay) == 0
+    with hg.Context(0) as ctx:
+        d_img = torch.from_numpy(img).to(dev)
+        out = torch.empty((n, 4096), dtype=torch.int16, device=dev)
+        ctx.hv_unpack_batch_dev(d_img.data_ptr(), d_img.numel(), [m["payload_off"] for m in meta], [m["hv_quant_bits"] for m in meta],
+                                lay, 4096, out.data_ptr())
+        got = out.cpu().numpy()
+    bp = np.array(lay) == hg.PAYLOAD_BITPACKER8X
+    assert np.array_equal(got[bp], hv[bp])
+    for i in np.nonzero(~bp)[0][::25]:
+        assert np.array_equal(got[i], orc.unpack_hv_naive(recs[i]["hv"], 4096, recs[i]["hv_quant_bits"])), i
+    # (all but the rows holding exactly -2^(q-1) round-trip in the naive layout too)
+    assert (got[~bp] == hv[~bp]).mean() > 0.999
