@@ -14,7 +14,17 @@
 // kernel moves the accumulator into i32 registers at chunk boundaries chosen from it.  If no chunk
 // size is safe (or |x| > 2048) the always-exact integer VALU kernel is used instead.  Either
 // way the dot product equals the reference's i32 value bit for bit; only logf differs from
-// glibc by <= 1 ulp.
+// glibc by <= 1 ulp.  Sketch hypervectors (hv = 2 * count - n) normally take the centred i8 operand path instead
+// (hg_dist_prep.h: prep_i8_kernel), twice the K per instruction on v_mfma_i32_16x16x64_i8.
+//
+// Where what lives (all private to this translation unit):
+//   hg_dist_common.h      vector typedefs, the reference's float32 ANI (ani_from_dot)
+//   hg_dist_prep.h        operand prepasses and their on-device exactness verdicts
+//   hg_dist_gemm.h        tile geometry, LDS layout, GemmArgs, development switches (-DHG_DIST_EXPERIMENT, -DHG_DIST_STAMPS)
+//   hg_dist_tile_order.h  the host-built workgroup slot -> tile table
+//   hg_dist_mainloop.h    dist_main_loop: the K loop (LDS-DMA staging, fragment reads, MFMAs)
+//   hg_dist_epilogue.h    tile words staged at kernel entry, pre-filter, candidate lists, exact ANI, hit list
+//   this file             the kernel skeleton, the integer fallback, the bit -> operand expanders, the launch logic
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
