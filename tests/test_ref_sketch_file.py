@@ -33,11 +33,19 @@ def test_reference_written_sketch_is_reproduced_byte_for_byte(orc):
             assert os.path.basename(ref["file_str"]) == name
             assert (ref["ksize"], ref["scaled"], ref["seed"], ref["canonical"], ref["hv_d"]) == (21, 100, 123, True, 4096)
             merged = orc.read_needletail(_fasta_text(name, g, L, orc).encode())
-            hv, n2, _ = orc.sketch_genome(merged, scaled=100, norm=orc.NORM_U2T)
-            q, packed = hg.hv_pack(hv)
+            # a host with AVX2 writes the AVX2 dimension order (src/sketch.rs:40-44) in BitPacker8x blocks (src/hd.rs:138-157);
+            # one without writes the scalar order (src/hd.rs:94-112) in the naive bit stream (src/hd.rs:158-166): the
+            # payload's length says which kind of host wrote the file
+            lay = hg.hv_payload_layout(4096, ref["hv_quant_bits"], ref["hv"].size * 2)
+            assert lay in (hg.PAYLOAD_BITPACKER8X, hg.PAYLOAD_NAIVE), name
+            naive = lay == hg.PAYLOAD_NAIVE
+            hv, n2, _ = orc.sketch_genome(merged, scaled=100, norm=orc.NORM_U2T, layout=orc.LAYOUT_SCALAR if naive else orc.LAYOUT_AVX2)
+            q, packed = (hg.hv_pack_naive if naive else hg.hv_pack)(hv)
+            packed = packed[: packed.size // 2 * 2]  # (the i16 view the file stores)
             assert ref["hv_norm_2"] == n2 and ref["hv_quant_bits"] == q, name
             diff = np.nonzero(ref["hv"].view(np.uint8) != packed)[0]
-            assert diff.size == 0, "%s: first differing payload byte %d (256-block %d)" % (name, diff[0], diff[0] // (32 * q))
+            assert diff.size == 0, "%s: first differing payload byte %d (%s)" % (
+                name, diff[0], "naive stream" if naive else "256-block %d" % (diff[0] // (32 * q)))
             mine.append(dict(ref, hv=packed.view(np.int16), hv_quant_bits=q, hv_norm_2=n2))
         out = os.path.join(td, "mine.sketch")
         hg.write_sketch_file(out, mine)
@@ -50,7 +58,8 @@ def test_reference_written_sketch_is_reproduced_byte_for_byte(orc):
 def test_reference_written_tsv_matches_the_oracle_ani(orc):
     import hypergen_amd as hg
     recs = hg.read_sketch_file(REF)
-    hv = np.stack([hg.hv_unpack(r["hv"].view(np.uint8), r["hv_d"], r["hv_quant_bits"]) for r in recs])
+    hv = np.stack([(hg.hv_unpack_naive if hg.hv_payload_layout(r["hv_d"], r["hv_quant_bits"], r["hv"].size * 2) == hg.PAYLOAD_NAIVE
+                    else hg.hv_unpack)(r["hv"].view(np.uint8), r["hv_d"], r["hv_quant_bits"]) for r in recs])
     n2 = np.array([r["hv_norm_2"] for r in recs], np.int32)
     want = orc.ani_matrix(hv, n2, hv, n2, 21)
     names = [r["file_str"] for r in recs]
