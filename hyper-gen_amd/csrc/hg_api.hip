@@ -139,6 +139,7 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   const std::string k = key, v = value ? value : "";
   if (k == "dist_tile") c->dbg_dist_tile = v;
   else if (k == "sort_test_buckets") c->dbg_sort_buckets = std::atoi(v.c_str());
+  else if (k == "pair_limit") c->dbg_pair_limit = std::strtoull(v.c_str(), nullptr, 10);  // hg_dist_block_dev / hg_hamming_search_block_dev: row blocks from this many pairs on
   else if (k == "dist_path") c->dbg_dist_path = v;
   else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;

@@ -56,10 +56,44 @@ extern "C" hg_status hg_dist_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32
                            d_out, cap, n_out);
 }
 
+static hg_status dist_block_once(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R, size_t ref_off,
+                                 const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, size_t qry_off, uint32_t hv_d,
+                                 uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *d_out, size_t cap, size_t *n_out);
+
 extern "C" hg_status hg_dist_block_dev(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R,
                                        size_t ref_off, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
                                        size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
                                        hg_ani_hit *d_out, size_t cap, size_t *n_out) {
+  // The kernels count hits in 32 bits.  A comparison of more than 2^32 - 1 pairs (66 000 x 66 000 and up) could report more
+  // hits than that with a low threshold, so it runs as blocks of reference rows with fewer pairs each -- global indices, the
+  // i < j rule and the hit list are those of the one call; the counts add up in 64 bits, and once the caller's buffer is full
+  // the remaining blocks only count (the contract: *n_out = all hits found, HG_ERR_CAPACITY if they did not fit).
+  const uint64_t pair_limit = (c && c->dbg_pair_limit) ? c->dbg_pair_limit : 0xFFFFFFFFull;  // ("pair_limit": test hook)
+  if (c && n_out && Q && (uint64_t)R * (uint64_t)Q > pair_limit && R <= 0x7FFFFFFFull && Q <= 0x7FFFFFFFull) {
+    const size_t rows_per = std::max<size_t>(1, (size_t)(pair_limit / (uint64_t)Q));
+    size_t total = 0;
+    bool full = false;
+    *n_out = 0;
+    for (size_t r0 = 0; r0 < R; r0 += rows_per) {
+      const size_t rows = std::min(rows_per, R - r0), room = total < cap ? cap - total : 0;
+      size_t got = 0;
+      const hg_status bs = dist_block_once(c, d_ref_hv + r0 * (size_t)hv_d, d_ref_norm2 + r0, rows, ref_off + r0, d_qry_hv, d_qry_norm2, Q,
+                                           qry_off, hv_d, ksize, symmetric, ani_th, d_out ? d_out + std::min(total, cap) : nullptr, room, &got);
+      if (bs == HG_ERR_CAPACITY) full = true;
+      else if (bs != HG_OK) return bs;
+      total += got;
+    }
+    *n_out = total;
+    if (full || total > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
+    return HG_OK;
+  }
+  return dist_block_once(c, d_ref_hv, d_ref_norm2, R, ref_off, d_qry_hv, d_qry_norm2, Q, qry_off, hv_d, ksize, symmetric, ani_th, d_out,
+                         cap, n_out);
+}
+
+static hg_status dist_block_once(hg_ctx *c, const int16_t *d_ref_hv, const int32_t *d_ref_norm2, size_t R, size_t ref_off,
+                                 const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, size_t qry_off, uint32_t hv_d,
+                                 uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *d_out, size_t cap, size_t *n_out) {
   if (!c) return HG_ERR_INVALID;
   if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
   *n_out = 0;

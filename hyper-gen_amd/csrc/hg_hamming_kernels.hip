@@ -8,6 +8,8 @@
 // The search is HBM/L2 + VALU work (v_xor_b32 + v_bcnt_u32_b32 per 32 dims and pair), not a GEMM: a
 // 128 x 128 tile of pairs per workgroup, 8 x 8 pairs per lane in registers, operand slices of 32
 // words staged through LDS with padded rows (conflict-free ds_read_b128).
+#include <algorithm>
+
 #include "hg_internal.h"
 
 namespace {
@@ -190,9 +192,37 @@ extern "C" hg_status hg_hamming_search_dev(hg_ctx *c, const uint32_t *d_ref_bits
   return hg_hamming_search_block_dev(c, d_ref_bits, R, 0, d_qry_bits, Q, 0, hv_d, max_dist, d_out, cap, n_out);
 }
 
+static hg_status hamming_block_once(hg_ctx *c, const uint32_t *d_ref_bits, size_t R, size_t ref_off, const uint32_t *d_qry_bits, size_t Q,
+                                    size_t qry_off, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap, size_t *n_out);
+
 extern "C" hg_status hg_hamming_search_block_dev(hg_ctx *c, const uint32_t *d_ref_bits, size_t R, size_t ref_off,
                                                  const uint32_t *d_qry_bits, size_t Q, size_t qry_off, uint32_t hv_d,
                                                  uint32_t max_dist, hg_ham_hit *d_out, size_t cap, size_t *n_out) {
+  // (32-bit hit counter: more than 2^32 - 1 pairs run as blocks of reference rows, see hg_dist_block_dev)
+  const uint64_t pair_limit = (c && c->dbg_pair_limit) ? c->dbg_pair_limit : 0xFFFFFFFFull;
+  if (c && n_out && Q && (uint64_t)R * (uint64_t)Q > pair_limit) {
+    const size_t rows_per = std::max<size_t>(1, (size_t)(pair_limit / (uint64_t)Q)), words = ((size_t)hv_d + 31) / 32;
+    size_t total = 0;
+    bool full = false;
+    *n_out = 0;
+    for (size_t r0 = 0; r0 < R; r0 += rows_per) {
+      const size_t rows = std::min(rows_per, R - r0), room = total < cap ? cap - total : 0;
+      size_t got = 0;
+      const hg_status bs = hamming_block_once(c, d_ref_bits + r0 * words, rows, ref_off + r0, d_qry_bits, Q, qry_off, hv_d, max_dist,
+                                              d_out ? d_out + std::min(total, cap) : nullptr, room, &got);
+      if (bs == HG_ERR_CAPACITY) full = true;
+      else if (bs != HG_OK) return bs;
+      total += got;
+    }
+    *n_out = total;
+    if (full || total > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
+    return HG_OK;
+  }
+  return hamming_block_once(c, d_ref_bits, R, ref_off, d_qry_bits, Q, qry_off, hv_d, max_dist, d_out, cap, n_out);
+}
+
+static hg_status hamming_block_once(hg_ctx *c, const uint32_t *d_ref_bits, size_t R, size_t ref_off, const uint32_t *d_qry_bits, size_t Q,
+                                    size_t qry_off, uint32_t hv_d, uint32_t max_dist, hg_ham_hit *d_out, size_t cap, size_t *n_out) {
   if (!c) return HG_ERR_INVALID;
   if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
   *n_out = 0;

@@ -105,6 +105,7 @@ struct hg_ctx {
   // development / test hooks (hg_ctx_set_debug); never read from the environment
   std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input, dbg_hostfed;
   int dbg_sort_buckets = 0;
+  uint64_t dbg_pair_limit = 0;  // test hook "pair_limit": pairs one kernel launch of a comparison may enumerate (0: 2^32 - 1, the hit counter's reach)
   // pinned host scratch
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;

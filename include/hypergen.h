@@ -76,6 +76,8 @@ int hg_device_count(void);
  *       "hostfed" = "" | "ascii" | "packed"                (what hg_sketch_batch / hg_kmer_hash_sample send over the link:
  *                                                           the library's choice / always ASCII / always 2-bit packed on the host)
  *       "sort_test_buckets" = "<n>"   (bucket count of the large-set sort; 0 = automatic)
+ *       "pair_limit" = "<n>"          (pairs one launch of a thresholded comparison / search may enumerate before the call is
+ *                                      split into blocks of reference rows; 0 = 2^32 - 1, the reach of the hit counter)
  * Nothing in the library reads environment variables. */
 hg_status hg_ctx_set_debug(hg_ctx *ctx, const char *key, const char *value);
 
@@ -216,7 +218,10 @@ typedef struct {
  * A set compared with itself (the reference's path_r == path_q case, src/dist.rs:13) is recognised by identical
  * pointers and row counts on both sides: hg_dist uploads it once, and the device path prepares its operands once
  * and runs the tiles on the matrix diagonal -- where such a comparison has its dense blocks of hits -- first.  The
- * result is the same set of hits either way. */
+ * result is the same set of hits either way.
+ * The kernels count hits in 32 bits: a call of more than 2^32 - 1 pairs (66 000 x 66 000 and up) runs as blocks of
+ * reference rows of fewer pairs each (hg_dist_block_dev does that by itself); counts add up in 64 bits, and once `out` is
+ * full the remaining blocks only count.  hg_hamming_search(_block)_dev likewise. */
 hg_status hg_dist(hg_ctx *ctx, const int16_t *ref_hv, const int32_t *ref_norm2, size_t R,
                   const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q, uint32_t hv_d,
                   uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *out, size_t cap,

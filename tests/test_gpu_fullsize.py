@@ -446,3 +446,44 @@ def test_device_decode_of_a_10k_sketch_file_image(orc, tmp_path):
         assert np.array_equal(got[i], orc.unpack_hv_naive(recs[i]["hv"], 4096, recs[i]["hv_quant_bits"])), i
     # (all but the rows holding exactly -2^(q-1) round-trip in the naive layout too)
     assert (got[~bp] == hv[~bp]).mean() > 0.999
+
+
+def test_dist_of_more_than_2_to_32_pairs():
+    """66 000 x 66 000 = 4.36e9 pairs, more than the kernels' 32-bit hit counter could count if every pair were reported:
+    hg_dist_dev splits such a call into blocks of reference rows by itself.  The hits must be those of two explicit
+    hg_dist_block_dev calls on row blocks that stay below 2^32 pairs each (same global indices, same ANI bits)."""
+    import bench
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    n = 66_000
+    assert n * n > 2**32
+    hv = bench.clustered_hvs(n, 0, dev)
+    n2 = (hv.int() ** 2).sum(1).int()
+    cap = 40_000_000
+    out = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+
+    def canon(t, k):
+        h = t[: 3 * k].view(-1, 3)
+        key = (h[:, 0].long() << 32) | (h[:, 1].long() & 0xFFFFFFFF)
+        order = torch.argsort(key)
+        return key[order].clone(), h[order, 2].clone()
+    with hg.Context(0) as c:
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        found, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, hv.data_ptr(), n2.data_ptr(), n, D, 21, False, 85.0, out.data_ptr(), cap)
+        torch.cuda.synchronize()
+        assert st == 0 and found > n * 100
+        k_all, v_all = canon(out, found)
+        half = n // 2
+        parts, total = [], 0
+        for r0, rows in ((0, half), (half, n - half)):
+            m, st = c.dist_block_dev(hv[r0:].data_ptr(), n2[r0:].data_ptr(), rows, r0, hv.data_ptr(), n2.data_ptr(), n, 0, D, 21, False, 85.0,
+                                     out.data_ptr(), cap)
+            torch.cuda.synchronize()
+            assert st == 0
+            parts.append(canon(out, m))
+            total += m
+        assert total == found
+        k2 = torch.cat([p[0] for p in parts])
+        v2 = torch.cat([p[1] for p in parts])
+        o = torch.argsort(k2)
+        assert torch.equal(k2[o], k_all) and torch.equal(v2[o], v_all)

@@ -981,3 +981,59 @@ def test_hamming_tile_orders_agree(ctx, orc):
     finally:
         ctx.set_debug("dist_order", "")
         ctx.set_debug("dist_tile", "")
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_comparisons_beyond_the_hit_counter_run_as_row_blocks(hg, orc, symmetric):
+    """The kernels count hits in 32 bits, so a comparison of more than 2^32 - 1 pairs (66 000 x 66 000 and up) runs as blocks
+    of reference rows.  The hook "pair_limit" lowers that border so that the path can be checked at a size that fits a test:
+    same hit set as the one-launch call (global indices, the i < j rule), the count added up over the blocks, and the
+    capacity contract -- a buffer that fills up half way still gets the total count back with HG_ERR_CAPACITY."""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    n = 3000
+    hv = bench.clustered_hvs(n, 0, dev, n=1200)
+    n2 = (hv.int() ** 2).sum(1).int()
+    qv = hv if symmetric else bench.clustered_hvs(n - 400, 0, dev, n=1200, salt=1)
+    qn = n2 if symmetric else (qv.int() ** 2).sum(1).int()
+    Q = qv.shape[0]
+    cap = 2_000_000
+    out = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+
+    def canon(t, k):
+        h = t[: 3 * k].view(-1, 3).cpu().numpy().view(np.uint32)
+        return h[np.lexsort((h[:, 1], h[:, 0]))]
+    with hg.Context(0) as c:
+        want_n, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, qv.data_ptr(), qn.data_ptr(), Q, 4096, 21, symmetric, 80.0, out.data_ptr(), cap)
+        assert st == 0 and want_n > 50_000
+        want = canon(out, want_n)
+        for limit in (n * Q // 3 + 17, 5 * Q + 1, Q):  # three blocks; blocks of five rows; one row per launch
+            if limit < 6 * Q and symmetric:
+                continue  # (600+ launches: once is enough)
+            c.set_debug("pair_limit", str(limit))
+            out.zero_()
+            got_n, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, qv.data_ptr(), qn.data_ptr(), Q, 4096, 21, symmetric, 80.0, out.data_ptr(), cap)
+            assert st == 0 and got_n == want_n, limit
+            assert np.array_equal(canon(out, got_n), want), limit
+        # the buffer fills up inside the second block: everything that fits is a hit of the full list, the count is the total
+        c.set_debug("pair_limit", str(n * Q // 3 + 17))
+        small = want_n // 2
+        out.zero_()
+        got_n, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, qv.data_ptr(), qn.data_ptr(), Q, 4096, 21, symmetric, 80.0, out.data_ptr(), small)
+        assert st == hg.ERR_CAPACITY and got_n == want_n
+        part = canon(out, small)
+        full = {(int(a), int(b)): int(v) for a, b, v in want}
+        assert all(full.get((int(a), int(b))) == int(v) for a, b, v in part[:: max(1, small // 5000)])
+        c.set_debug("pair_limit", "0")
+        # the bit-packed search takes the same route
+        bits = torch.empty((n, 128), dtype=torch.int32, device=dev)
+        c.hv_binarize_dev(hv.data_ptr(), n, 4096, bits.data_ptr())
+        hn, st = c.hamming_search_dev(bits.data_ptr(), n, bits.data_ptr(), n, 4096, 1200, out.data_ptr(), cap)
+        assert st == 0 and hn >= n
+        hw = canon(out, hn)
+        c.set_debug("pair_limit", str(n * n // 4 + 5))
+        out.zero_()
+        hn2, st = c.hamming_search_dev(bits.data_ptr(), n, bits.data_ptr(), n, 4096, 1200, out.data_ptr(), cap)
+        assert st == 0 and hn2 == hn and np.array_equal(canon(out, hn2), hw)
+        c.set_debug("pair_limit", "0")
