@@ -166,11 +166,46 @@ extern "C" hg_status hg_dist_prep_ops_dev(hg_ctx *c, const int16_t *d_hv, size_t
   return hg_run_dist_prep_ops(c, d_hv, (uint32_t)rows, hv_d, d_ops, d_meta, d_flag);
 }
 
+static hg_status dist_block_ops_once(hg_ctx *c, const uint8_t *d_ref_ops, const uint8_t *d_ref_meta, const int32_t *d_ref_norm2, size_t R,
+                                     size_t ref_off, const uint32_t *d_ref_index, const uint32_t *d_flags, size_t n_flags,
+                                     const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, size_t qry_off, uint32_t hv_d,
+                                     uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *d_out, size_t cap, size_t *n_out);
+
 extern "C" hg_status hg_dist_block_ops_dev(hg_ctx *c, const uint8_t *d_ref_ops, const uint8_t *d_ref_meta, const int32_t *d_ref_norm2,
                                            size_t R, size_t ref_off, const uint32_t *d_ref_index, const uint32_t *d_flags,
                                            size_t n_flags, const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q,
                                            size_t qry_off, uint32_t hv_d, uint32_t ksize, int symmetric, float ani_th,
                                            hg_ani_hit *d_out, size_t cap, size_t *n_out) {
+  // (32-bit hit counter, see hg_dist_block_dev; here the prepared reference block stays whole -- its padding rows belong to
+  // it -- and the QUERY rows go in blocks)
+  const uint64_t pair_limit = (c && c->dbg_pair_limit) ? c->dbg_pair_limit : 0xFFFFFFFFull;
+  if (c && n_out && R && (uint64_t)R * (uint64_t)Q > pair_limit && R <= 0x7FFFFFFFull && Q <= 0x7FFFFFFFull) {
+    const size_t cols_per = std::max<size_t>(1, (size_t)(pair_limit / (uint64_t)R));
+    size_t total = 0;
+    bool full = false;
+    *n_out = 0;
+    for (size_t q0 = 0; q0 < Q; q0 += cols_per) {
+      const size_t cols = std::min(cols_per, Q - q0), room = total < cap ? cap - total : 0;
+      size_t got = 0;
+      const hg_status bs = dist_block_ops_once(c, d_ref_ops, d_ref_meta, d_ref_norm2, R, ref_off, d_ref_index, d_flags, n_flags,
+                                               d_qry_hv + q0 * (size_t)hv_d, d_qry_norm2 + q0, cols, qry_off + q0, hv_d, ksize, symmetric, ani_th,
+                                               d_out ? d_out + std::min(total, cap) : nullptr, room, &got);
+      if (bs == HG_ERR_CAPACITY) full = true;
+      else if (bs != HG_OK) return bs;  // (HG_ERR_INEXACT included: the caller falls back for the whole call)
+      total += got;
+    }
+    *n_out = total;
+    if (full || total > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
+    return HG_OK;
+  }
+  return dist_block_ops_once(c, d_ref_ops, d_ref_meta, d_ref_norm2, R, ref_off, d_ref_index, d_flags, n_flags, d_qry_hv, d_qry_norm2, Q,
+                             qry_off, hv_d, ksize, symmetric, ani_th, d_out, cap, n_out);
+}
+
+static hg_status dist_block_ops_once(hg_ctx *c, const uint8_t *d_ref_ops, const uint8_t *d_ref_meta, const int32_t *d_ref_norm2, size_t R,
+                                     size_t ref_off, const uint32_t *d_ref_index, const uint32_t *d_flags, size_t n_flags,
+                                     const int16_t *d_qry_hv, const int32_t *d_qry_norm2, size_t Q, size_t qry_off, uint32_t hv_d,
+                                     uint32_t ksize, int symmetric, float ani_th, hg_ani_hit *d_out, size_t cap, size_t *n_out) {
   if (!c) return HG_ERR_INVALID;
   if (!n_out) return hg_fail(c, HG_ERR_INVALID, "n_out == NULL");
   *n_out = 0;

@@ -89,6 +89,15 @@ def test_prepared_operands_equal_the_one_call_result(hg, nhash, n, world):
         assert set(got) == set(want)
         assert all(got[k] == want[k] for k in want)  # the same float
         assert bool((ops[n:] == 0).all())  # rows behind R: zeroed by the call
+        # more pairs than the hit counter reaches run as blocks of QUERY rows here (the prepared reference block stays whole):
+        # the "pair_limit" hook moves that border down
+        c, (lo, hi) = ctxs[0], bounds[0]
+        c.set_debug("pair_limit", str(n * 97 + 5))
+        found, st = c.dist_block_ops_dev(ops.data_ptr(), meta.data_ptr(), n2.data_ptr(), n, 0, 0, flags.data_ptr(), world,
+                                         hv[lo:hi].data_ptr(), n2[lo:hi].data_ptr(), hi - lo, lo, D, K, False, 85.0, hits.data_ptr(), cap)
+        c.set_debug("pair_limit", "0")
+        blocked = hitset(hits, found)
+        assert st == 0 and blocked == {k: v for k, v in want.items() if lo <= k[1] < hi}
     finally:
         for c in ctxs:
             c.close()
