@@ -379,6 +379,17 @@ def main():
     def step_ascii():
         ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv_a.data_ptr(), n2_a.data_ptr(), nh_a.data_ptr())
 
+    # (disclosed beside the steady-state figures: what the very first call of the process costs -- workspaces, the code object,
+    # an idle GPU's clock -- and the first timed-looking call after it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    cold_first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    cold_second_ms = (time.perf_counter() - t0) * 1e3
     settle(step, SETTLE["sketch"])
     for _ in range(a.warmup):
         step()
@@ -433,6 +444,8 @@ def main():
     out = {
         "metric": "genomes/sec sketch (k=21,s=1500,D=4096)", "value": value, "unit": "genomes/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps": SETTLE, "ms_per_step": dt / a.steps * 1e3,
+        "cold_start": {"first_step_ms": cold_first_ms, "second_step_ms": cold_second_ms,
+                       "note": "the process's first two sketch steps, before the untimed clock settle (never part of `value`)"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": "%d synthetic 5 Mbp genomes per GPU (BASELINE configs[1]), sketch k=21 "
@@ -876,6 +889,15 @@ def main():
                                                rank * rows, HV_D, KSIZE, False, 85.0, hits.data_ptr(), cap)
             found = total
 
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dstep()
+        torch.cuda.synchronize()
+        dist_first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        dstep()
+        torch.cuda.synchronize()
+        dist_second_ms = (time.perf_counter() - t0) * 1e3
         settle(dstep, SETTLE["dist"])
         for _ in range(max(a.warmup, 1)):
             dstep()
@@ -919,6 +941,7 @@ def main():
         out["dist"] = {
             "metric": "M ANI-pairs/sec (D=4096, ani_th=85)", "value": pairs * a.steps / ddt / 1e6,
             "unit": "M ANI-pairs/sec", "ms_per_step": ddt / a.steps * 1e3, "scaling": "strong",
+            "cold_start": {"first_step_ms": dist_first_ms, "second_step_ms": dist_second_ms},
             "config": {"workload": "%d ref x %d query clustered synthetic HVs (BASELINE configs[3]), thresholded "
                                    "output" % (rows * world, rows * world), "hits_per_rank": int(found)},
             "exchange": ({"form": "prepared byte operands + control records, all-gathered in %d row chunks per rank, GEMM of chunk c "
