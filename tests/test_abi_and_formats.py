@@ -253,6 +253,12 @@ def test_cli_surface(hg):
     bad = subprocess.run([cli, "sketch", "-p", "/tmp", "-o", "/tmp/x", "-t", "300"], capture_output=True, text=True)
     assert bad.returncode != 0 and "invalid value" in bad.stderr  # -t is u8 (src/utils.rs:54-56)
     assert subprocess.run([cli, "frobnicate"], capture_output=True).returncode != 0
+    # the extension flags: documented, value-checked before any device is touched
+    assert "--pack_layout" in out.stdout and "--shards" in out.stdout and "--top_n" in out.stdout
+    bad = subprocess.run([cli, "sketch", "-p", "/tmp", "-o", "/tmp/x", "--pack_layout", "zip"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "pack_layout" in bad.stderr
+    bad = subprocess.run([cli, "dist", "-r", "/nonexistent", "-q", "/nonexistent", "-o", "/tmp/x", "--shards", "65"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "invalid value" in bad.stderr
 
 
 def test_reader_blocks_equal_whole_file_semantics(hg, orc, tmp_path):
