@@ -18,12 +18,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--leg", default="draft", choices=("clean", "draft", "small"))
 ap.add_argument("--form", default="packed", choices=("packed", "ascii"))
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--small-n", type=int, default=100_000)
+ap.add_argument("--small-len", type=int, default=50_000)
 ap.add_argument("--repeat", type=int, default=50_000, help="length of the draft leg's tandem repeat (171-base unit)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ctx = hg.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-N, L = (100_000, 50_000) if a.leg == "small" else (1000, bench.L_GENOME)
+N, L = (a.small_n, a.small_len) if a.leg == "small" else (1000, bench.L_GENOME)
 stride = (L + 1 + 15) // 16 * 16
 seq = torch.empty(N * stride + 64, dtype=torch.uint8, device=dev)
 ctx.synth_genomes_dev(0, N, L, stride, seq.data_ptr())
