@@ -100,6 +100,7 @@ L += ["", "## the other files", "",
       "| `%s_kmer_packed_isa.*`, `%s_kmer_isa.*` | static instruction budget of `kmer_sample_shared<21, true, PACKED>` by class, per k-mer | `tools/kmer_isa.py %s [packed]` |" % (tag, tag, tag),
       "| `r05_gemm_bounds.md` (+ `r05_l2_bound.txt`, `r05_mfma_shape.txt`, `r05_mfma_loop.txt`, `r05_epilogue_bounds.txt`) | what bounds the three GEMM kernels: the all-L2-hits build, MFMA shapes and operand values, the loop's ingredients, the uneven loader split, the epilogue's removable work | `tools/dist_only.py` on `-DHG_DIST_EXPERIMENT` builds, `tools/mfma_shape_microbench.hip`, `tools/mfma_microbench.hip` |",
       "| `r05_realistic_kernel_stats.txt` | `rocprofv3 --kernel-trace --stats` of the clean / draft-assembly / many-small-genomes sketch step, both resident forms | `tools/profile_realistic.sh r05` |",
+      "| `r05_cli_kernel_stats.txt` | `rocprofv3 --kernel-trace --stats` of the CLI binary itself (`hyper-gen dist` / `search` on two 10 000-sketch files): every kernel an end-to-end comparison launches | `tools/profile_cli.sh r05` |",
       "| `r05_cli_dist.txt` | `hyper-gen dist` / `search` end to end with the tool's own stage timings, at the start and at the end of round 5 | `tools/cli_dist_bench.py` |",
       "| `design_r04_full.md` | DESIGN.md as it stood at the end of round 4 (every round-1..4 narrative) | -- |",
       "| `r04_dist_tile_table.txt` | per-CU timelines of one dist launch (which CU ran which workgroups, from whole-tile stamps + `HW_ID`) with the blockIdx mapping and with the host-built slot -> tile table, and the timings of both | `tools/dist_cu_timeline.py` on a `-DHG_DIST_STAMPS` build, `tools/dist_only.py` |",
