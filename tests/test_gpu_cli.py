@@ -246,6 +246,18 @@ def test_device_unpack_matches_the_host_decoders(orc):
             # a payload that reaches past the buffer is refused, not read
             with pytest.raises(hg.HgError):
                 ctx.hv_unpack_batch_dev(img.data_ptr(), offs[-1] + 8, offs, qs, lays, hv_d, out.data_ptr())
+            # a buffer that itself starts at an odd address with the first payload at offset 0 and the last one ending with
+            # the buffer: the kernel's aligned staging loads may touch neither the bytes in front nor the bytes behind
+            for shift in (1, 2, 3):
+                body = np.concatenate(blobs)[offs[0]:]                      # from the first payload on
+                buf = torch.zeros(shift + body.size, dtype=torch.uint8, device=dev)
+                buf[shift:] = torch.from_numpy(body).to(dev)
+                rel = [o - offs[0] for o in offs]
+                out.fill_(777)
+                ctx.hv_unpack_batch_dev(buf.data_ptr() + shift, body.size, rel, qs, lays, hv_d, out.data_ptr())
+                got = out.cpu().numpy()
+                for i in (0, 1, 62, 63):
+                    assert np.array_equal(got[i], want[i]), (hv_d, shift, i)
 
 
 def test_cli_reads_and_writes_the_non_avx2_payload_layout(tmp_path, orc):
