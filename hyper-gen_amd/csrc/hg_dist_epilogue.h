@@ -337,17 +337,16 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
   // Two ways through the accumulators (in-kernel stamps, DESIGN.md 4.3: with one branch per element and the row words
   // read slab by slab the sweep took 20 000 cycles in a tile without a single candidate and 25 000 more in a tile with
   // the ~1 000 scattered candidates every tile of a real comparison has):
-  //  * LANE MASKS (every thresholded kernel, tiles off the diagonal of a symmetric comparison -- there a candidate is
-  //    "passes phase 0"; the f16 kernels' denominator test of the slab path is only a cheaper filter in front of the
-  //    exact phase 2: 0.69 -> 0.61 ms at 10 000 x 10 000 without it, the windowed kernel 0.85 -> 0.78): every lane shifts the sign of `d - ur - tq` of its 4 * NT elements of a 16-row slab
-  //    into one mask word per slab, no branches.  One barrier makes the waves' candidate counts known to all: a tile
-  //    without candidates ends there; if no list can overflow, every wave then appends its candidates on its own --
-  //    per slab one LDS atomic per lane that has any reserves its run of the list, predicated stores fill it -- and
-  //    the workgroup meets again in flush_all.
-  //  * SLABS (the full-matrix mode, diagonal tiles of a symmetric comparison, tiles whose candidates may overflow a
-  //    list): per 16-row slab the 4 * NT compares are OR-ed on the scalar side into one wave-uniform branch; a slab
-  //    with candidates takes one ballot per element, and a barrier per slab makes the decision to empty the lists
-  //    uniform.
+  //  * LANE MASKS (every thresholded kernel -- there a candidate is "passes phase 0"; the f16 kernels' denominator
+  //    test of the slab path is only a cheaper filter in front of the exact phase 2: 0.69 -> 0.61 ms at
+  //    10 000 x 10 000 without it, the windowed kernel 0.85 -> 0.78): every lane shifts the sign of `d - ur - tq` of
+  //    its 4 * NT elements of a 16-row slab into one mask word per slab, no branches.  One barrier makes the waves'
+  //    candidate counts known to all: a tile without candidates ends there; if no list can overflow, every wave then
+  //    appends its candidates on its own -- per slab one LDS atomic per lane that has any reserves its run of the
+  //    list, predicated stores fill it -- and the workgroup meets again in flush_all.
+  //  * SLABS (the full-matrix mode; tiles of the windowed kernel whose candidates may overflow a list): per 16-row
+  //    slab the 4 * NT compares are OR-ed on the scalar side into one wave-uniform branch; a slab with candidates
+  //    takes one ballot per element, and a barrier per slab makes the decision to empty the lists uniform.
   constexpr bool LANE_MASKS = !FULL;  // (f16 operands: phase 2 is exact, the slab path's denominator test is only a cheaper filter)
   constexpr uint32_t BNC_LANE = 80, BNC_WAVE = 64 * BNC_LANE;  // bytes of a lane's / a wave's bounce buffer (append loop)
   static_assert(NT * 16 <= (int)BNC_LANE, "a lane's slab fits its bounce buffer");
@@ -355,8 +354,15 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
   bool by_lane = false, have_masks = false;  // workgroup-uniform
   uint32_t notpass[LANE_MASKS ? WTM : 1], lane_cands = 0, wave_cands = 0;  // (wave_cands: lane w holds wave w's count)
   if constexpr (LANE_MASKS) {
-    if (!(g.symmetric && row0 + g.ref_off + (uint32_t)BM - 1u >= col0 + g.qry_off)) {
+    {
       have_masks = true;
+      // A tile that straddles the diagonal of a symmetric comparison (the reference's path_r == path_q case, src/dist.rs:243-265)
+      // reports i < j only: its elements with global row >= global column are masked out here like elements that fail the
+      // threshold, and the tile takes the same lists as every other one.  (Until round 5 such tiles -- the dense ones of a
+      // database compared with itself -- went through the per-slab path below.)
+      const bool on_diag = g.symmetric && row0 + g.ref_off + (uint32_t)BM - 1u >= col0 + g.qry_off;  // workgroup-uniform
+      // (global row of the lane's element r = 0 of slab 0) - (global column of its n = 0 element); indices are < 2^31
+      const int32_t diag0 = (int32_t)(row0 + g.ref_off + wm * (uint32_t)(WTM * 16) + fq * 4u) - (int32_t)(col0 + g.qry_off + wn * (uint32_t)(NT * 16) + fr);
       uint32_t lane_total = 0;
       dist_static_for(std::make_integer_sequence<int, WTM>{}, [&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -380,6 +386,16 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
             np = __builtin_amdgcn_alignbit(np, __float_as_uint(margin), 31);  // (np << 1) | sign: element e = r * NT + n at bit 4 NT - 1 - e
           });
         });
+        if (on_diag) {
+          uint32_t ex = 0;  // element e = r * NT + n at bit 4 NT - 1 - e, like np
+          dist_static_for(std::make_integer_sequence<int, 4>{}, [&](auto rc) {
+            dist_static_for(std::make_integer_sequence<int, NT>{}, [&](auto nc) {
+              constexpr int dd = 16 * m + decltype(rc)::value - 16 * decltype(nc)::value;
+              ex = (ex << 1) | (diag0 + dd >= 0 ? 1u : 0u);
+            });
+          });
+          np |= ex;
+        }
         notpass[m] = np;
         lane_total += (uint32_t)__popc(~np & SLAB_BITS);
       });
