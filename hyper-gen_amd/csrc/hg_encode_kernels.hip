@@ -530,12 +530,41 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
   }
 }
 
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// The lane's 64 bit-column counts, held bit-sliced in planes pl[0..P) (count < 2^P), as its 64 outputs 2 * count - n in the
+// AVX2 dimension order, two per dword, + their squares into acc.  Output position p of the 64-block holds bit
+// j = 16 * (p % 4) + p / 4 (src/hd.rs:14-92), so the pair (2 m, 2 m + 1) holds bits (b, b + 16) of ONE 32-bit half of the
+// planes, b = m / 2 of the low half for even m, of the high half for odd m: one shift and one v_and_or per plane moves
+// both bits of plane k to bit k of their 16-bit fields -- 2 P instructions per pair, then packed 16-bit arithmetic
+// (v_pk_lshlrev_b16, v_pk_sub_i16, v_dot2c_i32_i16).  (The generic form below extracts every bit of every plane on its own:
+// 2 900 instructions per lane for P = 14 against 32 (2 P + 3).)
+template <int P>
+__device__ __forceinline__ void expand_pairs_avx2(const uint64_t *pl, uint32_t n, uint32_t (&packed)[32], uint32_t &acc) {
+  const short2v nv = {(short)(uint16_t)n, (short)(uint16_t)n};
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const int t = m >> 1;
+      const uint32_t xw = (m & 1) ? (uint32_t)(pl[k] >> 32) : (uint32_t)pl[k];
+      const uint32_t sh = t >= k ? xw >> (t - k) : xw << (k - t);
+      c |= sh & (0x00010001u << k);
+    }
+    const short2v cv = __builtin_bit_cast(short2v, c), v = cv + cv - nv;  // i16 wrapping, like the reference's i16 sums
+    acc = (uint32_t)__builtin_amdgcn_sdot2(v, v, (int)acc, false);  // (no clamp: wraps like the i32 sum)
+    packed[m] = __builtin_bit_cast(uint32_t, v);
+  }
+}
+
 // One WAVE per genome (four genomes per workgroup) for hash sets of at most HG_ENC_WAVE_MAX hashes -- every
 // ordinary genome.  Lane i owns word i of the random stream (hv_d / 64 <= 64 words per pass), so the 64 bit
 // columns of that word are counted entirely inside the lane: bit-sliced carry-save planes over all hashes,
-// expanded once at the end straight into the output row.  No LDS, no atomics, no barrier; the
+// expanded once at the end straight into the output row.  No atomics, no barrier; the
 // eight-waves-per-genome kernel above (LDS counters, one flush per wave and word) remains for larger sets.
-// (Which genomes it takes: hg_launch_encode.)
+// (Which genomes it takes: hg_launch_encode.)  A genome of a few kbp has 1-30 hashes: there the expansion IS the kernel,
+// and it is specialised on the number of planes the counts can occupy (4 for n < 16).
 __global__ __launch_bounds__(256) void encode_wave_kernel(
     const hg_genome_meta *__restrict__ meta, const uint64_t *__restrict__ hits,
     const uint32_t *__restrict__ ndistinct, uint32_t n_genomes, uint32_t hv_d, uint32_t layout,
@@ -549,63 +578,95 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(
   const uint32_t n_words = hv_d / 64;
   int16_t *__restrict__ out = hv_out + (size_t)g * hv_d;
   const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(hv_out) & 15) == 0);
+  // A lane holds 128 consecutive bytes of the row: stored from the registers, every store instruction of the wave touches 64
+  // different 128-byte lines, 16 bytes of each.  For the shortest sets (n < 16: a genome of a few kbp), where the 8 KB row
+  // IS the genome's cost, the pass goes through the wave's 8 KB of LDS instead -- lane l's q-th 16 bytes at slot
+  // 8 l + (q ^ (l & 7)) -- and leaves with the lanes on consecutive addresses: 400 000 sets of 1-2 hashes 1.16 -> 0.78 ms
+  // (4.2 TB/s of rows).  Taken for n < 64 as well, the kernel needs 181 registers instead of 121 and every larger set pays
+  // (0.34 -> 0.46 ms at 33 hashes, 1.46 -> 2.14 at 3 300): not taken.
+  __shared__ uint4 s_rows[4][512];
+  uint4 *const s_row = s_rows[threadIdx.x >> 6];
+  const bool via_lds = vec_ok && n < 16 && layout == HG_LAYOUT_AVX2;  // wave-uniform
   uint32_t acc = 0;
   for (uint32_t grp = 0; grp * 64 < n_words; ++grp) {
     const uint32_t w = grp * 64 + lane;
     const uint64_t off = (uint64_t)(w + 1) * WY_INC;
-    uint64_t ones = 0, twos = 0, fours = 0, eights = 0;
-    uint64_t hp[HI_PLANES];
+    uint64_t pl[4 + HI_PLANES];  // ones, twos, fours, eights, then the 16s planes
 #pragma unroll
-    for (int p = 0; p < HI_PLANES; ++p) hp[p] = 0;
+    for (int p = 0; p < 4 + HI_PLANES; ++p) pl[p] = 0;
     for (uint32_t b0 = 0; b0 < n; b0 += 16) {
-      uint64_t x[16];
+      // (the sixteen hashes are wave-uniform scalar loads, all issued before the first is used: the index is clamped
+      // instead of the load being skipped, which would put every load of a short set behind its own branch and wait)
+      uint64_t h[16], x[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const uint32_t idx = b0 + t;
-        x[t] = (idx < n) ? wy_word(hs[idx], off) : 0ull;  // hs[idx] is wave-uniform
-      }
+      for (int t = 0; t < 16; ++t) h[t] = hs[b0 + t < n ? b0 + t : n - 1];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) x[t] = (b0 + t < n) ? wy_word(h[t], off) : 0ull;
       uint64_t twosA, twosB, foursA, foursB, eightsA, eightsB, sixteens;
-      csa(twosA, ones, ones, x[0], x[1]);
-      csa(twosB, ones, ones, x[2], x[3]);
-      csa(foursA, twos, twos, twosA, twosB);
-      csa(twosA, ones, ones, x[4], x[5]);
-      csa(twosB, ones, ones, x[6], x[7]);
-      csa(foursB, twos, twos, twosA, twosB);
-      csa(eightsA, fours, fours, foursA, foursB);
-      csa(twosA, ones, ones, x[8], x[9]);
-      csa(twosB, ones, ones, x[10], x[11]);
-      csa(foursA, twos, twos, twosA, twosB);
-      csa(twosA, ones, ones, x[12], x[13]);
-      csa(twosB, ones, ones, x[14], x[15]);
-      csa(foursB, twos, twos, twosA, twosB);
-      csa(eightsB, fours, fours, foursA, foursB);
-      csa(sixteens, eights, eights, eightsA, eightsB);
-      uint64_t carry = sixteens;
+      csa(twosA, pl[0], pl[0], x[0], x[1]);
+      csa(twosB, pl[0], pl[0], x[2], x[3]);
+      csa(foursA, pl[1], pl[1], twosA, twosB);
+      csa(twosA, pl[0], pl[0], x[4], x[5]);
+      csa(twosB, pl[0], pl[0], x[6], x[7]);
+      csa(foursB, pl[1], pl[1], twosA, twosB);
+      csa(eightsA, pl[2], pl[2], foursA, foursB);
+      csa(twosA, pl[0], pl[0], x[8], x[9]);
+      csa(twosB, pl[0], pl[0], x[10], x[11]);
+      csa(foursA, pl[1], pl[1], twosA, twosB);
+      csa(twosA, pl[0], pl[0], x[12], x[13]);
+      csa(twosB, pl[0], pl[0], x[14], x[15]);
+      csa(foursB, pl[1], pl[1], twosA, twosB);
+      csa(eightsB, pl[2], pl[2], foursA, foursB);
+      csa(sixteens, pl[3], pl[3], eightsA, eightsB);
+      if (n >= 16) {  // (wave-uniform; fewer than 16 hashes never carry out of the eights)
+        uint64_t carry = sixteens;
 #pragma unroll
-      for (int p = 0; p < HI_PLANES; ++p) {
-        const uint64_t t = hp[p] & carry;
-        hp[p] ^= carry;
-        carry = t;
+        for (int p = 0; p < HI_PLANES; ++p) {
+          const uint64_t t = pl[4 + p] & carry;
+          pl[4 + p] ^= carry;
+          carry = t;
+        }
       }
     }
-    if (w < n_words) {
-      // output position p of the 64-block holds bit j: scalar layout j = p, AVX2 layout j = 16*(p%4) + p/4
+    if (via_lds) {  // wave-uniform
+      if (w < n_words) {
+        uint32_t packed[32];
+        expand_pairs_avx2<4>(pl, n, packed, acc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          s_row[8 * lane + ((uint32_t)q ^ (lane & 7u))] = make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+      }
+      // (the wave's own LDS operations complete in order; the fences keep the compiler from moving them across each other)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t pass_words = n_words - grp * 64 < 64u ? n_words - grp * 64 : 64u;
+      uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)grp * 64 * 64);
+#pragma unroll 2
+      for (uint32_t sidx = 0; sidx < 8; ++sidx) {
+        const uint32_t i = sidx * 64 + lane, l = i >> 3, q = i & 7u;
+        if (l < pass_words) dst[i] = s_row[8 * l + (q ^ (l & 7u))];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next pass writes the same slots)
+      __builtin_amdgcn_wave_barrier();
+    } else if (w < n_words) {
       uint32_t packed[32];
+      if (layout == HG_LAYOUT_AVX2) {  // wave-uniform, and so is the choice of the plane count
+        if (n < 16) expand_pairs_avx2<4>(pl, n, packed, acc);
+        else if (n < 64) expand_pairs_avx2<6>(pl, n, packed, acc);
+        else if (n < 256) expand_pairs_avx2<8>(pl, n, packed, acc);
+        else expand_pairs_avx2<4 + HI_PLANES>(pl, n, packed, acc);
+      } else {  // scalar order: output position p holds bit p
 #pragma unroll
-      for (int p = 0; p < 64; ++p) {
-        const int js = p, ja = 16 * (p & 3) + (p >> 2);
-        auto count = [&](int j) {
-          uint32_t c = (uint32_t)((ones >> j) & 1) | ((uint32_t)((twos >> j) & 1) << 1) | ((uint32_t)((fours >> j) & 1) << 2) |
-                       ((uint32_t)((eights >> j) & 1) << 3);
+        for (int p = 0; p < 64; ++p) {
+          uint32_t c = 0;
 #pragma unroll
-          for (int q = 0; q < HI_PLANES; ++q) c |= (uint32_t)((hp[q] >> j) & 1) << (4 + q);
-          return c;
-        };
-        const uint32_t c = (layout == HG_LAYOUT_AVX2) ? count(ja) : count(js);
-        const int16_t v = (int16_t)(uint16_t)(2u * c - n);
-        acc += (uint32_t)((int32_t)v * (int32_t)v);
-        if (p & 1) packed[p >> 1] |= (uint32_t)(uint16_t)v << 16;
-        else packed[p >> 1] = (uint32_t)(uint16_t)v;
+          for (int q = 0; q < 4 + HI_PLANES; ++q) c |= (uint32_t)((pl[q] >> p) & 1) << q;
+          const int16_t v = (int16_t)(uint16_t)(2u * c - n);
+          acc += (uint32_t)((int32_t)v * (int32_t)v);
+          if (p & 1) packed[p >> 1] |= (uint32_t)(uint16_t)v << 16;
+          else packed[p >> 1] = (uint32_t)(uint16_t)v;
+        }
       }
       int16_t *dst = out + (size_t)w * 64;
       if (vec_ok) {

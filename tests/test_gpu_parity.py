@@ -183,6 +183,37 @@ def test_hv_encode_other_dims(ctx, orc, hg, d):
     assert (hv == want).all() and n2 == orc.hv_norm2(want)
 
 
+@pytest.mark.parametrize("d,layout", [(4096, "avx2"), (8192, "avx2"), (1024, "avx2"), (4096, "scalar"), (1000, "avx2")])
+def test_wave_encode_every_plane_count_in_a_large_batch(ctx, orc, hg, d, layout):
+    """A batch of >= 8 192 genomes sends every hash set of up to HG_ENC_WAVE_MAX hashes through the one-wave-per-genome
+    encoder, whose expansion is specialised on the set size (< 16 through LDS, < 64, < 256, larger): short sequences at
+    scaled = 1 (every k-mer is a hash) give sets of 0 .. ~2 900 hashes; each size class is compared with the oracle."""
+    rng = np.random.default_rng(d + len(layout))
+    n = 8300
+    lens = rng.integers(0, 60, n)  # most sets are tiny (0 .. 40 hashes)
+    lens[::9] = rng.integers(21, 120, lens[::9].size)
+    lens[::37] = rng.integers(200, 400, lens[::37].size)
+    lens[::211] = rng.integers(400, 3000, lens[::211].size)
+    lens[:6] = (0, 20, 21, 36, 37, 300)  # 0, 0, 1, 16, 17 hashes
+    seqs = [rand_seq(rng, int(L)) for L in lens]
+    lay, olay = (hg.LAYOUT_AVX2, orc.LAYOUT_AVX2) if layout == "avx2" else (hg.LAYOUT_SCALAR, orc.LAYOUT_SCALAR)
+    p = hg.default_params(scaled=1, hv_d=d, hv_layout=lay)
+    hv, n2, nh = ctx.sketch_batch(seqs, p)
+    classes = {0: 0, 1: 0, 2: 0, 3: 0}
+    checked = 0
+    for i in list(range(40)) + list(range(40, n, 23)) + list(range(0, n, 211)):
+        w_hv, w_n2, w_nh = orc.sketch_genome(seqs[i], scaled=1, hv_d=d, layout=olay)
+        assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (i, int(lens[i]), w_nh)
+        classes[0 if w_nh < 16 else 1 if w_nh < 64 else 2 if w_nh < 256 else 3] += 1
+        checked += 1
+    assert all(v >= 5 for v in classes.values()), classes
+    # every row: the norm is that of the row written, and a set of nh hashes gives entries of nh's parity within +-nh
+    hv32 = hv.astype(np.int64)
+    assert ((hv32 * hv32).sum(axis=1).astype(np.int32) == n2).all()
+    whole = d // 64 * 64
+    assert (np.abs(hv32[:, :whole]).max(axis=1) <= nh).all() and ((hv32[:, :whole] - nh[:, None]) % 2 == 0).all()
+
+
 def test_hv_encode_large_set_wraps_like_i16(ctx, orc, hg):
     rng = np.random.default_rng(11)
     hs = np.unique(rng.integers(0, 2**63, 40000, dtype=np.uint64))  # n > 32767: -(n as i16) wraps
