@@ -349,6 +349,60 @@ def test_config2_sketch_10k_x_5mbp_resident_and_sharded(orc):
         ctx.close()
 
 
+def test_one_genome_of_more_than_2_to_32_bases():
+    """Positions inside one genome are 64-bit (the reference's are usize): a 4.3 Gbp sequence -- a large plant or amphibian
+    chromosome set -- is sketched whole, ASCII- and 2-bit-resident, and as three overlapping pieces given as three genomes.
+    With k = 31 no sampled k-mer occurs twice in random sequence, so the pieces' hash sets are disjoint: the hash counts and
+    the (wrapping int16) hypervectors of the pieces must add up to the whole genome's.  A position truncated to 32 bits
+    anywhere on the path would make the whole differ from the pieces, which all stay below 2^32."""
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    K = 31
+    n_bps = (1 << 32) + 3_000_123
+    ctx = hg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        seq = torch.empty(n_bps + 64, dtype=torch.uint8, device=dev)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(20)
+        step = 1 << 28
+        for a in range(0, n_bps, step):
+            m = min(step, n_bps - a)
+            seq[a:a + m] = lut[torch.randint(0, 4, (m,), generator=gen, device=dev, dtype=torch.int32).long()]
+        # not-a-base runs: one across the 2^32 boundary, one behind it, lower case in front of it
+        seq[(1 << 32) - 5:(1 << 32) + 9] = ord("N")
+        seq[(1 << 32) + 1_000_000:(1 << 32) + 1_000_040] = ord("n")
+        seq[(1 << 32) - 2_000:(1 << 32) - 1_000] += 32
+        torch.cuda.synchronize()
+        p = hg.default_params(ksize=K)
+        cuts = [0, (1 << 31) + 76, (1 << 32) - 1_000_000, n_bps]  # piece starts are multiples of 4
+        offs = np.array([0] + cuts[:-1], np.uint64)
+        lens = np.array([n_bps] + [min(n_bps, cuts[i + 1] + K - 1) - cuts[i] for i in range(3)], np.uint64)
+        hv = torch.empty((4, D), dtype=torch.int16, device=dev)
+        n2 = torch.empty(4, dtype=torch.int32, device=dev)
+        nh = torch.empty(4, dtype=torch.int32, device=dev)
+        ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+        torch.cuda.synchronize()
+        nhc = nh.cpu().numpy().astype(np.int64)
+        assert abs(nhc[0] - n_bps / 1500) < 6 * (n_bps / 1500) ** 0.5  # FracMinHash keeps one k-mer in `scaled`
+        assert nhc[0] == nhc[1:].sum(), nhc
+        assert torch.equal(hv[1:].int().sum(0).to(torch.int16), hv[0])
+        assert torch.equal((hv.int() ** 2).sum(1).int(), n2)
+        # the same genome 2-bit resident (hg_pack2 on the device): the same sketch
+        blob = torch.empty(hg.lib().hg_pack2_size(n_bps) + 64, dtype=torch.uint8, device=dev)
+        ctx.pack2_dev(seq.data_ptr(), n_bps, blob.data_ptr())
+        hv_p = torch.empty((1, D), dtype=torch.int16, device=dev)
+        n2_p = torch.empty(1, dtype=torch.int32, device=dev)
+        nh_p = torch.empty(1, dtype=torch.int32, device=dev)
+        ctx.sketch_batch_dev_packed(blob.data_ptr(), np.zeros(1, np.uint64), np.array([n_bps], np.uint64), p, hv_p.data_ptr(),
+                                    n2_p.data_ptr(), nh_p.data_ptr())
+        torch.cuda.synchronize()
+        assert int(nh_p[0]) == nhc[0] and int(n2_p[0]) == int(n2[0]) and torch.equal(hv_p[0], hv[0])
+    finally:
+        ctx.close()
+
+
 def test_config4_hamming_search_50k_refs_fullsize(orc):
     """BASELINE configs[4] at full size: 50 000 bit-packed D = 16384 references x 1 000 queries.  The hit list is
     compared (a) with the CPU oracle's popcount matrix on a 2 000 x 1 000 slice, (b) for ALL 5*10^7 pairs with an
