@@ -83,7 +83,7 @@ def main():
 
     def log(m):
         print(m, flush=True)
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hyper-gen_amd", "hyper-gen")
+    exe = os.environ.get("HYPERGEN_CLI") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hyper-gen_amd", "hyper-gen")
     d = tempfile.mkdtemp(prefix="hgdist_", dir="/tmp")
     out = {"n": a.n, "threads": a.threads}
     try:
