@@ -53,6 +53,37 @@ def test_three_way_hash_sets(orc, g, L, k, scaled, canon, slots):
     assert got.size == want.size and (got == want).all(), "product vs oracle"
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("case", range(40))
+def test_three_way_random_cases(orc, case):
+    """Random k, sampling rate, seed, strand mode and contamination (N runs, lower case, IUPAC and other bytes, record
+    separators at random places): the reference's own kernel, the oracle and the product must give the same hash set."""
+    import hypergen_amd as hg
+    rng = np.random.default_rng(31_000 + case)
+    L = int(rng.integers(600, 40_000))
+    k = int(rng.integers(9, 33))
+    scaled = int(rng.choice([1, 2, 3, 7, 20, 50, 200]))
+    seed = int(rng.integers(0, 2**63))
+    canon = bool(rng.integers(0, 2))
+    seq = orc.synth_genome(500 + case, L).copy()
+    for _ in range(int(rng.integers(0, 6))):  # runs of not-a-base bytes
+        a = int(rng.integers(1, L))
+        seq[a:a + int(rng.integers(1, 40))] = int(rng.choice(list(b"NnRYKMSWryX-*.")))
+    for _ in range(int(rng.integers(0, 4))):  # soft-masked stretches
+        a = int(rng.integers(1, L))
+        b = min(L + 1, a + int(rng.integers(1, 3000)))
+        seq[a:b] = np.char.lower(seq[a:b].view("S1")).view(np.uint8)
+    seq[rng.choice(L, int(rng.integers(0, 20)), replace=False) + 1] = ord("N")  # record separators / single N's
+    ref = run_ref(seq, k, scaled, seed=seed, canonical=canon, slots=520)
+    want = orc.kmer_hash_sample(seq, k, scaled, seed, canon)
+    with hg.Context(0) as ctx:
+        for form in ("ascii", "packed"):
+            ctx.set_debug("kmer_input", form)
+            got = ctx.kmer_hash_sample(seq, k, scaled, seed, canon)
+            assert got.size == want.size and (got == want).all(), ("product vs oracle", form, k, scaled, canon, L)
+    assert ref.size == want.size and (ref == want).all(), ("reference kernel vs oracle", k, scaled, canon, L)
+
+
 def _g2_cases():
     from conftest import golden
     return golden("g2_ref_kernel.json")
