@@ -48,11 +48,12 @@ def parse():
     ap.add_argument("--hostfed-genomes", type=int, default=256, help="genomes of the host-fed (PCIe) leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realistic", action="store_true", help="skip the draft-assembly and many-small-genomes legs")
+    ap.add_argument("--cli-sketch-files", type=int, default=8192, help="files of the cli leg's `hyper-gen sketch` run (64 distinct 5 Mbp genomes + links; 0 = skip)")
     ap.add_argument("--no-dist-variants", action="store_true", help="skip dist.two_sets / dist.symmetric (profiling runs: their "
                                                                      "launches would enter the dist kernel's per-launch averages)")
     ap.add_argument("--small-genomes", type=int, default=100000, help="genomes of the many-small-genomes leg (50 kbp each)")
     ap.add_argument("--no-cli", action="store_true", help="skip the `cli` object (tools/cli_dist_bench.py as a child process: end-to-end "
-                                                           "hyper-gen dist / search at --dist-n sketches; N = 1 only, ~8 s)")
+                                                           "hyper-gen dist / search at --dist-n sketches and hyper-gen sketch over --cli-sketch-files FASTA files; N = 1 only, ~12 s)")
     ap.add_argument("--cli", action="store_true", help=argparse.SUPPRESS)  # (the leg is on by default since round 5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank logic on a box with fewer GPUs than ranks)")
@@ -1167,7 +1168,8 @@ def main():
         import subprocess
         torch.cuda.synchronize()
         try:  # (a measurement beside the line, never a reason to lose the line)
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_dist_bench.py"), "--n", str(a.dist_n)],
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_dist_bench.py"), "--n", str(a.dist_n),
+                                "--sketch-files", str(a.cli_sketch_files)],
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr.decode()[-1500:])
@@ -1175,6 +1177,10 @@ def main():
             log("cli: dist -r A -q A %.2f s, dist -r A -q B %.2f s, search %.2f s (wall, %d sketches)" % (
                 out["cli"]["dist_symmetric"]["wall_s"], out["cli"]["dist_two_files"]["wall_s"],
                 [v for k, v in out["cli"].items() if k.startswith("search")][0]["wall_s"], a.dist_n))
+            if "sketch" in out["cli"]:
+                log("cli: sketch -p DIR %.2f s wall for %d FASTA files of 5 Mbp = %.0f files/s (%.1f GB/s of FASTA, process start included)" % (
+                    out["cli"]["sketch"]["wall_s"], out["cli"]["sketch"]["files"], out["cli"]["sketch"]["files_per_s"],
+                    out["cli"]["sketch"]["fasta_gb_per_s"]))
         except Exception as e:  # pragma: no cover
             out["cli"] = {"error": repr(e)[:2000]}
             log("cli leg failed: %r" % (e,))

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--genomes", "16", "--dist-n", "1024", "--hamming-refs", "4096", "--cpu-seconds", "0.5", "--small-genomes", "3000"],
+                        "--genomes", "16", "--dist-n", "1024", "--hamming-refs", "4096", "--cpu-seconds", "0.5", "--small-genomes", "3000",
+                        "--cli-sketch-files", "48"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -42,6 +43,7 @@ def test_bench_json_contract():
     assert "error" not in c, c
     assert c["dist_symmetric"]["tsv_lines"] == d["symmetric"]["hits"] and c["dist_two_files"]["tsv_lines"] == d["two_sets"]["hits"]
     assert c["dist_two_files"]["wall_s"] > 0 and any(k.startswith("search") for k in c)
+    assert c["sketch"]["files"] == 48 and c["sketch"]["files_per_s"] > 0 and c["sketch"]["sketch_file_mb"] > 0.1
     assert j["parity_gate"]["status"] == "passed" and j["parity_gate"]["ani_two_sets_hits_checked"] > 0
 
 
