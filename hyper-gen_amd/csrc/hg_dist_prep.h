@@ -425,12 +425,13 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
   uint32_t par = 0, bad = 0;
   const bool vec_ok = (hv_d % 8 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
   const uint32_t nchunks = (kp8 + 511) / 512;
-  for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {  // four 16-byte loads in flight per lane
-    uint32_t d0s[4];
-    uint4 raw[4];
-    bool vec[4];
+  constexpr int INFL = 4;  // 16-byte loads in flight per lane (8 -- a whole row of 4 096 dimensions -- costs registers: 27 -> 30 us for 10 000 rows)
+  for (uint32_t q0 = 0; q0 < nchunks; q0 += INFL) {
+    uint32_t d0s[INFL];
+    uint4 raw[INFL];
+    bool vec[INFL];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < INFL; ++t) {
       // chunk order rotated by the row index: a power-of-two row pitch otherwise sends every wave to the same channels
       d0s[t] = q0 + t < nchunks ? ((q0 + t + row) % nchunks) * 512 + lane * 8 : kp8;
       vec[t] = vec_ok && d0s[t] + 8 <= hv_d;
@@ -438,23 +439,54 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const int16_t *__restrict_
       if (vec[t]) raw[t] = *reinterpret_cast<const uint4 *>(src + d0s[t]);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < INFL; ++t) {
       const uint32_t d0 = d0s[t];
       if (d0 >= kp8) continue;
-      int32_t x[8];
       if (vec[t]) {
+        // Eight real values as four dwords: packed 16-bit arithmetic, two values per instruction (v_pk_add_u16, v_pk_ashrrev_i16,
+        // v_pk_max_i16 / v_pk_min_i16, v_pk_sub_i16, v_dot2c_i32_i16), one test for clamped entries per chunk.  (Element by
+        // element this loop was ~19 instructions per value and the kernel, 10 waves per SIMD deep, was bound by them: 31 us for
+        // 10 000 rows of which ~20 were issue time.)  x + e may wrap at 32 767: the residual then exceeds a byte and the row
+        // vetoes the path, which is what the true value does as well.
         const uint32_t w[4] = {raw[t].x, raw[t].y, raw[t].z, raw[t].w};
+        const short2v ev = {(short)e, (short)e}, hi = {127, 127}, lo = {-127, -127}, one = {1, 1};
+        const uint32_t x0p = (uint32_t)(uint16_t)x0 * 0x00010001u;
+        uint32_t ab[4], ball = 0;
+        short2v bv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[2 * i] = (int16_t)(w[i] & 0xffffu), x[2 * i + 1] = (int16_t)(w[i] >> 16);
-      } else {
+        for (int i = 0; i < 4; ++i) {
+          par |= (w[i] ^ x0p) & 0x00010001u;
+          const short2v cc = (__builtin_bit_cast(short2v, w[i]) + ev) >> 1;
+          S = __builtin_amdgcn_sdot2(cc, one, S, false);
+          const short2v a = __builtin_elementwise_min(__builtin_elementwise_max(cc, lo), hi);
+          bv[i] = cc - a;
+          ball |= __builtin_bit_cast(uint32_t, bv[i]);
+          ab[i] = __builtin_bit_cast(uint32_t, a);
+        }
+        if (ball != 0) {  // rare: ~1e-5 of the entries at 3 350 hashes, one in 10^3 at 6 000
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = d0 + i < hv_d ? (int32_t)src[d0 + i] : -e;  // padding: c = 0
+          for (int i = 0; i < 8; ++i) {
+            const int32_t b = bv[i >> 1][i & 1];
+            if (b != 0) {
+              if (b > 127 || b < -127) bad |= 4u;
+              const uint32_t idx = atomicAdd(&s_n[wv], 1u);
+              if (idx < I8_ROW_ENT_MAX) s_ent[wv][idx] = (d0 + i) | ((uint32_t)(uint8_t)(int8_t)b << 16);
+            }
+          }
+        }
+        // low bytes of the eight clamped values: bytes 0 and 2 of every pair
+        *reinterpret_cast<uint2 *>(out_a + (size_t)row * ldk8 + d0) =
+            make_uint2(__builtin_amdgcn_perm(ab[1], ab[0], 0x06040200u), __builtin_amdgcn_perm(ab[3], ab[2], 0x06040200u));
+        continue;
       }
+      // the ragged end of a row (hv_d % 8 != 0), a misaligned matrix, the zero padding up to the K-step: value by value
+      int32_t x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = d0 + i < hv_d ? (int32_t)src[d0 + i] : -e;  // padding: c = 0
       uint32_t pk[2] = {0, 0};
-      const bool all_real = d0 + 8 <= hv_d;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        par |= (all_real || d0 + i < hv_d) ? (uint32_t)((x[i] ^ x0) & 1) : 0u;
+        par |= d0 + i < hv_d ? (uint32_t)((x[i] ^ x0) & 1) : 0u;
         const int32_t cc = (x[i] + e) >> 1;
         S += cc;
         const int32_t a = cc > 127 ? 127 : (cc < -127 ? -127 : cc), b = cc - a;
