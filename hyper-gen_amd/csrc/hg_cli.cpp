@@ -725,9 +725,9 @@ int run_search(const Cli &c) {
 
 int main(int argc, char **argv) {
   const Cli c = parse(argc, argv);
-  const int rc = c.mode == "sketch" ? run_sketch(c) : c.mode == "dist" ? run_dist(c) : run_search(c);
-  // The output files are written and closed and the devices released: leave without the runtime's exit handlers (unloading
-  // its code objects and tearing down its queues costs a `dist` of 10 000 x 10 000 sketches 20-40 ms of its ~150).
-  std::fflush(nullptr);
-  _exit(rc);
+  // (a normal return: leaving through _exit once the outputs are closed saves the runtime's exit handlers -- 20-40 ms of a
+  // 10 000 x 10 000 dist -- but those handlers are also where rocprofv3 and other tools write what they collected)
+  if (c.mode == "sketch") return run_sketch(c);
+  if (c.mode == "dist") return run_dist(c);
+  return run_search(c);
 }
