@@ -242,8 +242,11 @@ hg_status hg_ensure(hg_ctx *c, hg_ctx::Buf &b, size_t bytes) {
 }
 
 namespace {
-__global__ void publish_words_kernel(const uint32_t *__restrict__ src, uint32_t n, volatile uint32_t *dst, uint32_t seq) {
+// zero_n > 0: the first zero_n device words (<= 64) are cleared behind the copy -- the call's counters are ready for the next
+// call without a fill command of their own in the stream
+__global__ void publish_words_kernel(uint32_t *__restrict__ src, uint32_t n, volatile uint32_t *dst, uint32_t seq, uint32_t zero_n) {
   if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+  if (threadIdx.x < zero_n) src[threadIdx.x] = 0u;
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -253,8 +256,8 @@ __global__ void publish_words_kernel(const uint32_t *__restrict__ src, uint32_t 
 }
 }  // namespace
 
-hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const uint32_t **out) {
-  if (n > 16) return hg_fail(c, HG_ERR_INVALID, "hg_publish_words: at most 16 words");
+hg_status hg_publish_words(hg_ctx *c, uint32_t *d_words, uint32_t n, const uint32_t **out, uint32_t zero_n) {
+  if (n > 16 || zero_n > 64) return hg_fail(c, HG_ERR_INVALID, "hg_publish_words: at most 16 words");
   if (!c->h_res) {
     void *p = nullptr;
     // (coherent = fine-grained: the device's writes and the fence between words and sequence number are seen by the polling host)
@@ -264,7 +267,7 @@ hg_status hg_publish_words(hg_ctx *c, const uint32_t *d_words, uint32_t n, const
     std::memset(c->h_res, 0, 32 * sizeof(uint32_t));
   }
   const uint32_t seq = ++c->res_seq ? c->res_seq : ++c->res_seq;  // never 0
-  hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, c->stream, d_words, n, c->h_res, seq);
+  hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, c->stream, d_words, n, c->h_res, seq, zero_n);
   HG_HIP(c, hipGetLastError());
   volatile uint32_t *flag = c->h_res + 16;
   // Poll for a bounded time (the common case: a sub-millisecond GEMM, the word arrives within the poll), then hand the

@@ -120,7 +120,9 @@ static hg_status dist_block_once(hg_ctx *c, const int16_t *d_ref_hv, const int32
   int spec_cover = -1;
   if ((s = hg_run_dist(c, a, d_count + 1, &spec_cover)) != HG_OK) return s;
   const uint32_t *h_res = nullptr;
-  if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
+  // (the publishing kernel clears the control words behind the copy: they are ready for a second pass, or for the next call)
+  if ((s = hg_publish_words(c, d_count, 16, &h_res, 16)) != HG_OK) return s;
+  c->misc_zeroed = d_count;
   const bool i8_tried = h_res[9] != 0;  // the i8 prepass wrote its K-step count
   if (i8_tried && h_res[8] != 1u) c->i8_skip = 16;  // vetoed on the device: f16 ran; do not probe again for a while
   if (h_res[8] == 1u) {
@@ -140,13 +142,13 @@ static hg_status dist_block_once(hg_ctx *c, const int16_t *d_ref_hv, const int32
   // no guarded launch applied (or the raw f16 chain was not queued behind a trusted i8 / centred attempt that failed after
   // all): statistics-driven schedule
   if (h_res[8] == 0u && (spec_cover == -2 || (spec_cover >= 0 && (int)h_res[1] > spec_cover))) {
-    HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
+    c->misc_zeroed = nullptr;
     if ((s = hg_run_dist(c, a)) != HG_OK) return s;
-    if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
+    if ((s = hg_publish_words(c, d_count, 16, &h_res, 16)) != HG_OK) return s;
+    c->misc_zeroed = d_count;
   }
   const uint32_t found = h_res[0];
   *n_out = found;
-  if (hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
   return HG_OK;
 }
@@ -232,11 +234,11 @@ static hg_status dist_block_ops_once(hg_ctx *c, const uint8_t *d_ref_ops, const 
   int spec = -1;
   if ((s = hg_run_dist(c, a, d_count + 1, &spec)) != HG_OK) return s;
   const uint32_t *h_res = nullptr;
-  if ((s = hg_publish_words(c, d_count, 16, &h_res)) != HG_OK) return s;
+  if ((s = hg_publish_words(c, d_count, 16, &h_res, 16)) != HG_OK) return s;
+  c->misc_zeroed = d_count;
   const bool valid = h_res[8] == 1u;
   const uint32_t found = h_res[0];
   c->i8_sig_ref = c->i8_sig_qry = nullptr;
-  if (hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (!valid) {
     // an owner's rows, or this call's query rows, do not fit the byte-operand scheme (mixed parity, a residual beyond a
     // byte, more clamped entries than a row's slots): nothing was reported; the caller gathers the i16 rows instead

@@ -253,10 +253,10 @@ static hg_status hamming_block_once(hg_ctx *c, const uint32_t *d_ref_bits, size_
                    cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap, max_dist, (uint32_t)ref_off, (uint32_t)qry_off);
   if (s != HG_OK) return s;
   const uint32_t *h_res = nullptr;
-  if ((s = hg_publish_words(c, d_count, 1, &h_res)) != HG_OK) return s;
+  if ((s = hg_publish_words(c, d_count, 1, &h_res, 16)) != HG_OK) return s;
+  c->misc_zeroed = d_count;
   const uint32_t found = h_res[0];
   *n_out = found;
-  if (hipMemsetAsync(d_count, 0, 64, c->stream) == hipSuccess) c->misc_zeroed = d_count;
   if (found > cap) return hg_fail(c, HG_ERR_CAPACITY, "hit buffer too small");
   return HG_OK;
 }

@@ -120,7 +120,7 @@ hg_status hg_ensure_pinned(hg_ctx *ctx, size_t bytes);
 // n <= 16 words of device memory into the ctx's page-locked result block and raises a sequence number behind them;
 // the host polls that word (and the stream's own completion as a fallback) instead of paying a D2H copy command and a
 // stream synchronisation.  On return everything queued on the stream before the call has finished.  *out -> the n words.
-hg_status hg_publish_words(hg_ctx *ctx, const uint32_t *d_words, uint32_t n, const uint32_t **out);
+hg_status hg_publish_words(hg_ctx *ctx, uint32_t *d_words, uint32_t n, const uint32_t **out, uint32_t zero_n = 0);
 
 // RAII bracket: records events around the launches issued while it is alive (no-op unless
 // timing is enabled).
