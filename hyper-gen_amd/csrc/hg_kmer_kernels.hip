@@ -166,9 +166,18 @@ constexpr int WG = 256;                              // lanes per workgroup
 constexpr int GEN_STARTS = 32;                       // long-k kernel: starts per lane
 constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 
+// One hit straight to the genome's list.  The lanes of a wave that arrive here together (a divergent branch: g is
+// wave-uniform) reserve their slots with ONE atomic: the counters of a genome are one address for all of its work items,
+// and per-lane atomics on it serialise at ~3.5 ns each (1 000 x 5 Mbp at scaled = 50, when every work item overflowed its
+// LDS list by 300 hits: 194 ms instead of 9).
 __device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm, uint32_t g,
                                            uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
-  uint32_t idx = atomicAdd(&cnt[g], 1u);  // hipcc folds this into one atomic per wave
+  const unsigned long long m = __ballot(1);  // the lanes in this branch
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&cnt[g], (uint32_t)__popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);  // (the first active lane is the one that asked)
+  const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   if (idx < gm.hit_cap) hits[gm.hit_off + idx] = h;
 }
 
@@ -189,17 +198,33 @@ __device__ __forceinline__ void stage_hit(HitStage &st, uint64_t h, const hg_gen
   if (idx < HIT_STAGE) st.h[idx] = h;
   else append_hit(h, gm, g, hits, cnt);
 }
+// AGAIN: the list is emptied between two tiles and filled again afterwards (the caller's next barrier lies between this
+// call's reads and the next writes)
+template <bool AGAIN = false>
 __device__ __forceinline__ void flush_hits(HitStage &st, const hg_genome_meta &gm, uint32_t g,
                                            uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
   __syncthreads();
   const uint32_t n = st.n < HIT_STAGE ? st.n : HIT_STAGE;
   if (threadIdx.x == 0 && n) st.base = atomicAdd(&cnt[g], n);
   __syncthreads();
+  if (AGAIN && threadIdx.x == 0) st.n = 0;  // (every lane has read it)
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t idx = st.base + i;
     if (idx < gm.hit_cap) hits[gm.hit_off + idx] = st.h[i];
   }
 }
+// Between two tiles (behind the barrier that ends a tile: st.n is final and the same for every lane): a list that is a
+// quarter full goes out now.  At the default sampling rate a work item collects ~18 hits and never gets here; a denser
+// sketch (scaled = 100: 270 hits per item) used to overflow the list and pay a global atomic per hit.
+__device__ __forceinline__ void flush_hits_if_filling(HitStage &st, const hg_genome_meta &gm, uint32_t g,
+                                                      uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+  if (st.n >= HIT_STAGE / 4) flush_hits<true>(st, gm, g, hits, cnt);  // workgroup-uniform
+}
+// Whether the sampling rate can fill a quarter of the list within one work item at all (a kernel argument: the test
+// between the tiles is a scalar branch that the default rate, 1 in 1 500, never takes -- the LDS read of the fill level
+// cost the headline 0.2 %): more than ~32 expected hits per 27 000 starts, i.e. scaled < 850.  (A repeat that piles more hits than that into an
+// item of a sparse sketch overflows the list as before; those hits go out one atomic per wave.)
+__device__ __forceinline__ bool dense_sampling(uint64_t threshold) { return threshold > (~0ull / 850ull); }
 
 // =========================================================================================
 // shared-image kernel: compile-time k in [1, 21], both strand modes
@@ -808,6 +833,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     }
     if (!(HG_KS_EXP & 1)) __syncthreads();  // every read of the images is done: the next tile may overwrite them
     if (tid == 0) s_dirty[par] = 0u;  // (raised again in two tiles' time at the earliest, behind the next tile's barriers)
+    if (dense_sampling(threshold)) flush_hits_if_filling(stage, gm, g, hits, cnt);
   }
   flush_hits(stage, gm, g, hits, cnt);
 }
@@ -904,6 +930,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
 
   for (uint64_t tile0 = item_start; tile0 < item_start + GEN_ITEM && tile0 < n_starts; tile0 += LONG_TILE) {
     __syncthreads();  // previous tile's readers are done
+    if (dense_sampling(threshold)) flush_hits_if_filling(stage, gm, g, hits, cnt);
     for (uint32_t i = tid; i < LONG_DW; i += WG) s_f[i] = 0u, s_rc[i] = 0u;
     __syncthreads();
     // ---- stage: 6 consecutive bytes per lane

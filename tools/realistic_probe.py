@@ -20,6 +20,7 @@ ap.add_argument("--form", default="packed", choices=("packed", "ascii"))
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--small-n", type=int, default=100_000)
 ap.add_argument("--small-len", type=int, default=50_000)
+ap.add_argument("--scaled", type=int, default=1500, help="FracMinHash sampling rate 1/scaled (denser sketches: more hits per work item)")
 ap.add_argument("--repeat", type=int, default=50_000, help="length of the draft leg's tandem repeat (171-base unit)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -36,7 +37,7 @@ bsz = hg.lib().hg_pack2_size(L + 1)
 boffs = np.arange(N, dtype=np.uint64) * bsz
 blobs = torch.empty(N * bsz + 64, dtype=torch.uint8, device=dev)
 ctx.pack2_batch_dev(seq.data_ptr(), offs, lens, blobs.data_ptr(), boffs)
-p = hg.default_params()
+p = hg.default_params(scaled=a.scaled)
 hv = torch.empty((N, 4096), dtype=torch.int16, device=dev)
 n2, nh = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
 
