@@ -82,9 +82,12 @@ hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, si
 // h_cnt: raw per-genome counters (host copy).  Synchronises the stream when it had work to do.
 hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt, size_t n, uint64_t threshold,
                           uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_nd) {
-  constexpr uint32_t TARGET = 2048, MAX_BUCKETS = 8192;  // keys per bucket aimed at / buckets per genome
+  // keys per bucket aimed at (512-1 024 land in one; the sort's LDS is sized for four times that, hg_launch_sort_large) /
+  // buckets per genome
+  constexpr uint32_t TARGET = 1024, MAX_BUCKETS = 16384;
   std::vector<hg_bucket_job> jobs;
   std::vector<uint32_t> chunk_job, bucket_job, inplace;
+  uint32_t cap_keys = 4 * TARGET;  // keys the bucket sort's LDS is sized for: four times what a bucket is expected to hold
   for (size_t g = 0; g < n; ++g) {
     const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
     if (cnt <= HG_SORT_LDS_MAX_KEYS) continue;
@@ -96,6 +99,7 @@ hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt,
       inplace.push_back((uint32_t)g);
       continue;
     }
+    cap_keys = std::max<uint32_t>(cap_keys, 4 * ((cnt + P - 1) / P));  // (a genome with more keys than MAX_BUCKETS * TARGET fills its buckets further)
     hg_bucket_job j{};
     j.hit_off = pl.meta[g].hit_off, j.n = cnt, j.P = P, j.genome = (uint32_t)g;
     // bucket(h) = floor(h * P / threshold) for h < threshold, as a multiply-high by ceil(P * 2^64 / threshold)
@@ -127,7 +131,8 @@ hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt,
     {
       hg_timed tm(c, HG_T_SORT);
       HG_HIP(c, hg_launch_sort_large(c->stream, d_jobs, (uint32_t)jobs.size(), d_chunk, (uint32_t)chunk_job.size(), d_bucket,
-                                     (uint32_t)bucket_job.size(), d_bk, d_hits, static_cast<uint64_t *>(c->w_hits2.p), d_nd));
+                                     (uint32_t)bucket_job.size(), d_bk, d_hits, static_cast<uint64_t *>(c->w_hits2.p), d_nd,
+                                     c->dbg_sort_buckets ? HG_SORT_LDS_MAX_KEYS : cap_keys));
     }
     HG_HIP(c, hipMemcpyAsync(fail.data(), d_bk + 5 * bucket_job.size(), jobs.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(c, hipStreamSynchronize(c->stream));  // also keeps the host vectors alive until the uploads are done

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int SORT_WG = 512;
-constexpr uint32_t SORT_LDS_MAX_KEYS = HG_SORT_LDS_MAX_KEYS;  // 128 KiB of the 160 KiB LDS
+constexpr uint32_t SORT_LDS_MAX_KEYS = HG_SORT_LDS_MAX_KEYS;  // 64 KiB of keys + 32 KiB of counters of the 160 KiB LDS
 
 // one compare-exchange pass of the bitonic network over a[0..n2), n2 a power of two
 template <class Ptr>
@@ -86,6 +86,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratc
 // network's 78.  A bucket with more than SORT_BUCKET_LIMIT keys (repeats: equal hashes share a bucket) sends the genome
 // to the bitonic sort after all -- the keys are in LDS by then.
 constexpr uint32_t SORT_BUCKET_MAX_KEYS = 8192, SORT_BUCKET_LIMIT = 16, SORT_KPT = SORT_BUCKET_MAX_KEYS / SORT_WG;
+static_assert(SORT_BUCKET_MAX_KEYS == SORT_LDS_MAX_KEYS, "every set the one-workgroup sort takes can take its counting sort");
+constexpr size_t SORT_LDS_BYTES_MAX = (size_t)SORT_LDS_MAX_KEYS * (sizeof(uint64_t) + sizeof(uint32_t));  // keys + counters
 
 template <bool USE_LDS>
 __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
@@ -227,16 +229,33 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, const hg_bucket_job &j
   return b < job.P ? b : job.P - 1;
 }
 
-// grid: key chunks.  bcount[bucket] += 1 per key (no value returned: the waves do not wait)
+// grid: key chunks.  bcount[bucket] += the chunk's keys of that bucket.  A chunk of 4 096 keys of a genome with up to
+// BK_PRIV_MAX buckets counts in LDS first and adds its non-zero counters once (a global atomic per KEY on the genome's few
+// counters ran at 0.38 TB/s of keys: 1.0 ms for 50 M keys); beyond that a key hits a bucket less than four times per chunk
+// and goes straight to the global counter (no value returned: the waves do not wait).
+constexpr uint32_t BK_PRIV_MAX = 2048, BK_KPT = HG_BUCKET_CHUNK / BK_WG;
+static_assert(HG_BUCKET_CHUNK % BK_WG == 0, "whole keys per thread");
 __global__ __launch_bounds__(BK_WG) void bucket_count_kernel(const hg_bucket_job *__restrict__ jobs,
                                                              const uint32_t *__restrict__ chunk_job,
                                                              const uint64_t *__restrict__ hits,
                                                              uint32_t *__restrict__ bcount) {
+  __shared__ uint32_t s_h[BK_PRIV_MAX];
   const hg_bucket_job job = jobs[chunk_job[blockIdx.x]];
   const uint32_t k0 = (blockIdx.x - job.chunk_first) * HG_BUCKET_CHUNK;
   const uint32_t k1 = k0 + HG_BUCKET_CHUNK < job.n ? k0 + HG_BUCKET_CHUNK : job.n;
-  for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG)
-    atomicAdd(&bcount[job.bucket_first + bucket_of(hits[job.hit_off + i], job)], 1u);
+  if (job.P > BK_PRIV_MAX) {  // workgroup-uniform
+    for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG)
+      atomicAdd(&bcount[job.bucket_first + bucket_of(hits[job.hit_off + i], job)], 1u);
+    return;
+  }
+  for (uint32_t b = threadIdx.x; b < job.P; b += BK_WG) s_h[b] = 0;
+  __syncthreads();
+  for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG) atomicAdd(&s_h[bucket_of(hits[job.hit_off + i], job)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < job.P; b += BK_WG) {
+    const uint32_t v = s_h[b];
+    if (v) atomicAdd(&bcount[job.bucket_first + b], v);
+  }
 }
 
 // grid: jobs.  out[b] = exclusive prefix of in[b] over the job's buckets; optionally the total per genome
@@ -258,36 +277,67 @@ __global__ __launch_bounds__(SORT_WG) void bucket_scan_kernel(const hg_bucket_jo
   if (total_per_genome && threadIdx.x == 0) total_per_genome[job.genome] = run;
 }
 
-// grid: key chunks.  Every key moves to its bucket's range of the scratch buffer.
+// grid: key chunks.  Every key moves to its bucket's range of the scratch buffer.  With up to BK_PRIV_MAX buckets the chunk
+// ranks its keys per bucket in LDS (returning LDS atomics), reserves ONE run per non-empty bucket (a returning global atomic
+// per bucket instead of per key: 2.1 -> ... ms for 50 M keys) and writes the keys, held in registers meanwhile, into the runs.
 __global__ __launch_bounds__(BK_WG) void bucket_scatter_kernel(const hg_bucket_job *__restrict__ jobs,
                                                                const uint32_t *__restrict__ chunk_job,
                                                                const uint64_t *__restrict__ hits,
                                                                const uint32_t *__restrict__ bstart,
                                                                uint32_t *__restrict__ bcursor,
                                                                uint64_t *__restrict__ tmp) {
+  __shared__ uint32_t s_h[BK_PRIV_MAX];
   const hg_bucket_job job = jobs[chunk_job[blockIdx.x]];
   const uint32_t k0 = (blockIdx.x - job.chunk_first) * HG_BUCKET_CHUNK;
   const uint32_t k1 = k0 + HG_BUCKET_CHUNK < job.n ? k0 + HG_BUCKET_CHUNK : job.n;
-  for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG) {
-    const uint64_t h = hits[job.hit_off + i];
-    const uint32_t gb = job.bucket_first + bucket_of(h, job);
-    const uint32_t pos = atomicAdd(&bcursor[gb], 1u);
-    tmp[job.hit_off + bstart[gb] + pos] = h;
+  if (job.P > BK_PRIV_MAX) {  // workgroup-uniform
+    for (uint32_t i = k0 + threadIdx.x; i < k1; i += BK_WG) {
+      const uint64_t h = hits[job.hit_off + i];
+      const uint32_t gb = job.bucket_first + bucket_of(h, job);
+      const uint32_t pos = atomicAdd(&bcursor[gb], 1u);
+      tmp[job.hit_off + bstart[gb] + pos] = h;
+    }
+    return;
   }
+  for (uint32_t b = threadIdx.x; b < job.P; b += BK_WG) s_h[b] = 0;
+  __syncthreads();
+  uint64_t kk[BK_KPT];
+  uint32_t bb[BK_KPT], rr[BK_KPT];
+#pragma unroll
+  for (uint32_t u = 0; u < BK_KPT; ++u) {
+    const uint32_t i = k0 + threadIdx.x + u * BK_WG;
+    if (i < k1) {
+      kk[u] = hits[job.hit_off + i];
+      bb[u] = bucket_of(kk[u], job);
+      rr[u] = atomicAdd(&s_h[bb[u]], 1u);  // rank among the chunk's keys of that bucket
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < job.P; b += BK_WG) {  // count -> where the chunk's run of bucket b starts in the scratch copy
+    const uint32_t v = s_h[b], gb = job.bucket_first + b;
+    if (v) s_h[b] = bstart[gb] + atomicAdd(&bcursor[gb], v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t u = 0; u < BK_KPT; ++u)
+    if (k0 + threadIdx.x + u * BK_WG < k1) tmp[job.hit_off + s_h[bb[u]] + rr[u]] = kk[u];
 }
 
 // grid: buckets.  Sort + unique in LDS; the distinct keys go back to the start of the bucket's scratch range.
 // A bucket with more keys than LDS holds (only possible when duplicates pile up: the map is balanced for
 // distinct hashes) is first de-duplicated through an LDS hash set; if even its distinct keys do not fit the
 // job is flagged and the caller sorts that genome in place instead.
-constexpr uint32_t HSET_SLOTS = SORT_LDS_MAX_KEYS, HSET_MAX = HSET_SLOTS / 4 * 3;
 __global__ __launch_bounds__(SORT_WG) void bucket_sort_kernel(const hg_bucket_job *__restrict__ jobs,
                                                               const uint32_t *__restrict__ bucket_job,
                                                               const uint32_t *__restrict__ bcount,
                                                               const uint32_t *__restrict__ bstart,
                                                               uint64_t *__restrict__ tmp,
                                                               uint32_t *__restrict__ bdist,
-                                                              uint32_t *__restrict__ fail) {
+                                                              uint32_t *__restrict__ fail, uint32_t cap_keys) {
+  // cap_keys (a power of two, <= SORT_LDS_MAX_KEYS): keys the launch's LDS holds -- 12 bytes each, keys + counters.  The
+  // launcher sizes it to four times the bucket size the plan aims at: 48 KiB for 512-1 024 expected keys, three workgroups
+  // per CU (with the full 96 KiB in every launch one workgroup per CU sorted 1 500 keys at a time).
+  const uint32_t HSET_SLOTS = cap_keys, HSET_MAX = HSET_SLOTS / 4 * 3;
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
   __shared__ uint32_t s_scan[SORT_WG / 64 + 1];
   __shared__ uint32_t s_distinct;
@@ -299,13 +349,13 @@ __global__ __launch_bounds__(SORT_WG) void bucket_sort_kernel(const hg_bucket_jo
     if (tid == 0) bdist[gb] = 0;
     return;
   }
-  if (n > SORT_LDS_MAX_KEYS) {
+  if (n > cap_keys) {
     for (uint32_t i = tid; i < HSET_SLOTS; i += SORT_WG) s_keys[i] = ~0ull;  // no hash equals ~0 (h < threshold)
     if (tid == 0) s_distinct = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += SORT_WG) {
       const uint64_t h = base[i];
-      uint32_t slot = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 50) & (HSET_SLOTS - 1);
+      uint32_t slot = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 40) & (HSET_SLOTS - 1);
       for (;;) {
         if (s_distinct > HSET_MAX) break;  // hopeless: flagged below
         const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_keys[slot]), ~0ull, (unsigned long long)h);
@@ -329,9 +379,69 @@ __global__ __launch_bounds__(SORT_WG) void bucket_sort_kernel(const hg_bucket_jo
     return;
   }
   const uint32_t n2 = next_pow2(n);
-  for (uint32_t i = tid; i < n2; i += SORT_WG) s_keys[i] = (i < n) ? base[i] : ~0ull;
-  __syncthreads();
-  bitonic_sort(s_keys, n2, tid, SORT_WG);
+  bool sorted = false;  // workgroup-uniform
+  if (n2 >= (uint32_t)SORT_WG) {
+    // The bucket's keys are uniform over its value range: the same counting sort as sort_unique_kernel's, one level down --
+    // sub-bucket = the top bits of the FRACTION of h * mul (its integer part is the bucket; the fraction grows with h inside
+    // it), 0.5-1 keys per sub-bucket, ranks by returning LDS atomics, one scan, one scatter, an insertion pass per thread.
+    // Five passes over the keys instead of the bitonic network's 66 (2 048 keys): 3.4 -> ... ms for 50 M keys in 32 000 buckets.
+    __shared__ uint32_t s_over;
+    uint32_t *s_bk = reinterpret_cast<uint32_t *>(s_keys + cap_keys);  // n2 counters, then sub-bucket starts
+    const uint32_t shift = 64u - (uint32_t)__builtin_ctz(n2), per = n2 / SORT_WG;
+    for (uint32_t i = tid; i < n2; i += SORT_WG) s_bk[i] = 0;
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    uint64_t kk[SORT_KPT];
+    uint32_t bb[SORT_KPT], rr[SORT_KPT];
+#pragma unroll
+    for (uint32_t u = 0; u < SORT_KPT; ++u) {
+      const uint32_t i = tid + u * SORT_WG;
+      if (i < n) {
+        kk[u] = base[i];
+        // (keys the bucket map clamped into the last bucket -- integer part >= P -- have no usable fraction: last sub-bucket)
+        const bool clamped = (uint32_t)__umul64hi(kk[u], job.mul) >= job.P;
+        bb[u] = clamped ? n2 - 1 : (uint32_t)((kk[u] * job.mul) >> shift);
+        rr[u] = atomicAdd(&s_bk[bb[u]], 1u);
+      }
+    }
+    __syncthreads();
+    {
+      uint32_t c[SORT_KPT], sum = 0, mx = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < SORT_KPT; ++q)
+        if (q < per) c[q] = s_bk[tid * per + q], sum += c[q], mx = c[q] > mx ? c[q] : mx;
+      if (mx > SORT_BUCKET_LIMIT) s_over = 1u;  // (same value from every writer)
+      uint32_t total;
+      uint32_t run0 = block_excl_scan(sum, s_scan, &total);
+#pragma unroll
+      for (uint32_t q = 0; q < SORT_KPT; ++q)
+        if (q < per) s_bk[tid * per + q] = run0, run0 += c[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < SORT_KPT; ++u)
+      if (tid + u * SORT_WG < n) s_keys[s_bk[bb[u]] + rr[u]] = kk[u];
+    __syncthreads();
+    sorted = s_over == 0u;
+    if (sorted) {
+      for (uint32_t q = 0; q < per; ++q) {  // order the keys inside each of this thread's sub-buckets
+        const uint32_t b = tid * per + q, lo = s_bk[b], hi = b + 1 < n2 ? s_bk[b + 1] : n;
+        for (uint32_t i = lo + 1; i < hi; ++i) {
+          const uint64_t v = s_keys[i];
+          uint32_t j2 = i;
+          while (j2 > lo && s_keys[j2 - 1] > v) s_keys[j2] = s_keys[j2 - 1], --j2;
+          s_keys[j2] = v;
+        }
+      }
+    } else {
+      for (uint32_t i = n + tid; i < n2; i += SORT_WG) s_keys[i] = ~0ull;  // (piled-up duplicates: the network after all)
+    }
+    __syncthreads();
+  } else {
+    for (uint32_t i = tid; i < n2; i += SORT_WG) s_keys[i] = (i < n) ? base[i] : ~0ull;
+    __syncthreads();
+  }
+  if (!sorted) bitonic_sort(s_keys, n2, tid, SORT_WG);
   uint32_t run = 0;
   for (uint32_t c0 = 0; c0 < n; c0 += SORT_WG) {
     const uint32_t i = c0 + tid;
@@ -737,11 +847,12 @@ static bool attr_done_on_this_device(std::atomic<uint64_t> &mask, bool set) {
 static hipError_t sort_lds_attr() {
   static std::atomic<uint64_t> done{0};
   if (attr_done_on_this_device(done, false)) return hipSuccess;
+  // (keys + the counting sort's counters)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_unique_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_KEYS * sizeof(uint64_t));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES_MAX);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bucket_sort_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_KEYS * sizeof(uint64_t));
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES_MAX);
   if (e == hipSuccess) attr_done_on_this_device(done, true);
   return e;
 }
@@ -803,8 +914,10 @@ hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, 
 hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uint32_t n_jobs,
                                 const uint32_t *d_chunk_job, uint32_t n_chunks, const uint32_t *d_bucket_job,
                                 uint32_t n_buckets, uint32_t *d_bk, uint64_t *d_hits, uint64_t *d_tmp,
-                                uint32_t *d_ndistinct) {
+                                uint32_t *d_ndistinct, uint32_t bucket_cap_keys) {
   if (n_jobs == 0) return hipSuccess;
+  uint32_t cap_keys = (uint32_t)SORT_WG;  // (a power of two: the counting sort deals n2 / SORT_WG sub-buckets to a thread)
+  while (cap_keys < bucket_cap_keys && cap_keys < SORT_LDS_MAX_KEYS) cap_keys <<= 1;
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
   uint32_t *bcount = d_bk, *bstart = d_bk + n_buckets, *bcursor = d_bk + 2 * (size_t)n_buckets;
@@ -814,8 +927,8 @@ hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uin
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(n_jobs), dim3(SORT_WG), 0, st, d_jobs, bcount, bstart, (uint32_t *)nullptr);
   hipLaunchKernelGGL(bucket_scatter_kernel, dim3(n_chunks), dim3(BK_WG), 0, st, d_jobs, d_chunk_job, d_hits, bstart,
                      bcursor, d_tmp);
-  hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(SORT_WG), SORT_LDS_MAX_KEYS * sizeof(uint64_t), st, d_jobs,
-                     d_bucket_job, bcount, bstart, d_tmp, bdist, fail);
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(n_buckets), dim3(SORT_WG), (size_t)cap_keys * (sizeof(uint64_t) + sizeof(uint32_t)), st,
+                     d_jobs, d_bucket_job, bcount, bstart, d_tmp, bdist, fail, cap_keys);
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(n_jobs), dim3(SORT_WG), 0, st, d_jobs, bdist, bout, d_ndistinct);
   hipLaunchKernelGGL(bucket_copy_kernel, dim3(n_buckets), dim3(BK_WG), 0, st, d_jobs, d_bucket_job, bstart, bdist, bout,
                      fail, d_tmp, d_hits);

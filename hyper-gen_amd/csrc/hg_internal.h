@@ -179,7 +179,7 @@ hipError_t hg_launch_pack2(hipStream_t st, const uint8_t *d_seq, const uint64_t 
 
 // keys one workgroup can sort in LDS; genomes with more sampled hashes are sorted in place in
 // global memory, which needs a power-of-two sized hit region (the host rounds hit_cap up).
-#define HG_SORT_LDS_MAX_KEYS 16384u
+#define HG_SORT_LDS_MAX_KEYS 8192u  // keys one workgroup orders in LDS with its counting sort (was 16 384 with the bitonic network behind 8 192)
 
 // ---- sort/unique + encode kernels ---------------------------------------------------------
 // Sorts each genome's hits ascending, removes duplicates in place (region start),
@@ -213,7 +213,7 @@ struct hg_bucket_job {
 hipError_t hg_launch_sort_large(hipStream_t st, const hg_bucket_job *d_jobs, uint32_t n_jobs,
                                 const uint32_t *d_chunk_job, uint32_t n_chunks, const uint32_t *d_bucket_job,
                                 uint32_t n_buckets, uint32_t *d_bk, uint64_t *d_hits, uint64_t *d_tmp,
-                                uint32_t *d_ndistinct);
+                                uint32_t *d_ndistinct, uint32_t bucket_cap_keys);
 // in-place global-memory sort + unique of the listed genomes (power-of-two sized hit regions)
 hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, const uint32_t *d_todo,
                                   uint32_t n_todo, uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct);

@@ -242,6 +242,28 @@ def test_sketch_batch_matches_oracle(ctx, orc, hg):
         assert nh[i] == w[2] and n2[i] == w[1] and (hv[i] == w[0]).all()
 
 
+@pytest.mark.parametrize("scaled,L", [(50, 600_000), (20, 600_000), (5, 600_000), (1, 150_000), (100, 2_000_000)])
+def test_dense_sketches_match_oracle(ctx, orc, hg, scaled, L):
+    """Sampling rates far above the default (1 k-mer in 5 .. 100 instead of 1 in 1 500): a work item's LDS hit list is
+    emptied between tiles or overflows into wave-aggregated appends, and hash sets of 9 000 .. 150 000 keys take the
+    value-bucketed sort (LDS-privatised count and scatter, a counting sort per bucket) instead of the one-workgroup one.
+    A tandem repeat piles duplicates into single buckets."""
+    seqs = [orc.synth_genome(300 + g, L + 17 * g).copy() for g in range(6)]
+    unit = seqs[1][1000:1171].copy()
+    seqs[1][50_000:50_000 + 171 * 200] = np.tile(unit, 200)  # 200 copies of a 171-base unit
+    seqs[2][10_000:10_050] = ord("N")
+    p = hg.default_params(scaled=scaled)
+    hv, n2, nh = ctx.sketch_batch(seqs, p)
+    for i, sq in enumerate(seqs):
+        w_hv, w_n2, w_nh = orc.sketch_genome(sq, scaled=scaled)
+        assert nh[i] == w_nh and n2[i] == w_n2 and (hv[i] == w_hv).all(), (scaled, i, int(nh[i]), w_nh)
+    assert nh.min() > 8192  # every set is past the one-workgroup sort
+    for i in (0, 1):
+        got = ctx.kmer_hash_sample(seqs[i], 21, scaled)
+        want = orc.kmer_hash_sample(seqs[i], 21, scaled)
+        assert got.size == want.size and (got == want).all(), (scaled, i)
+
+
 def test_config1_test_fna(ctx, orc, hg):
     g = golden("g1_test_fna.json")
     seq = orc.read_merge_seq(g["fasta"].encode())
