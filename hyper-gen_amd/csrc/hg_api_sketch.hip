@@ -93,6 +93,10 @@ hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt,
     if (cnt <= HG_SORT_LDS_MAX_KEYS) continue;
     uint32_t P = 2;
     while (P < MAX_BUCKETS && (uint64_t)P * TARGET < cnt) P <<= 1;
+    // (the counting and scattering workgroups keep a genome's bucket counters in LDS up to PRIV buckets -- beyond that every
+    // key pays a global atomic: a set of up to PRIV * 4 096 keys rather fills fewer, larger buckets)
+    constexpr uint32_t PRIV = 2048;
+    if (P > PRIV && (uint64_t)cnt <= (uint64_t)PRIV * 4096) P = PRIV;
     if (c->dbg_sort_buckets) {  // test hook (hg_ctx_set_debug): force overflowing buckets / the fallback
       P = (uint32_t)std::max(2, c->dbg_sort_buckets);
     } else if ((uint64_t)P * (HG_SORT_LDS_MAX_KEYS / 2) < cnt) {  // more than ~8 k keys per bucket expected: too many for LDS

@@ -187,38 +187,41 @@ __device__ __forceinline__ void append_hit(uint64_t h, const hg_genome_meta &gm,
 // workgroup reserves its range of the genome's hit buffer once, at the end of its work item.  A list that
 // overflows (low-complexity sequence: every position of a repeat samples the same hash) spills straight to
 // the global path; the raw counter semantics (it keeps counting past the capacity) are unchanged.
-constexpr uint32_t HIT_STAGE = 256;
+constexpr uint32_t HIT_STAGE = 256, HIT_STAGE_MAX = 4096;
 struct HitStage {
-  uint64_t h[HIT_STAGE];
   uint32_t n, base;
 };
-__device__ __forceinline__ void stage_hit(HitStage &st, uint64_t h, const hg_genome_meta &gm, uint32_t g,
+// The list itself is the kernels' dynamic LDS: `cap` entries, HIT_STAGE at the default sampling rate and up to HIT_STAGE_MAX
+// when a tile alone yields hundreds of hits (hg_launch_kmer_sample sizes it: scaled = 5 samples 610 of a tile's 3 048
+// starts, and a list of 256 sent the rest through a global atomic per wave and k-mer step -- 168 ms for 1 000 x 5 Mbp).
+extern __shared__ __attribute__((aligned(8))) uint64_t s_stage_h[];
+__device__ __forceinline__ void stage_hit(HitStage &st, uint32_t cap, uint64_t h, const hg_genome_meta &gm, uint32_t g,
                                           uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
   const uint32_t idx = atomicAdd(&st.n, 1u);
-  if (idx < HIT_STAGE) st.h[idx] = h;
+  if (idx < cap) s_stage_h[idx] = h;
   else append_hit(h, gm, g, hits, cnt);
 }
 // AGAIN: the list is emptied between two tiles and filled again afterwards (the caller's next barrier lies between this
 // call's reads and the next writes)
 template <bool AGAIN = false>
-__device__ __forceinline__ void flush_hits(HitStage &st, const hg_genome_meta &gm, uint32_t g,
+__device__ __forceinline__ void flush_hits(HitStage &st, uint32_t cap, const hg_genome_meta &gm, uint32_t g,
                                            uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
   __syncthreads();
-  const uint32_t n = st.n < HIT_STAGE ? st.n : HIT_STAGE;
+  const uint32_t n = st.n < cap ? st.n : cap;
   if (threadIdx.x == 0 && n) st.base = atomicAdd(&cnt[g], n);
   __syncthreads();
   if (AGAIN && threadIdx.x == 0) st.n = 0;  // (every lane has read it)
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t idx = st.base + i;
-    if (idx < gm.hit_cap) hits[gm.hit_off + idx] = st.h[i];
+    if (idx < gm.hit_cap) hits[gm.hit_off + idx] = s_stage_h[i];
   }
 }
 // Between two tiles (behind the barrier that ends a tile: st.n is final and the same for every lane): a list that is a
 // quarter full goes out now.  At the default sampling rate a work item collects ~18 hits and never gets here; a denser
 // sketch (scaled = 100: 270 hits per item) used to overflow the list and pay a global atomic per hit.
-__device__ __forceinline__ void flush_hits_if_filling(HitStage &st, const hg_genome_meta &gm, uint32_t g,
+__device__ __forceinline__ void flush_hits_if_filling(HitStage &st, uint32_t cap, const hg_genome_meta &gm, uint32_t g,
                                                       uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
-  if (st.n >= HIT_STAGE / 4) flush_hits<true>(st, gm, g, hits, cnt);  // workgroup-uniform
+  if (st.n >= cap / 4) flush_hits<true>(st, cap, gm, g, hits, cnt);  // workgroup-uniform
 }
 // Whether the sampling rate can fill a quarter of the list within one work item at all (a kernel argument: the test
 // between the tiles is a scalar branch that the default rate, 1 in 1 500, never takes -- the LDS read of the fill level
@@ -433,7 +436,7 @@ template <int K, bool CANON, bool PACKED>
 __global__ __launch_bounds__(WG) void kmer_sample_shared(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
-    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt, uint32_t stage_cap) {
   using G = GeoS<K>;
   constexpr int M = G::M, DW = G::DW, S = G::S, ND = G::ND, NB = G::NB, NW = G::NW, N_R = G::N_R, WIN = G::WIN;
   typedef typename std::conditional<(WIN > 32), uint64_t, uint32_t>::type inv_t;  // validity bits of the code window
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
           if (hmask != 0) {  // wave-uniform: some lane's hash is below the threshold (1 k-mer in `scaled`)
             uint32_t below;
             asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(below) : "s"(hmask));
-            if (below && valid && hashing) stage_hit(stage, hval, gm, g, hits, cnt);
+            if (below && valid && hashing) stage_hit(stage, stage_cap, hval, gm, g, hits, cnt);
           }
         });
       }
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
         if constexpr (j == 0) fetch_words(jc, wq[0]);
         if constexpr (j + 1 < M) fetch_words(std::integral_constant<int, j + 1>{}, wq[(j + 1) & 1]);
         const uint64_t h = t1ha2_fixed_w<K>(wq[j & 1], seed);
-        if (valid && hashing && h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+        if (valid && hashing && h < threshold) stage_hit(stage, stage_cap, h, gm, g, hits, cnt);
       });
     };
     if constexpr (ASM_BODY) {
@@ -833,9 +836,9 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     }
     if (!(HG_KS_EXP & 1)) __syncthreads();  // every read of the images is done: the next tile may overwrite them
     if (tid == 0) s_dirty[par] = 0u;  // (raised again in two tiles' time at the earliest, behind the next tile's barriers)
-    if (dense_sampling(threshold)) flush_hits_if_filling(stage, gm, g, hits, cnt);
+    if (dense_sampling(threshold)) flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
   }
-  flush_hits(stage, gm, g, hits, cnt);
+  flush_hits(stage, stage_cap, gm, g, hits, cnt);
 }
 
 // 2-bit code of one base (long-k kernel)
@@ -910,7 +913,7 @@ template <bool PACKED>
 __global__ __launch_bounds__(WG) void kmer_sample_long(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
-    uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt) {
+    uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt, uint32_t stage_cap) {
   __shared__ HitStage stage;
   __shared__ uint32_t s_f[LONG_DW], s_rc[LONG_DW];
   __shared__ uint16_t s_bad[LONG_BYTES + 8];  // s_bad[i] = invalid bytes among the first i staged bytes
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
 
   for (uint64_t tile0 = item_start; tile0 < item_start + GEN_ITEM && tile0 < n_starts; tile0 += LONG_TILE) {
     __syncthreads();  // previous tile's readers are done
-    if (dense_sampling(threshold)) flush_hits_if_filling(stage, gm, g, hits, cnt);
+    if (dense_sampling(threshold)) flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
     for (uint32_t i = tid; i < LONG_DW; i += WG) s_f[i] = 0u, s_rc[i] = 0u;
     __syncthreads();
     // ---- stage: 6 consecutive bytes per lane
@@ -991,10 +994,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
         }
       }
       const uint64_t h = t1ha2_long(use_rc ? r : f, ksize, seed);
-      if (h < threshold) stage_hit(stage, h, gm, g, hits, cnt);
+      if (h < threshold) stage_hit(stage, stage_cap, h, gm, g, hits, cnt);
     }
   }
-  flush_hits(stage, gm, g, hits, cnt);
+  flush_hits(stage, stage_cap, gm, g, hits, cnt);
 }
 
 }  // namespace
@@ -1017,9 +1020,17 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
                                  uint64_t *d_hits, uint32_t *d_cnt, bool packed) {
   if (n_items == 0) return hipSuccess;
   const uint32_t u2t = (norm_mode == HG_NORM_U2T && !packed) ? 1u : 0u;  // (a blob was normalised when it was packed)
+  // entries of a work item's LDS hit list: twice what one tile is expected to sample (+ slack), 256 .. 4 096
+  auto stage_entries = [&](uint32_t tile_starts) {
+    const double per_tile = (double)tile_starts * ((double)threshold / 18446744073709551616.0);
+    uint32_t cap = HIT_STAGE;
+    while (cap < HIT_STAGE_MAX && (double)cap < 2.0 * per_tile + 128.0) cap <<= 1;
+    return cap;
+  };
+  const uint32_t cap_s = stage_entries((uint32_t)GeoS<21>::TILE), cap_l = stage_entries(LONG_TILE);
 #define HG_K_LAUNCH(KK, CN, PK)                                                                            \
-  hipLaunchKernelGGL((kmer_sample_shared<KK, CN, PK>), dim3(n_items), dim3(WG), 0, st, d_seq, d_meta,      \
-                     d_item_genome, threshold, seed, u2t, d_hits, d_cnt)
+  hipLaunchKernelGGL((kmer_sample_shared<KK, CN, PK>), dim3(n_items), dim3(WG), cap_s * sizeof(uint64_t), st, d_seq, d_meta, \
+                     d_item_genome, threshold, seed, u2t, d_hits, d_cnt, cap_s)
 #define HG_K_CASE(KK)                                                                                     \
   case KK:                                                                                                \
     if (canonical && packed) HG_K_LAUNCH(KK, true, true);                                                 \
@@ -1039,10 +1050,10 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
 #undef HG_K_LAUNCH
   // 33 <= k <= 255
   if (packed)
-    hipLaunchKernelGGL(kmer_sample_long<true>, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
-                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+    hipLaunchKernelGGL(kmer_sample_long<true>, dim3(n_items), dim3(WG), cap_l * sizeof(uint64_t), st, d_seq, d_meta, d_item_genome, ksize,
+                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt, cap_l);
   else
-    hipLaunchKernelGGL(kmer_sample_long<false>, dim3(n_items), dim3(WG), 0, st, d_seq, d_meta, d_item_genome, ksize,
-                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt);
+    hipLaunchKernelGGL(kmer_sample_long<false>, dim3(n_items), dim3(WG), cap_l * sizeof(uint64_t), st, d_seq, d_meta, d_item_genome, ksize,
+                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt, cap_l);
   return hipGetLastError();
 }
