@@ -21,6 +21,9 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--small-n", type=int, default=100_000)
 ap.add_argument("--small-len", type=int, default=50_000)
 ap.add_argument("--scaled", type=int, default=1500, help="FracMinHash sampling rate 1/scaled (denser sketches: more hits per work item)")
+ap.add_argument("--ksize", type=int, default=21)
+ap.add_argument("--hv-d", type=int, default=4096)
+ap.add_argument("--non-canonical", action="store_true")
 ap.add_argument("--repeat", type=int, default=50_000, help="length of the draft leg's tandem repeat (171-base unit)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -37,8 +40,8 @@ bsz = hg.lib().hg_pack2_size(L + 1)
 boffs = np.arange(N, dtype=np.uint64) * bsz
 blobs = torch.empty(N * bsz + 64, dtype=torch.uint8, device=dev)
 ctx.pack2_batch_dev(seq.data_ptr(), offs, lens, blobs.data_ptr(), boffs)
-p = hg.default_params(scaled=a.scaled)
-hv = torch.empty((N, 4096), dtype=torch.int16, device=dev)
+p = hg.default_params(scaled=a.scaled, ksize=a.ksize, hv_d=a.hv_d, canonical=0 if a.non_canonical else 1)
+hv = torch.empty((N, a.hv_d), dtype=torch.int16, device=dev)
 n2, nh = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
 
 
