@@ -88,6 +88,34 @@ def test_cli_sketch_dist_roundtrip(tmp_path, orc):
     assert len(rows) >= 5 and all(x[2] == "100.000" for x in rows[:5])
 
 
+@pytest.mark.parametrize("scaled", [1, 5, 20])
+def test_cli_sketch_dense_sampling(tmp_path, orc, scaled):
+    """`hyper-gen sketch -s 1 | 5 | 20`: every k-mer, or one in 5 / 20, through the streaming path -- hit lists sized to the
+    rate, hash sets of 20 000 .. 400 000 keys through the value-bucketed sort, HVs whose counts need 11+ bits -- against the
+    oracle's sketch of the same files."""
+    import hypergen_amd as hg
+    d = tmp_path / "fa"
+    d.mkdir()
+    L = 400_000
+    files = []
+    for g in (3, 4, 5, 6):
+        seq = orc.synth_genome(g, L + 1000 * g)[1:].copy()
+        if g == 4:
+            seq[20_000:20_000 + 171 * 150] = np.tile(seq[500:671].copy(), 150)  # a tandem repeat
+        write_fasta(str(d / ("g%03d.fna" % g)), seq, "g%d" % g, two_records=(g == 5))
+        files.append(str(d / ("g%03d.fna" % g)))
+    out = str(tmp_path / "dense.sketch")
+    r = subprocess.run([hg.CLI_PATH, "sketch", "-p", str(d), "-o", out, "-s", str(scaled), "-t", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    recs = hg.read_sketch_file(out)
+    assert [x["file_str"] for x in recs] == sorted(files)
+    for x in recs:
+        hv, n2, nh = orc.sketch_genome(hg.read_merge_seq(x["file_str"]), scaled=scaled, norm=orc.NORM_U2T)
+        assert nh > 8192 and x["scaled"] == scaled and x["hv_norm_2"] == n2
+        q, packed = orc.pack_hv(hv)
+        assert x["hv_quant_bits"] == q and (x["hv"].view(np.uint8) == packed).all(), (scaled, x["file_str"])
+
+
 def test_cli_reference_fixture(tmp_path):
     """BASELINE config 1: the reference's test/test.fna (40 bases) -> empty hash set, zero HV, 6-bit payload."""
     import hypergen_amd as hg
