@@ -547,8 +547,12 @@ int run_dist(const Cli &c) {
     multi = open_all_devices(c.shards);
     debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
   });
-  load(c.path_r, R);
-  if (!sym) load(c.path_q, Qs);
+  {  // two files are read and parsed side by side
+    std::thread second;
+    if (!sym) second = std::thread([&] { load(c.path_q, Qs); });
+    load(c.path_r, R);
+    if (second.joinable()) second.join();
+  }
   debugf("sketch files loaded in %.1f ms", (now_s() - tp) * 1e3);
   opener.join();
   const Loaded &Q = sym ? R : Qs;
@@ -664,8 +668,11 @@ int run_search(const Cli &c) {
     multi = open_all_devices(c.shards);
     debugf("devices opened in %.1f ms", (now_s() - td) * 1e3);
   });
-  load(c.path_r, R);
-  load(c.path_q, Q);
+  {  // the two files are read and parsed side by side
+    std::thread second([&] { load(c.path_q, Q); });
+    load(c.path_r, R);
+    second.join();
+  }
   debugf("sketch files loaded in %.1f ms", (now_s() - tp) * 1e3);
   opener.join();
   if (R.ksize != Q.ksize) die("Ref and query sketches use different kmer sizes!");
@@ -696,22 +703,54 @@ int run_search(const Cli &c) {
   hg_dev_free(ctx, d_hits), hg_dev_free(ctx, d_out), hg_dev_free(ctx, d_cnt);
   debugf("top-%u per query in %.1f ms", k, (now_s() - tp) * 1e3);
   tp = now_s();
-  std::string tsv;
-  char line[32];
-  size_t reported = 0;
-  for (size_t q = 0; q < Q.n; ++q)
-    for (uint32_t r = 0; r < cnt[q]; ++r) {
-      const hg_ani_hit &h = best[q * k + r];
-      tsv += hg_sketch_file_get(Q.f, q)->file_str;
-      tsv += '\t';
-      tsv += hg_sketch_file_get(R.f, h.ref_idx)->file_str;
-      tsv.append(line, put_ani(line, h.ani));
-      ++reported;
-    }
+  // "query<TAB>reference<TAB>ani" per result, queries in file order, best first; formatted by -t threads over contiguous
+  // ranges of the queries (like dist's lines: two memcpy and put_ani per line)
+  std::vector<size_t> first(Q.n + 1, 0);  // results in front of query q
+  for (size_t q = 0; q < Q.n; ++q) first[q + 1] = first[q] + std::min<uint32_t>(cnt[q], k);
+  const size_t reported = first[Q.n];
+  const size_t FT = std::max<size_t>(1, std::min<size_t>(c.threads, reported / 4096 + 1));
+  std::vector<std::string> part(FT);
+  {
+    std::vector<uint32_t> len_r(R.n), len_q(Q.n);
+    for (size_t i = 0; i < R.n; ++i) len_r[i] = (uint32_t)std::strlen(hg_sketch_file_get(R.f, i)->file_str);
+    for (size_t i = 0; i < Q.n; ++i) len_q[i] = (uint32_t)std::strlen(hg_sketch_file_get(Q.f, i)->file_str);
+    auto fmt = [&](size_t t) {
+      const size_t q_lo = Q.n * t / FT, q_hi = Q.n * (t + 1) / FT;
+      size_t need = 0;
+      for (size_t q = q_lo; q < q_hi; ++q)
+        for (size_t r = 0; r < first[q + 1] - first[q]; ++r) need += (size_t)len_q[q] + len_r[best[q * k + r].ref_idx] + 10;
+      std::string &o = part[t];
+      o.resize(need);
+      char *w = &o[0];
+      for (size_t q = q_lo; q < q_hi; ++q) {
+        const char *qs = hg_sketch_file_get(Q.f, q)->file_str;
+        for (size_t r = 0; r < first[q + 1] - first[q]; ++r) {
+          const hg_ani_hit &h = best[q * k + r];
+          std::memcpy(w, qs, len_q[q]);
+          w += len_q[q];
+          *w++ = '\t';
+          std::memcpy(w, hg_sketch_file_get(R.f, h.ref_idx)->file_str, len_r[h.ref_idx]);
+          w += len_r[h.ref_idx];
+          w += put_ani(w, h.ani);
+        }
+      }
+      o.resize((size_t)(w - &o[0]));
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < FT; ++t) th.emplace_back(fmt, t);
+    fmt(0);
+    for (auto &t : th) t.join();
+  }
+  debugf("TSV formatted in %.1f ms", (now_s() - tp) * 1e3);
+  size_t tsv_bytes = 0;
   FILE *f = std::fopen(c.out.c_str(), "wb");
-  if (!f || (tsv.size() && std::fwrite(tsv.data(), 1, tsv.size(), f) != tsv.size())) die("Dump search file failed!");
-  std::fclose(f);
-  debugf("TSV formatted and written (%.1f MB) in %.1f ms", tsv.size() / 1e6, (now_s() - tp) * 1e3);
+  if (!f) die("Dump search file failed!");
+  for (const auto &o : part) {
+    if (o.size() && std::fwrite(o.data(), 1, o.size(), f) != o.size()) die("Dump search file failed!");
+    tsv_bytes += o.size();
+  }
+  if (std::fclose(f) != 0) die("Dump search file failed!");
+  debugf("TSV formatted and written (%.1f MB) in %.1f ms", tsv_bytes / 1e6, (now_s() - tp) * 1e3);
   char buf[256];
   std::snprintf(buf, sizeof buf, "Searched %zu queries against %zu references: %zu results (top %u, ANI >= %.1f) took %.3fs",
                 Q.n, R.n, reported, k, c.ani_th, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
