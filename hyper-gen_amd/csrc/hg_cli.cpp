@@ -248,7 +248,8 @@ int run_sketch(const Cli &c) {
   std::vector<Slot> slots(T * S);
   std::vector<Slot *> slot_of(n, nullptr);
   std::mutex mu;
-  std::condition_variable cv_space, cv_stream;
+  std::condition_variable cv_stream;
+  std::vector<std::condition_variable> cv_space(T);  // one per reader: a result wakes the reader that owns the buffer, not all sixteen
   hg_sketch_stream *stream = nullptr;
   std::atomic<size_t> next{0};
   std::atomic<uint64_t> read_ns{0};
@@ -269,7 +270,7 @@ int run_sketch(const Cli &c) {
         size_t in_flight = 0;
         for (size_t q = 0; q < S; ++q) in_flight += slots[tid * S + q].busy ? 1 : 0;
         pack = in_flight >= 2;
-        cv_space.wait(lk, [&] { return !sl.busy; });
+        cv_space[tid].wait(lk, [&] { return !sl.busy; });
       }
       const double tr0 = now_s();
       if (hg_read_fastx_pinned(files[i].c_str(), read_mode | (pack ? pack_flags : 0u), &sl.p, &sl.cap, &sl.len) != HG_OK)
@@ -311,11 +312,13 @@ int run_sketch(const Cli &c) {
     const double tw0 = now_s();
     if (hg_sketch_stream_pop(stream, &f, hv.data(), &n2, &nh, &got) != HG_OK || !got)
       die(std::string("sketch: ") + hg_sketch_stream_last_error(stream));
+    size_t owner;
     {
       std::lock_guard<std::mutex> lk(mu);
       slot_of[f]->busy = false;  // the sequence is not needed any more
+      owner = (size_t)(slot_of[f] - slots.data()) / S;
     }
-    cv_space.notify_all();
+    cv_space[owner].notify_one();
     const double ts1 = now_s();
     const uint32_t q = hg_hv_quant_bits(hv.data(), (uint32_t)c.hv_d);  // if_compressed is hard-wired true (utils.rs:200)
     const size_t pk_bytes = c.pack_naive ? hg_hv_packed_bytes_naive((uint32_t)c.hv_d, q) : hg_hv_packed_bytes((uint32_t)c.hv_d, q);
