@@ -866,12 +866,15 @@ constexpr uint32_t LONG_TILE = 1024;                 // k-mer starts per tile
 constexpr uint32_t LONG_BYTES = 1536;                // staged bytes per tile (>= LONG_TILE + 254), 6 per lane
 constexpr uint32_t LONG_DW = LONG_BYTES / 4 + 4;     // + zero slack for the funnel's second dword
 
+// A strand of the tile in LDS in all four byte phases (image phi holds bytes [4 i + phi, 4 i + phi + 4) at dword i, the
+// images LONG_DW dwords apart): every dword of a k-mer that starts at ANY byte is one aligned read of the image of its
+// start's phase -- the pattern of kmer_sample_shared.  (With one image the k-mer's dwords were cut out of two neighbours
+// each: twice the LDS reads and a v_alignbyte per dword, ~50 reads per k = 33 k-mer.)
 struct LdsStrand {
-  const uint32_t *w32;  // LDS array of bytes, dword view
-  uint32_t byte0;       // first byte of the k-mer in that array
+  const uint32_t *w32;  // the four phase images
+  uint32_t byte0;       // first byte of the k-mer in the strand
   __device__ __forceinline__ uint32_t dword(uint32_t i) const {  // bytes [byte0 + 4i, byte0 + 4i + 4)
-    const uint32_t o = byte0 + 4 * i, a = o >> 2;
-    return __builtin_amdgcn_alignbyte(w32[a + 1], w32[a], o & 3u);
+    return w32[(byte0 & 3u) * LONG_DW + (byte0 >> 2) + i];
   }
   __device__ __forceinline__ uint64_t word(uint32_t byte_off, uint32_t nbytes) const {  // little endian, byte_off % 8 == 0
     uint32_t lo = dword(byte_off / 4), hi = nbytes > 4 ? dword(byte_off / 4 + 1) : 0u;
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
     const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
     uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt, uint32_t stage_cap) {
   __shared__ HitStage stage;
-  __shared__ uint32_t s_f[LONG_DW], s_rc[LONG_DW];
+  __shared__ uint32_t s_f[4 * LONG_DW], s_rc[4 * LONG_DW];  // forward / reverse-complement strand, four byte phases each
   __shared__ uint16_t s_bad[LONG_BYTES + 8];  // s_bad[i] = invalid bytes among the first i staged bytes
   __shared__ uint16_t s_scan[WG];
   const uint32_t item = blockIdx.x, tid = threadIdx.x;
@@ -939,14 +942,30 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
     // ---- stage: 6 consecutive bytes per lane
     uint32_t nbad = 0;
     uint8_t fbyte[6];
+    // the lane's six bases with two loads (packed: 16 codes and 16 validity bits from the byte its first base lies in) or
+    // one (ASCII: 8 bytes) instead of twelve / six byte loads; the caller leaves 32 readable bytes behind every genome
+    typedef uint32_t __attribute__((aligned(1))) u32u_t;
+    typedef uint16_t __attribute__((aligned(1))) u16u_t;
+    typedef uint64_t __attribute__((aligned(1))) u64u_t;
+    const uint64_t pos0 = tile0 + (uint64_t)tid * 6;
+    uint64_t raw = 0;
+    uint32_t cw = 0, mw = 0;
+    if (tid * 6 < n_stage && pos0 < n_bps) {
+      if constexpr (PACKED) {
+        cw = *reinterpret_cast<const u32u_t *>(gseq + (pos0 >> 2)) >> (2 * (uint32_t)(pos0 & 3));
+        mw = (uint32_t)*reinterpret_cast<const u16u_t *>(gmask + (pos0 >> 3)) >> (uint32_t)(pos0 & 7);
+      } else {
+        raw = *reinterpret_cast<const u64u_t *>(gseq + pos0);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const uint32_t i = tid * 6 + j;
       const uint64_t pos = tile0 + i;
       uint32_t code = 4;
       if (i < n_stage && pos < n_bps) {
-        if constexpr (PACKED) code = ((gmask[pos >> 3] >> (pos & 7)) & 1u) ? 4u : (uint32_t)(gseq[pos >> 2] >> (2 * (pos & 3))) & 3u;
-        else code = base_code(gseq[pos], u2t);
+        if constexpr (PACKED) code = ((mw >> j) & 1u) ? 4u : (cw >> (2 * j)) & 3u;
+        else code = base_code((uint8_t)(raw >> (8 * j)), u2t);
       }
       fbyte[j] = code < 4 ? (uint8_t)(0x54474341u >> (8 * code)) : (uint8_t)0;  // "ACGT"
       nbad += code < 4 ? 0u : 1u;
@@ -955,23 +974,37 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
         rb[n_stage - 1 - i] = code < 4 ? (uint8_t)(0x41434754u >> (8 * code)) : (uint8_t)0;  // "TGCA"
       }
     }
-    // exclusive scan of the per-lane invalid counts (Hillis-Steele over WG entries)
-    s_scan[tid] = (uint16_t)nbad;
-    __syncthreads();
-    for (uint32_t o = 1; o < WG; o <<= 1) {
-      const uint16_t add = tid >= o ? s_scan[tid - o] : (uint16_t)0;
-      __syncthreads();
-      s_scan[tid] = (uint16_t)(s_scan[tid] + add);
-      __syncthreads();
+    // exclusive scan of the per-lane invalid counts: inside the wave by shuffles, across the four waves through LDS (two
+    // barriers; the Hillis-Steele network over 256 LDS entries it replaces took sixteen per tile)
+    uint32_t incl = nbad;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o);
+      if ((tid & 63u) >= (uint32_t)o) incl += up;
     }
+    if ((tid & 63u) == 63u) s_scan[tid >> 6] = (uint16_t)incl;
+    __syncthreads();
     {
-      uint32_t run = (uint32_t)s_scan[tid] - nbad;  // invalid bytes before this lane's first byte
+      uint32_t before = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < WG / 64; ++w) before += w < (tid >> 6) ? (uint32_t)s_scan[w] : 0u;
+      uint32_t run = before + incl - nbad;  // invalid bytes before this lane's first byte
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         s_bad[tid * 6 + j] = (uint16_t)run;
         run += fbyte[j] ? 0u : 1u;
       }
       if (tid == WG - 1) s_bad[LONG_BYTES] = (uint16_t)run;
+    }
+    __syncthreads();
+    // phases 1..3 of both strands from phase 0 (the bytes as staged; zero behind them)
+    for (uint32_t i = tid; i < LONG_DW - 1; i += WG) {
+      const uint32_t f0 = s_f[i], f1 = s_f[i + 1], r0 = s_rc[i], r1 = s_rc[i + 1];
+#pragma unroll
+      for (uint32_t ph = 1; ph < 4; ++ph) {
+        s_f[ph * LONG_DW + i] = __builtin_amdgcn_alignbyte(f1, f0, ph);
+        s_rc[ph * LONG_DW + i] = __builtin_amdgcn_alignbyte(r1, r0, ph);
+      }
     }
     __syncthreads();
     // ---- the lane's four starts
