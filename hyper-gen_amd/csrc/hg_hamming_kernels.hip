@@ -44,17 +44,22 @@ struct HamArgs {
   uint32_t ref_off, qry_off;  // global index of row 0 / column 0 (a shard of a larger database)
 };
 
+// JN: query columns per lane -- the tile is HT reference rows x 16 JN queries.  8 = the square tile; 2 and 1 serve searches
+// with up to 32 / 16 queries (a handful of genomes against a large database: with the square tile 1 000 000 x 10 did the
+// xor + popcount work of 128 query columns, 3.5 ms where the reference bits alone stream in 0.3).
+template <int JN>
 __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
+  constexpr int HQ = 16 * JN;  // query columns of a tile
   __shared__ __attribute__((aligned(16))) uint32_t sAB[2 * HT * HROW];
   uint32_t *sA = sAB, *sB = sAB + HT * HROW;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t tx = tid & 15, ty = tid >> 4;  // 16 x 16 lanes, lane (ty,tx) owns rows ty+16i, cols tx+16j
-  const uint32_t row0 = blockIdx.y * HT, col0 = blockIdx.x * HT;
-  uint32_t acc[8][8];
+  const uint32_t row0 = blockIdx.y * HT, col0 = blockIdx.x * HQ;
+  uint32_t acc[8][JN];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+    for (int j = 0; j < JN; ++j) acc[i][j] = 0;
 
   // staging: 128 rows x 32 words = 1024 pieces of 16 B per operand -> 4 per thread
   const uint32_t srow = tid >> 3, spc = tid & 7;
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
           if (w + 2 < a.words) va.z = p[2];
         }
       }
-      if (col0 + r < a.Q) {
+      if (r < (uint32_t)HQ && col0 + r < a.Q) {
         const uint32_t *p = a.qry + (size_t)(col0 + r) * a.words + w;
         if (w + 4 <= a.words) vb = *reinterpret_cast<const uint4 *>(p);
         else {
@@ -83,20 +88,20 @@ __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
         }
       }
       *reinterpret_cast<uint4 *>(&sA[r * HROW + spc * 4]) = va;
-      *reinterpret_cast<uint4 *>(&sB[r * HROW + spc * 4]) = vb;
+      if (r < (uint32_t)HQ) *reinterpret_cast<uint4 *>(&sB[r * HROW + spc * 4]) = vb;
     }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < HK; kk += 4) {
-      uint4 rb[8];  // the B quads stay in registers, the A quads stream through (keeps the kernel
+      uint4 rb[JN];  // the B quads stay in registers, the A quads stream through (keeps the kernel
                     // near 128 VGPRs instead of 240: 4 waves per SIMD instead of 2)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rb[j] = *reinterpret_cast<const uint4 *>(&sB[(tx + 16 * j) * HROW + kk]);
+      for (int j = 0; j < JN; ++j) rb[j] = *reinterpret_cast<const uint4 *>(&sB[(tx + 16 * j) * HROW + kk]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint4 ra = *reinterpret_cast<const uint4 *>(&sA[(ty + 16 * i) * HROW + kk]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < JN; ++j) {
           acc[i][j] += __builtin_popcount(ra.x ^ rb[j].x);
           acc[i][j] += __builtin_popcount(ra.y ^ rb[j].y);
           acc[i][j] += __builtin_popcount(ra.z ^ rb[j].z);
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void hamming_kernel(HamArgs a) {
   for (int i = 0; i < 8; ++i) {
     const uint32_t r = row0 + ty + 16 * i;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < JN; ++j) {
       const uint32_t c = col0 + tx + 16 * j;
       const bool ok = r < a.R && c < a.Q;
       if (ok && a.dist_out) a.dist_out[(size_t)r * a.Q + c] = acc[i][j];
@@ -167,10 +172,13 @@ static hg_status ham_launch(hg_ctx *c, const uint32_t *d_ref, size_t R, const ui
   const uint32_t words = (hv_d + 31) / 32;
   if (words % 4) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be a multiple of 128 for the packed path");
   HamArgs a{d_ref, d_qry, (uint32_t)R, (uint32_t)Q, words, d_dist, d_hits, d_count, cap, max_dist, ref_off, qry_off};
-  dim3 grid((unsigned)((Q + HT - 1) / HT), (unsigned)((R + HT - 1) / HT));
+  const uint32_t cols = Q <= 16 ? 16u : Q <= 32 ? 32u : (uint32_t)HT;  // query columns per tile
+  dim3 grid((unsigned)((Q + cols - 1) / cols), (unsigned)((R + HT - 1) / HT));
   if (grid.y > 65535) return hg_fail(c, HG_ERR_UNSUPPORTED, "too many reference rows for one launch");
   hg_timed tm(c, HG_T_DIST);
-  hipLaunchKernelGGL(hamming_kernel, grid, dim3(256), 0, c->stream, a);
+  if (cols == 16) hipLaunchKernelGGL(hamming_kernel<1>, grid, dim3(256), 0, c->stream, a);
+  else if (cols == 32) hipLaunchKernelGGL(hamming_kernel<2>, grid, dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL(hamming_kernel<8>, grid, dim3(256), 0, c->stream, a);
   HG_HIP(c, hipGetLastError());
   return HG_OK;
 }
@@ -240,7 +248,10 @@ static hg_status hamming_block_once(hg_ctx *c, const uint32_t *d_ref_bits, size_
   // partner; hv_d % 128 == 0 only); small ones -- and everything when the hook says "popc" -- on the xor + popcount
   // kernel above.  All three give the same integers.
   const bool want_i8 = c->dbg_ham_path == "mfma" && hv_d % 128 == 0;
-  const bool mfma = c->dbg_ham_path != "popc" && hv_d <= 65536 && R < 0x7FFFFFFFull && Q < 0x7FFFFFFFull &&
+  // (up to 32 queries: the popcount kernel's narrow tiles stream the references once, whatever their number -- the matrix
+  // pipe's 320 query columns per tile would be 3-10 % used)
+  const bool skinny = Q <= 32 && ((hv_d + 31) / 32) % 4 == 0 && (R + HT - 1) / HT <= 65535 && c->dbg_ham_path.empty();
+  const bool mfma = !skinny && c->dbg_ham_path != "popc" && hv_d <= 65536 && R < 0x7FFFFFFFull && Q < 0x7FFFFFFFull &&
                     ((uint64_t)R * Q >= (uint64_t)1 << 24 || want_i8 || c->dbg_ham_path == "fp4" ||
                      ((hv_d + 31) / 32) % 4 != 0 /* the popcount kernel reads rows in 16-byte pieces */);
   c->last_ham_path = mfma ? (want_i8 ? 1 : 2) : 0;

@@ -415,6 +415,34 @@ def test_dist_of_sketched_synthetic_cluster(ctx, orc, hg):
 
 
 # ---- bit-packed extension (BASELINE configs[4]; the oracle's popcount definition is the reference) ----
+@pytest.mark.parametrize("R,Q,d", [(3000, 1, 2048), (3000, 10, 16384), (700, 16, 1024), (700, 17, 1024), (3000, 32, 2048), (300, 33, 2048)])
+def test_hamming_search_with_a_handful_of_queries(ctx, orc, R, Q, d):
+    """Searches with up to 16 / 32 queries take the popcount kernel's narrow tiles (128 references x 16 / 32 queries), whatever
+    the number of references; the full matrix and the thresholded hits must be the oracle's."""
+    import torch
+    rng = np.random.default_rng(R + 7 * Q + d)
+    wr = rng.integers(0, 2**32, (R, d // 32), dtype=np.uint64).astype(np.uint32)
+    wq = wr[rng.choice(R, Q, replace=False)].copy()
+    wq[:, 0] ^= rng.integers(0, 2**32, Q, dtype=np.uint64).astype(np.uint32)  # near copies: planted hits
+    if Q > 2:
+        wq[Q // 2:] = rng.integers(0, 2**32, (Q - Q // 2, d // 32), dtype=np.uint64).astype(np.uint32)
+    dev = torch.device("cuda:0")
+    br, bq = torch.from_numpy(wr.view(np.int32)).to(dev), torch.from_numpy(wq.view(np.int32)).to(dev)
+    want = orc.hamming_matrix(wr, wq)
+    out = torch.empty((R, Q), dtype=torch.int32, device=dev)
+    ctx.hamming_full_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, out.data_ptr())
+    ctx.sync()
+    assert (out.cpu().numpy().view(np.uint32) == want).all()
+    max_dist = int(d * 0.47)
+    cap = R * Q
+    hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+    n, st = ctx.hamming_search_dev(br.data_ptr(), R, bq.data_ptr(), Q, d, max_dist, hits.data_ptr(), cap)
+    assert st == 0 and ctx.last_hamming_path() == (0 if Q <= 32 else ctx.last_hamming_path())
+    exp = {(i, j, int(want[i, j])) for i, j in zip(*np.nonzero(want <= max_dist))}
+    got = hits.cpu().numpy().view(np.uint32)[: 3 * n].reshape(-1, 3)
+    assert n == len(exp) >= min(Q, 2) // 2 and {(int(a), int(b), int(c)) for a, b, c in got} == exp
+
+
 @pytest.mark.parametrize("R,Q,d", [(1, 1, 128), (37, 300, 16384), (200, 129, 4096), (130, 5, 256), (70, 330, 2464), (9, 600, 96)])
 def test_binarize_and_hamming(ctx, orc, R, Q, d):
     import torch
