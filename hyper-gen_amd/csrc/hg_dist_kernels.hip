@@ -26,6 +26,7 @@
 //   hg_dist_epilogue.h    tile words staged at kernel entry, pre-filter, candidate lists, exact ANI, hit list
 //   this file             the kernel skeleton, the integer fallback, the bit -> operand expanders, the launch logic
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -190,6 +191,97 @@ __global__ __launch_bounds__(FB_T *FB_T) void dist_int_kernel(const int16_t *__r
   if (a.hit_count && ani >= a.ani_th) {
     const uint32_t idx = atomicAdd(a.hit_count, 1u);
     if (idx < a.hit_cap) a.hits[idx] = hg_ani_hit{i + a.ref_off, j + a.qry_off, ani};
+  }
+}
+
+
+// ---- a handful of sketches against a database (hyper-gen search / dist with one or a few genomes on one side) ----------
+// With <= 16 rows on one side the tiles of the matrix-pipe kernels are 3-6 % used and the other side's operand prepass alone
+// costs more than reading it: here the small side sits in LDS as it is (int16), every wave streams rows of the large side
+// once (16 bytes per lane and load, a row of 4 096 dimensions = eight loads in flight), forms the exact int32 dot products
+// with v_dot2_i32_i16 (wrapping like the reference's i32 sum, src/dist.rs:147-151), reduces them across the wave and lets
+// lane s finish pair (row, s): ANI, threshold, one aggregated append per wave.  100 000 x 1 / 10 / 16 at D = 4 096:
+// 0.53 / 0.54 / 0.54 -> 0.155 / 0.23 / 0.48 ms per call (the 820 MB of rows stream in 0.15).  SWAP: the small side is the REFERENCE side (rows of the matrix).
+constexpr uint32_t SK_T = 512, SK_MAX = 16, SK_C = 8;  // threads, rows of the small side, 16-byte pieces per lane and pass
+typedef short short2s __attribute__((ext_vector_type(2)));
+template <bool SWAP>
+__global__ __launch_bounds__(SK_T) void dist_skinny_kernel(const int16_t *__restrict__ big, const int32_t *__restrict__ big_n2,
+                                                           uint32_t n_big, const int16_t *__restrict__ sml,
+                                                           const int32_t *__restrict__ sml_n2, uint32_t n_sml, hg_dist_args a,
+                                                           float kf) {
+  extern __shared__ __attribute__((aligned(16))) uint4 s_sml[];  // n_sml rows of hv_d / 8 pieces
+  const uint32_t pieces = a.hv_d / 8, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < n_sml * pieces; i += SK_T) s_sml[i] = reinterpret_cast<const uint4 *>(sml)[i];
+  __syncthreads();
+  // Two rows of the large side per wave and step: every 16-byte read of the small side serves both (with sixteen small rows
+  // the LDS reads, 128 KB per large row, were what the kernel waited for: 0.69 ms for 100 000 x 16, slower than the tiles)
+  const uint32_t waves = gridDim.x * (SK_T / 64);
+  for (uint32_t row0 = 2 * (blockIdx.x * (SK_T / 64) + wave); row0 < n_big; row0 += 2 * waves) {  // wave-uniform
+    const bool two = row0 + 1 < n_big;
+    const uint4 *__restrict__ src0 = reinterpret_cast<const uint4 *>(big + (size_t)row0 * a.hv_d);
+    const uint4 *__restrict__ src1 = reinterpret_cast<const uint4 *>(big + (size_t)(two ? row0 + 1 : row0) * a.hv_d);
+    int32_t acc0[SK_MAX], acc1[SK_MAX];
+#pragma unroll
+    for (uint32_t q = 0; q < SK_MAX; ++q) acc0[q] = 0, acc1[q] = 0;
+    for (uint32_t p0 = 0; p0 < pieces; p0 += 64 * SK_C) {
+      uint4 v0[SK_C], v1[SK_C];
+#pragma unroll
+      for (uint32_t c = 0; c < SK_C; ++c) {
+        const uint32_t p = p0 + c * 64 + lane;
+        v0[c] = p < pieces ? src0[p] : make_uint4(0, 0, 0, 0);
+        v1[c] = p < pieces ? src1[p] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < SK_MAX; ++q) {
+        if (q < n_sml) {  // wave-uniform
+          int32_t t0 = acc0[q], t1 = acc1[q];
+#pragma unroll
+          for (uint32_t c = 0; c < SK_C; ++c) {
+            const uint32_t p = p0 + c * 64 + lane;
+            if (p0 + c * 64 < pieces) {  // wave-uniform
+              const uint4 w = s_sml[q * pieces + (p < pieces ? p : 0)];  // (a lane past the row's end multiplies zeros)
+              t0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v0[c].x), __builtin_bit_cast(short2s, w.x), t0, false);
+              t0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v0[c].y), __builtin_bit_cast(short2s, w.y), t0, false);
+              t0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v0[c].z), __builtin_bit_cast(short2s, w.z), t0, false);
+              t0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v0[c].w), __builtin_bit_cast(short2s, w.w), t0, false);
+              t1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v1[c].x), __builtin_bit_cast(short2s, w.x), t1, false);
+              t1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v1[c].y), __builtin_bit_cast(short2s, w.y), t1, false);
+              t1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v1[c].z), __builtin_bit_cast(short2s, w.z), t1, false);
+              t1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2s, v1[c].w), __builtin_bit_cast(short2s, w.w), t1, false);
+            }
+          }
+          acc0[q] = t0, acc1[q] = t1;
+        }
+      }
+    }
+    // wave totals; lane q keeps row 0's total of small row q, lane 32 + q row 1's
+    int32_t mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < SK_MAX; ++q) {
+      if (q < n_sml) {  // wave-uniform
+        int32_t t0 = acc0[q], t1 = acc1[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t0 += __shfl_xor(t0, o), t1 += __shfl_xor(t1, o);
+        if (lane == q) mine = t0;
+        if (lane == 32 + q) mine = t1;
+      }
+    }
+    bool hit = false;
+    float ani = 0.0f;
+    const uint32_t sq = lane & 31u, row = row0 + (lane >> 5);  // this lane's small row and large row
+    const uint32_t i = SWAP ? sq : row, j = SWAP ? row : sq;   // (reference row, query column) of its pair
+    if (sq < n_sml && (lane < 32 || two) && !(a.symmetric && i + a.ref_off >= j + a.qry_off)) {
+      ani = SWAP ? ani_from_dot(mine, sml_n2[sq], big_n2[row], kf) : ani_from_dot(mine, big_n2[row], sml_n2[sq], kf);
+      hit = ani >= a.ani_th;
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (bal) {  // wave-uniform
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(a.hit_count, (uint32_t)__popcll(bal));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (hit && idx < a.hit_cap) a.hits[idx] = hg_ani_hit{i + a.ref_off, j + a.qry_off, ani};
+    }
   }
 }
 
@@ -365,6 +457,36 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
   const bool ops_given = a.ref_ops != nullptr;
   const bool same = !ops_given && (a.ref_hv == a.qry_hv) && (a.R == a.Q);
   hg_status s;
+  // ---- a handful of rows on one side: the streaming kernel (no operand prepass, no tiles)
+  {
+    const bool q_small = a.Q <= a.R;
+    const uint32_t n_sml = q_small ? a.Q : a.R, n_big = q_small ? a.R : a.Q;
+    const size_t lds = (size_t)n_sml * a.hv_d * sizeof(int16_t);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.ref_hv) | reinterpret_cast<uintptr_t>(a.qry_hv)) & 15) == 0;
+    if (!ops_given && !a.ani_out && a.hits && a.hit_count && n_sml >= 1 && n_sml <= SK_MAX && a.hv_d % 8 == 0 && aligned &&
+        lds <= 128 * 1024 && c->dbg_dist_path.empty() && c->dbg_dist_tile.empty()) {
+      static std::atomic<uint64_t> done{0};
+      int dev = 0;
+      HG_HIP(c, hipGetDevice(&dev));
+      if (dev >= 0 && dev < 64 && !((done.load() >> dev) & 1)) {
+        HG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&dist_skinny_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&dist_skinny_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        done.fetch_or(1ull << dev);
+      }
+      const float kf = (float)a.ksize;
+      const uint32_t rows_per_wg = 2 * (SK_T / 64);
+      const uint32_t grid = std::min<uint32_t>((n_big + rows_per_wg - 1) / rows_per_wg, 256u * 8u);
+      hg_timed tm(c, HG_T_DIST);
+      c->last_dist_path = 2;  // exact integer dot products
+      c->last_kernel[HG_T_DIST] = q_small ? "dist_skinny_kernel<false>" : "dist_skinny_kernel<true>";
+      if (q_small)
+        hipLaunchKernelGGL(dist_skinny_kernel<false>, dim3(grid), dim3(SK_T), lds, c->stream, a.ref_hv, a.ref_n2, n_big, a.qry_hv, a.qry_n2, n_sml, a, kf);
+      else
+        hipLaunchKernelGGL(dist_skinny_kernel<true>, dim3(grid), dim3(SK_T), lds, c->stream, a.qry_hv, a.qry_n2, n_big, a.ref_hv, a.ref_n2, n_sml, a, kf);
+      HG_HIP(c, hipGetLastError());
+      return HG_OK;
+    }
+  }
   // ---- i8 operand attempt (thresholded, large problems): queued first; every f16 kernel below carries its verdict
   // word as a veto and returns at once when the i8 kernels did the work.  After a failed attempt the next few calls
   // go straight to f16 (large sketches never qualify; probing them every time would cost ~50 us per call).

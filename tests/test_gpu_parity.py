@@ -414,6 +414,42 @@ def test_dist_of_sketched_synthetic_cluster(ctx, orc, hg):
     assert ani[0, 0] == 100.0 and 98.5 < ani[0, 1] < 99.5 and 94 < ani[0, 2] < 96 and ani[0, 4] < 85
 
 
+@pytest.mark.parametrize("R,Q,d,sym", [(3000, 1, 4096, False), (3000, 10, 4096, False), (5, 2500, 4096, False), (16, 700, 1024, False),
+                                       (700, 16, 8192, False), (9, 9, 4096, True), (2000, 3, 256, False), (1, 1, 4096, False)])
+def test_dist_with_a_handful_of_rows_on_one_side(ctx, orc, hg, R, Q, d, sym):
+    """Up to 16 rows on one side (one or a few genomes against a database): the streaming kernel -- the small side in LDS,
+    exact int32 dot products by v_dot2_i32_i16 -- must report the oracle's pairs and ANIs, on either side and symmetric."""
+    import torch
+    rng = np.random.default_rng(R * 31 + Q * 7 + d)
+    n = 2000
+    base = (rng.integers(0, 2, (24, d)) * 2 - 1).astype(np.int64)
+    def sketches(m):
+        hv = np.zeros((m, d), np.int64)
+        for i in range(m):
+            hv[i] = -n + 2 * rng.binomial(n, 0.5, d) + 300 * base[i % 24]  # members of 24 families: planted similar pairs
+        return hv.astype(np.int16)
+    r = sketches(R)
+    q = r if sym else sketches(Q)
+    rn, qn = (r.astype(np.int64) ** 2).sum(1).astype(np.int32), (q.astype(np.int64) ** 2).sum(1).astype(np.int32)
+    want = orc.ani_matrix(r, rn, q, qn, 21)
+    dev = torch.device("cuda:0")
+    tr, tq = torch.from_numpy(r).to(dev), torch.from_numpy(q).to(dev)
+    trn, tqn = torch.from_numpy(rn).to(dev), torch.from_numpy(qn).to(dev)
+    th = 60.0
+    cap = R * Q
+    hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
+    found, st = ctx.dist_dev(tr.data_ptr(), trn.data_ptr(), R, (tr if sym else tq).data_ptr(), (trn if sym else tqn).data_ptr(), Q, d, 21, sym, th,
+                             hits.data_ptr(), cap)
+    assert st == 0 and ctx.last_kernel("dist").startswith("dist_skinny_kernel") == (min(R, Q) * d * 2 <= 128 * 1024)  # (the small side fits LDS)
+    h = hits.cpu().numpy()[: 3 * found].reshape(-1, 3)
+    got = {(int(a), int(b)): float(np.array([c], np.int32).view(np.float32)[0]) for a, b, c in h}
+    exp = {(i, j) for i in range(R) for j in range(Q) if want[i, j] >= th and (not sym or i < j)}
+    near = {(i, j) for i in range(R) for j in range(Q) if abs(want[i, j] - th) < 1e-3}
+    assert set(got) - near == exp - near and len(got) == found
+    assert all(abs(v - want[k]) <= 1e-4 for k, v in got.items())
+    assert len(exp) > 0 or R * Q < 4
+
+
 # ---- bit-packed extension (BASELINE configs[4]; the oracle's popcount definition is the reference) ----
 @pytest.mark.parametrize("R,Q,d", [(3000, 1, 2048), (3000, 10, 16384), (700, 16, 1024), (700, 17, 1024), (3000, 32, 2048), (300, 33, 2048)])
 def test_hamming_search_with_a_handful_of_queries(ctx, orc, R, Q, d):

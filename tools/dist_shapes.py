@@ -19,7 +19,7 @@ big_n2 = (big.int() ** 2).sum(1).int()
 cap = 60_000_000
 hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
 base = None
-for R, Q in ((10_000, 10_000), (1_000, 1_000), (100, 100), (100_000, 100), (100, 100_000), (100_000, 1), (1, 100_000),
+for R, Q in ((10_000, 10_000), (1_000, 1_000), (100, 100), (100_000, 100), (100, 100_000), (100_000, 1), (1, 100_000), (100_000, 10), (100_000, 16),
              (100_000, 1_000), (1_000, 100_000), (30_000, 30_000), (100_000, 100_000)):
     r, rn = big[:R], big_n2[:R]
     q, qn = big[100_000 - Q:], big_n2[100_000 - Q:]
