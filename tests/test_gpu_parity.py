@@ -415,7 +415,8 @@ def test_dist_of_sketched_synthetic_cluster(ctx, orc, hg):
 
 
 @pytest.mark.parametrize("R,Q,d,sym", [(3000, 1, 4096, False), (3000, 10, 4096, False), (5, 2500, 4096, False), (16, 700, 1024, False),
-                                       (700, 16, 8192, False), (9, 9, 4096, True), (2000, 3, 256, False), (1, 1, 4096, False)])
+                                       (700, 16, 8192, False), (9, 9, 4096, True), (2000, 3, 256, False), (1, 1, 4096, False),
+                                       (50, 3, 1000, False), (40, 2, 8, False), (33, 7, 4104, False), (7, 1001, 520, False)])
 def test_dist_with_a_handful_of_rows_on_one_side(ctx, orc, hg, R, Q, d, sym):
     """Up to 16 rows on one side (one or a few genomes against a database): the streaming kernel -- the small side in LDS,
     exact int32 dot products by v_dot2_i32_i16 -- must report the oracle's pairs and ANIs, on either side and symmetric."""
