@@ -61,7 +61,7 @@ class FileSketch(C.Structure):
 
 EXPORTS = [
     "hg_status_str", "hg_last_error", "hg_version", "hg_ctx_create", "hg_ctx_destroy",
-    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
+    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_ctx_sketch_step_counts", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
     "hg_copy_h2d", "hg_copy_d2h", "hg_sketch_params_default", "hg_kmer_hash_sample",
     "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack", "hg_hv_packed_bytes",
@@ -132,6 +132,7 @@ def lib():
         "hg_ctx_set_stream": (C.c_int, [vp, vp]),
         "hg_ctx_reset_stream": (C.c_int, [vp]),
         "hg_ctx_sync": (C.c_int, [vp]),
+        "hg_ctx_sketch_step_counts": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "hg_device_count": (C.c_int, []),
         "hg_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
         "hg_dev_free": (C.c_int, [vp, vp]),
@@ -326,7 +327,14 @@ class Context:
         self._ck(lib().hg_ctx_reset_stream(self._h))
 
     def sync(self):
+        """hg_ctx_sync: reads a queued sketch step's check word (re-running the step if it asks for it), then waits for the stream."""
         self._ck(lib().hg_ctx_sync(self._h))
+
+    def sketch_step_counts(self):
+        """(sync-free, synchronous, re-run) sketch steps of this ctx so far (hg_ctx_sketch_step_counts)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(lib().hg_ctx_sketch_step_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def last_kernel(self, cls):
         """Name of the kernel the last call launched for a timing class ("kmer", "dist"), as rocprofv3 prints it."""

@@ -101,6 +101,9 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
   for (auto e : c->t_pool) (void)hipEventDestroy(e);
   if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->h_chk) (void)hipHostFree(c->h_chk);
+  if (c->h_plan) (void)hipHostFree(c->h_plan);
+  if (c->plan_uploaded) (void)hipEventDestroy(c->plan_uploaded);
   for (auto e : c->copy_events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) {
     if (c->pack_buf[i]) (void)hipHostFree(c->pack_buf[i]);
@@ -116,7 +119,7 @@ extern "C" void hg_ctx_destroy(hg_ctx *c) {
 // old one: otherwise the next call's kernels could overwrite workspaces the old stream still reads.
 static hg_status switch_stream(hg_ctx *c, hipStream_t to) {
   if (to == c->stream) return HG_OK;
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   HG_HIP(c, hipStreamSynchronize(c->stream));
   c->stream = to;
   return HG_OK;
@@ -144,6 +147,7 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
   else if (k == "dist_order") c->dbg_dist_order = v;  // "plain": no diagonal-first tile order
   else if (k == "ham_path") c->dbg_ham_path = v;
   else if (k == "hostfed") c->dbg_hostfed = v;  // hg_sketch_batch / hg_kmer_hash_sample: "ascii" never 2-bit pack on the host, "packed" always
+  else if (k == "sketch_path") c->dbg_sketch_path = v;  // "sync": every sketch step takes the synchronous path (counters read back between sort and encode)
   else if (k == "kmer_input") c->dbg_kmer_input = v;  // "packed": ASCII batches are 2-bit packed on the device first and take the packed kernels
   else return hg_fail(c, HG_ERR_INVALID, "unknown debug key " + k);
   return HG_OK;
@@ -151,7 +155,16 @@ extern "C" hg_status hg_ctx_set_debug(hg_ctx *c, const char *key, const char *va
 
 extern "C" hg_status hg_ctx_sync(hg_ctx *c) {
   if (!c) return HG_ERR_INVALID;
+  HG_ENTER(c);  // (a queued sketch step whose check word asks for it is run again here)
   HG_HIP(c, hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+extern "C" hg_status hg_ctx_sketch_step_counts(hg_ctx *c, uint64_t *sync_free, uint64_t *synchronous, uint64_t *redone) {
+  if (!c) return HG_ERR_INVALID;
+  if (sync_free) *sync_free = c->n_fast_steps;
+  if (synchronous) *synchronous = c->n_sync_steps;
+  if (redone) *redone = c->n_redone_steps;
   return HG_OK;
 }
 
@@ -313,18 +326,20 @@ hg_status hg_ensure_pinned(hg_ctx *c, size_t bytes) {
 
 extern "C" hg_status hg_dev_alloc(hg_ctx *c, size_t bytes, void **dptr) {
   if (!c || !dptr) return HG_ERR_INVALID;
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
   if (e != hipSuccess) return hg_fail(c, HG_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
   return HG_OK;
 }
 extern "C" hg_status hg_dev_free(hg_ctx *c, void *dptr) {
   if (!c) return HG_ERR_INVALID;
+  HG_ENTER(c);  // (the block may be an operand of the queued sketch step)
   if (dptr) HG_HIP(c, hipFree(dptr));
   return HG_OK;
 }
 extern "C" hg_status hg_copy_h2d(hg_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!c) return HG_ERR_INVALID;
+  HG_ENTER(c);
   if (bytes) {
     HG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HG_HIP(c, hipStreamSynchronize(c->stream));
@@ -333,6 +348,7 @@ extern "C" hg_status hg_copy_h2d(hg_ctx *c, void *dst, const void *src, size_t b
 }
 extern "C" hg_status hg_copy_d2h(hg_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!c) return HG_ERR_INVALID;
+  HG_ENTER(c);
   if (bytes) {
     HG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HG_HIP(c, hipStreamSynchronize(c->stream));

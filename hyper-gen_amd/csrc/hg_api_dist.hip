@@ -40,7 +40,7 @@ extern "C" hg_status hg_dist_full_dev(hg_ctx *c, const int16_t *d_ref_hv, const 
   if (s != HG_OK) return s;
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || !d_ani_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   hg_dist_args a{};
   a.ref_hv = d_ref_hv, a.ref_n2 = d_ref_norm2, a.qry_hv = d_qry_hv, a.qry_n2 = d_qry_norm2;
   a.R = (uint32_t)R, a.Q = (uint32_t)Q, a.hv_d = hv_d, a.ksize = ksize;
@@ -102,7 +102,7 @@ static hg_status dist_block_once(hg_ctx *c, const int16_t *d_ref_hv, const int32
   if (ref_off + R > 0x7FFFFFFFull || qry_off + Q > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "global indices must be < 2^31");
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_hv || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   // [0] hit counter, [1] exactness verdict, [2] its window length, [4..12] control words of the i8 operand attempt
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
@@ -164,7 +164,7 @@ extern "C" hg_status hg_dist_prep_ops_dev(hg_ctx *c, const int16_t *d_hv, size_t
   if (rows == 0) return HG_OK;
   if (!d_hv || !d_ops || !d_meta || !d_flag || hv_d == 0) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   if (rows > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 rows");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   return hg_run_dist_prep_ops(c, d_hv, (uint32_t)rows, hv_d, d_ops, d_meta, d_flag);
 }
 
@@ -218,7 +218,7 @@ static hg_status dist_block_ops_once(hg_ctx *c, const uint8_t *d_ref_ops, const 
   if (!d_ref_ops || !d_ref_meta || !d_ref_norm2 || !d_qry_hv || !d_qry_norm2 || (cap && !d_out) || (n_flags && !d_flags))
     return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   if (d_ref_index && symmetric) return hg_fail(c, HG_ERR_UNSUPPORTED, "symmetric needs contiguous reference indices (no d_ref_index)");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);
   if (c->misc_zeroed != d_count) HG_HIP(c, hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), c->stream));
@@ -285,7 +285,7 @@ extern "C" hg_status hg_dist_full(hg_ctx *c, const int16_t *ref_hv, const int32_
   if (s != HG_OK) return s;
   if (R == 0 || Q == 0) return HG_OK;
   if (!ref_hv || !ref_norm2 || !qry_hv || !qry_norm2 || !ani_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   StagedDist sd;
   if ((s = stage_dist(c, ref_hv, ref_norm2, R, qry_hv, qry_norm2, Q, hv_d, sd)) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_ani, R * Q * sizeof(float) + 64)) != HG_OK) return s;
@@ -306,7 +306,7 @@ extern "C" hg_status hg_dist(hg_ctx *c, const int16_t *ref_hv, const int32_t *re
   if (s != HG_OK) return s;
   if (R == 0 || Q == 0) return HG_OK;
   if (!ref_hv || !ref_norm2 || !qry_hv || !qry_norm2 || (cap && !out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   StagedDist sd;
   if ((s = stage_dist(c, ref_hv, ref_norm2, R, qry_hv, qry_norm2, Q, hv_d, sd)) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_ani, cap * sizeof(hg_ani_hit) + 64)) != HG_OK) return s;

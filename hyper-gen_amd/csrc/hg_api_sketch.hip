@@ -19,364 +19,31 @@
 
 #include "hg_host.h"
 
-#include "hg_internal.h"
-
-// ---------------------------------------------------------------------------------------------
-// sketch core: hash+sample -> sort/unique -> (optional) encode, all genomes of a batch
-// ---------------------------------------------------------------------------------------------
-namespace {
-
-struct BatchPlan {
-  uint32_t max_hits = ~0u;  // largest stored raw hit count of the batch (upper bound of the distinct counts)
-  std::vector<std::pair<uint32_t, uint32_t>> big;  // (genome, stored raw hits) with more than HG_ENC_SLAB hits
-  std::vector<hg_genome_meta> meta;
-  std::vector<uint32_t> item_genome;
-  uint64_t total_slots = 0;
-  uint32_t max_cap = 0;
-};
-
-uint32_t round_cap(uint64_t cap) {
-  if (cap > HG_SORT_LDS_MAX_KEYS) {  // in-place global sort needs a power of two
-    uint64_t p = 1;
-    while (p < cap) p <<= 1;
-    cap = p;
-  }
-  return cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cap;
-}
-
-// want_caps: optional per-genome minimum capacities (retry after overflow)
-hg_status make_plan(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize,
-                    uint64_t scaled, const std::vector<uint32_t> *want_caps, BatchPlan &pl, const uint64_t *mask_offs = nullptr) {
-  const uint64_t item_starts = hg_kmer_item_starts(ksize);
-  pl.meta.resize(n);
-  pl.item_genome.clear();
-  uint64_t slot = 0;
-  uint32_t max_cap = 0;
-  for (size_t g = 0; g < n; ++g) {
-    if (offsets[g] & 3) return hg_fail(c, HG_ERR_INVALID, "genome offsets must be multiples of 4");
-    hg_genome_meta &m = pl.meta[g];
-    m.seq_off = offsets[g];
-    m.n_bps = lens[g];
-    m.mask_off = mask_offs ? mask_offs[g] : offsets[g] + (((lens[g] + 3) / 4 + 15) & ~(uint64_t)15);  // (read by the packed kernels only)
-    const uint64_t n_starts = lens[g] >= ksize ? lens[g] - ksize + 1 : 0;
-    uint64_t cap = n_starts / scaled * 2 + 1024;  // expected n_starts/scaled; sd ~ sqrt of that
-    if (cap > n_starts) cap = n_starts;             // can never exceed the number of k-mers
-    if (want_caps && (*want_caps)[g] > cap) cap = (*want_caps)[g];
-    if (cap == 0) cap = 1;
-    m.hit_cap = round_cap(cap);
-    m.hit_off = slot;
-    slot += m.hit_cap;
-    max_cap = std::max(max_cap, m.hit_cap);
-    const uint64_t n_items = (n_starts + item_starts - 1) / item_starts;
-    if (pl.item_genome.size() + n_items > 0x7FFFFFFFull)
-      return hg_fail(c, HG_ERR_UNSUPPORTED, "batch too large for one launch; split it");
-    m.item_first = (uint32_t)pl.item_genome.size();
-    pl.item_genome.insert(pl.item_genome.end(), (size_t)n_items, (uint32_t)g);
-  }
-  pl.total_slots = slot;
-  pl.max_cap = max_cap;
-  return HG_OK;
-}
-
-// Sorts + de-duplicates the genomes whose sampled hash count exceeds what one workgroup sorts in LDS.
-// h_cnt: raw per-genome counters (host copy).  Synchronises the stream when it had work to do.
-hg_status sort_large_sets(hg_ctx *c, const BatchPlan &pl, const uint32_t *h_cnt, size_t n, uint64_t threshold,
-                          uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_nd) {
-  // keys per bucket aimed at (512-1 024 land in one; the sort's LDS is sized for four times that, hg_launch_sort_large) /
-  // buckets per genome
-  constexpr uint32_t TARGET = 1024, MAX_BUCKETS = 16384;
-  std::vector<hg_bucket_job> jobs;
-  std::vector<uint32_t> chunk_job, bucket_job, inplace;
-  uint32_t cap_keys = 4 * TARGET;  // keys the bucket sort's LDS is sized for: four times what a bucket is expected to hold
-  for (size_t g = 0; g < n; ++g) {
-    const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
-    if (cnt <= HG_SORT_LDS_MAX_KEYS) continue;
-    uint32_t P = 2;
-    while (P < MAX_BUCKETS && (uint64_t)P * TARGET < cnt) P <<= 1;
-    // (the counting and scattering workgroups keep a genome's bucket counters in LDS up to PRIV buckets -- beyond that every
-    // key pays a global atomic: a set of up to PRIV * 4 096 keys rather fills fewer, larger buckets)
-    constexpr uint32_t PRIV = 2048;
-    if (P > PRIV && (uint64_t)cnt <= (uint64_t)PRIV * 4096) P = PRIV;
-    if (c->dbg_sort_buckets) {  // test hook (hg_ctx_set_debug): force overflowing buckets / the fallback
-      P = (uint32_t)std::max(2, c->dbg_sort_buckets);
-    } else if ((uint64_t)P * (HG_SORT_LDS_MAX_KEYS / 2) < cnt) {  // more than ~8 k keys per bucket expected: too many for LDS
-      inplace.push_back((uint32_t)g);
-      continue;
-    }
-    cap_keys = std::max<uint32_t>(cap_keys, 4 * ((cnt + P - 1) / P));  // (a genome with more keys than MAX_BUCKETS * TARGET fills its buckets further)
-    hg_bucket_job j{};
-    j.hit_off = pl.meta[g].hit_off, j.n = cnt, j.P = P, j.genome = (uint32_t)g;
-    // bucket(h) = floor(h * P / threshold) for h < threshold, as a multiply-high by ceil(P * 2^64 / threshold)
-    const unsigned __int128 num = ((unsigned __int128)P << 64) + threshold - 1;
-    const unsigned __int128 q = num / (threshold ? threshold : 1);
-    j.mul = q > (unsigned __int128)UINT64_MAX ? UINT64_MAX : (uint64_t)q;
-    j.bucket_first = (uint32_t)bucket_job.size(), j.chunk_first = (uint32_t)chunk_job.size();
-    bucket_job.insert(bucket_job.end(), P, (uint32_t)jobs.size());
-    chunk_job.insert(chunk_job.end(), (cnt + HG_BUCKET_CHUNK - 1) / HG_BUCKET_CHUNK, (uint32_t)jobs.size());
-    jobs.push_back(j);
-  }
-  if (jobs.empty() && inplace.empty()) return HG_OK;
-  hg_status s;
-  const size_t jb = (jobs.size() * sizeof(hg_bucket_job) + 63) & ~(size_t)63;
-  const size_t cb = (chunk_job.size() * 4 + 63) & ~(size_t)63, bb = (bucket_job.size() * 4 + 63) & ~(size_t)63;
-  const size_t kb = ((5 * bucket_job.size() + jobs.size()) * 4 + 63) & ~(size_t)63;
-  const size_t tb = ((std::max(inplace.size(), jobs.size())) * 4 + 63) & ~(size_t)63;
-  if ((s = hg_ensure(c, c->w_lsort, jb + cb + bb + kb + tb + 64)) != HG_OK) return s;
-  auto *base = static_cast<uint8_t *>(c->w_lsort.p);
-  auto *d_jobs = reinterpret_cast<hg_bucket_job *>(base);
-  auto *d_chunk = reinterpret_cast<uint32_t *>(base + jb), *d_bucket = reinterpret_cast<uint32_t *>(base + jb + cb);
-  auto *d_bk = reinterpret_cast<uint32_t *>(base + jb + cb + bb), *d_todo = reinterpret_cast<uint32_t *>(base + jb + cb + bb + kb);
-  if (!jobs.empty()) {
-    if ((s = hg_ensure(c, c->w_hits2, pl.total_slots * sizeof(uint64_t) + 16)) != HG_OK) return s;
-    HG_HIP(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(hg_bucket_job), hipMemcpyHostToDevice, c->stream));
-    HG_HIP(c, hipMemcpyAsync(d_chunk, chunk_job.data(), chunk_job.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HG_HIP(c, hipMemcpyAsync(d_bucket, bucket_job.data(), bucket_job.size() * 4, hipMemcpyHostToDevice, c->stream));
-    std::vector<uint32_t> fail(jobs.size());
-    {
-      hg_timed tm(c, HG_T_SORT);
-      HG_HIP(c, hg_launch_sort_large(c->stream, d_jobs, (uint32_t)jobs.size(), d_chunk, (uint32_t)chunk_job.size(), d_bucket,
-                                     (uint32_t)bucket_job.size(), d_bk, d_hits, static_cast<uint64_t *>(c->w_hits2.p), d_nd,
-                                     c->dbg_sort_buckets ? HG_SORT_LDS_MAX_KEYS : cap_keys));
-    }
-    HG_HIP(c, hipMemcpyAsync(fail.data(), d_bk + 5 * bucket_job.size(), jobs.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HG_HIP(c, hipStreamSynchronize(c->stream));  // also keeps the host vectors alive until the uploads are done
-    for (size_t k = 0; k < jobs.size(); ++k)
-      if (fail[k]) inplace.push_back(jobs[k].genome);
-  }
-  if (!inplace.empty()) {
-    HG_HIP(c, hipMemcpyAsync(d_todo, inplace.data(), inplace.size() * 4, hipMemcpyHostToDevice, c->stream));
-    {
-      hg_timed tm(c, HG_T_SORT);
-      HG_HIP(c, hg_launch_sort_inplace(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), d_todo, (uint32_t)inplace.size(),
-                                       d_hits, d_cnt, d_nd));
-    }
-    HG_HIP(c, hipStreamSynchronize(c->stream));
-  }
-  return HG_OK;
-}
-
-// Runs hash+sample and sort/unique.  On return (stream synchronised) the device hit buffer holds
-// each genome's ascending distinct hashes at meta[g].hit_off and *d_ndistinct_out the counts.
-// ASCII genomes -> hg_pack2 blobs on the device (stream-ordered): genome i of d_seq (seq_offs[i], lens[i]) to
-// d_blobs + blob_offs[i].  The offset tables travel through the ctx's pinned scratch (overwritten: callers stage
-// nothing there across this call).
-hg_status pack_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *seq_offs, const uint64_t *lens, size_t n,
-                     uint32_t norm_mode, uint8_t *d_blobs, const uint64_t *blob_offs) {
-  if (n == 0) return HG_OK;
-  hg_status s;
-  if ((s = hg_ensure(c, c->w_pktab, 3 * n * sizeof(uint64_t) + 64)) != HG_OK) return s;
-  if ((s = hg_ensure_pinned(c, 3 * n * sizeof(uint64_t) + 64)) != HG_OK) return s;
-  HG_HIP(c, hipStreamSynchronize(c->stream));  // (the scratch may still feed an earlier upload)
-  auto *tab = static_cast<uint64_t *>(c->h_pin);
-  uint64_t max_len = 0;
-  for (size_t g = 0; g < n; ++g) {
-    if ((seq_offs[g] & 3) || (blob_offs[g] & 15)) return hg_fail(c, HG_ERR_INVALID, "pack2: sequence offsets must be multiples of 4, blob offsets of 16");
-    tab[3 * g] = seq_offs[g], tab[3 * g + 1] = lens[g], tab[3 * g + 2] = blob_offs[g];
-    max_len = std::max(max_len, lens[g]);
-  }
-  HG_HIP(c, hipMemcpyAsync(c->w_pktab.p, tab, 3 * n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  const uint64_t groups = ((((max_len + 7) / 8 + 15) & ~(uint64_t)15) + 3) / 4;  // lanes per genome: one per 4 bitmap bytes
-  const uint64_t blocks = (groups + 255) / 256;
-  if (blocks > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "pack2: genome too long for one launch");
-  if (blocks)
-    HG_HIP(c, hg_launch_pack2(c->stream, d_seq, static_cast<const uint64_t *>(c->w_pktab.p), (uint32_t)n, (uint32_t)blocks,
-                              norm_mode == HG_NORM_U2T ? 1u : 0u, d_blobs));
-  HG_HIP(c, hipStreamSynchronize(c->stream));  // (the pinned table is free again)
-  return HG_OK;
-}
-
-// One-genome callers that want the sorted hash list on the host (hg_kmer_hash_sample): the distinct count and the first
-// max_hashes hashes ride back with the counter copy sample_batch synchronises on anyway -- one synchronisation per call
-// instead of three.  valid is set when the list the LDS sort produced is final (no overflow, no second sort pass).
-struct SampleFetch {
-  size_t max_hashes = 0;
-  const uint64_t *h_hashes = nullptr;  // in the ctx's page-locked scratch: consume before the next call on the ctx
-  uint32_t nd = 0;
-  bool valid = false;
-};
-
-hg_status sample_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens,
-                       size_t n, uint32_t ksize, uint64_t threshold, uint64_t scaled_for_cap, uint64_t seed,
-                       bool canonical, uint32_t norm_mode, BatchPlan &pl, uint32_t **d_ndistinct_out, bool packed = false,
-                       const uint64_t *mask_offs = nullptr, SampleFetch *fetch = nullptr) {
-  if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
-  std::vector<uint64_t> hook_offs;
-  if (!packed && c->dbg_kmer_input == "packed") {
-    // test hook: the batch arrived as ASCII -- pack it here and run the packed kernels on the blobs, so that every
-    // ASCII entry point (and with it every parity test) can be driven through both input forms
-    hook_offs.resize(n);
-    uint64_t total = 0;
-    for (size_t g = 0; g < n; ++g) hook_offs[g] = total, total += hg_pack2_size(lens[g]);
-    hg_status s;
-    if ((s = hg_ensure(c, c->w_pk, total + 64)) != HG_OK) return s;
-    if ((s = pack_batch(c, d_seq, offsets, lens, n, norm_mode, static_cast<uint8_t *>(c->w_pk.p), hook_offs.data())) != HG_OK) return s;
-    d_seq = static_cast<const uint8_t *>(c->w_pk.p), offsets = hook_offs.data(), packed = true;
-  }
-  std::vector<uint32_t> want;
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    hg_status s;
-    // same geometry as the previous call (typical for a stream of equally shaped batches): the
-    // work-item table and the per-genome records are still on the device
-    const bool reuse = attempt == 0 && c->plan_valid && c->plan_ksize == ksize && c->plan_scaled == scaled_for_cap &&
-                       c->plan_packed == packed && c->plan_offs.size() == n && std::memcmp(c->plan_offs.data(), offsets, n * 8) == 0 &&
-                       std::memcmp(c->plan_lens.data(), lens, n * 8) == 0 &&
-                       (mask_offs ? (c->plan_masks.size() == n && std::memcmp(c->plan_masks.data(), mask_offs, n * 8) == 0) : c->plan_masks.empty());
-    size_t n_items;
-    if (reuse) {
-      n_items = c->plan_items;
-      pl.total_slots = c->plan_slots, pl.max_cap = c->plan_max_cap;
-      pl.meta.resize(n);
-      uint64_t slot = 0;
-      for (size_t g = 0; g < n; ++g) {  // only what callers read back: capacities and hit offsets
-        pl.meta[g].hit_cap = c->plan_caps[g];
-        pl.meta[g].hit_off = slot;
-        slot += c->plan_caps[g];
-      }
-    } else {
-      c->plan_valid = false;
-      if ((s = make_plan(c, offsets, lens, n, ksize, scaled_for_cap, attempt ? &want : nullptr, pl, mask_offs)) != HG_OK) return s;
-      n_items = pl.item_genome.size();
-    }
-    if ((s = hg_ensure(c, c->w_gmeta, n * sizeof(hg_genome_meta) + 16)) != HG_OK) return s;
-    if ((s = hg_ensure(c, c->w_items, n_items * sizeof(uint32_t) + 16)) != HG_OK) return s;
-    if ((s = hg_ensure(c, c->w_hits, pl.total_slots * sizeof(uint64_t) + 16)) != HG_OK) return s;
-    if ((s = hg_ensure(c, c->w_cnt, 2 * n * sizeof(uint32_t) + 16)) != HG_OK) return s;
-    const size_t pin_meta = (n * sizeof(hg_genome_meta) + 63) & ~(size_t)63;
-    const size_t pin_items = (n_items * sizeof(uint32_t) + 63) & ~(size_t)63;
-    // (the fetch block lies behind the plan's staging area whether this call uses that or not)
-    const size_t fetch_off = ((n * sizeof(uint32_t) + 63) & ~(size_t)63) + pin_meta + pin_items;
-    const size_t fetch_n = (fetch && n == 1) ? std::min<size_t>({fetch->max_hashes, pl.meta[0].hit_cap, (size_t)1 << 16}) : 0;
-    if ((s = hg_ensure_pinned(c, n * sizeof(uint32_t) + 64 + (reuse ? 0 : pin_meta + pin_items) +
-                                     (fetch && n == 1 ? fetch_off + 64 + fetch_n * 8 : 0))) != HG_OK) return s;
-    auto *d_meta = static_cast<hg_genome_meta *>(c->w_gmeta.p);
-    auto *d_items = static_cast<uint32_t *>(c->w_items.p);
-    auto *d_hits = static_cast<uint64_t *>(c->w_hits.p);
-    auto *d_cnt = static_cast<uint32_t *>(c->w_cnt.p);
-    uint32_t *d_nd = d_cnt + n;
-    auto *h_cnt = static_cast<uint32_t *>(c->h_pin);
-    if (!reuse) {  // upload through pinned staging so that the copies are truly asynchronous
-      uint8_t *pin = static_cast<uint8_t *>(c->h_pin) + ((n * sizeof(uint32_t) + 63) & ~(size_t)63);
-      std::memcpy(pin, pl.meta.data(), n * sizeof(hg_genome_meta));
-      HG_HIP(c, hipMemcpyAsync(d_meta, pin, n * sizeof(hg_genome_meta), hipMemcpyHostToDevice, c->stream));
-      if (n_items) {
-        std::memcpy(pin + pin_meta, pl.item_genome.data(), n_items * sizeof(uint32_t));
-        HG_HIP(c, hipMemcpyAsync(d_items, pin + pin_meta, n_items * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-      }
-    }
-    HG_HIP(c, hipMemsetAsync(d_cnt, 0, 2 * n * sizeof(uint32_t), c->stream));
-    {
-      hg_timed tm(c, HG_T_KMER);
-      c->last_kernel[HG_T_KMER] = hg_kmer_kernel_name(ksize, canonical, packed);
-      HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
-                                      seed, canonical, norm_mode, d_hits, d_cnt, packed));
-    }
-    uint32_t sort_cap = pl.max_cap;
-    {
-      // The LDS sort is sized by the genomes' CAPACITIES (twice the expected count + 1 024: 64 KiB for a 5 Mbp genome,
-      // two workgroups per CU).  When the plan is a repeat, the counts of its last run are known: size by those (+ 12.5 %,
-      // 32 KiB -> five workgroups per CU); a genome that outgrows it is left to the large-set path below, as always.
-      if (reuse && c->plan_max_hits) sort_cap = (uint32_t)std::min<uint64_t>(sort_cap, (uint64_t)c->plan_max_hits + c->plan_max_hits / 8 + 16);
-      hg_timed tm(c, HG_T_SORT, HG_T_KMER);
-      HG_HIP(c, hg_launch_sort_unique(c->stream, d_meta, (uint32_t)n, d_hits, d_cnt, d_nd, sort_cap, threshold));
-    }
-    // overflow check on the raw counters (they keep counting past the capacity)
-    HG_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    uint8_t *h_fetch = static_cast<uint8_t *>(c->h_pin) + fetch_off;
-    if (fetch && n == 1) {
-      fetch->valid = false;
-      HG_HIP(c, hipMemcpyAsync(h_fetch, d_nd, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-      if (fetch_n)
-        HG_HIP(c, hipMemcpyAsync(h_fetch + 64, d_hits + pl.meta[0].hit_off, fetch_n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    }
-    HG_HIP(c, hipStreamSynchronize(c->stream));
-    bool overflow = false;
-    want.assign(n, 0);
-    for (size_t g = 0; g < n; ++g)
-      if (h_cnt[g] > pl.meta[g].hit_cap) overflow = true, want[g] = h_cnt[g];
-    if (!overflow) {
-      if (hg_sort_lds_keys(sort_cap) < hg_sort_lds_keys(pl.max_cap)) {
-        // the count-sized sort left out every genome that grew past its size: those again, with the capacity-sized one
-        std::vector<uint32_t> redo;
-        const uint32_t keys = hg_sort_lds_keys(sort_cap);
-        for (size_t g = 0; g < n; ++g) {
-          const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
-          if (cnt > keys && cnt <= HG_SORT_LDS_MAX_KEYS) redo.push_back((uint32_t)g);
-        }
-        if (!redo.empty()) {
-          if ((s = hg_ensure(c, c->w_redo, redo.size() * 4 + 64)) != HG_OK) return s;
-          // staged in the ctx's page-locked scratch behind the counters (which were consumed above) and uploaded on the
-          // ctx's own stream like every other command of this path: no legacy-stream copy that would also synchronise
-          // with the other ctxs of the device
-          const size_t redo_off = (n * sizeof(uint32_t) + 63) & ~(size_t)63;
-          if (c->h_pin_cap < redo_off + redo.size() * 4) {
-            std::vector<uint32_t> keep(h_cnt, h_cnt + n);  // (growing the scratch frees the block the counters live in)
-            if ((s = hg_ensure_pinned(c, redo_off + redo.size() * 4)) != HG_OK) return s;
-            h_cnt = static_cast<uint32_t *>(c->h_pin);
-            std::memcpy(h_cnt, keep.data(), n * sizeof(uint32_t));
-          }
-          uint32_t *h_redo = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->h_pin) + redo_off);
-          std::memcpy(h_redo, redo.data(), redo.size() * 4);
-          HG_HIP(c, hipMemcpyAsync(c->w_redo.p, h_redo, redo.size() * 4, hipMemcpyHostToDevice, c->stream));
-          HG_HIP(c, hipStreamSynchronize(c->stream));  // (rare path; the next call may rewrite the scratch at once)
-          hg_timed tm(c, HG_T_SORT);
-          HG_HIP(c, hg_launch_sort_unique_todo(c->stream, d_meta, static_cast<uint32_t *>(c->w_redo.p), (uint32_t)redo.size(),
-                                               d_hits, d_cnt, d_nd, pl.max_cap, threshold));
-        }
-      }
-      // hash sets beyond the LDS sort: bucketed multi-workgroup sort (or, where that cannot work, in place)
-      if ((s = sort_large_sets(c, pl, h_cnt, n, threshold, d_hits, d_cnt, d_nd)) != HG_OK) return s;
-      h_cnt = static_cast<uint32_t *>(c->h_pin);  // (unchanged unless the pinned scratch grew)
-      pl.big.clear();
-      pl.max_hits = 0;
-      for (size_t g = 0; g < n; ++g) {
-        const uint32_t cnt = std::min(h_cnt[g], pl.meta[g].hit_cap);
-        pl.max_hits = std::max(pl.max_hits, cnt);
-        if (cnt > HG_ENC_SLAB) pl.big.emplace_back((uint32_t)g, cnt);
-      }
-      if (!reuse) {  // remember this plan for the next call
-        c->plan_offs.assign(offsets, offsets + n);
-        c->plan_lens.assign(lens, lens + n);
-        if (mask_offs) c->plan_masks.assign(mask_offs, mask_offs + n);
-        else c->plan_masks.clear();
-        c->plan_caps.resize(n);
-        for (size_t g = 0; g < n; ++g) c->plan_caps[g] = pl.meta[g].hit_cap;
-        c->plan_ksize = ksize, c->plan_scaled = scaled_for_cap, c->plan_packed = packed;
-        c->plan_slots = pl.total_slots, c->plan_max_cap = pl.max_cap, c->plan_items = n_items;
-        c->plan_valid = true;
-      }
-      c->plan_max_hits = pl.max_hits;
-      *d_ndistinct_out = d_nd;
-      if (fetch && n == 1) {
-        // the copies above saw the final list iff the first sort pass covered the set
-        const uint32_t cnt = std::min(h_cnt[0], pl.meta[0].hit_cap);
-        if (cnt <= hg_sort_lds_keys(sort_cap) && cnt <= HG_SORT_LDS_MAX_KEYS) {  // (then nothing above touched the scratch either)
-          uint32_t nd;
-          std::memcpy(&nd, h_fetch, sizeof nd);
-          if (nd <= fetch_n) fetch->valid = true, fetch->nd = nd, fetch->h_hashes = reinterpret_cast<const uint64_t *>(h_fetch + 64);
-        }
-      }
-      return HG_OK;
-    }
-    c->plan_valid = false;
-  }
-  return hg_fail(c, HG_ERR_HIP, "hit buffer overflow persisted after resizing");
-}
-
-hg_status check_params(hg_ctx *c, const hg_sketch_params *p) {
-  if (!p) return hg_fail(c, HG_ERR_INVALID, "params == NULL");
-  if (p->ksize < 1) return hg_fail(c, HG_ERR_INVALID, "ksize must be >= 1");
-  if (p->ksize > 255) return hg_fail(c, HG_ERR_UNSUPPORTED, "ksize must be <= 255 (the reference's -k is u8)");
-  if (p->scaled < 1) return hg_fail(c, HG_ERR_INVALID, "scaled must be >= 1");
-  if (p->hv_layout > HG_LAYOUT_AVX2 || p->norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad layout / norm mode");
-  if (p->hv_d == 0 || p->hv_d > 32768) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be in 1..32768");
-  return HG_OK;
-}
-
-}  // namespace
+#include "hg_sketch.h"
 
 static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
                                        const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed,
-                                       const uint64_t *mask_offs = nullptr);
+                                       const uint64_t *mask_offs = nullptr) {
+  if (!c) return HG_ERR_INVALID;
+  hg_status s = hg_check_sketch_params(c, p);
+  if (s != HG_OK) return s;
+  if (n == 0) return HG_OK;
+  if (!d_seq || !offsets || !lens || !d_hv || !d_norm2 || !d_nhash) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
+  if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
+  HG_HIP(c, hipSetDevice(c->device));  // (no HG_ENTER: hg_sketch_step reads the previous step's check word behind its own launches)
+  if (!packed && c->dbg_kmer_input == "packed") {
+    // test hook: the batch arrived as ASCII -- pack it here and run the packed kernels on the blobs, so that every
+    // ASCII entry point (and with it every parity test) can be driven through both input forms
+    if ((s = hg_sketch_resolve(c)) != HG_OK) return s;
+    std::vector<uint64_t> hook_offs(n);
+    uint64_t total = 0;
+    for (size_t g = 0; g < n; ++g) hook_offs[g] = total, total += hg_pack2_size(lens[g]);
+    if ((s = hg_ensure(c, c->w_pk, total + 64)) != HG_OK) return s;
+    if ((s = hg_pack_batch(c, d_seq, offsets, lens, n, p->norm_mode, static_cast<uint8_t *>(c->w_pk.p), hook_offs.data())) != HG_OK) return s;
+    return hg_sketch_step(c, static_cast<const uint8_t *>(c->w_pk.p), hook_offs.data(), lens, n, p, d_hv, d_norm2, d_nhash, true, nullptr);
+  }
+  return hg_sketch_step(c, d_seq, offsets, lens, n, p, d_hv, d_norm2, d_nhash, packed, mask_offs);
+}
 
 hg_status hg_sketch_batch_dev_packed_masks(hg_ctx *c, const uint8_t *d_blobs, const uint64_t *code_offs, const uint64_t *mask_offs,
                                            const uint64_t *n_bps, size_t n, const hg_sketch_params *p, int16_t *d_hv,
@@ -405,8 +72,8 @@ extern "C" hg_status hg_pack2_batch_dev(hg_ctx *c, const uint8_t *d_seq, const u
   if (n == 0) return HG_OK;
   if (!d_seq || !offsets || !lens || !d_blobs || !blob_offsets || norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad argument");
   if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 genomes in one batch");
-  HG_HIP(c, hipSetDevice(c->device));
-  return pack_batch(c, d_seq, offsets, lens, n, norm_mode, d_blobs, blob_offsets);
+  HG_ENTER(c);
+  return hg_pack_batch(c, d_seq, offsets, lens, n, norm_mode, d_blobs, blob_offsets);
 }
 
 extern "C" hg_status hg_pack2_dev(hg_ctx *c, const uint8_t *d_seq, size_t n_bps, uint32_t norm_mode, uint8_t *d_blob) {
@@ -414,51 +81,6 @@ extern "C" hg_status hg_pack2_dev(hg_ctx *c, const uint8_t *d_seq, size_t n_bps,
   if (((uintptr_t)d_seq & 3) || ((uintptr_t)d_blob & 15)) return hg_fail(c, HG_ERR_INVALID, "hg_pack2_dev: d_seq must be 4-byte, d_blob 16-byte aligned");
   const uint64_t zero = 0, len = n_bps;
   return hg_pack2_batch_dev(c, d_seq, &zero, &len, 1, norm_mode, d_blob, &zero);
-}
-
-static hg_status sketch_batch_dev_impl(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offsets, const uint64_t *lens, size_t n,
-                                       const hg_sketch_params *p, int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash, bool packed,
-                                       const uint64_t *mask_offs) {
-  if (!c) return HG_ERR_INVALID;
-  hg_status s = check_params(c, p);
-  if (s != HG_OK) return s;
-  if (n == 0) return HG_OK;
-  if (!d_seq || !offsets || !lens || !d_hv || !d_norm2 || !d_nhash) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
-  BatchPlan pl;
-  uint32_t *d_nd = nullptr;
-  const uint64_t threshold = UINT64_MAX / p->scaled;  // src/sketch.rs:73
-  s = sample_batch(c, d_seq, offsets, lens, n, p->ksize, threshold, p->scaled, p->seed, p->canonical != 0,
-                   p->norm_mode, pl, &d_nd, packed, mask_offs);
-  if (s != HG_OK) return s;
-  // genomes with very large hash sets are encoded by several workgroups each (plan from the raw hit counts)
-  hg_encode_split split{};
-  std::vector<uint32_t> items, genomes;
-  if (!pl.big.empty() && pl.big.size() < 65536) {
-    for (size_t k = 0; k < pl.big.size(); ++k) {
-      const uint32_t slabs = std::min<uint32_t>((pl.big[k].second + HG_ENC_SLAB - 1) / HG_ENC_SLAB, 65535u);
-      for (uint32_t sl = 0; sl < slabs; ++sl) items.push_back(pl.big[k].first), items.push_back(sl | ((uint32_t)k << 16));
-      genomes.push_back(pl.big[k].first);
-    }
-    const size_t ib = (items.size() * 4 + 63) & ~(size_t)63, gb = (genomes.size() * 4 + 63) & ~(size_t)63;
-    if ((s = hg_ensure(c, c->w_lsort, ib + gb + 64)) != HG_OK) return s;
-    if ((s = hg_ensure(c, c->w_hits2, genomes.size() * (size_t)p->hv_d * 4 + 64)) != HG_OK) return s;
-    auto *d_items = static_cast<uint32_t *>(c->w_lsort.p);
-    auto *d_genomes = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->w_lsort.p) + ib);
-    HG_HIP(c, hipMemcpyAsync(d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HG_HIP(c, hipMemcpyAsync(d_genomes, genomes.data(), genomes.size() * 4, hipMemcpyHostToDevice, c->stream));
-    split.d_items = d_items, split.d_genomes = d_genomes, split.d_accum = static_cast<uint32_t *>(c->w_hits2.p);
-    split.n_items = (uint32_t)(items.size() / 2), split.n_genomes = (uint32_t)genomes.size();
-  }
-  {
-    hg_timed tm(c, HG_T_ENCODE);
-    HG_HIP(c, hg_launch_encode(c->stream, static_cast<hg_genome_meta *>(c->w_gmeta.p), (uint32_t)n,
-                               static_cast<uint64_t *>(c->w_hits.p), d_nd, p->hv_d, p->hv_layout, d_hv, d_norm2,
-                               split.n_items ? &split : nullptr, pl.max_hits));
-  }
-  if (split.n_items) HG_HIP(c, hipStreamSynchronize(c->stream));  // the pageable item tables must outlive their upload
-  HG_HIP(c, hipMemcpyAsync(d_nhash, d_nd, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-  return HG_OK;
 }
 
 // NUMA node the device hangs off (sysfs of its PCI function), -1 when unknown.  Page-locked buffers filled by
@@ -626,11 +248,11 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
                                      const hg_sketch_params *p, int16_t *hv_out, int32_t *norm2_out,
                                      uint32_t *nhash_out) {
   if (!c) return HG_ERR_INVALID;
-  hg_status s = check_params(c, p);
+  hg_status s = hg_check_sketch_params(c, p);
   if (s != HG_OK) return s;
   if (n == 0) return HG_OK;
   if (!seqs || !lens || !hv_out || !norm2_out || !nhash_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   // The link is what limits this entry point (50 GB/s = 10 k genomes/s of 5 Mbp as ASCII): a batch that is worth it goes
   // over as 2-bit packed bases -- hg_pack2 blobs, 0.375 bytes per base, packed by a few host threads of this call into the
   // page-locked staging buffers while the previous sub-batch uploads -- and is sketched by the packed-input kernels
@@ -712,6 +334,7 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
     c->copy_events.push_back(e);
   }
 
+  const uint64_t redone_before = c->n_redone_steps;  // (a sub-batch whose step is run again leaves stale rows in the copies queued behind it)
   std::mutex mu;
   std::condition_variable cv;
   size_t queued = 0;  // sub-batches whose uploads and event are queued
@@ -823,6 +446,10 @@ extern "C" hg_status hg_sketch_batch(hg_ctx *c, const uint8_t *const *seqs, cons
     (void)hipStreamSynchronize(c->stream);
     return s;
   }
+  // the last sub-batch's check word (the earlier ones were read as their successors were queued)
+  if ((s = hg_sketch_resolve(c)) != HG_OK) return s;
+  if (c->n_redone_steps != redone_before)
+    HG_HIP(c, hipMemcpyAsync(hv_out, d_hv, hv_bytes, hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipMemcpyAsync(norm2_out, d_n2, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipMemcpyAsync(nhash_out, d_nh, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HG_HIP(c, hipStreamSynchronize(c->stream));
@@ -840,7 +467,7 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   if (norm_mode > HG_NORM_U2T) return hg_fail(c, HG_ERR_INVALID, "bad norm mode");
   if (n_bps && !seq) return hg_fail(c, HG_ERR_INVALID, "NULL sequence");
   if (n_bps < ksize) return HG_OK;
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   const std::vector<uint64_t> offs{0}, l64{n_bps};
   hg_status s = hg_ensure(c, c->w_seq, n_bps + 64);
   if (s != HG_OK) return s;
@@ -862,12 +489,12 @@ extern "C" hg_status hg_kmer_hash_sample(hg_ctx *c, const uint8_t *seq, size_t n
   // capacity heuristic wants "scaled"; derive it from the threshold (threshold = MAX / scaled)
   uint64_t scaled = threshold ? UINT64_MAX / threshold : UINT64_MAX;
   if (scaled < 1) scaled = 1;
-  BatchPlan pl;
+  hg_batch_tables pl;
   uint32_t *d_nd = nullptr;
-  SampleFetch fetch;
+  hg_sample_fetch fetch;
   fetch.max_hashes = out_hashes ? cap : 0;
-  s = sample_batch(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), 1, ksize, threshold, scaled,
-                   seed, canonical != 0, norm_mode, pl, &d_nd, packed, nullptr, &fetch);
+  s = hg_sample_batch_sync(c, static_cast<uint8_t *>(c->w_seq.p), offs.data(), l64.data(), 1, ksize, threshold, scaled,
+                         seed, canonical != 0, norm_mode, pl, &d_nd, packed, nullptr, &fetch);
   if (s != HG_OK) return s;
   if (fetch.valid) {  // count and hashes came back with sample_batch's own synchronisation
     *n_out = fetch.nd;
@@ -895,13 +522,13 @@ extern "C" hg_status hg_hv_encode(hg_ctx *c, const uint64_t *hashes, size_t n, u
   if (hv_layout > HG_LAYOUT_AVX2) return hg_fail(c, HG_ERR_INVALID, "bad layout");
   if ((n && !hashes) || !hv_out || !norm2_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   if (n > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "too many hashes");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   hg_status s;
   if ((s = hg_ensure(c, c->w_gmeta, sizeof(hg_genome_meta))) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_hits, (n + 1) * sizeof(uint64_t))) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_cnt, 2 * sizeof(uint32_t))) != HG_OK) return s;
   if ((s = hg_ensure(c, c->w_hv, (size_t)hv_d * sizeof(int16_t) + 64)) != HG_OK) return s;
-  c->plan_valid = false;  // w_gmeta is about to be overwritten
+  c->plan.reset();  // w_gmeta is about to be overwritten
   hg_genome_meta m{};
   m.hit_off = 0, m.hit_cap = (uint32_t)n;
   const uint32_t nd = (uint32_t)n;

@@ -89,17 +89,14 @@ constexpr uint32_t SORT_BUCKET_MAX_KEYS = 8192, SORT_BUCKET_LIMIT = 16, SORT_KPT
 static_assert(SORT_BUCKET_MAX_KEYS == SORT_LDS_MAX_KEYS, "every set the one-workgroup sort takes can take its counting sort");
 constexpr size_t SORT_LDS_BYTES_MAX = (size_t)SORT_LDS_MAX_KEYS * (sizeof(uint64_t) + sizeof(uint32_t));  // keys + counters
 
+// The sort + unique of ONE genome by the calling workgroup (n = its stored raw hits).  Returns early -- whole waves, or
+// the whole workgroup -- on the paths that need no barrier; a caller that loops over genomes puts a barrier between them.
 template <bool USE_LDS>
-__global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
-    const hg_genome_meta *__restrict__ meta, uint64_t *__restrict__ hits,
-    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ ndistinct, uint32_t lds_keys,
-    const uint32_t *__restrict__ todo, uint64_t bucket_mul) {
+__device__ __forceinline__ void sort_unique_one(const uint32_t g, const hg_genome_meta &gm, const uint32_t n,
+                                                uint64_t *__restrict__ hits, uint32_t *__restrict__ ndistinct,
+                                                const uint32_t lds_keys, const uint64_t bucket_mul) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
   __shared__ uint32_t s_scan[SORT_WG / 64 + 1];
-  const uint32_t g = todo ? todo[blockIdx.x] : blockIdx.x;
-  const hg_genome_meta gm = meta[g];
-  uint32_t n = cnt[g];
-  if (n > gm.hit_cap) n = gm.hit_cap;  // overflow is reported by the host from cnt[]
   uint64_t *region = hits + gm.hit_off;
   const uint32_t n2 = next_pow2(n);
   const bool in_lds = n2 <= lds_keys;
@@ -220,6 +217,65 @@ __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
     __syncthreads();
   }
   if (tid == 0) ndistinct[g] = base;
+}
+
+// One workgroup per genome (of the todo list, if there is one).
+template <bool USE_LDS>
+__global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
+    const hg_genome_meta *__restrict__ meta, uint64_t *__restrict__ hits,
+    const uint32_t *__restrict__ cnt, uint32_t *__restrict__ ndistinct, uint32_t lds_keys,
+    const uint32_t *__restrict__ todo, uint64_t bucket_mul, uint32_t *__restrict__ flags) {
+  const uint32_t g = todo ? todo[blockIdx.x] : blockIdx.x;
+  const hg_genome_meta gm = meta[g];
+  uint32_t n = cnt[g];
+  if (flags) {
+    // the sync-free step: nobody on the host looks at cnt[] before the encoders run -- a genome this launch and its
+    // hg_launch_sort_unique_rest cannot finish is marked for them and reported through the step's flag word
+    const bool over = n > gm.hit_cap;
+    if (over || n > SORT_LDS_MAX_KEYS) {
+      if (threadIdx.x == 0) atomicOr(flags, over ? HG_STEP_OVERFLOW : HG_STEP_LARGE_SET), ndistinct[g] = HG_NHASH_PENDING;
+      return;
+    }
+  }
+  if (n > gm.hit_cap) n = gm.hit_cap;  // overflow is reported by the host from cnt[]
+  sort_unique_one<USE_LDS>(g, gm, n, hits, ndistinct, lds_keys, bucket_mul);
+}
+
+// grid: SORT_WG genomes per workgroup.  The genomes whose raw count is in (skip_keys, lds_keys] -- what a launch of
+// sort_unique_kernel with skip_keys of LDS left out -- are picked out of the counters by the workgroup itself and sorted
+// one after the other (rare by construction: skip_keys is 1.125 times the expected count, or last run's largest).
+__global__ __launch_bounds__(SORT_WG) void sort_unique_rest_kernel(
+    const hg_genome_meta *__restrict__ meta, uint64_t *__restrict__ hits, const uint32_t *__restrict__ cnt,
+    uint32_t *__restrict__ ndistinct, uint32_t n_genomes, uint32_t skip_keys, uint32_t lds_keys, uint64_t bucket_mul) {
+  __shared__ uint32_t s_list[SORT_WG], s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t g = blockIdx.x * SORT_WG + threadIdx.x;
+  if (g < n_genomes) {
+    const uint32_t c = cnt[g];
+    if (c > skip_keys && c <= lds_keys && c <= meta[g].hit_cap) s_list[atomicAdd(&s_n, 1u)] = g;
+  }
+  __syncthreads();
+  const uint32_t todo = s_n;
+  for (uint32_t i = 0; i < todo; ++i) {
+    const uint32_t gi = s_list[i];
+    const hg_genome_meta gm = meta[gi];
+    sort_unique_one<true>(gi, gm, cnt[gi], hits, ndistinct, lds_keys, bucket_mul);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void sketch_finish_kernel(const uint32_t *__restrict__ ndistinct, uint32_t *__restrict__ nhash,
+                                                            uint32_t n_genomes, const uint32_t *__restrict__ flags,
+                                                            volatile uint32_t *h_slot, uint32_t seq) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g < n_genomes) nhash[g] = ndistinct[g];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    h_slot[0] = *flags;
+    __threadfence_system();
+    h_slot[1] = seq;
+    __threadfence_system();
+  }
 }
 
 // ---- large hash sets: bucket by value, sort + unique each bucket in LDS -----------------------------------
@@ -521,7 +577,7 @@ __global__ __launch_bounds__(ENC_WG) void encode_kernel(
   const uint32_t g = SPLIT ? items[blockIdx.x].x : blockIdx.x;
   const hg_genome_meta gm = meta[g];
   const uint32_t n_all = ndistinct[g];
-  if (!SPLIT && (n_all > split_over || n_all <= wave_max)) return;  // split launch / encode_wave_kernel
+  if (!SPLIT && (n_all > split_over || n_all <= wave_max || n_all == HG_NHASH_PENDING)) return;  // split launch / encode_wave_kernel / left to the redo
   const uint32_t slab = SPLIT ? (items[blockIdx.x].y & 0xffffu) : 0u, slot = SPLIT ? (items[blockIdx.x].y >> 16) : 0u;
   const uint32_t h0 = SPLIT ? slab * HG_ENC_SLAB : 0u;
   if (SPLIT && h0 >= n_all) return;  // the plan was made from the raw (pre-unique) count
@@ -853,6 +909,9 @@ static hipError_t sort_lds_attr() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bucket_sort_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES_MAX);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_unique_rest_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_BYTES_MAX);
   if (e == hipSuccess) attr_done_on_this_device(done, true);
   return e;
 }
@@ -883,13 +942,13 @@ hipError_t hg_launch_sort_unique_todo(hipStream_t st, const hg_genome_meta *d_me
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_todo), dim3(SORT_WG), sort_lds_bytes(keys, bucket_mul), st, d_meta,
-                     d_hits, d_cnt, d_ndistinct, keys, d_todo, bucket_mul);
+                     d_hits, d_cnt, d_ndistinct, keys, d_todo, bucket_mul, (uint32_t *)nullptr);
   return hipGetLastError();
 }
 
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
-                                 uint32_t max_cap, uint64_t threshold) {
+                                 uint32_t max_cap, uint64_t threshold, uint32_t *d_flags) {
   if (n_genomes == 0) return hipSuccess;
   const uint32_t keys = hg_sort_lds_keys(max_cap);
   const uint64_t bucket_mul = sort_bucket_mul(keys, threshold);
@@ -897,9 +956,29 @@ hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, u
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
   // genomes whose hit count exceeds the LDS budget are skipped here: the caller learns the counts and
-  // runs hg_launch_sort_large / hg_launch_sort_inplace for them
+  // runs hg_launch_sort_large / hg_launch_sort_inplace for them (or, with d_flags, reads the step's flag word)
   hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_genomes), dim3(SORT_WG), lds, st, d_meta,
-                     d_hits, d_cnt, d_ndistinct, keys, (const uint32_t *)nullptr, bucket_mul);
+                     d_hits, d_cnt, d_ndistinct, keys, (const uint32_t *)nullptr, bucket_mul, d_flags);
+  return hipGetLastError();
+}
+
+hipError_t hg_launch_sort_unique_rest(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes, uint64_t *d_hits,
+                                      const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t done_cap, uint32_t max_cap,
+                                      uint64_t threshold) {
+  const uint32_t skip = hg_sort_lds_keys(done_cap), keys = hg_sort_lds_keys(max_cap);
+  if (n_genomes == 0 || skip >= keys) return hipSuccess;
+  const uint64_t bucket_mul = sort_bucket_mul(keys, threshold);
+  hipError_t e = sort_lds_attr();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sort_unique_rest_kernel, dim3((n_genomes + SORT_WG - 1) / SORT_WG), dim3(SORT_WG),
+                     sort_lds_bytes(keys, bucket_mul), st, d_meta, d_hits, d_cnt, d_ndistinct, n_genomes, skip, keys, bucket_mul);
+  return hipGetLastError();
+}
+
+hipError_t hg_launch_sketch_finish(hipStream_t st, const uint32_t *d_ndistinct, uint32_t *d_nhash, uint32_t n_genomes,
+                                   const uint32_t *d_flags, uint32_t *h_slot, uint32_t seq) {
+  hipLaunchKernelGGL(sketch_finish_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, st, d_ndistinct, d_nhash, n_genomes,
+                     d_flags, h_slot, seq);
   return hipGetLastError();
 }
 
@@ -907,7 +986,7 @@ hipError_t hg_launch_sort_inplace(hipStream_t st, const hg_genome_meta *d_meta, 
                                   uint32_t n_todo, uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct) {
   if (n_todo == 0) return hipSuccess;
   hipLaunchKernelGGL((sort_unique_kernel<false>), dim3(n_todo), dim3(SORT_WG), 0, st, d_meta, d_hits, d_cnt,
-                     d_ndistinct, SORT_LDS_MAX_KEYS, d_todo, (uint64_t)0);
+                     d_ndistinct, SORT_LDS_MAX_KEYS, d_todo, (uint64_t)0, (uint32_t *)nullptr);
   return hipGetLastError();
 }
 

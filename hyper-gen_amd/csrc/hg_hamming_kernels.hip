@@ -155,7 +155,7 @@ extern "C" hg_status hg_hv_binarize_dev(hg_ctx *c, const int16_t *d_hv, size_t n
   if (!c) return HG_ERR_INVALID;
   if (n == 0) return HG_OK;
   if (!d_hv || !d_bits || hv_d == 0) return hg_fail(c, HG_ERR_INVALID, "bad binarize arguments");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   const uint32_t words = (hv_d + 31) / 32;
   for (size_t g0 = 0; g0 < n; g0 += 65535) {
     const uint32_t m = (uint32_t)std::min<size_t>(65535, n - g0);
@@ -190,7 +190,7 @@ extern "C" hg_status hg_hamming_full_dev(hg_ctx *c, const uint32_t *d_ref_bits, 
   if (!c) return HG_ERR_INVALID;
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_bits || !d_qry_bits || !d_dist_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   return ham_launch(c, d_ref_bits, R, d_qry_bits, Q, hv_d, d_dist_out, nullptr, nullptr, 0, 0);
 }
 
@@ -237,7 +237,7 @@ static hg_status hamming_block_once(hg_ctx *c, const uint32_t *d_ref_bits, size_
   if (R == 0 || Q == 0) return HG_OK;
   if (!d_ref_bits || !d_qry_bits || (cap && !d_out)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   if (ref_off + R > 0xFFFFFFFFull || qry_off + Q > 0xFFFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "global indices must fit 32 bits");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   hg_status s;
   if ((s = hg_ensure(c, c->w_misc, 64)) != HG_OK) return s;
   auto *d_count = static_cast<uint32_t *>(c->w_misc.p);

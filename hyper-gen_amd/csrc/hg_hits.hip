@@ -258,7 +258,7 @@ extern "C" hg_status hg_sort_ani_hits_dev(hg_ctx *c, hg_ani_hit *d_hits, size_t 
   if (n < 2) return HG_OK;
   if (!d_hits) return hg_fail(c, HG_ERR_INVALID, "NULL hit list");
   if (n > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "hit list too long for the device sort");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   const uint32_t m = (uint32_t)n, grid = (m + 255) / 256;
   SortWs w;
   hg_status s = sort_workspace(c, m, w);
@@ -290,7 +290,7 @@ extern "C" hg_status hg_sort_ani_hits_staged(hg_ctx *c, hg_ani_hit *hits, size_t
   if (!c) return HG_ERR_INVALID;
   if (n < 2) return HG_OK;
   if (!hits) return hg_fail(c, HG_ERR_INVALID, "NULL hit list");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   hg_status s = hg_ensure(c, c->w_ani, n * sizeof(hg_ani_hit) + 64);
   if (s != HG_OK) return s;
   HG_HIP(c, hipMemcpyAsync(c->w_ani.p, hits, n * sizeof(hg_ani_hit), hipMemcpyHostToDevice, c->stream));
@@ -306,7 +306,7 @@ extern "C" hg_status hg_topk_per_query_dev(hg_ctx *c, const hg_ani_hit *d_hits, 
   if (Q == 0 || k == 0) return HG_OK;
   if (!d_out || !d_counts || (n && !d_hits)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   if (n > 0xFFFFFFF0ull || Q > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "hit list too long for the device sort");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   const size_t slots = Q * (size_t)k;
   hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c->stream, d_out, slots);
   HG_HIP(c, hipGetLastError());

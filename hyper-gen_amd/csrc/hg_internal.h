@@ -4,10 +4,38 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/hypergen.h"
+
+// ---- sketch batch plans (hg_sketch_plan.hip) ----------------------------------------------------------------
+// Geometry of one sketch batch as the k-mer kernel sees it: hit regions and work items per genome.  Kept by the ctx
+// between calls (the device tables stay valid for a batch of the same shape) and by a queued step until its check
+// word has been read (the redo of a step needs the offsets it was queued with).
+struct hg_sketch_plan {
+  std::vector<uint64_t> offs, lens, masks;  // the caller's arrays (masks empty: bitmaps directly behind the codes)
+  std::vector<uint32_t> caps;               // hit_cap per genome
+  uint32_t ksize = 0;
+  bool packed = false;
+  uint64_t scaled = 0, total_slots = 0;
+  uint32_t max_cap = 0;
+  uint32_t max_expect = 0;  // largest expected sampled count (k-mer starts / scaled) of a genome
+  uint32_t max_hits = 0;    // largest raw hit count the plan's last synchronous run saw (0: unknown)
+  size_t n_items = 0;
+};
+struct hg_sketch_pending {
+  bool active = false;
+  uint32_t seq = 0;
+  int slot = 0;
+  std::shared_ptr<const hg_sketch_plan> plan;
+  const uint8_t *d_seq = nullptr;
+  hg_sketch_params p{};
+  int16_t *d_hv = nullptr;
+  int32_t *d_norm2 = nullptr;
+  uint32_t *d_nhash = nullptr;
+};
 
 // ---- error plumbing ----------------------------------------------------------------
 struct hg_ctx {
@@ -79,16 +107,17 @@ struct hg_ctx {
   std::vector<TimedLaunch> t_pending;   // recorded, not yet read
   std::vector<hipEvent_t> t_pool;       // reusable events
   // cached batch plan of the last sketch call: when the next call has the same geometry the host
-  // neither rebuilds the work-item table nor uploads it again (see sample_batch)
-  std::vector<uint64_t> plan_offs, plan_lens, plan_masks;
-  std::vector<uint32_t> plan_caps;  // hit_cap per genome of the cached plan
-  uint32_t plan_ksize = 0;
-  bool plan_packed = false;  // the cached plan's genomes were hg_pack2 blobs
-  uint64_t plan_scaled = 0, plan_slots = 0;
-  uint32_t plan_max_cap = 0;
-  uint32_t plan_max_hits = 0;  // largest raw hit count the cached plan's last run saw (sizes the LDS sort of the next)
-  size_t plan_items = 0;
-  bool plan_valid = false;
+  // neither rebuilds the work-item table nor uploads it again (hg_sketch.h)
+  std::shared_ptr<hg_sketch_plan> plan;  // != nullptr: w_gmeta / w_items hold (or are being sent) this plan's tables
+  hipEvent_t plan_uploaded = nullptr;    // behind the last upload from the plan staging area (h_plan)
+  bool plan_upload_pending = false;
+  void *h_plan = nullptr;                // page-locked staging of the plan tables (meta records + work items)
+  size_t h_plan_cap = 0;
+  // the sync-free sketch step (hg_sketch_step.hip): its check word comes back through h_chk one call late
+  hg_sketch_pending pending;
+  uint32_t *h_chk = nullptr;   // 2 slots of 16 page-locked words the device writes {flags, ..., seq} into
+  uint32_t chk_seq = 0;
+  uint64_t n_fast_steps = 0, n_sync_steps = 0, n_redone_steps = 0;  // (hg_ctx_sketch_path_counts: tests, bench)
   // host-fed batches: uploads run on their own stream, one event per sub-batch (hg_sketch_batch)
   hipStream_t copy_stream = nullptr;
   std::vector<hipEvent_t> copy_events;
@@ -103,7 +132,7 @@ struct hg_ctx {
   uint32_t pad_a_rows = 0, pad_a_ldk = 0, pad_b_rows = 0, pad_b_ldk = 0;
   std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was already raised on this device
   // development / test hooks (hg_ctx_set_debug); never read from the environment
-  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input, dbg_hostfed;
+  std::string dbg_dist_tile, dbg_dist_path, dbg_ham_path, dbg_dist_order, dbg_kmer_input, dbg_hostfed, dbg_sketch_path;
   int dbg_sort_buckets = 0;
   uint64_t dbg_pair_limit = 0;  // test hook "pair_limit": pairs one kernel launch of a comparison may enumerate (0: 2^32 - 1, the hit counter's reach)
   // pinned host scratch
@@ -142,6 +171,17 @@ struct hg_timed {
     if (e__ != hipSuccess)                                                             \
       return hg_fail((ctx), HG_ERR_HIP,                                                \
                      std::string(#expr) + ": " + hipGetErrorString(e__));              \
+  } while (0)
+
+// Reads the check word of the ctx's queued sketch step, if there is one, and re-runs the step through the synchronous
+// path when it reports a genome that outgrew its hit region or the one-workgroup sort (hg_sketch_step.hip).  Every entry
+// point that takes a ctx starts with it (HG_ENTER): whatever it reads or overwrites is final / free by then.
+hg_status hg_sketch_resolve(hg_ctx *ctx, bool *redone = nullptr);
+#define HG_ENTER(ctx)                                        \
+  do {                                                       \
+    HG_HIP((ctx), hipSetDevice((ctx)->device));              \
+    const hg_status s__ = hg_sketch_resolve((ctx));          \
+    if (s__ != HG_OK) return s__;                            \
   } while (0)
 
 // ---- k-mer sampling kernel interface ---------------------------------------------------
@@ -192,9 +232,23 @@ hipError_t hg_launch_sort_unique_todo(hipStream_t st, const hg_genome_meta *d_me
                                       uint64_t threshold);
 // (threshold: every key is below it -- the sampling threshold; it scales the buckets of the counting-sort fast path,
 // 0 = bitonic only)
+// d_flags != nullptr (the sync-free step): a genome whose raw count exceeds its hit region (HG_STEP_OVERFLOW) or the
+// one-workgroup sort (HG_STEP_LARGE_SET) is not sorted -- its bit is or-ed into *d_flags and its distinct count becomes
+// HG_NHASH_PENDING, which the encoders skip.
 hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes,
                                  uint64_t *d_hits, const uint32_t *d_cnt, uint32_t *d_ndistinct,
-                                 uint32_t max_cap, uint64_t threshold);
+                                 uint32_t max_cap, uint64_t threshold, uint32_t *d_flags = nullptr);
+#define HG_STEP_OVERFLOW 1u
+#define HG_STEP_LARGE_SET 2u
+// The genomes a sort sized for `done_cap` left out (more raw hits than its LDS held keys), with one sized for max_cap:
+// the workgroups find them in the counters themselves -- no list from the host.
+hipError_t hg_launch_sort_unique_rest(hipStream_t st, const hg_genome_meta *d_meta, uint32_t n_genomes, uint64_t *d_hits,
+                                      const uint32_t *d_cnt, uint32_t *d_ndistinct, uint32_t done_cap, uint32_t max_cap,
+                                      uint64_t threshold);
+// Last kernel of a sync-free step: d_nhash[g] = d_ndistinct[g], and the step's flag word goes to the page-locked
+// check slot with the step's sequence number behind it (h_slot[0] = flags, h_slot[1] = seq).
+hipError_t hg_launch_sketch_finish(hipStream_t st, const uint32_t *d_ndistinct, uint32_t *d_nhash, uint32_t n_genomes,
+                                   const uint32_t *d_flags, uint32_t *h_slot, uint32_t seq);
 
 // Genomes with more than HG_SORT_LDS_MAX_KEYS sampled hashes: keys are bucketed by value (monotone map, so
 // the concatenation of sorted buckets is sorted), every bucket is sorted + de-duplicated in LDS by its own

@@ -615,6 +615,11 @@ extern "C" hg_status hg_dist_multi_dev(hg_multi *m, const int16_t *const *d_ref_
   if (!d_ref_hv || !d_ref_norm2 || !ref_rows || (cap && !out)) return mfail(m, HG_ERR_INVALID, "NULL argument");
   if (d_qry_hv && (!d_qry_norm2 || !qry_rows)) return mfail(m, HG_ERR_INVALID, "query shards need norms and row counts");
   const int ns = (int)m->ctx.size();
+  for (int s = 0; s < ns; ++s) {  // the shards' operands may be the outputs of a sketch step still queued on their ctx
+    if (hipSetDevice(m->dev[s]) != hipSuccess) return mfail(m, HG_ERR_HIP, "hipSetDevice");
+    const hg_status st = hg_sketch_resolve(m->ctx[s]);
+    if (st != HG_OK) return mfail(m, st, hg_last_error(m->ctx[s]));
+  }
   DistPlan pl;
   pl.rlo.resize(ns), pl.rhi.resize(ns);
   for (int s = 0; s < ns; ++s) {

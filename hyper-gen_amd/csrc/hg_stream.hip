@@ -509,6 +509,22 @@ void computer(hg_sketch_stream *s, Engine *ep, int wi) {
       ST_HIP(s, hipMemcpyAsync(w.h_res + hvb_al, w.d_n2, m * 4, hipMemcpyDeviceToHost, w.ctx->stream));
       ST_HIP(s, hipMemcpyAsync(w.h_res + hvb_al + CHUNK_GENOMES * 4, w.d_nh, m * 4, hipMemcpyDeviceToHost, w.ctx->stream));
       ST_HIP(s, hipStreamSynchronize(w.ctx->stream));
+      {
+        // the step's check word: a chunk with a genome that outgrew its hit region is sketched again (synchronous path),
+        // and the rows copied above are fetched once more
+        bool redone = false;
+        st = hg_sketch_resolve(w.ctx, &redone);
+        if (st != HG_OK) {
+          fail(s, st, std::string("device ") + std::to_string(e.device) + ": " + hg_last_error(w.ctx));
+          return false;
+        }
+        if (redone) {
+          ST_HIP(s, hipMemcpyAsync(w.h_res, w.d_hv, hvb, hipMemcpyDeviceToHost, w.ctx->stream));
+          ST_HIP(s, hipMemcpyAsync(w.h_res + hvb_al, w.d_n2, m * 4, hipMemcpyDeviceToHost, w.ctx->stream));
+          ST_HIP(s, hipMemcpyAsync(w.h_res + hvb_al + CHUNK_GENOMES * 4, w.d_nh, m * 4, hipMemcpyDeviceToHost, w.ctx->stream));
+          ST_HIP(s, hipStreamSynchronize(w.ctx->stream));
+        }
+      }
       Done d;
       d.tags = c.tags;
       d.hv.assign(reinterpret_cast<int16_t *>(w.h_res), reinterpret_cast<int16_t *>(w.h_res) + m * D);
@@ -738,7 +754,7 @@ extern "C" hg_status hg_unpack2_dev(hg_ctx *c, const uint8_t *d_blob, size_t n_b
   if (n_bps == 0) return HG_OK;
   if (!d_blob || !d_seq_out) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
   if (((uintptr_t)d_blob | (uintptr_t)d_seq_out) & 15) return hg_fail(c, HG_ERR_INVALID, "hg_unpack2_dev: pointers must be 16-byte aligned");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   const uint64_t groups = (n_bps + 15) / 16;
   hipLaunchKernelGGL(unpack2_one_kernel, dim3((unsigned)((groups + UNPACK_GROUPS_PER_BLOCK - 1) / UNPACK_GROUPS_PER_BLOCK)),
                      dim3(256), 0, c->stream, d_blob, d_seq_out, (uint64_t)n_bps);

@@ -43,7 +43,7 @@ extern "C" hg_status hg_synth_genomes_dev(hg_ctx *c, uint64_t first_genome, size
   if (!c) return HG_ERR_INVALID;
   if (n == 0) return HG_OK;
   if (!d_out || cluster_size == 0 || stride < L + 1 || n > 65535) return hg_fail(c, HG_ERR_INVALID, "bad synth arguments");
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   const uint64_t words = (L + 31) / 32;
   dim3 grid((unsigned)((words + 255) / 256 ? (words + 255) / 256 : 1), (unsigned)n);
   hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, c->stream, first_genome, L, cluster_size,

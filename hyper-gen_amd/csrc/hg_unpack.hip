@@ -164,7 +164,7 @@ extern "C" hg_status hg_hv_unpack_batch_dev(hg_ctx *c, const uint8_t *d_payloads
   if (!d_payloads || !offsets || !quant_bits || !d_hv || hv_d == 0) return hg_fail(c, HG_ERR_INVALID, "hg_hv_unpack_batch_dev: bad argument");
   if (n > 0x7FFFFFFFull) return hg_fail(c, HG_ERR_UNSUPPORTED, "more than 2^31 sketches in one call");
   if (hv_d > (1u << 24)) return hg_fail(c, HG_ERR_UNSUPPORTED, "hv_d must be at most 2^24");  // (32-bit byte counts in the kernel)
-  HG_HIP(c, hipSetDevice(c->device));
+  HG_ENTER(c);
   hg_status s;
   if ((s = hg_ensure(c, c->w_pktab, n * sizeof(UnpackRow) + 64)) != HG_OK) return s;
   if ((s = hg_ensure_pinned(c, n * sizeof(UnpackRow) + 64)) != HG_OK) return s;

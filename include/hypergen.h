@@ -62,6 +62,10 @@ void hg_ctx_destroy(hg_ctx *ctx);
 hg_status hg_ctx_set_stream(hg_ctx *ctx, void *hip_stream);
 hg_status hg_ctx_reset_stream(hg_ctx *ctx);
 hg_status hg_ctx_sync(hg_ctx *ctx);
+/* How many sketch steps (hg_sketch_batch_dev / _packed calls, sub-batches of the host-fed entry points) the ctx has queued
+ * without a host round trip, how many it ran through the synchronous path, and how many of the former it had to run again
+ * because their check word asked for it (see "Completion of hg_sketch_batch_dev" below).  NULL pointers are skipped. */
+hg_status hg_ctx_sketch_step_counts(hg_ctx *ctx, uint64_t *sync_free, uint64_t *synchronous, uint64_t *redone);
 int hg_device_count(void);
 /* development / test hook (no reference counterpart): force an internal code path of THIS ctx.
  * keys: "dist_tile" = "" | "small" | "big" | "wide"      (GEMM tile geometry)
@@ -157,6 +161,21 @@ hg_status hg_hv_encode(hg_ctx *ctx, const uint64_t *hashes, size_t n, uint32_t h
 hg_status hg_sketch_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t *offsets,
                               const uint64_t *lens, size_t n, const hg_sketch_params *p,
                               int16_t *d_hv, int32_t *d_norm2, uint32_t *d_nhash);
+/* Completion of hg_sketch_batch_dev / _packed.  The call queues the whole step -- hash + sample, sort / unique, encode --
+ * on the ctx's stream and returns; no host round trip separates the kernels.  What the host used to read back between
+ * them (did a genome outgrow its hit region -- more than twice its expected number of sampled k-mers + 1 024, the
+ * signature of a sampled k-mer repeated thousands of times -- or the one-workgroup sort) comes back as ONE check word
+ * behind the last kernel, and the library reads it when the NEXT call on the ctx, or hg_ctx_sync, arrives: a step that
+ * reported such a genome is then run again through the synchronous path (exact capacities, multi-workgroup sort), before
+ * that call does anything else.  Hence:
+ *   - d_seq, d_hv, d_norm2, d_nhash belong to the library until the next call on the ctx or hg_ctx_sync has returned;
+ *   - results are FINAL after hg_ctx_sync (or any later call on the ctx) has returned.  A consumer that orders itself
+ *     behind the call on the stream alone sees final rows too, except for the genomes of such a step: their d_nhash holds
+ *     HG_NHASH_PENDING (and their HV rows are untouched) until the library has redone the step;
+ *   - an error of the re-run is returned by the call that triggered it.
+ * Batches whose genomes are EXPECTED to exceed the one-workgroup sort (more than ~7 000 sampled k-mers: 10 Mbp at
+ * scaled = 1 500) take the synchronous path at once and are final in stream order. */
+#define HG_NHASH_PENDING 0xFFFFFFFFu
 /* The same batch with the genomes resident as 2-bit PACKED bases: genome i is the hg_pack2 blob (layout below:
  * 4 bases per byte + the not-a-base bitmap, 0.375 bytes per base in HBM instead of 1) at d_blobs + offsets[i]
  * (multiples of 16; 32 readable bytes behind every blob), n_bps[i] = its number of bases.  The k-mer kernels read the

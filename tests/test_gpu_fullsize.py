@@ -27,7 +27,7 @@ def sketched(orc):
         n2 = torch.empty(N, dtype=torch.int32, device=dev)
         nh = torch.empty(N, dtype=torch.int32, device=dev)
         ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
-        torch.cuda.synchronize()
+        ctx.sync()  # (reads the step's check word, then waits for the stream)
         out.append((hv, n2, nh))
     yield ctx, seq, stride, out
     ctx.close()
@@ -294,7 +294,7 @@ def test_config2_sketch_10k_x_5mbp_resident_and_sharded(orc):
         n2 = torch.empty(n10, dtype=torch.int32, device=dev)
         nh = torch.empty(n10, dtype=torch.int32, device=dev)
         ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
-        torch.cuda.synchronize()
+        ctx.sync()  # (reads the step's check word, then waits for the stream)
         nhc = nh.cpu().numpy()
         assert 3050 < nhc.min() and nhc.max() < 3650 and abs(nhc.mean() - (L - 20) / 1500) < 30
         assert torch.equal((hv.int() ** 2).sum(1).int(), n2)
@@ -314,7 +314,7 @@ def test_config2_sketch_10k_x_5mbp_resident_and_sharded(orc):
             s_n2 = torch.empty(m, dtype=torch.int32, device=dev)
             s_nh = torch.empty(m, dtype=torch.int32, device=dev)
             ctx.sketch_batch_dev(s_seq.data_ptr(), offs[:m], lens[:m], p, s_hv.data_ptr(), s_n2.data_ptr(), s_nh.data_ptr())
-            torch.cuda.synchronize()
+            ctx.sync()  # (reads the step's check word, then waits for the stream)
             assert torch.equal(s_hv, hv[lo:hi]) and torch.equal(s_n2, n2[lo:hi]) and torch.equal(s_nh, nh[lo:hi]), r
             del s_seq, s_hv
         del seq
@@ -383,7 +383,7 @@ def test_one_genome_of_more_than_2_to_32_bases():
         n2 = torch.empty(4, dtype=torch.int32, device=dev)
         nh = torch.empty(4, dtype=torch.int32, device=dev)
         ctx.sketch_batch_dev(seq.data_ptr(), offs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
-        torch.cuda.synchronize()
+        ctx.sync()  # (reads the step's check word, then waits for the stream)
         nhc = nh.cpu().numpy().astype(np.int64)
         assert abs(nhc[0] - n_bps / 1500) < 6 * (n_bps / 1500) ** 0.5  # FracMinHash keeps one k-mer in `scaled`
         assert nhc[0] == nhc[1:].sum(), nhc
@@ -397,7 +397,7 @@ def test_one_genome_of_more_than_2_to_32_bases():
         nh_p = torch.empty(1, dtype=torch.int32, device=dev)
         ctx.sketch_batch_dev_packed(blob.data_ptr(), np.zeros(1, np.uint64), np.array([n_bps], np.uint64), p, hv_p.data_ptr(),
                                     n2_p.data_ptr(), nh_p.data_ptr())
-        torch.cuda.synchronize()
+        ctx.sync()  # (reads the step's check word, then waits for the stream)
         assert int(nh_p[0]) == nhc[0] and int(n2_p[0]) == int(n2[0]) and torch.equal(hv_p[0], hv[0])
     finally:
         ctx.close()

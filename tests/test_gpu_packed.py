@@ -93,7 +93,7 @@ def test_packed_batch_equals_ascii_batch_and_oracle(hg, ctx, orc, k, scaled, can
             d2 = torch.zeros_like(d_blobs)
             ctx.pack2_batch_dev(d_seq.data_ptr(), offs, ln, d2.data_ptr(), boffs)
             ctx.sketch_batch_dev_packed(d2.data_ptr(), boffs, ln, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
-        torch.cuda.synchronize()
+        ctx.sync()  # (reads the step's check word, then waits for the stream)
         out.append((hv.cpu().numpy(), n2.cpu().numpy(), nh.cpu().numpy()))
     for o in out[1:]:
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2])
@@ -145,7 +145,7 @@ def test_packed_1000x5mbp_equals_ascii_and_takes_three_eighths_of_the_memory(hg,
             del seq  # the ASCII copy is gone: the packed call cannot be reading it
             torch.cuda.empty_cache()
             ctx.sketch_batch_dev_packed(blobs.data_ptr(), boffs, lens, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
-        torch.cuda.synchronize()
+        ctx.sync()  # (reads the step's check word, then waits for the stream)
         res.append((hv, n2, nh))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     for g in (3, 777):
