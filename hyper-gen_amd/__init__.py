@@ -61,7 +61,7 @@ class FileSketch(C.Structure):
 
 EXPORTS = [
     "hg_status_str", "hg_last_error", "hg_version", "hg_ctx_create", "hg_ctx_destroy",
-    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_ctx_sketch_step_counts", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
+    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_ctx_sketch_step_counts", "hg_logf_dev", "hg_ani_from_dots_dev", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
     "hg_copy_h2d", "hg_copy_d2h", "hg_sketch_params_default", "hg_kmer_hash_sample",
     "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack", "hg_hv_packed_bytes",
@@ -132,6 +132,8 @@ def lib():
         "hg_ctx_set_stream": (C.c_int, [vp, vp]),
         "hg_ctx_reset_stream": (C.c_int, [vp]),
         "hg_ctx_sync": (C.c_int, [vp]),
+        "hg_logf_dev": (C.c_int, [vp, vp, C.c_uint32, sz, vp]),
+        "hg_ani_from_dots_dev": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint32, vp]),
         "hg_ctx_sketch_step_counts": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "hg_device_count": (C.c_int, []),
         "hg_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
@@ -329,6 +331,13 @@ class Context:
     def sync(self):
         """hg_ctx_sync: reads a queued sketch step's check word (re-running the step if it asks for it), then waits for the stream."""
         self._ck(lib().hg_ctx_sync(self._h))
+
+    def logf_dev(self, d_out, n, d_x=None, first_bits=0):
+        """hg_logf_dev: the library's logf of n floats (d_x), or of the bit patterns first_bits .. first_bits + n - 1"""
+        self._ck(lib().hg_logf_dev(self._h, C.c_void_p(d_x or 0), first_bits, n, C.c_void_p(d_out)))
+
+    def ani_from_dots_dev(self, d_dot, d_nr, d_nq, n, ksize, d_ani):
+        self._ck(lib().hg_ani_from_dots_dev(self._h, C.c_void_p(d_dot), C.c_void_p(d_nr), C.c_void_p(d_nq), n, ksize, C.c_void_p(d_ani)))
 
     def sketch_step_counts(self):
         """(sync-free, synchronous, re-run) sketch steps of this ctx so far (hg_ctx_sketch_step_counts)."""

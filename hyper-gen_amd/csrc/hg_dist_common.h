@@ -4,6 +4,7 @@
 #include <utility>
 
 #include "hg_internal.h"
+#include "hg_logf.h"
 
 namespace {
 
@@ -22,7 +23,7 @@ __device__ __forceinline__ float ani_from_dot(int32_t dot, int32_t nr, int32_t n
   const float jaccard = (float)dot / (float)den;
   const float inner = 1.0f / jaccard + 1.0f;
   const float x = 2.0f / inner;
-  float ani = 1.0f + logf(x) / kf;
+  float ani = 1.0f + hg_logf(x) / kf;  // (glibc's logf, bit for bit: hg_logf.h)
   if (ani != ani) return 0.0f;  // is_nan -> 0
   ani = fminf(ani, 1.0f);
   ani = fmaxf(ani, 0.0f);

@@ -937,3 +937,38 @@ extern "C" hg_status hg_dist_tile_order(uint32_t tiles_m, uint32_t tiles_n, uint
   }
   return HG_OK;
 }
+
+// ---- the ANI formula and its logarithm on their own (diagnostics; tests/test_gpu_ani_exact.py) ------------------------
+namespace {
+__global__ void logf_kernel(const float *__restrict__ x, uint32_t first_bits, size_t n, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = hg_logf(x ? x[i] : __uint_as_float(first_bits + (uint32_t)i));
+}
+__global__ void ani_from_dots_kernel(const int32_t *__restrict__ dot, const int32_t *__restrict__ nr, const int32_t *__restrict__ nq,
+                                     size_t n, float kf, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ani_from_dot(dot[i], nr[i], nq[i], kf);
+}
+}  // namespace
+
+extern "C" hg_status hg_logf_dev(hg_ctx *c, const float *d_x, uint32_t first_bits, size_t n, float *d_out) {
+  if (!c) return HG_ERR_INVALID;
+  if (n == 0) return HG_OK;
+  if (!d_out || n > ((size_t)1 << 32)) return hg_fail(c, HG_ERR_INVALID, "hg_logf_dev: bad argument");
+  HG_ENTER(c);
+  hipLaunchKernelGGL(logf_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_x, first_bits, n, d_out);
+  HG_HIP(c, hipGetLastError());
+  return HG_OK;
+}
+
+extern "C" hg_status hg_ani_from_dots_dev(hg_ctx *c, const int32_t *d_dot, const int32_t *d_norm2_r, const int32_t *d_norm2_q, size_t n,
+                                          uint32_t ksize, float *d_ani) {
+  if (!c) return HG_ERR_INVALID;
+  if (n == 0) return HG_OK;
+  if (!d_dot || !d_norm2_r || !d_norm2_q || !d_ani || ksize == 0 || n > ((size_t)1 << 32)) return hg_fail(c, HG_ERR_INVALID, "hg_ani_from_dots_dev: bad argument");
+  HG_ENTER(c);
+  hipLaunchKernelGGL(ani_from_dots_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_dot, d_norm2_r, d_norm2_q, n,
+                     (float)ksize, d_ani);
+  HG_HIP(c, hipGetLastError());
+  return HG_OK;
+}

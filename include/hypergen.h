@@ -204,7 +204,10 @@ hg_status hg_sketch_batch(hg_ctx *ctx, const uint8_t *const *seqs, const size_t 
  * replaces dist::compute_hv_ani / compute_pairwise_ani (src/dist.rs:139-161,231-294).
  * ref_hv: R x hv_d int16 row-major (decompressed sketches), qry_hv: Q x hv_d.
  * ani_out[r * Q + q] = ANI in percent (0..100), float32 arithmetic in the reference's
- * operation order.  Dot products are exact integers (HG_ERR_INEXACT is never a silent
+ * operation order, INCLUDING its logarithm: Rust's f32::ln is the C library's logf, and the device evaluates glibc's logf
+ * algorithm (sysdeps/ieee754/flt-32/e_logf.c) operation for operation (csrc/hg_logf.h), so an ANI value is the float the
+ * reference computes for the same dot product and norms, bit for bit -- and with it the third decimal of a TSV line, the
+ * side of `ani >= ani_th` and the order of near-ties.  Dot products are exact integers (HG_ERR_INEXACT is never a silent
  * rounding: it is returned only if no exact device path applies). */
 hg_status hg_dist_full(hg_ctx *ctx, const int16_t *ref_hv, const int32_t *ref_norm2,
                        size_t R, const int16_t *qry_hv, const int32_t *qry_norm2, size_t Q,
@@ -218,9 +221,15 @@ hg_status hg_dist_full_dev(hg_ctx *ctx, const int16_t *d_ref_hv, const int32_t *
  * kernel queued on the stream before and by the call has finished (the hit count comes back through a page-locked
  * block the last kernel writes and the host polls for a bounded time before it falls back to a blocking stream
  * synchronisation); one 64-byte hipMemsetAsync that re-zeroes the call's counter words may still be pending on the
- * stream -- it touches nothing the caller sees.  hg_sketch_batch_dev and
- * hg_dist_full_dev may return with their last kernels still running -- hg_ctx_sync (or the caller's own stream
- * synchronisation) completes them. */
+ * stream -- it touches nothing the caller sees.  hg_dist_full_dev may return with its last kernels still running --
+ * hg_ctx_sync (or the caller's own stream synchronisation) completes them; for hg_sketch_batch_dev see "Completion of
+ * hg_sketch_batch_dev" above. */
+/* The ANI formula's two pieces on their own (diagnostics): d_out[i] = the library's logf of d_x[i] -- or, with d_x ==
+ * NULL, of the float whose bit pattern is first_bits + i (an exhaustive sweep needs no input array); d_ani[i] = the tail
+ * of compute_pairwise_ani (src/dist.rs:153-160) for the integer dot product d_dot[i] and the norms.  Stream-ordered. */
+hg_status hg_logf_dev(hg_ctx *ctx, const float *d_x, uint32_t first_bits, size_t n, float *d_out);
+hg_status hg_ani_from_dots_dev(hg_ctx *ctx, const int32_t *d_dot, const int32_t *d_norm2_r, const int32_t *d_norm2_q,
+                               size_t n, uint32_t ksize, float *d_ani);
 
 /* one reported pair: what dump_ani_file prints per line (src/utils.rs:275-285) */
 typedef struct {

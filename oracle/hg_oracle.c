@@ -466,6 +466,123 @@ float orc_ani_from_dot(int32_t dot, int32_t nr, int32_t nq, unsigned ksize) {
   return ani * 100.0f;
 }
 
+/* ---- logf --------------------------------------------------------------------
+ * src/dist.rs:154 calls f32::ln = the C library's logf.  glibc >= 2.27 implements it as
+ * sysdeps/ieee754/flt-32/e_logf.c (table of 16 {1/c, log c}, cubic in double; NOT correctly rounded), and on
+ * x86-64 an ifunc picks the build of that file with -mfma where the CPU has FMA: there the compiler fuses the
+ * five multiply-adds of the source.  Both forms are restated here from the published algorithm.  Compared
+ * exhaustively in this image (glibc 2.35, a host with FMA): the host's logf, the fused form and the unfused form
+ * return the same float for every one of the 2^32 inputs (orc_logf_sweep: 0 mismatches for either form; the
+ * double results differ in their last bit for most inputs, never across a float rounding boundary) -- so "glibc's
+ * logf" is ONE function of x, whatever the host CPU.  The device function hyper-gen_amd/csrc/hg_logf.h is the fused
+ * form; tests/test_gpu_ani_exact.py compares it with the host's logf on every float in (0, 1].
+ * The table values are glibc's __logf_data (the same bytes as in this image's libm.so.6 .rodata). */
+static const double ORC_LOGF_TAB[32] = {
+    0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2, 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2,
+    0x1.49539f0f010bp+0,  -0x1.01eae7f513a67p-2, 0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3,
+    0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3, 0x1.25e227b0b8eap+0,  -0x1.1aa2bc79c81p-3,
+    0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4, 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4,
+    0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5, 0x1p+0,               0x0p+0,
+    0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5,  0x1.ca4b31f026aap-1,  0x1.c5e53aa362eb4p-4,
+    0x1.b2036576afce6p-1, 0x1.526e57720db08p-3,  0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3,
+    0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2};
+
+float orc_logf_glibc(float x, int fused) {
+  const double LN2 = 0x1.62e42fefa39efp-1;
+  const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  uint32_t ix;
+  memcpy(&ix, &x, 4);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2u == 0u) return -INFINITY;
+    if (ix == 0x7f800000u) return x;
+    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return NAN;
+    volatile float xs = x * 0x1p23f; /* subnormal: normalise */
+    float t = xs;
+    memcpy(&ix, &t, 4);
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const uint32_t i = (tmp >> 19) & 15u;
+  const int32_t k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  const double invc = ORC_LOGF_TAB[2 * i], logc = ORC_LOGF_TAB[2 * i + 1];
+  float zf;
+  memcpy(&zf, &iz, 4);
+  const double z = (double)zf;
+  if (fused) { /* __logf_fma: every multiply-add of the source is one fma */
+    const double r = fma(z, invc, -1.0);
+    const double y0 = fma((double)k, LN2, logc);
+    const double r2 = r * r;
+    double y = fma(A1, r, A2);
+    y = fma(A0, r2, y);
+    y = fma(y, r2, r + y0);
+    return (float)y;
+  }
+  /* __logf_sse2: each product rounded on its own (volatile: no contraction whatever the compiler flags) */
+  volatile double p;
+  p = z * invc;
+  const double r = p - 1.0;
+  p = (double)k * LN2;
+  const double y0 = logc + p;
+  p = r * r;
+  const double r2 = p;
+  p = A1 * r;
+  double y = p + A2;
+  p = A0 * r2;
+  y = p + y;
+  p = y * r2;
+  y = p + (y0 + r);
+  return (float)y;
+}
+
+/* bit patterns in [first_bits, first_bits + n) on which the host's logf differs from the restatement (NaN == NaN);
+ * *first_bad = the first of them */
+uint64_t orc_logf_sweep(uint32_t first_bits, uint64_t n, int fused, uint32_t *first_bad) {
+  uint64_t bad = 0;
+  uint32_t fb = 0xFFFFFFFFu;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(min : fb)
+  for (long long t = 0; t < (long long)n; t++) {
+    const uint32_t b = first_bits + (uint32_t)t;
+    float x;
+    memcpy(&x, &b, 4);
+    const float h = logf(x), r = orc_logf_glibc(x, fused);
+    if ((h != h) != (r != r) || (h == h && memcmp(&h, &r, 4))) {
+      bad++;
+      if (b < fb) fb = b;
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}
+
+/* bit patterns in the range on which the two restated forms differ (how often a host without FMA would disagree) */
+uint64_t orc_logf_forms_differ(uint32_t first_bits, uint64_t n, uint32_t *out, size_t cap) {
+  uint64_t bad = 0;
+  for (uint64_t t = 0; t < n; t++) {
+    const uint32_t b = first_bits + (uint32_t)t;
+    float x;
+    memcpy(&x, &b, 4);
+    const float f = orc_logf_glibc(x, 1), u = orc_logf_glibc(x, 0);
+    if (memcmp(&f, &u, 4) && !(f != f && u != u)) {
+      if (bad < cap) out[bad] = b;
+      bad++;
+    }
+  }
+  return bad;
+}
+
+void orc_logf_array(const float *x, size_t n, float *out, int form) {
+#pragma omp parallel for schedule(static)
+  for (long long t = 0; t < (long long)n; t++)
+    out[t] = form < 0 ? logf(x[t]) : orc_logf_glibc(x[t], form);
+}
+
+void orc_ani_from_dots(const int32_t *dot, const int32_t *nr, const int32_t *nq, size_t n, unsigned ksize, float *out) {
+#pragma omp parallel for schedule(static)
+  for (long long t = 0; t < (long long)n; t++) out[t] = orc_ani_from_dot(dot[t], nr[t], nq[t], ksize);
+}
+
 void orc_set_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);

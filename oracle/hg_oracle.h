@@ -99,6 +99,17 @@ int32_t orc_hv_dot(const int16_t *r, const int16_t *q, size_t hv_d);
 float orc_ani_from_dot(int32_t dot, int32_t norm2_r, int32_t norm2_q,
                        unsigned ksize);
 
+void orc_ani_from_dots(const int32_t *dot, const int32_t *nr, const int32_t *nq, size_t n, unsigned ksize, float *out);
+
+/* glibc's logf algorithm (sysdeps/ieee754/flt-32/e_logf.c) restated: fused = 1 as the -mfma build evaluates it
+ * (__logf_fma), 0 with every product rounded on its own (__logf_sse2).  orc_logf_sweep: number of bit patterns in
+ * [first_bits, first_bits + n) on which the HOST's logf differs from the restatement (*first_bad: the first one).
+ * orc_logf_array: form -1 = the host's logf, 0 / 1 = the restatements. */
+float orc_logf_glibc(float x, int fused);
+uint64_t orc_logf_sweep(uint32_t first_bits, uint64_t n, int fused, uint32_t *first_bad);
+uint64_t orc_logf_forms_differ(uint32_t first_bits, uint64_t n, uint32_t *out, size_t cap);
+void orc_logf_array(const float *x, size_t n, float *out, int form);
+
 /* OpenMP team size for orc_ani_matrix */
 void orc_set_threads(int n);
 

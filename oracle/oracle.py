@@ -67,6 +67,14 @@ def lib():
         L.orc_hv_dot.argtypes = [i16p, i16p, C.c_size_t]
         L.orc_ani_from_dot.restype = C.c_float
         L.orc_ani_from_dot.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint]
+        L.orc_ani_from_dots.restype = None
+        L.orc_ani_from_dots.argtypes = [i32p, i32p, i32p, C.c_size_t, C.c_uint, f32p]
+        L.orc_logf_glibc.restype = C.c_float
+        L.orc_logf_glibc.argtypes = [C.c_float, C.c_int]
+        L.orc_logf_sweep.restype = C.c_uint64
+        L.orc_logf_sweep.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_logf_array.restype = None
+        L.orc_logf_array.argtypes = [f32p, C.c_size_t, f32p, C.c_int]
         L.orc_ani_matrix.restype = None
         L.orc_ani_matrix.argtypes = [i16p, i32p, C.c_size_t, i16p, i32p, C.c_size_t,
                                      C.c_size_t, C.c_uint, f32p]
@@ -253,6 +261,28 @@ def ani_from_dot(dot, nr, nq, ksize=21):
 
 def set_threads(n):
     lib().orc_set_threads(int(n))
+
+
+def ani_from_dots(dot, nr, nq, ksize=21):
+    d, a, b = (np.ascontiguousarray(v, np.int32) for v in (dot, nr, nq))
+    out = np.empty(d.size, np.float32)
+    lib().orc_ani_from_dots(_p(d, C.c_int32), _p(a, C.c_int32), _p(b, C.c_int32), d.size, ksize, _p(out, C.c_float))
+    return out
+
+
+def logf_sweep(first_bits, n, fused=1):
+    """(mismatches, first bad bit pattern) of the HOST's logf against the restated glibc algorithm on n consecutive bit patterns"""
+    fb = C.c_uint32()
+    bad = lib().orc_logf_sweep(first_bits, n, fused, C.byref(fb))
+    return int(bad), int(fb.value)
+
+
+def logf_array(x, form=-1):
+    """form -1: the host's logf (what orc_ani_from_dot calls); 0 / 1: glibc's algorithm restated, unfused / fused"""
+    a = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(a)
+    lib().orc_logf_array(_p(a, C.c_float), a.size, _p(out, C.c_float), form)
+    return out
 
 
 def ani_matrix(ref_hv, ref_n2, qry_hv, qry_n2, ksize=21):

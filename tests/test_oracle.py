@@ -229,9 +229,24 @@ def test_naive_layout_follows_the_reference_loops(orc):
 def test_ani_golden(orc):
     for c in golden("g4_ani.json"):
         got = orc.ani_from_dot(c["dot"], c["nr"], c["nq"], c["k"])
-        assert abs(got - c["ani"]) <= 1e-4, c
+        assert np.float32(got) == np.float32(c["ani"]), c  # equal: the fixture's logarithm is glibc's algorithm in Python doubles
     assert orc.ani_from_dot(0, 10, 10) == 0.0 and orc.ani_from_dot(-3, 10, 10) == 0.0
     assert orc.ani_from_dot(10, 10, 10) == 100.0
+
+
+def test_host_logf_is_the_restated_glibc_algorithm(orc):
+    """The oracle's ANI calls the host's logf (what Rust's f32::ln calls).  It must be glibc's table-driven routine, in either
+    of its two builds (fused / unfused multiply-adds: they agree on all 2^32 inputs) -- the device restates that algorithm
+    (hyper-gen_amd/csrc/hg_logf.h), so a host with another libm would make "equal to the oracle" mean something else.
+    2^27 bit patterns around 1.0, where 2 / (1 / J + 1) lives, + subnormals + a stride over the rest."""
+    for fused in (1, 0):
+        assert orc.logf_sweep(0x3F000000 - (1 << 26), 1 << 27, fused)[0] == 0
+        assert orc.logf_sweep(0, 1 << 16, fused)[0] == 0 and orc.logf_sweep(0x7F7F0000, 1 << 17, fused)[0] == 0
+    x = np.arange(0, 1 << 32, 4099, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    h, f, u = orc.logf_array(x, -1), orc.logf_array(x, 1), orc.logf_array(x, 0)
+    nan = np.isnan(h)
+    assert (np.isnan(f) == nan).all() and (np.isnan(u) == nan).all()
+    assert (h.view(np.uint32)[~nan] == f.view(np.uint32)[~nan]).all() and (h.view(np.uint32)[~nan] == u.view(np.uint32)[~nan]).all()
 
 
 def test_ani_matrix_matches_pairwise(orc):

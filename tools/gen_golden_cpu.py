@@ -9,7 +9,10 @@ Sources of the numbers (none is produced by the code under test):
   * g1_test_fna.json -- SURVEY.md 8c "G1": the reference's own kernel source
     (src/cuda_kernel.cu) executed on the reference fixture test/test.fna.
   * g4_ani.json     -- src/dist.rs:153-160 evaluated with numpy float32 scalars (the i32 denominator wraps like the
-    reference's release build, Cargo.toml:63-65); this script is not the oracle and shares no code with it.
+    reference's release build, Cargo.toml:63-65); this script is not the oracle and shares no code with it.  The
+    logarithm is glibc's logf algorithm (f32::ln = the C library's logf; sysdeps/ieee754/flt-32/e_logf.c) written out
+    in Python doubles below -- NOT numpy's own float32 log, whose last bit differs from glibc's for ~0.5 % of the
+    inputs -- so the fixture's values are the floats the reference computes and the tests assert equality.
 """
 import json
 import os
@@ -42,13 +45,56 @@ G1_K5_S1 = """05154f11423d6f2d 1087f45976b8c17d 3736bdc2862be4cf 37490079ec20f05
 a66dcaadba250048 e02a59e9b5121e75 ec4ebc51bcb9a28f edb41fdf139cc8f5 ff1b1c5541e296b1""".split()
 
 
+LOGF_TAB = [float.fromhex(v) for v in """
+0x1.661ec79f8f3bep+0 -0x1.57bf7808caadep-2 0x1.571ed4aaf883dp+0 -0x1.2bef0a7c06ddbp-2 0x1.49539f0f010bp+0 -0x1.01eae7f513a67p-2
+0x1.3c995b0b80385p+0 -0x1.b31d8a68224e9p-3 0x1.30d190c8864a5p+0 -0x1.6574f0ac07758p-3 0x1.25e227b0b8eap+0 -0x1.1aa2bc79c81p-3
+0x1.1bb4a4a1a343fp+0 -0x1.a4e76ce8c0e5ep-4 0x1.12358f08ae5bap+0 -0x1.1973c5a611cccp-4 0x1.0953f419900a7p+0 -0x1.252f438e10c1ep-5
+0x1p+0 0x0p+0 0x1.e608cfd9a47acp-1 0x1.aa5aa5df25984p-5 0x1.ca4b31f026aap-1 0x1.c5e53aa362eb4p-4 0x1.b2036576afce6p-1
+0x1.526e57720db08p-3 0x1.9c2d163a1aa2dp-1 0x1.bc2860d22477p-3 0x1.886e6037841edp-1 0x1.1058bc8a07ee1p-2 0x1.767dcf5534862p-1
+0x1.4043057b6ee09p-2""".split()]
+LOGF_LN2 = float.fromhex("0x1.62e42fefa39efp-1")
+LOGF_A = [float.fromhex(v) for v in ("-0x1.00ea348b88334p-2", "0x1.5575b0be00b6ap-2", "-0x1.ffffef20a4123p-2")]
+
+
+def glibc_logf(x):
+    """glibc >= 2.27 logf(float32) -> float32: table of 16 {1/c, log c}, log(x) = log1p(z/c - 1) + log c + k ln 2, cubic in
+    double (Python floats are IEEE doubles; every product rounded on its own -- the -mfma build of the same file, which fuses
+    them, returns the same float for all 2^32 inputs: oracle/hg_oracle.c orc_logf_sweep)"""
+    f = np.float32
+    x = f(x)
+    ix = int(x.view(np.uint32))
+    if ix == 0x3F800000:
+        return f(0.0)
+    if (ix - 0x00800000) % 2**32 >= 0x7F800000 - 0x00800000:
+        if (ix * 2) % 2**32 == 0:
+            return f(-np.inf)
+        if ix == 0x7F800000:
+            return x
+        if (ix & 0x80000000) or (ix * 2) % 2**32 >= 0xFF000000:
+            return f(np.nan)
+        ix = int(f(x * f(2.0**23)).view(np.uint32)) - (23 << 23)
+    tmp = (ix - 0x3F330000) % 2**32
+    i = (tmp >> 19) & 15
+    k = (tmp >> 23) - (512 if tmp & 0x80000000 else 0)  # arithmetic shift of the int32
+    iz = (ix - (tmp & 0xFF800000)) % 2**32
+    z = float(np.uint32(iz).view(np.float32))
+    invc, logc = LOGF_TAB[2 * i], LOGF_TAB[2 * i + 1]
+    r = z * invc - 1.0
+    y0 = logc + k * LOGF_LN2
+    r2 = r * r
+    y = LOGF_A[1] * r + LOGF_A[2]
+    y = LOGF_A[0] * r2 + y
+    y = y * r2 + (y0 + r)
+    return f(y)
+
+
 def ani_f32(dot, nr, nq, k):
     f = np.float32
     with np.errstate(all="ignore"):
         den = (int(nr) + int(nq) - int(dot) + 2**31) % 2**32 - 2**31  # i32 wrapping sum (release build: no overflow check)
         den = np.int32(den)
         j = f(dot) / f(den)
-        ani = f(1.0) + np.log(f(2.0) / (f(1.0) / j + f(1.0)), dtype=np.float32) / f(k)
+        ani = f(1.0) + glibc_logf(f(2.0) / (f(1.0) / j + f(1.0))) / f(k)
     if np.isnan(ani):
         return 0.0
     return float(np.maximum(np.minimum(ani, f(1.0)), f(0.0)) * f(100.0))
@@ -83,6 +129,11 @@ def main():
         nr, nq = (int(x) for x in rng.integers(1_000_000, 30_000_000, 2))
         dot = int(rng.integers(-200_000, min(nr, nq)))
         tuples.append((dot, nr, nq, int(rng.choice([15, 21, 31]))))
+    rng2 = np.random.default_rng(70)  # (a second stream: the first 69 cases keep their order)
+    for _ in range(600):  # sketch-like: norms ~ D n, dot products spread up to the Cauchy-Schwarz bound
+        nr, nq = (int(x) for x in rng2.integers(8_000_000, 20_000_000, 2))
+        dot = int((nr * nq) ** 0.5 * rng2.random() ** 0.5)
+        tuples.append((dot, nr, nq, int(rng2.choice([16, 21, 31]))))
     for dot, nr, nq, k in tuples:
         cases.append({"dot": dot, "nr": nr, "nq": nq, "k": k, "ani": ani_f32(dot, nr, nq, k)})
     json.dump(cases, open(os.path.join(OUT, "g4_ani.json"), "w"), indent=1)
