@@ -5,6 +5,8 @@ must equal the one-call result of hg_dist_dev -- also when the gathered rows are
 exchange, d_ref_index), when most rows carry clamped entries, and through the veto -> i16 fallback."""
 import numpy as np
 import pytest
+
+from conftest import ANI_TOL
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -224,7 +226,7 @@ def test_prepared_operands_random_ragged_shapes(hg, orc, seed):
                                          hits.data_ptr(), cap)
         assert st == 0
         got = hitset(hits, found)
-    sure = {(i, j) for i, j in zip(*np.nonzero(want >= th + 1e-4))}
-    maybe = {(i, j) for i, j in zip(*np.nonzero(want >= th - 1e-4))}
+    sure = {(i, j) for i, j in zip(*np.nonzero(want >= th + ANI_TOL))}
+    maybe = {(i, j) for i, j in zip(*np.nonzero(want >= th - ANI_TOL))}
     assert sure <= set(got) <= maybe
-    assert all(abs(float(v) - float(want[k])) <= 1e-4 for k, v in got.items())
+    assert all(abs(float(v) - float(want[k])) <= ANI_TOL for k, v in got.items())

@@ -2,6 +2,8 @@
 in seconds): determinism, sampled full parity, norm / dot identities, ANI symmetry, hit-set consistency."""
 import numpy as np
 import pytest
+
+from conftest import ANI_TOL
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -73,16 +75,14 @@ def test_dist_of_the_1000_sketches_properties(sketched, orc):
     # (member m differs from its root by 0.1*m %, two members by up to ~20 %)
     # unrelated genomes sit at the estimator's noise floor (chance dot > 0 => up to ~87 % at D=4096, n~3333)
     assert float(full[0, :100].min()) > 89.0 and float(full[:100, 100:].max()) < 90.0
-    # thresholded path == thresholded full matrix (up to pairs within 1e-4 of the threshold)
+    # thresholded path == thresholded full matrix
     cap = 1 << 20
     hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
     n, st = ctx.dist_dev(hv.data_ptr(), n2.data_ptr(), N, hv.data_ptr(), n2.data_ptr(), N, D, 21, True, 95.0,
                          hits.data_ptr(), cap)
     assert st == 0
     iu = torch.triu(torch.ones((N, N), dtype=torch.bool, device=dev), 1)
-    lo = int(((full >= 95.0 + 1e-4) & iu).sum())
-    hi = int(((full >= 95.0 - 1e-4) & iu).sum())
-    assert lo <= n <= hi and n > 1000
+    assert n == int(((full >= 95.0) & iu).sum()) and n > 1000  # the same float in both kernels: the same set
     h = hits[: 3 * n].view(-1, 3)
     vals = h[:, 2].view(torch.float32)
     assert float((full[h[:, 0].long(), h[:, 1].long()] - vals).abs().max()) == 0.0  # same kernel arithmetic
@@ -130,9 +130,10 @@ def _independent_block(orc, hv, n2, rows, k=21):
     return o, a
 
 
-def _check_hits_against_block(h, rows, indep, th, sym):
-    """thresholded hits whose reference row lies in `rows` == the independent matrix thresholded (pairs within 1e-4 of
-    the threshold may fall either way); reported ANI within 1e-4 of the independent value"""
+def _check_hits_against_block(h, rows, indep, th, sym, tol):
+    """thresholded hits whose reference row lies in `rows` == the independent matrix thresholded, reported ANI == the independent
+    value -- with tol = 0 for the CPU oracle; the fp64 / torch.log model is given 1e-4 (pairs that close to the threshold may
+    fall either way)"""
     lo, hi = rows.start, rows.stop
     sel = (h[:, 0] >= lo) & (h[:, 0] < hi)
     ri, qi, ani = h[sel, 0].long() - lo, h[sel, 1].long(), h[sel, 2].contiguous().view(torch.float32)
@@ -141,9 +142,9 @@ def _check_hits_against_block(h, rows, indep, th, sym):
     live = torch.ones_like(got)
     if sym:
         live = torch.arange(lo, hi, device=indep.device)[:, None] < torch.arange(indep.shape[1], device=indep.device)[None, :]
-    sure_in, sure_out = (indep >= th + 1e-4) & live, (indep < th - 1e-4) | ~live
+    sure_in, sure_out = (indep >= th + tol) & live, (indep < th - tol) | ~live
     assert bool(got[sure_in].all()) and not bool(got[sure_out].any())
-    assert float((ani - indep[ri, qi]).abs().max()) <= 1e-4
+    assert float((ani - indep[ri, qi]).abs().max()) <= tol
     return int(sel.sum())
 
 
@@ -171,7 +172,7 @@ def test_dist_10k_thresholded_equals_full_matrix(orc, tile, nhash):
     torch.cuda.synchronize()
     rows = slice(3900, 4412)
     ind_orc, ind_f64 = _independent_block(orc, hv, n2, rows)
-    assert float((full[rows] - ind_orc).abs().max()) <= 1e-4 and float((full[rows] - ind_f64).abs().max()) <= 1e-4
+    assert float((full[rows] - ind_orc).abs().max()) <= ANI_TOL and float((full[rows] - ind_f64).abs().max()) <= 1e-4
     cap = 4_000_000
     hits = torch.empty(cap * 3, dtype=torch.int32, device=dev)
     try:
@@ -190,9 +191,9 @@ def test_dist_10k_thresholded_equals_full_matrix(orc, tile, nhash):
             got = torch.zeros_like(want)
             got[ri, qi] = True
             assert bool((got == want).all())
-            assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
-            for indep in (ind_orc, ind_f64):  # ... and not only against another variant of the same kernel
-                assert _check_hits_against_block(h, rows, indep, th, sym) > 0
+            assert float((ani - full[ri, qi]).abs().max()) <= ANI_TOL
+            for indep, tol in ((ind_orc, ANI_TOL), (ind_f64, 1e-4)):  # ... and not only against another variant of the same kernel
+                assert _check_hits_against_block(h, rows, indep, th, sym, tol) > 0
     finally:
         ctx.close()
 
@@ -233,7 +234,7 @@ def test_dist_windowed_192_wide_tiles_ragged_q():
             got = torch.zeros_like(want)
             got[ri, qi] = True
             assert bool((got == want).all())
-            assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+            assert float((ani - full[ri, qi]).abs().max()) <= ANI_TOL
     finally:
         ctx.close()
 
@@ -336,12 +337,12 @@ def test_config2_sketch_10k_x_5mbp_resident_and_sharded(orc):
         got = torch.zeros_like(want)
         got[ri, qi] = True
         assert int(sel.sum()) == int(want.sum()) and bool((got == want).all())
-        assert float((ani - full[ri, qi]).abs().max()) <= 1e-4
+        assert float((ani - full[ri, qi]).abs().max()) <= ANI_TOL
         # independent of the kernels: CPU oracle and fp64 GEMM on a 512-row block of the REAL sketches
         rows = slice(1490, 2002)
-        for indep in _independent_block(orc, hv, n2, rows):
-            assert float((full[rows] - indep).abs().max()) <= 1e-4
-            assert _check_hits_against_block(h, rows, indep, 90.0, True) > 0
+        for indep, tol in zip(_independent_block(orc, hv, n2, rows), (ANI_TOL, 1e-4)):
+            assert float((full[rows] - indep).abs().max()) <= tol
+            assert _check_hits_against_block(h, rows, indep, 90.0, True, tol) > 0
         # estimator sanity on real data: member m of cluster 0 vs its root
         est = full[0, 1:100].cpu().numpy()
         assert np.abs(est - 100.0 * (1.0 - 0.001 * np.arange(1, 100))).max() < 1.0

@@ -5,6 +5,8 @@ thresholded dist calls against the full ANI matrix."""
 import numpy as np
 import pytest
 
+from conftest import ANI_TOL
+
 pytestmark = pytest.mark.gpu
 
 import os
@@ -93,13 +95,13 @@ def test_random_thresholded_dist(ctx, orc, seed):
     qn = np.array([orc.hv_norm2(x) for x in q], np.int32)
     k = int(rng.choice([16, 21, 31]))
     want = orc.ani_matrix(r, rn, q, qn, k)
-    assert np.abs(ctx.dist_full(r, rn, q, qn, k) - want).max() <= 1e-4
+    assert np.abs(ctx.dist_full(r, rn, q, qn, k) - want).max() <= ANI_TOL
     for th in (float(np.percentile(want, 30)), float(np.percentile(want, 95)), 0.0, 100.5):
         hits = ctx.dist(r, rn, q, qn, k, symmetric=False, ani_th=th)
         got = {(int(h["ref_idx"]), int(h["qry_idx"])) for h in hits}
-        near = np.abs(want - th) <= 1e-4
+        near = np.abs(want - th) <= ANI_TOL
         must = {(i, j) for i, j in zip(*np.nonzero((want >= th) & ~near))}
         may = {(i, j) for i, j in zip(*np.nonzero((want >= th) | near))}
         assert must <= got <= may and len(hits) == len(got), (seed, th)
         for h in hits[:: max(1, len(hits) // 500)]:
-            assert abs(h["ani"] - want[h["ref_idx"], h["qry_idx"]]) <= 1e-4
+            assert abs(h["ani"] - want[h["ref_idx"], h["qry_idx"]]) <= ANI_TOL
