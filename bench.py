@@ -1202,6 +1202,7 @@ def main():
             if r.returncode != 0:
                 raise RuntimeError(r.stderr.decode()[-1500:])
             out["cli"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            out["cli"]["source_sha"] = hg.cli_source_stamp()  # library sources + hg_cli.cpp: measured in THIS run on this tree
             log("cli: dist -r A -q A %.2f s, dist -r A -q B %.2f s, search %.2f s (wall, %d sketches)" % (
                 out["cli"]["dist_symmetric"]["wall_s"], out["cli"]["dist_two_files"]["wall_s"],
                 [v for k, v in out["cli"].items() if k.startswith("search")][0]["wall_s"], a.dist_n))

@@ -102,6 +102,15 @@ def source_stamp():
     return h.hexdigest()[:16]
 
 
+def cli_source_stamp():
+    """source_stamp() extended by the command-line tool's source: what a measurement of the `hyper-gen` binary belongs to
+    (bench.py's `cli` object and the profiles/rNN_cli_* files carry it)."""
+    import hashlib
+    h = hashlib.sha256(source_stamp().encode())
+    h.update(open(os.path.join(_HERE, "csrc", "hg_cli.cpp"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile the library and CLI in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     if force:

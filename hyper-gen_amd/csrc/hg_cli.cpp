@@ -446,7 +446,12 @@ void release(hg_multi *m, DevSet &D) {
 // default rounding mode), is the correctly rounded decimal -- what Rust's exact-mode float formatting and glibc's %.3f
 // both print.  Ties exist (ani = odd / 16: about one f32 in 16 000 near 96) and round-half-up would print 400 of the 1.1e9
 // floats in [0, 100] differently: checked exhaustively against 128-bit integer arithmetic.  Writes "\t<int>.<3 digits>\n".
+// (The library clamps ANI to [0, 100] -- src/dist.rs:156-159 -- so at most 3 + 1 + 3 digits follow the tab: the callers
+// reserve 10 bytes per line for this.  The bound must not hang on another translation unit's arithmetic: anything that is
+// not a number in [0, 100] -- a NaN, a negative value, a corrupted hit -- is brought into the range here.)
 inline size_t put_ani(char *o, float ani) {
+  if (!(ani >= 0.0f)) ani = 0.0f;  // NaN too
+  if (ani > 100.0f) ani = 100.0f;
   const uint64_t v = (uint64_t)__builtin_rint((double)ani * 1000.0);
   uint64_t ip = v / 1000;
   const uint32_t fp = (uint32_t)(v % 1000);

@@ -257,7 +257,8 @@ extern "C" hg_status hg_sort_ani_hits_dev(hg_ctx *c, hg_ani_hit *d_hits, size_t 
   if (!c) return HG_ERR_INVALID;
   if (n < 2) return HG_OK;
   if (!d_hits) return hg_fail(c, HG_ERR_INVALID, "NULL hit list");
-  if (n > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "hit list too long for the device sort");
+  // (the sort's kernels index elements in 32 bits, a tile of RS_TILE at a time: the last tile's indices must not wrap)
+  if (n > 0xFFFFFFFFull - RS_TILE) return hg_fail(c, HG_ERR_UNSUPPORTED, "hit list too long for the device sort");
   HG_ENTER(c);
   const uint32_t m = (uint32_t)n, grid = (m + 255) / 256;
   SortWs w;
@@ -305,7 +306,7 @@ extern "C" hg_status hg_topk_per_query_dev(hg_ctx *c, const hg_ani_hit *d_hits, 
   if (!c) return HG_ERR_INVALID;
   if (Q == 0 || k == 0) return HG_OK;
   if (!d_out || !d_counts || (n && !d_hits)) return hg_fail(c, HG_ERR_INVALID, "NULL argument");
-  if (n > 0xFFFFFFF0ull || Q > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "hit list too long for the device sort");
+  if (n > 0xFFFFFFFFull - RS_TILE || Q > 0xFFFFFFF0ull) return hg_fail(c, HG_ERR_UNSUPPORTED, "hit list too long for the device sort");
   HG_ENTER(c);
   const size_t slots = Q * (size_t)k;
   hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c->stream, d_out, slots);

@@ -836,7 +836,12 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     }
     if (!(HG_KS_EXP & 1)) __syncthreads();  // every read of the images is done: the next tile may overwrite them
     if (tid == 0) s_dirty[par] = 0u;  // (raised again in two tiles' time at the earliest, behind the next tile's barriers)
-    if (dense_sampling(threshold)) flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
+    // (flush_hits_if_filling branches on the staged count, workgroup-uniform only behind the barrier above: a development
+    // build that compiles that barrier out puts its own in front)
+    if (dense_sampling(threshold)) {
+      if (HG_KS_EXP & 1) __syncthreads();
+      flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
+    }
   }
   flush_hits(stage, stage_cap, gm, g, hits, cnt);
 }

@@ -77,7 +77,7 @@ def test_cli_sketch_dist_roundtrip(tmp_path, orc):
     assert len(got) == len(lines_model) >= 3
     for (a, b, v), (ma, mb, mv) in zip(got, lines_model):
         assert (a, b) == (ma, mb)
-        assert abs(float(v) - mv) <= 1e-3 + 1e-4  # 3 printed decimals
+        assert v == "%.3f" % mv  # the oracle's float32 value, printed like "{:.3}": the same text
     # ref != query path: all R x Q pairs, including self pairs at 100.000
     out2 = str(tmp_path / "copy.sketch")
     hg.write_sketch_file(out2, recs)
@@ -183,7 +183,7 @@ def test_cli_search_topn_and_cpu_mode_reader(tmp_path, orc):
     qh = np.stack([hg.hv_unpack(x["hv"].view(np.uint8), 4096, x["hv_quant_bits"]) for x in recs])
     qn = np.array([x["hv_norm_2"] for x in recs], np.int32)
     model = orc.ani_matrix(hvs, n2s, qh, qn, 21)
-    assert abs(anis[0] - float(model[0, 0])) <= 1e-3 + 1e-4 and abs(anis[2] - float(model[3, 1])) <= 1e-3 + 1e-4
+    assert rows[0][2] == "%.3f" % float(model[0, 0]) and rows[2][2] == "%.3f" % float(model[3, 1])  # the oracle's text
     # -D gpu honours -C false (src/cuda_kernel.cu:312-314) and reads lines as they are (plain FASTA only)
     gq = tmp_path / "gq"
     gq.mkdir()
@@ -227,11 +227,11 @@ def test_cli_hv_d_not_a_multiple_of_256_follows_the_reference(tmp_path, orc):
     r = subprocess.run([hg.CLI_PATH, "dist", "-r", out, "-q", out, "-o", tsv, "-a", "0"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     want = orc.ani_matrix(np.stack(hvs), np.array(n2s, np.int32), np.stack(hvs), np.array(n2s, np.int32), 21)
-    got = {(a, b): float(v) for a, b, v in (l.split("\t") for l in open(tsv).read().splitlines())}
+    got = {(a, b): v for a, b, v in (l.split("\t") for l in open(tsv).read().splitlines())}
     assert len(got) == 3
     for i in range(3):
         for j in range(i + 1, 3):
-            assert abs(got[(files[i], files[j])] - want[i, j]) <= 1e-3 + 1e-4
+            assert got[(files[i], files[j])] == "%.3f" % float(want[i, j])
 
 
 def test_device_unpack_matches_the_host_decoders(orc):
@@ -327,7 +327,7 @@ def test_cli_reads_and_writes_the_non_avx2_payload_layout(tmp_path, orc):
             i, j = idx[a], idx[b]
             ref_row = dec[i] if (sk == out_n or i in (1, 3)) else hvs[i]
             w = orc.ani_matrix(ref_row[None], n2[i: i + 1], hvs[j][None], n2[j: j + 1], 21)[0, 0]
-            assert abs(float(v) - w) <= 1e-3 + 1e-4, (sk, a, b)
+            assert v == "%.3f" % float(w), (sk, a, b)
     assert want.shape == (4, 4)
     # a payload of neither length is refused
     bad = dict(ra[0])
@@ -337,8 +337,26 @@ def test_cli_reads_and_writes_the_non_avx2_payload_layout(tmp_path, orc):
     assert r.returncode != 0 and "corrupt sketch payload" in r.stderr
 
 
-def test_cli_dist_tsv_is_the_library_hits_in_dump_order_with_exact_formatting(tmp_path):
-    """`hyper-gen dist` on two different files: the TSV must be, byte for byte, the library's own hits (hg_dist) in
+def oracle_tsv(orc, hv_r, n2r, hv_q, n2q, names_r, names_q, k, ani_th, sym, ani=None):
+    """What the reference's dist writes (src/dist.rs:231-294 + src/utils.rs:260-308) from the ORACLE's ANI values: pairs in
+    enumeration order (row-major, i < j only when the two files are the same), stable ascending sort by ANI, reversed, printed
+    while ani >= ani_th as "{}\\t{}\\t{:.3}"."""
+    full = orc.ani_matrix(hv_r, n2r, hv_q, n2q, k) if ani is None else ani
+    R, Q = full.shape
+    if sym:
+        ii, jj = np.triu_indices(R, 1)  # (row-major, like the reference's nested loops)
+    else:
+        ii, jj = np.divmod(np.arange(R * Q), Q)
+    v = full[ii, jj]
+    keep = v >= np.float32(ani_th)
+    ii, jj, v = ii[keep], jj[keep], v[keep]
+    order = np.argsort(v, kind="stable")[::-1]
+    return "".join("%s\t%s\t%.3f\n" % (names_r[ii[t]], names_q[jj[t]], float(v[t])) for t in order)
+
+
+def test_cli_dist_tsv_is_the_library_hits_in_dump_order_with_exact_formatting(tmp_path, orc):
+    """`hyper-gen dist` on two different files: the TSV must be, byte for byte, the ORACLE's lines (oracle_tsv: its ANI values,
+    the reference's enumeration, order and format) -- and the library's own hits (hg_dist) in
     dump_ani_file's order (hg_sort_ani_hits) printed as "{}\\t{}\\t{:.3}" -- the CLI formats without printf (ties at the third
     decimal round to even, as Rust's and glibc's exact formatting do), decodes the payloads on the device and, with one
     device, orders the hits there before they leave it"""
@@ -366,6 +384,7 @@ def test_cli_dist_tsv_is_the_library_hits_in_dump_order_with_exact_formatting(tm
             hits = ctx.dist(hv_r, n2r, hv_q, n2q, 21, symmetric=sym, ani_th=80.0)
             hits = hg.sort_ani_hits(hits, n, symmetric=sym)
             want = "".join("%s\t%s\t%.3f\n" % (nr[h["ref_idx"]], nq[h["qry_idx"]], float(h["ani"])) for h in hits)
+            assert want == oracle_tsv(orc, hv_r, n2r, hv_q, n2q, nr, nq, 21, 80.0, sym)  # ... which are the ORACLE's lines
             # one shard per visible GPU (the hits never touch the host unordered), and three shards dealt round the GPUs: the
             # several-GPU path (row blocks decoded per shard, peer pulls, per-shard hit lists merged and ordered through
             # device 0) on however many GPUs the box has

@@ -1,5 +1,7 @@
 """BASELINE-size runs checked through size-independent properties (the oracle cannot redo 1 000 x 5 Mbp
 in seconds): determinism, sampled full parity, norm / dot identities, ANI symmetry, hit-set consistency."""
+import os
+
 import numpy as np
 import pytest
 
@@ -542,3 +544,61 @@ def test_dist_of_more_than_2_to_32_pairs():
         v2 = torch.cat([p[1] for p in parts])
         o = torch.argsort(k2)
         assert torch.equal(k2[o], k_all) and torch.equal(v2[o], v_all)
+
+
+def test_cli_dist_10k_x_10k_tsv_equals_the_oracles_bytes(tmp_path, orc):
+    """BASELINE configs[3] through the drop-in surface: `hyper-gen dist -r A.sketch -q B.sketch` on 10 000 x 10 000 sketches
+    must write, byte for byte, the TSV the reference writes -- ANI values from the ORACLE's formula (orc_ani_from_dot: the
+    host's logf, float32 operations in src/dist.rs:153-160's order) on exact dot products, pairs in dist.rs:243-265's
+    enumeration order, dump_ani_file's stable-sort-then-reverse order (src/utils.rs:260-308), "{:.3}" text.
+    The 10^8 dot products come from an fp64 torch GEMM (exact: |dot| << 2^53; 4 * 10^11 scalar MACs are out of the oracle's
+    reach in a test); a 256-row band of them is checked against the oracle's own scalar dot (orc_ani_matrix)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    import hypergen_amd as hg
+    dev = torch.device("cuda:0")
+    n = 10000
+    a = bench.clustered_hvs(n, 0, dev)
+    b = bench.clustered_hvs(n, 0, dev, salt=1)
+    n2a, n2b = (a.int() ** 2).sum(1).int(), (b.int() ** 2).sum(1).int()
+    # expected ANI of every pair: exact dots (fp64 GEMM in row blocks) -> the oracle's formula on the host
+    ani = np.empty((n, n), np.float32)
+    bd, nb_ = b.double(), n2b.cpu().numpy()
+    for r0 in range(0, n, 2000):
+        dots = (a[r0:r0 + 2000].double() @ bd.T).round().to(torch.int32).cpu().numpy()
+        nr = np.repeat(n2a[r0:r0 + 2000].cpu().numpy(), n)
+        ani[r0:r0 + 2000] = orc.ani_from_dots(dots.ravel(), nr, np.tile(nb_, dots.shape[0]), 21).reshape(dots.shape)
+    del bd
+    band = slice(4900, 5156)
+    ah, bh = a.cpu().numpy(), b.cpu().numpy()
+    assert np.array_equal(ani[band], orc.ani_matrix(ah[band], n2a.cpu().numpy()[band], bh, nb_, 21))
+    paths, names = [], []
+    for tag, hv, n2 in (("a", ah, n2a.cpu().numpy()), ("b", bh, nb_)):
+        recs = []
+        for i in range(n):
+            q, pk = hg.hv_pack(hv[i])
+            recs.append(dict(ksize=21, scaled=1500, canonical=True, seed=123, hv_d=4096, hv_quant_bits=q, hv_norm_2=int(n2[i]),
+                             file_str="/data/%s/genome_%05d.fna" % (tag, i), hv=pk.view(np.int16)))
+        p = str(tmp_path / (tag + ".sketch"))
+        hg.write_sketch_file(p, recs)
+        paths.append(p)
+        names.append([r["file_str"] for r in recs])
+    del a, b
+    torch.cuda.empty_cache()
+    # the expected text (the pairs >= 85: ~1.3 M lines)
+    ii, jj = np.nonzero(ani >= np.float32(85.0))  # row-major = enumeration order
+    v = ani[ii, jj]
+    order = np.argsort(v, kind="stable")[::-1]
+    want = "".join("%s\t%s\t%.3f\n" % (names[0][ii[t]], names[1][jj[t]], float(v[t])) for t in order)
+    tsv = str(tmp_path / "ani.tsv")
+    r = subprocess.run([hg.CLI_PATH, "dist", "-r", paths[0], "-q", paths[1], "-o", tsv, "-a", "85"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = open(tsv).read()
+    assert len(order) > 1_000_000
+    if got != want:  # say where, not just that
+        gl, wl = got.splitlines(), want.splitlines()
+        first = next((t for t in range(min(len(gl), len(wl))) if gl[t] != wl[t]), min(len(gl), len(wl)))
+        raise AssertionError("TSV differs: %d vs %d lines, first difference at line %d: %r vs %r" % (
+            len(gl), len(wl), first, gl[first] if first < len(gl) else None, wl[first] if first < len(wl) else None))
