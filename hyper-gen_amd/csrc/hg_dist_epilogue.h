@@ -283,6 +283,13 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
   auto flush_all = [&](auto p2uc) __attribute__((always_inline)) {  // p2uc: batches a wave keeps in flight in phase 2
     constexpr uint32_t P2_U = decltype(p2uc)::value;
     if (lane == 0) s_len[wave] = staged;
+#ifdef HG_DIST_STAMPS
+    unsigned long long fl_t0 = 0;
+    if (tid == 0 && blockIdx.x < 2048) {
+      if (g_dist_tile_all[blockIdx.x][7] == 0) g_dist_tile_all[blockIdx.x][7] = __builtin_amdgcn_s_memtime();  // (append done: the first flush begins)
+      fl_t0 = __builtin_amdgcn_s_memtime();
+    }
+#endif
     __syncthreads();
 #ifdef HG_DIST_STAMPS
     if (tid == 0 && blockIdx.x < 2048)
@@ -300,6 +307,10 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
     HG_TSTAMP(6)
     if (lane == 0) s_cnt[wave] = nh;
     __syncthreads();
+#ifdef HG_DIST_STAMPS
+    unsigned long long fl_t1 = 0;
+    if (tid == 0 && blockIdx.x < 2048) fl_t1 = __builtin_amdgcn_s_memtime(), g_dist_tile_all[blockIdx.x][8] += fl_t1 - fl_t0;
+#endif
     if (tid == 0) {
       uint32_t total = 0;
 #pragma unroll
@@ -308,6 +319,13 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
     }
     __syncthreads();
     HG_TSTAMP(7)
+#ifdef HG_DIST_STAMPS
+    unsigned long long fl_t2 = 0;
+    if (tid == 0 && blockIdx.x < 2048) {
+      fl_t2 = __builtin_amdgcn_s_memtime(), g_dist_tile_all[blockIdx.x][9] += fl_t2 - fl_t1, g_dist_tile_all[blockIdx.x][12] += 1;
+      for (uint32_t w = 0; w < NW_; ++w) g_dist_tile_all[blockIdx.x][13] += s_cnt[w];
+    }
+#endif
     uint32_t off = s_cnt[NW_];
     for (uint32_t w = 0; w < wave; ++w) off += s_cnt[w];
     kglob = 0;
@@ -319,8 +337,15 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
       kglob += nb;
     }
     HG_TSTAMP(8)
+#ifdef HG_DIST_STAMPS
+    unsigned long long fl_t3 = 0;
+    if (tid == 0 && blockIdx.x < 2048) fl_t3 = __builtin_amdgcn_s_memtime(), g_dist_tile_all[blockIdx.x][10] += fl_t3 - fl_t2;
+#endif
     staged = 0;
     __syncthreads();  // the lists may be refilled only after every wave has read them
+#ifdef HG_DIST_STAMPS
+    if (tid == 0 && blockIdx.x < 2048) g_dist_tile_all[blockIdx.x][11] += __builtin_amdgcn_s_memtime() - fl_t3;
+#endif
   };
   // Phase 0: `d >= ur(row) + tq(column)` with the thresholds staged at kernel entry: the lane's NT column thresholds are
   // fetched here, the four row thresholds of a slab with one 16-byte read per slab (all 4 * WTM of them kept in
@@ -403,6 +428,7 @@ __device__ __forceinline__ void dist_epilogue(const GemmArgs &g, _Float16 *sAB, 
       for (int o = 32; o > 0; o >>= 1) lane_total += __shfl_xor(lane_total, o);
       if (lane == 0) s_tot[wave] = lane_total;
       __syncthreads();
+      HG_TSTAMP(9)
       wave_cands = lane < (uint32_t)(THREADS / 64) ? s_tot[lane] : 0u;
       if (__ballot(wave_cands != 0u) == 0) {  // nothing in this tile
         HG_TSTAMP(4)

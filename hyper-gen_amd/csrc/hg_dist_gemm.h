@@ -123,12 +123,20 @@ __device__ unsigned long long g_dist_stamps[16][2][8][6];
 __device__ unsigned long long g_dist_tile_stamps[16][8][10];
 __device__ unsigned long long g_dist_tile_real[2048][2];  // s_memrealtime (100 MHz) at points 1 and 2: with the stamps of
                                                           // g_dist_tile_stamps' wave 0 this gives the shader clock of the main loop
-__device__ unsigned long long g_dist_tile_all[2048][5];  // per workgroup: entry, main loop done, tile done, candidates evaluated, XCC id | HW_ID << 8
+// per workgroup: 0 entry, 1 main loop done, 2 tile done, 3 candidates evaluated, 4 XCC id | HW_ID << 8, 5 norms staged (point 3),
+// 6 phase-0 masks built and the waves' counts known (point 9), 7 candidates appended / sweep done (point 4; the first time),
+// and summed over the tile's flushes: 8 flush start -> candidates evaluated (phase 2), 9 -> range reserved, 10 -> hits
+// written, 11 -> lists free again (the closing barrier); 12 flushes, 13 hits
+__device__ unsigned long long g_dist_tile_all[2048][16];
 #define HG_TSTAMP(pt)                                                                                      \
-  if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528)                                    \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x >= 512 && blockIdx.x < 528 && (pt) < 9)                        \
     g_dist_tile_stamps[blockIdx.x - 512][threadIdx.x >> 6][pt] = __builtin_amdgcn_s_memtime();            \
   if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 0 || (pt) == 2 || (pt) == 5))                      \
     g_dist_tile_all[blockIdx.x][(pt) == 0 ? 0 : ((pt) == 2 ? 1 : 2)] = __builtin_amdgcn_s_memtime();       \
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 3 || (pt) == 9))                                   \
+    g_dist_tile_all[blockIdx.x][(pt) == 3 ? 5 : 6] = __builtin_amdgcn_s_memtime();                         \
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && (pt) == 4 && g_dist_tile_all[blockIdx.x][7] == 0)           \
+    g_dist_tile_all[blockIdx.x][7] = __builtin_amdgcn_s_memtime();                                         \
   if (threadIdx.x == 0 && blockIdx.x < 2048 && ((pt) == 1 || (pt) == 2))                                   \
     g_dist_tile_real[blockIdx.x][(pt)-1] = __builtin_amdgcn_s_memrealtime();
 #else

@@ -74,6 +74,9 @@ __global__ __launch_bounds__((TileCfg<BIG, 4>::THREADS)) void dist_mfma_kernel(G
 #ifdef HG_DIST_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 2048)
     g_dist_tile_all[blockIdx.x][3] = 0, g_dist_tile_all[blockIdx.x][1] = 0, g_dist_tile_all[blockIdx.x][2] = 0,
+    g_dist_tile_all[blockIdx.x][5] = 0, g_dist_tile_all[blockIdx.x][6] = 0, g_dist_tile_all[blockIdx.x][7] = 0,
+    g_dist_tile_all[blockIdx.x][8] = 0, g_dist_tile_all[blockIdx.x][9] = 0, g_dist_tile_all[blockIdx.x][10] = 0,
+    g_dist_tile_all[blockIdx.x][11] = 0, g_dist_tile_all[blockIdx.x][12] = 0, g_dist_tile_all[blockIdx.x][13] = 0,
     g_dist_tile_all[blockIdx.x][4] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) |  // hwreg(HW_REG_XCC_ID, 0, 4)
                                      ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8);  // HW_REG_HW_ID
 #endif
@@ -912,8 +915,8 @@ hg_status hg_run_dist_prep_ops(hg_ctx *c, const int16_t *d_hv, uint32_t rows, ui
 extern "C" int hg_debug_dist_tile_real(unsigned long long *out /* 2048 * 2 */) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_real), sizeof(unsigned long long) * 2048 * 2);
 }
-extern "C" int hg_debug_dist_tile_all(unsigned long long *out /* 2048 * 5 */) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_all), sizeof(unsigned long long) * 2048 * 5);
+extern "C" int hg_debug_dist_tile_all(unsigned long long *out /* 2048 * 16 */) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_all), sizeof(unsigned long long) * 2048 * 16);
 }
 extern "C" int hg_debug_dist_tile_stamps(unsigned long long *out /* 16 * 8 * 10 */) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dist_tile_stamps), sizeof(unsigned long long) * 16 * 8 * 10);

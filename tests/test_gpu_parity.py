@@ -55,6 +55,20 @@ def test_hash_sets_all_k(ctx, orc, k):
         assert got.size == want.size and (got == want).all(), (k, canonical)
 
 
+def test_long_k_dna_vectors_of_every_length_33_to_255(ctx):
+    """tests/golden/kat_t1ha2.json "dna_33_255": one DNA string per length, hashed by a Python-integer t1ha2 that reproduces
+    upstream's 81 self-check values -- through kmer_sample_long as a sequence of exactly one k-mer, both strand modes"""
+    g = golden("kat_t1ha2.json")
+    tr = bytes.maketrans(b"ACGT", b"TGCA")
+    for c in g["dna_33_255"]:
+        sq = c["seq"].encode()
+        k = len(sq)
+        arr = np.frombuffer(sq, np.uint8)
+        assert [int(x) for x in ctx.kmer_hash_sample(arr, k, 1, 123, False)] == [int(c["hash"], 16)], k
+        want = int(c["hash"], 16) if sq <= sq.translate(tr)[::-1] else int(c["hash_revcomp"], 16)
+        assert [int(x) for x in ctx.kmer_hash_sample(arr, k, 1, 123, True)] == [want], k
+
+
 @pytest.mark.parametrize("k", [33, 40, 41, 51, 63, 64, 65, 96, 97, 128, 255])
 def test_hash_sets_long_k(ctx, orc, k):
     """k > 32: t1ha2's long-input loop on the device (the CPU path supports it, src/cuda_kernel.cu does not)."""

@@ -12,6 +12,27 @@ def test_t1ha2_upstream_selfcheck(orc):
         assert orc.t1ha2_atonce(pat[: c["len"]], int(c["seed"])) == int(c["hash"], 16), c
 
 
+def test_t1ha2_whole_upstream_table_and_dna_beyond_32_bytes(orc):
+    """all 81 entries of upstream's t1ha_refval_2atonce (47 inputs longer than 32 bytes: the loop src/cuda_kernel.cu:196-246
+    omits and src/sketch.rs:90 reaches through the t1ha crate for k > 32), and DNA strings of every length 33..255 hashed by
+    tools/gen_golden_cpu.py's own Python-integer t1ha2 (which reproduces the 81 first)"""
+    g = golden("kat_t1ha2.json")
+    assert len(g["upstream_selfcheck"]) == 81 and sum(len(c["data"]) // 2 > 32 for c in g["upstream_selfcheck"]) == 47
+    for c in g["upstream_selfcheck"]:
+        assert orc.t1ha2_atonce(bytes.fromhex(c["data"]), int(c["seed"])) == int(c["hash"], 16), c["name"]
+    assert [len(c["seq"]) for c in g["dna_33_255"]] == list(range(33, 256))
+    for c in g["dna_33_255"]:
+        sq = c["seq"].encode()
+        rc = sq.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
+        assert orc.t1ha2_atonce(sq, int(c["seed"])) == int(c["hash"], 16), len(sq)
+        assert orc.t1ha2_atonce(rc, int(c["seed"])) == int(c["hash_revcomp"], 16), len(sq)
+        # ... and through the k-mer walk: one k-mer of length k, both strand modes (src/sketch.rs:89: the smaller string)
+        arr = np.frombuffer(sq, np.uint8)
+        assert [int(x) for x in orc.kmer_hash_sample(arr, len(sq), 1, 123, False)] == [int(c["hash"], 16)]
+        want = int(c["hash"], 16) if sq <= rc else int(c["hash_revcomp"], 16)
+        assert [int(x) for x in orc.kmer_hash_sample(arr, len(sq), 1, 123, True)] == [want]
+
+
 def test_wyrng_upstream_kat(orc):
     g = golden("kat_wyrng.json")
     assert orc.wyrng_stream(g["seed"], 1)[0] == int(g["first"], 16) == 0x3E99A772750DCBE  # wyhash crate README

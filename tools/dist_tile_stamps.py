@@ -36,7 +36,7 @@ for th in (101.0, 85.0):
     rl = rl.astype(np.int64)[512:528]
     ml = st[:, 0, 2] - st[:, 0, 1]
     print("   main loop: %.0f shader ticks in %.0f ticks of the 100 MHz clock = %.0f MHz" % (ml.mean(), (rl[:, 1] - rl[:, 0]).mean(), ml.mean() / (rl[:, 1] - rl[:, 0]).mean() * 100))
-    al = np.zeros((2048, 5), np.uint64)
+    al = np.zeros((2048, 16), np.uint64)
     assert hg.lib().hg_debug_dist_tile_all(C.c_void_p(al.ctypes.data)) == 0
     al = al.astype(np.int64)[:1440]
     ok = (al[:, 2] > al[:, 0]) & (al[:, 2] - al[:, 0] < 2000000) & (al[:, 1] > al[:, 0])  # (slots that returned at once keep stale stamps)

@@ -2,9 +2,11 @@
 """Writes the CPU-side golden fixtures under tests/golden/.
 
 Sources of the numbers (none is produced by the code under test):
-  * kat_t1ha2.json  -- upstream t1ha self-check table for t1ha2_atonce (test pattern,
-    seed = 1 << (len-1)), lengths 0..18 and the 64-byte/seed-0 entry.  The values are
-    typed in here; the oracle merely has to reproduce them.
+  * kat_t1ha2.json  -- upstream t1ha's self-check table for t1ha2_atonce, all 81 entries (t1ha_refval_2atonce: test
+    pattern prefixes of 1..63 bytes, unaligned 57..63-byte inputs, 128..247-byte inputs -- 47 of them longer than 32 bytes,
+    the loop src/cuda_kernel.cu omits), typed in here; + DNA strings of every length 33..255 hashed by a Python-integer
+    t1ha2 written in this script, which must reproduce the 81 upstream values first.  The oracle and the kernels merely have
+    to reproduce both.
   * kat_wyrng.json  -- NOT written here: tools/gen_golden_wyrng.py (the published wyrng definition in Python integers).
   * g1_test_fna.json -- SURVEY.md 8c "G1": the reference's own kernel source
     (src/cuda_kernel.cu) executed on the reference fixture test/test.fna.
@@ -25,16 +27,96 @@ PATTERN = [0, 1, 2, 3, 4, 5, 6, 7, 0xFF, 0x7F, 0x3F, 0x1F, 0xF, 8, 16, 32, 64, 0
            0xFC, 0xF8, 0xF0, 0xE0, 0xC0, 0xFD, 0xFB, 0xF7, 0xEF, 0xDF, 0xBF, 0x55, 0xAA, 11,
            17, 19, 23, 29, 37, 42, 43] + list(b"abcdefghijklmnopqrstuvwx")
 
-T1HA2 = [  # (len, seed, value)
-    (0, 0, 0x0),
-    (0, 2**64 - 1, 0x772C7311BE32FF42),
-    (64, 0, 0x444753D23F207E03),
-] + [(i + 1, 1 << i, v) for i, v in enumerate([
-    0x71F6DF5DA3B4F532, 0x555859635365F660, 0xE98808F1CD39C626, 0x2EB18FAF2163BB09,
-    0x7B9DD892C8019C87, 0xE2B1431C4DA4D15A, 0x1984E718A5477F70, 0x08DD17B266484F79,
-    0x4C83A05D766AD550, 0x92DCEBB131D1907D, 0xD67BC6FC881B8549, 0xF6A9886555FBF66B,
-    0x6E31616D7F33E25E, 0x36E31B7426E3049D, 0x4F8E4FAF46A13F5F, 0x03EB0CB3253F819F,
-    0x636A7769905770D2, 0x3ADF3781D16D1148])]
+# t1ha_refval_2atonce[81]: upstream's self-check table for t1ha2_atonce, in the order of its t1ha_selfcheck():
+#   [0] empty, seed 0   [1] empty, seed ~0   [2] pattern[0:64], seed 0
+#   [3..65]  pattern[0:i], seed 1 << (i - 1), i = 1..63        (33..63 bytes: one round of the long-input loop + a tail)
+#   [66..72] pattern[i:64], seed ~0 << i, i = 1..7              (unaligned starts, 57..63 bytes)
+#   [73..80] long[i : i + 128 + 17 i], seed ~0 << 7, i = 0..7   (long[j] = j & 255: 128..247 bytes, 4..7 rounds)
+REFVAL_2ATONCE = [
+    0x0000000000000000, 0x772C7311BE32FF42, 0x444753D23F207E03, 0x71F6DF5DA3B4F532, 0x555859635365F660,
+    0xE98808F1CD39C626, 0x2EB18FAF2163BB09, 0x7B9DD892C8019C87, 0xE2B1431C4DA4D15A, 0x1984E718A5477F70,
+    0x08DD17B266484F79, 0x4C83A05D766AD550, 0x92DCEBB131D1907D, 0xD67BC6FC881B8549, 0xF6A9886555FBF66B,
+    0x6E31616D7F33E25E, 0x36E31B7426E3049D, 0x4F8E4FAF46A13F5F, 0x03EB0CB3253F819F, 0x636A7769905770D2,
+    0x3ADF3781D16D1148, 0x92D19CB1818BC9C2, 0x283E68F4D459C533, 0xFA83A8A88DECAA04, 0x8C6F00368EAC538C,
+    0x7B66B0CF3797B322, 0x5131E122FDABA3FF, 0x6E59FF515C08C7A9, 0xBA2C5269B2C377B0, 0xA9D24FD368FE8A2B,
+    0x22DB13D32E33E891, 0x7B97DFC804B876E5, 0xC598BDFCD0E834F9, 0xB256163D3687F5A7, 0x66D7A73C6AEF50B3,
+    0x25A7201C85D9E2A3, 0x911573EDA15299AA, 0x5C0062B669E18E4C, 0x17734ADE08D54E28, 0xFFF036E33883F43B,
+    0xFE0756E7777DF11E, 0x37972472D023F129, 0x6CFCE201B55C7F57, 0xE019D1D89F02B3E1, 0xAE5CC580FA1BB7E6,
+    0x295695FB7E59FC3A, 0x76B6C820A40DD35E, 0xB1680A1768462B17, 0x2FB6AF279137DADA, 0x28FB6B4366C78535,
+    0xEC278E53924541B1, 0x164F8AAB8A2A28B5, 0xB6C330AEAC4578AD, 0x7F6F371070085084, 0x94DEAD60C0F448D3,
+    0x99737AC232C559EF, 0x6F54A6F9CA8EDD57, 0x979B01E926BFCE0C, 0xF7D20BC85439C5B4, 0x64EDB27CD8087C12,
+    0x11488DE5F79C0BE2, 0x25541DDD1680B5A4, 0x8B633D33BE9D1973, 0x404A3113ACF7F6C6, 0xC59DBDEF8550CD56,
+    0x039D23C68F4F992C, 0x5BBB48E4BDD6FD86, 0x41E312248780DF5A, 0xD34791CE75D4E94F, 0xED523E5D04DCDCFF,
+    0x7A6BCE0B6182D879, 0x21FB37483CAC28D8, 0x19A1B66E8DA878AD, 0x6F804C5295B09ABE, 0x2A4BE5014115BA81,
+    0xA678ECC5FC924BE0, 0x50F7A54A99A36F59, 0x0FD7E63A39A66452, 0x5AB1B213DD29C4E4, 0xF3ED80D9DF6534C5,
+    0xC736B12EF90615FD]
+M64 = 2**64 - 1
+
+
+def selfcheck_inputs():
+    """(data, seed, value, name) in upstream's order"""
+    pat, long_ = bytes(PATTERN), bytes(j & 255 for j in range(512))
+    out = [(b"", 0, "empty-zero"), (b"", M64, "empty-all1"), (pat[:64], 0, "bin64-zero")]
+    out += [(pat[:i], 1 << (i - 1), "bin%02d-1p%02d" % (i, i - 1)) for i in range(1, 64)]
+    out += [(pat[i:64], (M64 << i) & M64, "align%d_F%d" % (i, i)) for i in range(1, 8)]
+    out += [(long_[i:i + 128 + 17 * i], (M64 << 7) & M64, "long-%05d" % (128 + 17 * i)) for i in range(8)]
+    return [(d, s, v, nm) for (d, s, nm), v in zip(out, REFVAL_2ATONCE)]
+
+
+# ---- t1ha2_atonce in Python integers, from the published description (little-endian, unaligned reads) ------------------
+# Written for this script only -- it shares no code with oracle/hg_oracle.c or the kernels -- and checked against all 81
+# upstream values above before anything it produces is written.  It then generates the vectors upstream has none for:
+# DNA strings of every length 33..255 (the k-mer lengths `-k` can take beyond the reference CUDA kernel's 32).
+T1HA_PRIMES = (0xEC99BF0D8372CAAB, 0x82434FE90EDCEF39, 0xD4F06DB99D67BE4B, 0xBD9CACC22C6E9571, 0x9C06FAF4D023E3AB,
+               0xC060724A8424F345, 0xCB5AF53AE3AAAC31)
+
+
+def py_t1ha2_atonce(data, seed):
+    rot = lambda v, s: ((v >> s) | (v << (64 - s))) & M64
+    le = lambda off, n: int.from_bytes(data[off:off + n], "little")
+    p = T1HA_PRIMES
+    n, pos = len(data), 0
+    st = {"a": seed, "b": n}
+
+    def mixup(x, y, v, prime):  # st[x] ^= lo, st[y] += hi of (st[y] + v) * prime
+        m = ((st[y] + v) & M64) * prime
+        st[x] ^= m & M64
+        st[y] = (st[y] + (m >> 64)) & M64
+
+    if n > 32:
+        c = (rot(n, 23) + (~seed & M64)) & M64
+        d = ((~n & M64) + rot(seed, 19)) & M64
+        a, b = st["a"], st["b"]
+        while True:
+            w = [le(pos + 8 * t, 8) for t in range(4)]
+            pos += 32
+            d02 = (w[0] + rot((w[2] + d) & M64, 56)) & M64
+            c13 = (w[1] + rot((w[3] + c) & M64, 19)) & M64
+            d ^= (b + rot(w[1], 38)) & M64
+            c ^= (a + rot(w[0], 57)) & M64
+            b ^= (p[6] * ((c13 + w[2]) & M64)) & M64
+            a ^= (p[5] * ((d02 + w[3]) & M64)) & M64
+            if pos >= n - 31:
+                break
+        a ^= (p[6] * ((c + rot(d, 23)) & M64)) & M64
+        b ^= (p[5] * ((rot(c, 19) + d) & M64)) & M64
+        st["a"], st["b"] = a, b
+    rem = n - pos if n > 32 else n
+    rem &= 31 if n > 32 else M64
+    # the tail: up to four words, primes 4, 3, 2, 1, alternating which of (a, b) takes the low half
+    plan = [("a", "b", 4, 24), ("b", "a", 3, 16), ("a", "b", 2, 8)]
+    for x, y, pi, above in plan:
+        if rem > above:
+            mixup(x, y, le(pos, 8), p[pi])
+            pos, rem = pos + 8, rem - 8
+    if rem > 0:
+        mixup("b", "a", le(pos, rem), p[1])
+    a, b = st["a"], st["b"]
+    x = (((a + rot(b, 41)) & M64) * p[0]) & M64
+    y = (((rot(a, 23) + b) & M64) * p[6]) & M64
+    m = (x ^ y) * p[5]
+    return (m & M64) ^ (m >> 64)
+
 
 G1_FASTA = ">test_seq\nAGCTCTTANNAGCCCNTTacgttacagccctgaaaacttt"  # reference test/test.fna
 G1_K21_S1 = ["908794018d1f0246", "967bde3c7bcdbcba", "c0bd0cee44a5f3e0", "e003c78b7d4bace3"]
@@ -102,8 +184,26 @@ def ani_f32(dot, nr, nq, k):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    checks = selfcheck_inputs()
+    for data, seed, value, name in checks:
+        assert py_t1ha2_atonce(data, seed) == value, name  # the Python restatement reproduces all 81 upstream values
+    rng_k = np.random.default_rng(2133)
+    dna = []
+    for n in range(33, 256):  # one DNA string per k-mer length beyond the reference kernel's 32
+        sq = bytes(rng_k.choice(np.frombuffer(b"ACGT", np.uint8), n))
+        rc = sq.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]  # the other strand: canonical = the smaller of the two strings
+        dna.append({"seq": sq.decode(), "seed": "123", "hash": "%016x" % py_t1ha2_atonce(sq, 123),
+                    "hash_revcomp": "%016x" % py_t1ha2_atonce(rc, 123)})
     json.dump({"pattern": PATTERN,
-               "cases": [{"len": l, "seed": str(s), "hash": "%016x" % v} for l, s, v in T1HA2]},
+               # (kept from round 1: lengths 0..18 and the 64-byte entry, by length)
+               "cases": [{"len": 0, "seed": "0", "hash": "%016x" % REFVAL_2ATONCE[0]},
+                         {"len": 0, "seed": str(M64), "hash": "%016x" % REFVAL_2ATONCE[1]},
+                         {"len": 64, "seed": "0", "hash": "%016x" % REFVAL_2ATONCE[2]}] +
+                        [{"len": i, "seed": str(1 << (i - 1)), "hash": "%016x" % REFVAL_2ATONCE[2 + i]} for i in range(1, 19)],
+               # the whole upstream table t1ha_refval_2atonce[81], inputs spelled out (hex)
+               "upstream_selfcheck": [{"name": nm, "data": d.hex(), "seed": str(sd), "hash": "%016x" % v} for d, sd, v, nm in checks],
+               # DNA strings of length 33..255 hashed by this script's own Python-integer t1ha2 (seed 123, the sketch default)
+               "dna_33_255": dna},
               open(os.path.join(OUT, "kat_t1ha2.json"), "w"), indent=1)
     json.dump({"fasta": G1_FASTA, "seed": 123, "canonical": True,
                "k21_scaled1": G1_K21_S1, "k5_scaled1": G1_K5_S1, "k21_scaled1500": []},
