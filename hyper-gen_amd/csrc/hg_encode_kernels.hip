@@ -89,6 +89,28 @@ constexpr uint32_t SORT_BUCKET_MAX_KEYS = 8192, SORT_BUCKET_LIMIT = 16, SORT_KPT
 static_assert(SORT_BUCKET_MAX_KEYS == SORT_LDS_MAX_KEYS, "every set the one-workgroup sort takes can take its counting sort");
 constexpr size_t SORT_LDS_BYTES_MAX = (size_t)SORT_LDS_MAX_KEYS * (sizeof(uint64_t) + sizeof(uint32_t));  // keys + counters
 
+// Up to 64 keys ordered and de-duplicated by ONE wave in registers (lane = the calling lane, 0..63): a 64-lane bitonic
+// network over shuffles, no LDS, no barrier.
+__device__ __forceinline__ void sort_unique_wave(uint64_t *__restrict__ region, const uint32_t n, const uint32_t lane,
+                                                 uint32_t *__restrict__ nd_out) {
+  uint64_t key = lane < n ? region[lane] : ~0ull;  // hashes are < threshold < ~0
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j) << 32) |
+                             (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j);
+      const bool lower = (lane & j) == 0, asc = (lane & k) == 0;
+      const bool take_min = lower == asc;
+      key = (take_min == (other < key)) ? other : key;
+    }
+  const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(key >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)key, 1);
+  const bool keep = lane < n && (lane == 0 || key != prev);
+  const unsigned long long kb = __ballot(keep);
+  if (keep) region[__popcll(kb & ((1ull << lane) - 1ull))] = key;  // (every key was read before the first one is written)
+  if (lane == 0) *nd_out = (uint32_t)__popcll(kb);
+}
+
 // The sort + unique of ONE genome by the calling workgroup (n = its stored raw hits).  Returns early -- whole waves, or
 // the whole workgroup -- on the paths that need no barrier; a caller that loops over genomes puts a barrier between them.
 template <bool USE_LDS>
@@ -113,22 +135,7 @@ __device__ __forceinline__ void sort_unique_one(const uint32_t g, const hg_genom
     // leave.  (Through the workgroup-wide network with its barrier per pass, 100 000 such genomes took 0.96 ms; the k-mer
     // kernel of the same batch 9.3 ms.)
     if (tid >= 64) return;  // whole waves
-    uint64_t key = tid < n ? region[tid] : ~0ull;  // hashes are < threshold < ~0
-#pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1)
-#pragma unroll
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j) << 32) |
-                               (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j);
-        const bool lower = (tid & j) == 0, asc = (tid & k) == 0;
-        const bool take_min = lower == asc;
-        key = (take_min == (other < key)) ? other : key;
-      }
-    const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(key >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)key, 1);
-    const bool keep = tid < n && (tid == 0 || key != prev);
-    const unsigned long long kb = __ballot(keep);
-    if (keep) region[__popcll(kb & ((1ull << tid) - 1ull))] = key;  // (every key was read before the first one is written)
-    if (tid == 0) ndistinct[g] = (uint32_t)__popcll(kb);
+    sort_unique_wave(region, n, tid, ndistinct + g);
     return;
   }
   if (in_lds) {
@@ -239,6 +246,33 @@ __global__ __launch_bounds__(SORT_WG) void sort_unique_kernel(
   }
   if (n > gm.hit_cap) n = gm.hit_cap;  // overflow is reported by the host from cnt[]
   sort_unique_one<USE_LDS>(g, gm, n, hits, ndistinct, lds_keys, bucket_mul);
+}
+
+// One WAVE per genome, four genomes per workgroup: the first sort launch of a batch whose genomes are EXPECTED to sample at
+// most a few dozen k-mers (plasmids, viral genomes, contigs of a few kbp: 400 000 genomes of 2 kbp have 1.3 hashes each --
+// there one 512-thread workgroup per genome, seven of whose eight waves leave at once, cost 0.74 ms against 2.25 ms for
+// the k-mer kernel).  A genome with more than 64 raw hits is left to hg_launch_sort_unique_rest (skip_keys = 64).
+__global__ __launch_bounds__(256) void sort_unique_wave_kernel(
+    const hg_genome_meta *__restrict__ meta, uint64_t *__restrict__ hits, const uint32_t *__restrict__ cnt,
+    uint32_t *__restrict__ ndistinct, uint32_t n_genomes, uint32_t *__restrict__ flags) {
+  const uint32_t g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (g >= n_genomes) return;
+  uint32_t n = cnt[g];
+  const uint32_t cap = meta[g].hit_cap;
+  if (flags) {
+    const bool over = n > cap;
+    if (over || n > SORT_LDS_MAX_KEYS) {
+      if (lane == 0) atomicOr(flags, over ? HG_STEP_OVERFLOW : HG_STEP_LARGE_SET), ndistinct[g] = HG_NHASH_PENDING;
+      return;
+    }
+  }
+  if (n > cap) n = cap;  // overflow is reported by the host from cnt[]
+  if (n > 64) return;
+  if (n <= 1) {
+    if (lane == 0) ndistinct[g] = n;
+    return;
+  }
+  sort_unique_wave(hits + meta[g].hit_off, n, lane, ndistinct + g);
 }
 
 // grid: SORT_WG genomes per workgroup.  The genomes whose raw count is in (skip_keys, lds_keys] -- what a launch of
@@ -811,7 +845,11 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(
 #pragma unroll 2
       for (uint32_t sidx = 0; sidx < 8; ++sidx) {
         const uint32_t i = sidx * 64 + lane, l = i >> 3, q = i & 7u;
-        if (l < pass_words) dst[i] = s_row[8 * l + (q ^ (l & 7u))];
+        if (l < pass_words) {  // (written once, read by nobody on this device soon: past the caches)
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          const uint4 v = s_row[8 * l + (q ^ (l & 7u))];
+          __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(dst + i));
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next pass writes the same slots)
       __builtin_amdgcn_wave_barrier();
@@ -837,7 +875,8 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(
       int16_t *dst = out + (size_t)w * 64;
       if (vec_ok) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 8; ++q)  // (NOT past the caches like the LDS pass above: a lane's eight 16-byte stores lie in ONE 128-byte line the
+                                     // L2 puts together -- written non-temporally they reach HBM as partial lines, 0.33 -> 1.68 ms at 33 hashes)
           reinterpret_cast<uint4 *>(dst)[q] = make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
       } else {
 #pragma unroll
@@ -955,6 +994,11 @@ hipError_t hg_launch_sort_unique(hipStream_t st, const hg_genome_meta *d_meta, u
   const size_t lds = sort_lds_bytes(keys, bucket_mul);
   hipError_t e = sort_lds_attr();
   if (e != hipSuccess) return e;
+  if (keys <= 64) {  // tiny sets: a wave per genome
+    hipLaunchKernelGGL(sort_unique_wave_kernel, dim3((n_genomes + 3) / 4), dim3(256), 0, st, d_meta, d_hits, d_cnt, d_ndistinct,
+                       n_genomes, d_flags);
+    return hipGetLastError();
+  }
   // genomes whose hit count exceeds the LDS budget are skipped here: the caller learns the counts and
   // runs hg_launch_sort_large / hg_launch_sort_inplace for them (or, with d_flags, reads the step's flag word)
   hipLaunchKernelGGL((sort_unique_kernel<true>), dim3(n_genomes), dim3(SORT_WG), lds, st, d_meta,

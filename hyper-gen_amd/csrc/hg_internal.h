@@ -24,6 +24,7 @@ struct hg_sketch_plan {
   uint32_t max_expect = 0;  // largest expected sampled count (k-mer starts / scaled) of a genome
   uint32_t max_hits = 0;    // largest raw hit count the plan's last synchronous run saw (0: unknown)
   size_t n_items = 0;
+  size_t n_groups = 0;      // workgroups of the k-mer launch: groups of consecutive work items (w_items holds the table behind the items)
 };
 struct hg_sketch_pending {
   bool active = false;
@@ -208,10 +209,16 @@ const char *hg_kmer_kernel_name(uint32_t ksize, bool canonical, bool packed);
 // Launch the hash + sample kernel over all work items.  d_cnt[g] is incremented once per
 // sampled k-mer (it may exceed hit_cap: only the first hit_cap hashes are stored).
 // packed: genome g is a hg_pack2 blob at d_seq + seq_off (n_bps = its bases), not ASCII.
+// d_group_first (n_groups + 1 entries, or nullptr): workgroup w takes the work items [d_group_first[w], d_group_first[w + 1])
+// -- the plan's groups of small genomes (k <= 32; the long-k kernel takes one item per workgroup whatever is passed).
 hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
                                  const uint32_t *d_item_genome, uint32_t n_items, uint32_t ksize,
                                  uint64_t threshold, uint64_t seed, bool canonical, uint32_t norm_mode,
-                                 uint64_t *d_hits, uint32_t *d_cnt, bool packed = false);
+                                 uint64_t *d_hits, uint32_t *d_cnt, bool packed = false, const uint32_t *d_group_first = nullptr,
+                                 uint32_t n_groups = 0);
+// starts per tile / tiles per work item of the k <= 32 kernel (0 for k > 32: no grouping there)
+uint32_t hg_kmer_tile_starts(uint32_t ksize);
+uint32_t hg_kmer_item_tiles(uint32_t ksize);
 // ASCII -> hg_pack2 blobs on the device (bit-identical to the host's hg_pack2): genome i of d_seq at seq_offs[i] with
 // lens[i] bases goes to d_blobs + blob_offs[i] (multiples of 16).  d_tab: 3 * n uint64 of device scratch for the tables.
 hipError_t hg_launch_pack2(hipStream_t st, const uint8_t *d_seq, const uint64_t *d_tab, uint32_t n, uint32_t blocks_max,

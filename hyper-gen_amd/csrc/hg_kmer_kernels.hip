@@ -436,20 +436,25 @@ template <int K, bool CANON, bool PACKED>
 __global__ __launch_bounds__(WG) void kmer_sample_shared(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
     const uint32_t *__restrict__ item_genome, uint64_t threshold, uint64_t seed, uint32_t u2t,
-    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt, uint32_t stage_cap) {
+    uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt, uint32_t stage_cap, const uint32_t *__restrict__ group_first) {
   using G = GeoS<K>;
   constexpr int M = G::M, DW = G::DW, S = G::S, ND = G::ND, NB = G::NB, NW = G::NW, N_R = G::N_R, WIN = G::WIN;
   typedef typename std::conditional<(WIN > 32), uint64_t, uint32_t>::type inv_t;  // validity bits of the code window
   constexpr inv_t MASKK = (inv_t)(((uint64_t)1 << K) - 1);
 
-  const uint32_t item = blockIdx.x, tid = threadIdx.x;
-  const uint32_t g = item_genome[item];
-  const hg_genome_meta gm = meta[g];
-  const uint64_t n_bps = gm.n_bps;
-  if (n_bps < (uint64_t)K) return;
-  const uint64_t n_starts = n_bps - K + 1;
-  const uint8_t *__restrict__ gseq = seq + gm.seq_off;
-  const uint64_t item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+  // A workgroup takes the work items [item_lo, item_hi) one after the other: ONE item of a genome that fills it (TILES
+  // tiles), or the items of several consecutive SMALL genomes, TILES tiles between them (the host's plan groups them:
+  // hg_sketch_plan.hip) -- a genome of a few kbp is one or two tiles, and a workgroup of its own paid the launch, the
+  // dependent loads of its records and the table set-up below for 6 us of hashing.  Everything that describes the current
+  // item lives in the variables below; the staging lambdas read them by reference.
+  const uint32_t tid = threadIdx.x;
+  const uint32_t item_lo = group_first ? group_first[blockIdx.x] : blockIdx.x;
+  const uint32_t item_hi = group_first ? group_first[blockIdx.x + 1] : blockIdx.x + 1;
+  uint32_t g = 0;
+  hg_genome_meta gm{};
+  uint64_t n_bps = 0, n_starts = 0, item_start = 0;
+  const uint8_t *__restrict__ gseq = seq;
+  uint32_t tile_no = 0;  // tiles this workgroup has done (parity of the "dirty" flags)
 
   __shared__ HitStage stage;
   __shared__ __attribute__((aligned(16))) uint32_t s_f[4 * S / 4];                 // forward phase images
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
   // the genome end are invalid whatever the blob's padding says.
   typedef uint32_t __attribute__((aligned(1))) u32u;
   typedef uint64_t __attribute__((aligned(1))) u64u;
-  const uint8_t *__restrict__ gmask = seq + gm.mask_off;
+  const uint8_t *__restrict__ gmask = seq;
   auto stage_unit_packed = [&](uint32_t u, uint64_t tile_start, uint32_t par, uint32_t &c0, uint32_t &c1, uint32_t &c2,
                                inv_t &invw) __attribute__((always_inline)) {
     const uint64_t P = tile_start + (uint64_t)u * M;  // a multiple of 4: whole code bytes
@@ -623,11 +628,29 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     }
   };
 
+  // (the next item's records are requested while this one is hashed: two dependent scalar loads otherwise in front of
+  // every small genome)
+  uint32_t g_next = item_genome[item_lo];
+  hg_genome_meta gm_next = meta[g_next];
 #pragma unroll 1
-  for (int tile = 0; tile < G::TILES; ++tile) {
+  for (uint32_t item = item_lo; item < item_hi; ++item) {
+  g = g_next;
+  gm = gm_next;
+  if (item + 1 < item_hi) {
+    g_next = item_genome[item + 1];
+    gm_next = meta[g_next];
+  }
+  n_bps = gm.n_bps;
+  if (n_bps < (uint64_t)K) continue;  // (uniform; such a genome has no work item anyway)
+  n_starts = n_bps - K + 1;
+  gseq = seq + gm.seq_off;
+  gmask = seq + gm.mask_off;
+  item_start = (uint64_t)(item - gm.item_first) * G::ITEM;
+#pragma unroll 1
+  for (int tile = 0; tile < G::TILES; ++tile, ++tile_no) {
     const uint64_t tile_start = item_start + (uint64_t)tile * G::TILE;
     if (tile_start >= n_starts) break;  // uniform
-    const uint32_t par = (uint32_t)tile & 1u;
+    const uint32_t par = tile_no & 1u;
     uint32_t pc0 = 0, pc1 = 0, pc2 = 0;
     inv_t pinv = 0;
     if constexpr (PACKED) stage_unit_packed(tid, tile_start, par, pc0, pc1, pc2, pinv);
@@ -827,12 +850,18 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
         if (valid && hashing && h < threshold) stage_hit(stage, stage_cap, h, gm, g, hits, cnt);
       });
     };
-    if constexpr (ASM_BODY) {
-      if (!tile_dirty) kmers_asm(std::false_type{});
-      else kmers_asm(std::true_type{});
-    } else {
-      if (!tile_dirty) run_kmers(std::false_type{});
-      else run_kmers(std::true_type{});
+    // A wave whose 64 x M starts all lie behind the genome's last k-mer hashes nothing (wave-uniform): a 2 kbp genome fills
+    // three of its one tile's four waves, the last tile of a 10 kbp genome two -- the idle wave only meets the others at the
+    // barriers, and its issue slots go to the other workgroups of the CU (2 kbp genomes: 0.27 -> 0.4 of the per-base rate).
+    const bool wave_live = tile_start + (uint64_t)(tid & ~63u) * M < n_starts;
+    if (wave_live) {
+      if constexpr (ASM_BODY) {
+        if (!tile_dirty) kmers_asm(std::false_type{});
+        else kmers_asm(std::true_type{});
+      } else {
+        if (!tile_dirty) run_kmers(std::false_type{});
+        else run_kmers(std::true_type{});
+      }
     }
     if (!(HG_KS_EXP & 1)) __syncthreads();  // every read of the images is done: the next tile may overwrite them
     if (tid == 0) s_dirty[par] = 0u;  // (raised again in two tiles' time at the earliest, behind the next tile's barriers)
@@ -843,7 +872,11 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
       flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
     }
   }
-  flush_hits(stage, stage_cap, gm, g, hits, cnt);
+  // the item's hits to its genome's region (the list is empty again for the next item of the group: its first tile's
+  // barrier lies between this call's reads of the list and the next writes)
+  if (item + 1 < item_hi) flush_hits<true>(stage, stage_cap, gm, g, hits, cnt);
+  else flush_hits(stage, stage_cap, gm, g, hits, cnt);
+  }
 }
 
 // 2-bit code of one base (long-k kernel)
@@ -1052,11 +1085,22 @@ uint32_t hg_kmer_item_starts(uint32_t k) {
   return k >= 22 ? (uint32_t)GeoS<32>::ITEM : (uint32_t)GeoS<21>::ITEM;  // (the same within each code-window class)
 }
 
+uint32_t hg_kmer_tile_starts(uint32_t k) {
+  if (k > 32) return 0;  // (kmer_sample_long takes one item per workgroup)
+  return k >= 22 ? (uint32_t)GeoS<32>::TILE : (uint32_t)GeoS<21>::TILE;
+}
+// tiles a workgroup takes at most when the plan groups the work items of small genomes: three full items' worth (27 genomes of
+// up to 3 kbp, 6 of 10 kbp; an item that fills its TILES tiles alone still has a workgroup of its own)
+uint32_t hg_kmer_item_tiles(uint32_t k) { return k > 32 ? 0u : 3u * (uint32_t)GeoS<21>::TILES; }
+
 hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_genome_meta *d_meta,
                                  const uint32_t *d_item_genome, uint32_t n_items, uint32_t ksize,
                                  uint64_t threshold, uint64_t seed, bool canonical, uint32_t norm_mode,
-                                 uint64_t *d_hits, uint32_t *d_cnt, bool packed) {
+                                 uint64_t *d_hits, uint32_t *d_cnt, bool packed, const uint32_t *d_group_first,
+                                 uint32_t n_groups) {
   if (n_items == 0) return hipSuccess;
+  if (ksize > 32 || n_groups == 0) d_group_first = nullptr;
+  const uint32_t n_wg = d_group_first ? n_groups : n_items;
   const uint32_t u2t = (norm_mode == HG_NORM_U2T && !packed) ? 1u : 0u;  // (a blob was normalised when it was packed)
   // entries of a work item's LDS hit list: twice what one tile is expected to sample (+ slack), 256 .. 4 096
   auto stage_entries = [&](uint32_t tile_starts) {
@@ -1067,8 +1111,8 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
   };
   const uint32_t cap_s = stage_entries((uint32_t)GeoS<21>::TILE), cap_l = stage_entries(LONG_TILE);
 #define HG_K_LAUNCH(KK, CN, PK)                                                                            \
-  hipLaunchKernelGGL((kmer_sample_shared<KK, CN, PK>), dim3(n_items), dim3(WG), cap_s * sizeof(uint64_t), st, d_seq, d_meta, \
-                     d_item_genome, threshold, seed, u2t, d_hits, d_cnt, cap_s)
+  hipLaunchKernelGGL((kmer_sample_shared<KK, CN, PK>), dim3(n_wg), dim3(WG), cap_s * sizeof(uint64_t), st, d_seq, d_meta, \
+                     d_item_genome, threshold, seed, u2t, d_hits, d_cnt, cap_s, d_group_first)
 #define HG_K_CASE(KK)                                                                                     \
   case KK:                                                                                                \
     if (canonical && packed) HG_K_LAUNCH(KK, true, true);                                                 \

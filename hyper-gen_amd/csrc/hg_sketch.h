@@ -14,6 +14,8 @@
 struct hg_batch_tables {
   std::vector<hg_genome_meta> meta;   // (a plan taken from the ctx's cache fills hit_cap / hit_off only)
   std::vector<uint32_t> item_genome;  // work item -> genome (empty for a cached plan)
+  std::vector<uint32_t> group_first;  // workgroup -> its first work item, n_groups + 1 entries (empty for a cached plan / k > 32)
+  size_t n_groups = 0;
   uint64_t total_slots = 0;
   uint32_t max_cap = 0, max_expect = 0;
   size_t n_items = 0;
@@ -22,6 +24,11 @@ struct hg_batch_tables {
 };
 
 hg_status hg_check_sketch_params(hg_ctx *c, const hg_sketch_params *p);
+// where the group table lies in w_items: behind the n_items item words, 16-byte aligned
+inline size_t hg_plan_group_offset(size_t n_items) { return (n_items + 3) & ~(size_t)3; }
+inline const uint32_t *hg_plan_group_table(const hg_ctx *c, size_t n_items, size_t n_groups) {
+  return n_groups ? static_cast<const uint32_t *>(c->w_items.p) + hg_plan_group_offset(n_items) : nullptr;
+}
 
 // want_caps: optional per-genome minimum capacities (retry after overflow)
 hg_status hg_plan_build(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize, uint64_t scaled,
@@ -29,7 +36,8 @@ hg_status hg_plan_build(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens
 // the ctx's cached plan has this geometry (its tables are on the device)
 bool hg_plan_matches(const hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, const uint64_t *mask_offs, size_t n,
                      uint32_t ksize, uint64_t scaled, bool packed);
-void hg_plan_tables_from_cache(const hg_sketch_plan &pl, size_t n, hg_batch_tables &t);
+// with_meta = false: the totals only (the sync-free step reads no per-genome record on the host: 400 000 genomes are 16 MB of them)
+void hg_plan_tables_from_cache(const hg_sketch_plan &pl, size_t n, hg_batch_tables &t, bool with_meta = true);
 // Sends a freshly built plan's tables to w_gmeta / w_items through the page-locked plan staging (stream-ordered,
 // returns at once) and makes it the ctx's cached plan.
 hg_status hg_plan_upload(hg_ctx *c, const hg_batch_tables &t, const uint64_t *offsets, const uint64_t *lens,

@@ -28,6 +28,14 @@ hg_status hg_check_sketch_params(hg_ctx *c, const hg_sketch_params *p) {
 hg_status hg_plan_build(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize, uint64_t scaled,
                         const std::vector<uint32_t> *want_caps, hg_batch_tables &t, const uint64_t *mask_offs) {
   const uint64_t item_starts = hg_kmer_item_starts(ksize);
+  // groups of work items (one workgroup each): consecutive items of SMALL genomes are put together while the group stays
+  // within hg_kmer_item_tiles tiles; an item that fills a work item on its own (a piece of a large genome) stays alone, so
+  // that the launch of large genomes keeps its granularity
+  const uint32_t tile_starts = hg_kmer_tile_starts(ksize), item_tiles = hg_kmer_item_tiles(ksize);
+  const uint32_t full_item_tiles = tile_starts ? (uint32_t)((item_starts + tile_starts - 1) / tile_starts) : 0;
+  bool group_open = false;  // the last group may take more items
+  t.group_first.clear();
+  uint32_t group_tiles = 0;
   t.meta.resize(n);
   t.item_genome.clear();
   uint64_t slot = 0, max_expect = 0;
@@ -53,8 +61,23 @@ hg_status hg_plan_build(hg_ctx *c, const uint64_t *offsets, const uint64_t *lens
     if (t.item_genome.size() + n_items > 0x7FFFFFFFull)
       return hg_fail(c, HG_ERR_UNSUPPORTED, "batch too large for one launch; split it");
     m.item_first = (uint32_t)t.item_genome.size();
+    if (tile_starts) {
+      for (uint64_t it = 0; it < n_items; ++it) {
+        const uint64_t starts = std::min<uint64_t>(item_starts, n_starts - it * item_starts);
+        const uint32_t tiles = (uint32_t)((starts + tile_starts - 1) / tile_starts);
+        const bool alone = tiles >= full_item_tiles;
+        if (!group_open || alone || group_tiles + tiles > item_tiles) {
+          t.group_first.push_back((uint32_t)(t.item_genome.size() + it));
+          group_tiles = 0;
+        }
+        group_tiles += tiles;
+        group_open = !alone;
+      }
+    }
     t.item_genome.insert(t.item_genome.end(), (size_t)n_items, (uint32_t)g);
   }
+  t.n_groups = t.group_first.size();
+  if (t.n_groups) t.group_first.push_back((uint32_t)t.item_genome.size());
   t.total_slots = slot;
   t.max_cap = max_cap;
   t.max_expect = (uint32_t)std::min<uint64_t>(max_expect, 0xFFFFFFF0ull);
@@ -71,9 +94,15 @@ bool hg_plan_matches(const hg_ctx *c, const uint64_t *offsets, const uint64_t *l
   return pl->masks.empty();
 }
 
-void hg_plan_tables_from_cache(const hg_sketch_plan &pl, size_t n, hg_batch_tables &t) {
+void hg_plan_tables_from_cache(const hg_sketch_plan &pl, size_t n, hg_batch_tables &t, bool with_meta) {
   t.total_slots = pl.total_slots, t.max_cap = pl.max_cap, t.max_expect = pl.max_expect, t.n_items = pl.n_items;
+  t.n_groups = pl.n_groups;
   t.item_genome.clear();
+  t.group_first.clear();
+  if (!with_meta) {
+    t.meta.clear();
+    return;
+  }
   t.meta.resize(n);
   uint64_t slot = 0;
   for (size_t g = 0; g < n; ++g) {  // only what callers read back: capacities and hit offsets
@@ -89,9 +118,10 @@ hg_status hg_plan_upload(hg_ctx *c, const hg_batch_tables &t, const uint64_t *of
   hg_status s;
   const size_t n_items = t.item_genome.size();
   if ((s = hg_ensure(c, c->w_gmeta, n * sizeof(hg_genome_meta) + 16)) != HG_OK) return s;
-  if ((s = hg_ensure(c, c->w_items, n_items * sizeof(uint32_t) + 16)) != HG_OK) return s;
+  const size_t items_words = t.n_groups ? hg_plan_group_offset(n_items) + t.n_groups + 1 : n_items;  // items, then the group table
+  if ((s = hg_ensure(c, c->w_items, items_words * sizeof(uint32_t) + 16)) != HG_OK) return s;
   const size_t pin_meta = (n * sizeof(hg_genome_meta) + 63) & ~(size_t)63;
-  const size_t need = pin_meta + n_items * sizeof(uint32_t) + 64;
+  const size_t need = pin_meta + items_words * sizeof(uint32_t) + 64;
   // the staging area may still feed the previous plan's upload (a sync-free step returns with it queued): that upload
   // lies in front of that step's kernels, so this waits for the step BEFORE the previous one at most
   if (c->plan_upload_pending) {
@@ -112,7 +142,11 @@ hg_status hg_plan_upload(hg_ctx *c, const hg_batch_tables &t, const uint64_t *of
   HG_HIP(c, hipMemcpyAsync(c->w_gmeta.p, pin, n * sizeof(hg_genome_meta), hipMemcpyHostToDevice, c->stream));
   if (n_items) {
     std::memcpy(pin + pin_meta, t.item_genome.data(), n_items * sizeof(uint32_t));
-    HG_HIP(c, hipMemcpyAsync(c->w_items.p, pin + pin_meta, n_items * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (t.n_groups) {
+      std::memset(pin + pin_meta + n_items * sizeof(uint32_t), 0, (hg_plan_group_offset(n_items) - n_items) * sizeof(uint32_t));
+      std::memcpy(pin + pin_meta + hg_plan_group_offset(n_items) * sizeof(uint32_t), t.group_first.data(), (t.n_groups + 1) * sizeof(uint32_t));
+    }
+    HG_HIP(c, hipMemcpyAsync(c->w_items.p, pin + pin_meta, items_words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   }
   HG_HIP(c, hipEventRecord(c->plan_uploaded, c->stream));
   c->plan_upload_pending = true;
@@ -124,6 +158,7 @@ hg_status hg_plan_upload(hg_ctx *c, const hg_batch_tables &t, const uint64_t *of
   for (size_t g = 0; g < n; ++g) pl->caps[g] = t.meta[g].hit_cap;
   pl->ksize = ksize, pl->scaled = scaled, pl->packed = packed;
   pl->total_slots = t.total_slots, pl->max_cap = t.max_cap, pl->max_expect = t.max_expect, pl->n_items = n_items;
+  pl->n_groups = t.n_groups;
   c->plan = std::move(pl);
   return HG_OK;
 }

@@ -123,7 +123,8 @@ hg_status hg_sample_batch_sync(hg_ctx *c, const uint8_t *d_seq, const uint64_t *
       hg_timed tm(c, HG_T_KMER);
       c->last_kernel[HG_T_KMER] = hg_kmer_kernel_name(ksize, canonical, packed);
       HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)n_items, ksize, threshold,
-                                      seed, canonical, norm_mode, d_hits, d_cnt, packed));
+                                      seed, canonical, norm_mode, d_hits, d_cnt, packed,
+                                      hg_plan_group_table(c, n_items, pl.n_groups), (uint32_t)pl.n_groups));
     }
     uint32_t sort_cap = pl.max_cap;
     {

@@ -30,7 +30,10 @@ namespace {
 // expected count, + 12.5 % (seven standard deviations at 3 333)
 uint32_t first_sort_cap(const hg_sketch_plan &pl) {
   const uint64_t base = pl.max_hits ? pl.max_hits : pl.max_expect;
-  return (uint32_t)std::min<uint64_t>(pl.max_cap, base + base / 8 + 64);
+  // (a batch of genomes that sample at most ~35 k-mers each -- up to 50 kbp at scaled = 1 500 -- stays within the 64 keys one
+  // WAVE sorts: sort_unique_wave_kernel, four genomes per workgroup)
+  const uint64_t margin = base + base / 8 + 24 <= 64 ? 24 : 64;
+  return (uint32_t)std::min<uint64_t>(pl.max_cap, base + base / 8 + margin);
 }
 
 // the batch can go without the host: every genome is EXPECTED to fit the one-workgroup sort (those that do not after all
@@ -98,7 +101,7 @@ hg_status hg_sketch_step(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offset
   hg_status s;
   hg_batch_tables t;
   const bool reuse = hg_plan_matches(c, offsets, lens, mask_offs, n, p->ksize, p->scaled, packed);
-  if (reuse) hg_plan_tables_from_cache(*c->plan, n, t);
+  if (reuse) hg_plan_tables_from_cache(*c->plan, n, t, false);
   else if ((s = hg_plan_build(c, offsets, lens, n, p->ksize, p->scaled, nullptr, t, mask_offs)) != HG_OK) return s;
   if (!step_can_be_sync_free(c, t, n)) {
     if ((s = hg_sketch_resolve(c)) != HG_OK) return s;
@@ -129,7 +132,8 @@ hg_status hg_sketch_step(hg_ctx *c, const uint8_t *d_seq, const uint64_t *offset
     hg_timed tm(c, HG_T_KMER);
     c->last_kernel[HG_T_KMER] = hg_kmer_kernel_name(p->ksize, p->canonical != 0, packed);
     HG_HIP(c, hg_launch_kmer_sample(c->stream, d_seq, d_meta, d_items, (uint32_t)t.n_items, p->ksize, threshold, p->seed,
-                                    p->canonical != 0, p->norm_mode, d_hits, d_cnt, packed));
+                                    p->canonical != 0, p->norm_mode, d_hits, d_cnt, packed,
+                                    hg_plan_group_table(c, t.n_items, t.n_groups), (uint32_t)t.n_groups));
   }
   {
     // The LDS sort sized by the genomes' CAPACITIES (twice the expected count + 1 024) takes 64 KiB for a 5 Mbp genome: two

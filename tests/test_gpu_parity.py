@@ -1145,6 +1145,7 @@ def test_comparisons_beyond_the_hit_counter_run_as_row_blocks(hg, orc, symmetric
                 continue  # (600+ launches: once is enough)
             c.set_debug("pair_limit", str(limit))
             out.zero_()
+            torch.cuda.synchronize()  # (torch's stream, not the ctx's own: the fill must not overtake the first block's hits)
             got_n, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, qv.data_ptr(), qn.data_ptr(), Q, 4096, 21, symmetric, 80.0, out.data_ptr(), cap)
             assert st == 0 and got_n == want_n, limit
             assert np.array_equal(canon(out, got_n), want), limit
@@ -1152,6 +1153,7 @@ def test_comparisons_beyond_the_hit_counter_run_as_row_blocks(hg, orc, symmetric
         c.set_debug("pair_limit", str(n * Q // 3 + 17))
         small = want_n // 2
         out.zero_()
+        torch.cuda.synchronize()
         got_n, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, qv.data_ptr(), qn.data_ptr(), Q, 4096, 21, symmetric, 80.0, out.data_ptr(), small)
         assert st == hg.ERR_CAPACITY and got_n == want_n
         part = canon(out, small)
@@ -1166,6 +1168,7 @@ def test_comparisons_beyond_the_hit_counter_run_as_row_blocks(hg, orc, symmetric
         hw = canon(out, hn)
         c.set_debug("pair_limit", str(n * n // 4 + 5))
         out.zero_()
+        torch.cuda.synchronize()
         hn2, st = c.hamming_search_dev(bits.data_ptr(), n, bits.data_ptr(), n, 4096, 1200, out.data_ptr(), cap)
         assert st == 0 and hn2 == hn and np.array_equal(canon(out, hn2), hw)
         c.set_debug("pair_limit", "0")
