@@ -163,7 +163,7 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F 
 
 // ---- geometry ---------------------------------------------------------------------------
 constexpr int WG = 256;                              // lanes per workgroup
-constexpr int GEN_STARTS = 32;                       // long-k kernel: starts per lane
+constexpr int GEN_STARTS = 48;                       // long-k kernel: starts per lane and work item (eight tiles of 1 536)
 constexpr int GEN_ITEM = WG * GEN_STARTS;            // and per work item
 
 // One hit straight to the genome's list.  The lanes of a wave that arrive here together (a divergent branch: g is
@@ -894,20 +894,25 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
 // =========================================================================================
 // long-k kernel: 33 <= k <= 255 (the CPU path's t1ha2 long-input loop; src/cuda_kernel.cu has none)
 // =========================================================================================
-// Run-time k.  A workgroup stages 1 024 k-mer starts' worth of sequence (<= 1 278 bytes) into LDS three
-// ways: the normalised forward strand (upper-case ASCII, 0 for anything that is not a base), its reverse
-// complement (so that the reverse strand of a k-mer is an ascending byte range too), and a running count of
-// invalid bytes (a window is valid iff the count does not change across it).  Each lane then takes four
-// starts: strand choice by the first differing dword of the two byte strings (big-endian compare = the
-// reference's lexicographic compare), hash words cut out of LDS with a run-time v_alignbyte funnel.
-constexpr uint32_t LONG_TILE = 1024;                 // k-mer starts per tile
-constexpr uint32_t LONG_BYTES = 1536;                // staged bytes per tile (>= LONG_TILE + 254), 6 per lane
-constexpr uint32_t LONG_DW = LONG_BYTES / 4 + 4;     // + zero slack for the funnel's second dword
+// A workgroup stages 2 048 bytes of sequence per tile -- 1 536 k-mer starts and the up to 254 bytes behind the last one --
+// into LDS as the normalised forward strand (upper-case ASCII, 0 for anything that is not a base) and its reverse
+// complement (so that the reverse strand of a k-mer is an ascending byte range too), each in all four byte phases (image
+// phi holds bytes [4 i + phi, 4 i + phi + 4) at dword i: every dword of a k-mer that starts at ANY byte is one aligned read
+// of the image of its start's phase -- the pattern of kmer_sample_shared), plus one validity bit per byte.  A lane stages
+// eight bytes: it loads them with the dword in front and the dword behind (16 bytes), classifies all four dwords, and
+// writes its two dwords of all eight images itself -- the forward phases need the NEXT dword, the reverse-complement phases
+// the PREVIOUS one -- so a tile has two barriers and no pass over LDS.  (Until round 6: 1 024 starts per tile, bytes stored
+// one by one, a zero fill, an invalid-byte prefix scan and a second pass for phases 1..3 -- five barriers, and half of the
+// kernel's 25 ms for 1 000 x 5 Mbp at k = 33 was spent before any hashing.)
+// Each lane then takes six starts.  KC = 0: run-time k (65..255).  KC = 33..64: k is a compile-time constant -- the validity
+// test is two funnel shifts on the bit image, the strand choice one 64-bit compare of the first eight bases (the byte
+// strings differ there for all but one k-mer in 65 536), and t1ha2 is straight-line code: one round of its 32-byte loop
+// (two for k = 64) and a tail of k - 32 bytes.
+constexpr uint32_t LONG_TILE = 1536;                 // k-mer starts per tile (6 per lane)
+constexpr uint32_t LONG_BYTES = 2048;                // staged bytes per tile (>= LONG_TILE + 254), 8 per lane
+constexpr uint32_t LONG_DW = LONG_BYTES / 4 + 4;     // + zero slack behind the last dword
+static_assert(GEN_ITEM % LONG_TILE == 0 && LONG_TILE % 8 == 0 && LONG_BYTES == 8 * WG && LONG_TILE + 254 <= LONG_BYTES, "long-k tile geometry");
 
-// A strand of the tile in LDS in all four byte phases (image phi holds bytes [4 i + phi, 4 i + phi + 4) at dword i, the
-// images LONG_DW dwords apart): every dword of a k-mer that starts at ANY byte is one aligned read of the image of its
-// start's phase -- the pattern of kmer_sample_shared.  (With one image the k-mer's dwords were cut out of two neighbours
-// each: twice the LDS reads and a v_alignbyte per dword, ~50 reads per k = 33 k-mer.)
 struct LdsStrand {
   const uint32_t *w32;  // the four phase images
   uint32_t byte0;       // first byte of the k-mer in the strand
@@ -922,13 +927,17 @@ struct LdsStrand {
   }
 };
 
-__device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len, uint64_t seed) {
-  uint64_t a = seed, b = (uint64_t)len;
-  uint32_t off = 0;
-  if (len > 32) {  // published t1ha2: lanes c,d, 32 bytes per round, squash
+// t1ha2_atonce of `len` > 32 bytes (published t1ha2: lanes c, d, 32 bytes per round, squash, then the tail switch of
+// src/cuda_kernel.cu:207-245).  LEN > 0: len == LEN is a compile-time constant and everything below unrolls.
+template <uint32_t LEN>
+__device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len_rt, uint64_t seed) {
+  const uint32_t len0 = LEN ? LEN : len_rt;
+  uint64_t a = seed, b = (uint64_t)len0;
+  uint32_t off = 0, len = len0;
+  {
     uint64_t c = rot64((uint64_t)len, 23) + ~seed;
     uint64_t d = ~(uint64_t)len + rot64(seed, 19);
-    do {
+    auto round = [&]() __attribute__((always_inline)) {
       const uint64_t w0 = sb.word(off, 8), w1 = sb.word(off + 8, 8), w2 = sb.word(off + 16, 8), w3 = sb.word(off + 24, 8);
       off += 32;
       const uint64_t d02 = w0 + rot64(w2 + d, 56);
@@ -937,7 +946,15 @@ __device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len
       c ^= a + rot64(w0, 57);
       b ^= P6 * (c13 + w2);
       a ^= P5 * (d02 + w3);
-    } while (off + 31 < len);  // data < detent  <=>  off < len - 31
+    };
+    if constexpr (LEN != 0) {
+      static_assert(LEN > 32 && LEN <= 64, "compile-time lengths: one or two rounds");
+      round();
+      if constexpr (LEN == 64) round();  // (data < detent  <=>  off + 31 < len)
+    } else {
+      do round();
+      while (off + 31 < len);
+    }
     a ^= P6 * (c + rot64(d, 23));
     b ^= P5 * (rot64(c, 19) + d);
     len &= 31;
@@ -950,15 +967,39 @@ __device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len
   return final64(a, b);
 }
 
-template <bool PACKED>
+// four bases as ASCII -> {normalised forward ASCII, complement ASCII, invalid bytes as 0xFF}; bytes that are not a base
+// (after the optional u/U -> T) are 0 in both strands.  The classification of kmer_sample_shared's stage_unit.
+__device__ __forceinline__ void long_classify_ascii(uint32_t x, uint32_t u2t, uint32_t &fa, uint32_t &ca, uint32_t &bad) {
+  if (u2t) {
+    const uint32_t e = (x & 0xDFDFDFDFu) ^ 0x55555555u;
+    const uint32_t nz = ((e & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | e;  // bit 7 set <=> byte != 'U'
+    x ^= (~nz & 0x80808080u) >> 7;                               // 'U' ^ 'T' == 1
+  }
+  const uint32_t tt = x ^ (x >> 1);
+  const uint32_t cd = (tt >> 1) & 0x03030303u;  // A,C,G,T -> 0,1,2,3 per byte
+  const uint32_t f = __builtin_amdgcn_perm(0u, 0x54474341u, cd), c = __builtin_amdgcn_perm(0u, 0x41434754u, cd);
+  const uint32_t dif = (x & 0xDFDFDFDFu) ^ f;
+  const uint32_t z = (((dif & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | dif) & 0x80808080u;  // bit 7 of a byte set <=> not a base
+  bad = (z >> 7) * 0xFFu;
+  fa = f & ~bad, ca = c & ~bad;
+}
+// four bases as 2-bit codes (low byte of `codes`) + their four not-a-base bits
+__device__ __forceinline__ void long_classify_codes(uint32_t codes, uint32_t inv4, uint32_t &fa, uint32_t &ca, uint32_t &bad) {
+  const uint32_t cd = (codes & 3u) | ((codes & 0xCu) << 6) | ((codes & 0x30u) << 12) | ((codes & 0xC0u) << 18);
+  bad = (((inv4 & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+  fa = __builtin_amdgcn_perm(0u, 0x54474341u, cd) & ~bad;
+  ca = __builtin_amdgcn_perm(0u, 0x41434754u, cd) & ~bad;
+}
+
+template <int KC, bool PACKED>  // (PACKED last: a profiler's name of a packed-input kernel ends in "true>" for both kernels)
 __global__ __launch_bounds__(WG) void kmer_sample_long(
     const uint8_t *__restrict__ seq, const hg_genome_meta *__restrict__ meta,
-    const uint32_t *__restrict__ item_genome, uint32_t ksize, uint64_t threshold, uint64_t seed,
+    const uint32_t *__restrict__ item_genome, uint32_t ksize_rt, uint64_t threshold, uint64_t seed,
     uint32_t canonical, uint32_t u2t, uint64_t *__restrict__ hits, uint32_t *__restrict__ cnt, uint32_t stage_cap) {
   __shared__ HitStage stage;
   __shared__ uint32_t s_f[4 * LONG_DW], s_rc[4 * LONG_DW];  // forward / reverse-complement strand, four byte phases each
-  __shared__ uint16_t s_bad[LONG_BYTES + 8];  // s_bad[i] = invalid bytes among the first i staged bytes
-  __shared__ uint16_t s_scan[WG];
+  __shared__ uint32_t s_inv[LONG_BYTES / 32 + 12];          // bit i set <=> staged byte i is not a base (zero slack behind)
+  const uint32_t ksize = KC ? (uint32_t)KC : ksize_rt;
   const uint32_t item = blockIdx.x, tid = threadIdx.x;
   const uint32_t g = item_genome[item];
   const hg_genome_meta gm = meta[g];
@@ -969,102 +1010,100 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
   const uint8_t *__restrict__ gmask = seq + gm.mask_off;  // PACKED: the genome's not-a-base bitmap
   const uint64_t item_start = (uint64_t)(item - gm.item_first) * GEN_ITEM;
   if (tid == 0) stage.n = 0;
-  const uint32_t n_stage = LONG_TILE + ksize - 1;  // bytes a full tile needs
-  uint8_t *fb = reinterpret_cast<uint8_t *>(s_f), *rb = reinterpret_cast<uint8_t *>(s_rc);
+  if (tid < 4) s_f[tid * LONG_DW + LONG_BYTES / 4] = 0u, s_rc[tid * LONG_DW + LONG_BYTES / 4] = 0u;  // (read by a k-mer's last, masked dword)
+  if (tid < 12) s_inv[LONG_BYTES / 32 + tid] = 0u;
+  typedef uint32_t __attribute__((aligned(1))) u32u_t;
 
   for (uint64_t tile0 = item_start; tile0 < item_start + GEN_ITEM && tile0 < n_starts; tile0 += LONG_TILE) {
     __syncthreads();  // previous tile's readers are done
     if (dense_sampling(threshold)) flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
-    for (uint32_t i = tid; i < LONG_DW; i += WG) s_f[i] = 0u, s_rc[i] = 0u;
-    __syncthreads();
-    // ---- stage: 6 consecutive bytes per lane
-    uint32_t nbad = 0;
-    uint8_t fbyte[6];
-    // the lane's six bases with two loads (packed: 16 codes and 16 validity bits from the byte its first base lies in) or
-    // one (ASCII: 8 bytes) instead of twelve / six byte loads; the caller leaves 32 readable bytes behind every genome
-    typedef uint32_t __attribute__((aligned(1))) u32u_t;
-    typedef uint16_t __attribute__((aligned(1))) u16u_t;
-    typedef uint64_t __attribute__((aligned(1))) u64u_t;
-    const uint64_t pos0 = tile0 + (uint64_t)tid * 6;
-    uint64_t raw = 0;
-    uint32_t cw = 0, mw = 0;
-    if (tid * 6 < n_stage && pos0 < n_bps) {
-      if constexpr (PACKED) {
-        cw = *reinterpret_cast<const u32u_t *>(gseq + (pos0 >> 2)) >> (2 * (uint32_t)(pos0 & 3));
-        mw = (uint32_t)*reinterpret_cast<const u16u_t *>(gmask + (pos0 >> 3)) >> (uint32_t)(pos0 & 7);
-      } else {
-        raw = *reinterpret_cast<const u64u_t *>(gseq + pos0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const uint32_t i = tid * 6 + j;
-      const uint64_t pos = tile0 + i;
-      uint32_t code = 4;
-      if (i < n_stage && pos < n_bps) {
-        if constexpr (PACKED) code = ((mw >> j) & 1u) ? 4u : (cw >> (2 * j)) & 3u;
-        else code = base_code((uint8_t)(raw >> (8 * j)), u2t);
-      }
-      fbyte[j] = code < 4 ? (uint8_t)(0x54474341u >> (8 * code)) : (uint8_t)0;  // "ACGT"
-      nbad += code < 4 ? 0u : 1u;
-      if (i < n_stage) {
-        fb[i] = fbyte[j];
-        rb[n_stage - 1 - i] = code < 4 ? (uint8_t)(0x41434754u >> (8 * code)) : (uint8_t)0;  // "TGCA"
-      }
-    }
-    // exclusive scan of the per-lane invalid counts: inside the wave by shuffles, across the four waves through LDS (two
-    // barriers; the Hillis-Steele network over 256 LDS entries it replaces took sixteen per tile)
-    uint32_t incl = nbad;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o);
-      if ((tid & 63u) >= (uint32_t)o) incl += up;
-    }
-    if ((tid & 63u) == 63u) s_scan[tid >> 6] = (uint16_t)incl;
-    __syncthreads();
+    // ---- stage: the lane's eight bytes [pos0, pos0 + 8) with the four bytes in front of and behind them
     {
-      uint32_t before = 0;
+      const uint64_t pos0 = tile0 + (uint64_t)tid * 8;  // a multiple of 8
+      uint32_t fa[4], ca[4], bad[4];                     // dwords at pos0 - 4, pos0, pos0 + 4, pos0 + 8
 #pragma unroll
-      for (uint32_t w = 0; w < WG / 64; ++w) before += w < (tid >> 6) ? (uint32_t)s_scan[w] : 0u;
-      uint32_t run = before + incl - nbad;  // invalid bytes before this lane's first byte
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        s_bad[tid * 6 + j] = (uint16_t)run;
-        run += fbyte[j] ? 0u : 1u;
+      for (int t = 0; t < 4; ++t) {
+        const int64_t q = (int64_t)pos0 + 4 * t - 4;    // first base of this dword
+        fa[t] = ca[t] = 0u, bad[t] = ~0u;
+        if (q >= 0 && (uint64_t)q < n_bps) {             // (the caller leaves 32 readable bytes behind every genome)
+          if constexpr (PACKED) {
+            const uint32_t codes = gseq[(uint64_t)q >> 2];  // q is a multiple of 4: one code byte
+            const uint32_t inv4 = (uint32_t)gmask[(uint64_t)q >> 3] >> ((uint32_t)q & 4u);
+            long_classify_codes(codes, inv4, fa[t], ca[t], bad[t]);
+          } else {
+            long_classify_ascii(*reinterpret_cast<const u32u_t *>(gseq + q), u2t, fa[t], ca[t], bad[t]);
+          }
+          const uint64_t left = n_bps - (uint64_t)q;     // bases of the genome from q on: what lies behind them is not sequence
+          if (left < 4) {
+            const uint32_t keep = (1u << (8 * (uint32_t)left)) - 1u;
+            fa[t] &= keep, ca[t] &= keep, bad[t] |= ~keep;
+          }
+        }
       }
-      if (tid == WG - 1) s_bad[LONG_BYTES] = (uint16_t)run;
+      // forward images: dwords 2 tid and 2 tid + 1 of every phase
+#pragma unroll
+      for (uint32_t ph = 0; ph < 4; ++ph) {
+        s_f[ph * LONG_DW + 2 * tid] = ph ? __builtin_amdgcn_alignbyte(fa[2], fa[1], ph) : fa[1];
+        s_f[ph * LONG_DW + 2 * tid + 1] = ph ? __builtin_amdgcn_alignbyte(fa[3], fa[2], ph) : fa[2];
+      }
+      // reverse complement: byte LONG_BYTES - 1 - i holds the complement of forward byte i, so forward dword f is dword
+      // LONG_BYTES / 4 - 1 - f byte-reversed, and its successor in the image is the forward dword IN FRONT of it
+      const uint32_t r0 = __builtin_bswap32(ca[0]), r1 = __builtin_bswap32(ca[1]), r2 = __builtin_bswap32(ca[2]);
+      const uint32_t j1 = LONG_BYTES / 4 - 1 - 2 * tid;  // image dword of forward dword 2 tid (j1 - 1: of 2 tid + 1)
+#pragma unroll
+      for (uint32_t ph = 0; ph < 4; ++ph) {
+        s_rc[ph * LONG_DW + j1] = ph ? __builtin_amdgcn_alignbyte(r0, r1, ph) : r1;
+        s_rc[ph * LONG_DW + j1 - 1] = ph ? __builtin_amdgcn_alignbyte(r1, r2, ph) : r2;
+      }
+      // validity bits of the lane's eight bytes: byte tid of the bit image
+      const uint32_t b8 = ((((bad[1] & 0x01010101u) * 0x01020408u) >> 24) & 15u) | (((((bad[2] & 0x01010101u) * 0x01020408u) >> 24) & 15u) << 4);
+      reinterpret_cast<uint8_t *>(s_inv)[tid] = (uint8_t)b8;
     }
     __syncthreads();
-    // phases 1..3 of both strands from phase 0 (the bytes as staged; zero behind them)
-    for (uint32_t i = tid; i < LONG_DW - 1; i += WG) {
-      const uint32_t f0 = s_f[i], f1 = s_f[i + 1], r0 = s_rc[i], r1 = s_rc[i + 1];
-#pragma unroll
-      for (uint32_t ph = 1; ph < 4; ++ph) {
-        s_f[ph * LONG_DW + i] = __builtin_amdgcn_alignbyte(f1, f0, ph);
-        s_rc[ph * LONG_DW + i] = __builtin_amdgcn_alignbyte(r1, r0, ph);
-      }
-    }
-    __syncthreads();
-    // ---- the lane's four starts
+    // ---- the lane's six starts
 #pragma unroll 1
     for (uint32_t j = 0; j < LONG_TILE / WG; ++j) {
       const uint32_t p = tid + WG * j;
       if (tile0 + p >= n_starts) break;
-      if (s_bad[p + ksize] != s_bad[p]) continue;  // a non-base inside the window
-      const LdsStrand f{s_f, p}, r{s_rc, n_stage - p - ksize};
+      {  // a non-base inside the window [p, p + k)?
+        const uint32_t dw = p >> 5, sh = p & 31u;
+        bool any_bad;
+        if constexpr (KC != 0) {
+          const uint32_t d0 = s_inv[dw], d1 = s_inv[dw + 1], d2 = s_inv[dw + 2];
+          const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh);  // bits p .. p + 63
+          constexpr uint32_t M1 = KC >= 64 ? ~0u : (1u << (KC - 32)) - 1u;
+          any_bad = (w0 | (w1 & M1)) != 0u;
+        } else {
+          uint32_t acc = 0;
+          for (uint32_t t = 0; 32 * t < ksize; ++t) {
+            const uint32_t w = __builtin_amdgcn_alignbit(s_inv[dw + t + 1], s_inv[dw + t], sh);
+            const uint32_t left = ksize - 32 * t;
+            acc |= left >= 32 ? w : w & ((1u << left) - 1u);
+          }
+          any_bad = acc != 0u;
+        }
+        if (any_bad) continue;
+      }
+      const LdsStrand f{s_f, p}, r{s_rc, LONG_BYTES - p - ksize};
       bool use_rc = false;
-      if (canonical) {  // first differing dword decides (big-endian = lexicographic on the bytes)
-        for (uint32_t t = 0; 4 * t < ksize; ++t) {
-          uint32_t fw = __builtin_bswap32(f.dword(t)), rw = __builtin_bswap32(r.dword(t));
-          const uint32_t left = ksize - 4 * t;
-          if (left < 4) fw &= ~0u << (8 * (4 - left)), rw &= ~0u << (8 * (4 - left));
-          if (fw != rw) {
-            use_rc = rw < fw;
-            break;
+      if (canonical) {  // the lexicographically smaller byte string: big-endian compare of its first eight bytes, then the rest
+        const uint64_t fw = mk64(__builtin_bswap32(f.dword(1)), __builtin_bswap32(f.dword(0)));
+        const uint64_t rw = mk64(__builtin_bswap32(r.dword(1)), __builtin_bswap32(r.dword(0)));
+        if (fw != rw) {
+          use_rc = rw < fw;
+        } else {
+          for (uint32_t t = 2; 4 * t < ksize; ++t) {
+            uint32_t fd = __builtin_bswap32(f.dword(t)), rd = __builtin_bswap32(r.dword(t));
+            const uint32_t left = ksize - 4 * t;
+            if (left < 4) fd &= ~0u << (8 * (4 - left)), rd &= ~0u << (8 * (4 - left));
+            if (fd != rd) {
+              use_rc = rd < fd;
+              break;
+            }
           }
         }
       }
-      const uint64_t h = t1ha2_long(use_rc ? r : f, ksize, seed);
+      const uint64_t h = t1ha2_long<(uint32_t)KC>(use_rc ? r : f, ksize, seed);
       if (h < threshold) stage_hit(stage, stage_cap, h, gm, g, hits, cnt);
     }
   }
@@ -1075,7 +1114,10 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
 
 const char *hg_kmer_kernel_name(uint32_t k, bool canonical, bool packed) {  // mirrors hg_launch_kmer_sample
   static thread_local char buf[64];
-  if (k > 32) return packed ? "kmer_sample_long<true>" : "kmer_sample_long<false>";
+  if (k > 32) {
+    snprintf(buf, sizeof buf, "kmer_sample_long<%u, %s>", k <= 64 ? k : 0u, packed ? "true" : "false");
+    return buf;
+  }
   snprintf(buf, sizeof buf, "kmer_sample_shared<%u, %s, %s>", k, canonical ? "true" : "false", packed ? "true" : "false");
   return buf;
 }
@@ -1130,12 +1172,26 @@ hipError_t hg_launch_kmer_sample(hipStream_t st, const uint8_t *d_seq, const hg_
   }
 #undef HG_K_CASE
 #undef HG_K_LAUNCH
-  // 33 <= k <= 255
-  if (packed)
-    hipLaunchKernelGGL(kmer_sample_long<true>, dim3(n_items), dim3(WG), cap_l * sizeof(uint64_t), st, d_seq, d_meta, d_item_genome, ksize,
-                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt, cap_l);
-  else
-    hipLaunchKernelGGL(kmer_sample_long<false>, dim3(n_items), dim3(WG), cap_l * sizeof(uint64_t), st, d_seq, d_meta, d_item_genome, ksize,
-                       threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt, cap_l);
+  // 33 <= k <= 255: k up to 64 as a compile-time constant
+#define HG_KL_LAUNCH(PK, KK)                                                                                                   \
+  hipLaunchKernelGGL((kmer_sample_long<KK, PK>), dim3(n_items), dim3(WG), cap_l * sizeof(uint64_t), st, d_seq, d_meta, d_item_genome, \
+                     ksize, threshold, seed, canonical ? 1u : 0u, u2t, d_hits, d_cnt, cap_l)
+#define HG_KL_CASE(KK)                        \
+  case KK:                                    \
+    if (packed) HG_KL_LAUNCH(true, KK);       \
+    else HG_KL_LAUNCH(false, KK);             \
+    return hipGetLastError();
+  switch (ksize) {
+    HG_KL_CASE(33) HG_KL_CASE(34) HG_KL_CASE(35) HG_KL_CASE(36) HG_KL_CASE(37) HG_KL_CASE(38) HG_KL_CASE(39) HG_KL_CASE(40)
+    HG_KL_CASE(41) HG_KL_CASE(42) HG_KL_CASE(43) HG_KL_CASE(44) HG_KL_CASE(45) HG_KL_CASE(46) HG_KL_CASE(47) HG_KL_CASE(48)
+    HG_KL_CASE(49) HG_KL_CASE(50) HG_KL_CASE(51) HG_KL_CASE(52) HG_KL_CASE(53) HG_KL_CASE(54) HG_KL_CASE(55) HG_KL_CASE(56)
+    HG_KL_CASE(57) HG_KL_CASE(58) HG_KL_CASE(59) HG_KL_CASE(60) HG_KL_CASE(61) HG_KL_CASE(62) HG_KL_CASE(63) HG_KL_CASE(64)
+    default:
+      break;
+  }
+#undef HG_KL_CASE
+  if (packed) HG_KL_LAUNCH(true, 0);
+  else HG_KL_LAUNCH(false, 0);
+#undef HG_KL_LAUNCH
   return hipGetLastError();
 }

@@ -118,7 +118,7 @@ hg_status hg_copy_d2h(hg_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 /* mirrors SketchParams (src/types.rs:83-113); defaults k=21 scaled=1500 seed=123
  * canonical=1 hv_d=4096 */
 typedef struct {
-  uint32_t ksize;     /* 1..255 (u8 in the reference): 1..32 kmer_sample_shared, 33..255 kmer_sample_long */
+  uint32_t ksize;     /* 1..255 (u8 in the reference): 1..32 kmer_sample_shared, 33..64 kmer_sample_long<k>, 65..255 run-time k */
   uint32_t canonical; /* 0/1 (honoured like src/cuda_kernel.cu:306-314)             */
   uint64_t scaled;    /* threshold = UINT64_MAX / scaled (src/sketch.rs:73)          */
   uint64_t seed;
