@@ -466,7 +466,9 @@ hg_status hg_run_dist(hg_ctx *c, const hg_dist_args &a, uint32_t *d_verdict, int
     const uint32_t n_sml = q_small ? a.Q : a.R, n_big = q_small ? a.R : a.Q;
     const size_t lds = (size_t)n_sml * a.hv_d * sizeof(int16_t);
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.ref_hv) | reinterpret_cast<uintptr_t>(a.qry_hv)) & 15) == 0;
-    if (!ops_given && !a.ani_out && a.hits && a.hit_count && n_sml >= 1 && n_sml <= SK_MAX && a.hv_d % 8 == 0 && aligned &&
+    // (a count-only call -- no hit buffer, capacity 0: the trailing blocks of a comparison whose buffer is full -- streams too:
+    // the kernel writes a hit only below hit_cap)
+    if (!ops_given && !a.ani_out && (a.hits || a.hit_cap == 0) && a.hit_count && n_sml >= 1 && n_sml <= SK_MAX && a.hv_d % 8 == 0 && aligned &&
         lds <= 128 * 1024 && c->dbg_dist_path.empty() && c->dbg_dist_tile.empty()) {
       static std::atomic<uint64_t> done{0};
       int dev = 0;

@@ -1159,6 +1159,14 @@ def test_comparisons_beyond_the_hit_counter_run_as_row_blocks(hg, orc, symmetric
         part = canon(out, small)
         full = {(int(a), int(b)): int(v) for a, b, v in want}
         assert all(full.get((int(a), int(b))) == int(v) for a, b, v in part[:: max(1, small // 5000)])
+        if not symmetric:  # ... also when the blocks are a handful of rows (the streaming kernel): the trailing ones only count
+            c.set_debug("pair_limit", str(5 * Q + 1))
+            out.zero_()
+            torch.cuda.synchronize()
+            got_n, st = c.dist_dev(hv.data_ptr(), n2.data_ptr(), n, qv.data_ptr(), qn.data_ptr(), Q, 4096, 21, symmetric, 80.0, out.data_ptr(), small)
+            assert st == hg.ERR_CAPACITY and got_n == want_n and c.last_kernel("dist").startswith("dist_skinny_kernel")
+            part = canon(out, small)
+            assert all(full.get((int(a), int(b))) == int(v) for a, b, v in part[:: max(1, small // 5000)])
         c.set_debug("pair_limit", "0")
         # the bit-packed search takes the same route
         bits = torch.empty((n, 128), dtype=torch.int32, device=dev)
