@@ -653,8 +653,12 @@ __global__ __launch_bounds__(WG) void kmer_sample_shared(
     const uint32_t par = tile_no & 1u;
     uint32_t pc0 = 0, pc1 = 0, pc2 = 0;
     inv_t pinv = 0;
-    if constexpr (PACKED) stage_unit_packed(tid, tile_start, par, pc0, pc1, pc2, pinv);
-    else stage_unit(tid, tile_start, par);
+    // (a wave whose units all lie behind everything a live lane's window can reach -- the last k-mer start + WIN bases -- stages
+    // nothing: wave-uniform; its slots of the images keep what an earlier tile left there and nobody reads them)
+    if (tile_start + (uint64_t)(tid & ~63u) * M < n_starts + (uint64_t)WIN) {
+      if constexpr (PACKED) stage_unit_packed(tid, tile_start, par, pc0, pc1, pc2, pinv);
+      else stage_unit(tid, tile_start, par);
+    }
 #ifndef HG_KS_EXP
 #define HG_KS_EXP 0
 #endif
