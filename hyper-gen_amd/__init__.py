@@ -61,7 +61,7 @@ class FileSketch(C.Structure):
 
 EXPORTS = [
     "hg_status_str", "hg_last_error", "hg_version", "hg_ctx_create", "hg_ctx_destroy",
-    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_ctx_sketch_step_counts", "hg_logf_dev", "hg_ani_from_dots_dev", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
+    "hg_ctx_set_stream", "hg_ctx_reset_stream", "hg_ctx_sync", "hg_ctx_sketch_step_counts", "hg_sketch_plan_describe", "hg_logf_dev", "hg_ani_from_dots_dev", "hg_device_count", "hg_dev_alloc", "hg_dev_free",
     "hg_copy_h2d", "hg_copy_d2h", "hg_sketch_params_default", "hg_kmer_hash_sample",
     "hg_hv_encode", "hg_sketch_batch_dev", "hg_sketch_batch", "hg_dist_full", "hg_dist_full_dev",
     "hg_dist", "hg_dist_dev", "hg_sort_ani_hits", "hg_hv_quant_bits", "hg_hv_pack", "hg_hv_packed_bytes",
@@ -141,6 +141,7 @@ def lib():
         "hg_ctx_set_stream": (C.c_int, [vp, vp]),
         "hg_ctx_reset_stream": (C.c_int, [vp]),
         "hg_ctx_sync": (C.c_int, [vp]),
+        "hg_sketch_plan_describe": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), vp, sz]),
         "hg_logf_dev": (C.c_int, [vp, vp, C.c_uint32, sz, vp]),
         "hg_ani_from_dots_dev": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint32, vp]),
         "hg_ctx_sketch_step_counts": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -933,6 +934,24 @@ class SketchStream:
 
     def __exit__(self, *a):
         self.close()
+
+
+def sketch_plan_describe(offsets, lens, ksize=21, scaled=1500):
+    """hg_sketch_plan_describe: (dict of counts, group_first array or None) -- host arithmetic, needs no GPU"""
+    off = np.ascontiguousarray(offsets, np.uint64)
+    ln = np.ascontiguousarray(lens, np.uint64)
+    counts = (C.c_uint64 * 6)()
+    st = lib().hg_sketch_plan_describe(_ptr(off), _ptr(ln), off.size, ksize, scaled, counts, None, 0)
+    if st != OK:
+        raise HgError(st, "hg_sketch_plan_describe")
+    d = dict(zip(("items", "workgroups", "hit_slots", "max_cap", "max_expect", "item_tiles"), (int(x) for x in counts)))
+    gf = None
+    if ksize <= 32 and d["items"]:
+        gf = np.zeros(d["workgroups"] + 1, np.uint32)
+        st = lib().hg_sketch_plan_describe(_ptr(off), _ptr(ln), off.size, ksize, scaled, counts, _ptr(gf), gf.size)
+        if st != OK:
+            raise HgError(st, "hg_sketch_plan_describe")
+    return d, gf
 
 
 def write_sketch_file(path, records):

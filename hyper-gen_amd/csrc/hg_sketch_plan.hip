@@ -187,3 +187,23 @@ hg_status hg_pack_batch(hg_ctx *c, const uint8_t *d_seq, const uint64_t *seq_off
   HG_HIP(c, hipStreamSynchronize(c->stream));  // (the pinned table is free again)
   return HG_OK;
 }
+
+// The plan of a batch as numbers (host only, no device involved): for tests and for callers that want to size a batch before
+// they submit it.  counts[0..5] = work items, workgroups of the k-mer launch, hit slots, largest hit region, largest expected
+// sampled count, tiles per full work item; group_first (optional, cap entries) receives the first work item of every workgroup
+// followed by the item count.
+extern "C" hg_status hg_sketch_plan_describe(const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize, uint64_t scaled,
+                                             uint64_t counts[6], uint32_t *group_first, size_t cap) {
+  if ((n && (!offsets || !lens)) || !counts || ksize < 1 || ksize > 255 || scaled < 1) return HG_ERR_INVALID;
+  hg_batch_tables t;
+  const hg_status s = hg_plan_build(nullptr, offsets, lens, n, ksize, scaled, nullptr, t, nullptr);
+  if (s != HG_OK) return s;
+  const uint32_t tile = hg_kmer_tile_starts(ksize);
+  counts[0] = t.n_items, counts[1] = t.n_groups ? t.n_groups : t.n_items, counts[2] = t.total_slots, counts[3] = t.max_cap;
+  counts[4] = t.max_expect, counts[5] = tile ? (hg_kmer_item_starts(ksize) + tile - 1) / tile : 0;
+  if (group_first) {
+    if (t.group_first.size() > cap) return HG_ERR_CAPACITY;
+    for (size_t i = 0; i < t.group_first.size(); ++i) group_first[i] = t.group_first[i];
+  }
+  return HG_OK;
+}

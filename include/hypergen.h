@@ -176,6 +176,13 @@ hg_status hg_sketch_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t 
  * Batches whose genomes are EXPECTED to exceed the one-workgroup sort (more than ~7 000 sampled k-mers: 10 Mbp at
  * scaled = 1 500) take the synchronous path at once and are final in stream order. */
 #define HG_NHASH_PENDING 0xFFFFFFFFu
+/* How the library would lay a batch out for the k-mer launch (host arithmetic only; no ctx, no device): counts[0] = work items
+ * (pieces of 27 432 k-mer starts for k <= 21, 27 324 for k <= 32, 12 288 beyond), [1] = workgroups -- for k <= 32 the work
+ * items of consecutive SMALL genomes share a workgroup, up to three full items' worth of tiles --, [2] = hit slots, [3] = largest
+ * hit region, [4] = largest expected sampled count of a genome, [5] = tiles of a full work item (0 for k > 32).  group_first
+ * (optional, cap entries): first work item of every workgroup, then the item count (counts[1] + 1 entries; k <= 32 only). */
+hg_status hg_sketch_plan_describe(const uint64_t *offsets, const uint64_t *lens, size_t n, uint32_t ksize, uint64_t scaled,
+                                  uint64_t counts[6], uint32_t *group_first, size_t cap);
 /* The same batch with the genomes resident as 2-bit PACKED bases: genome i is the hg_pack2 blob (layout below:
  * 4 bases per byte + the not-a-base bitmap, 0.375 bytes per base in HBM instead of 1) at d_blobs + offsets[i]
  * (multiples of 16; 32 readable bytes behind every blob), n_bps[i] = its number of bases.  The k-mer kernels read the
