@@ -107,11 +107,12 @@ def main():
     hash_blocks = [i for i, c in enumerate(cnt) if c["v_mad_u64_u32"] >= 20]
     assert len(hash_blocks) == 2 * M, "expected two copies of the %d-k-mer loop, found %d hash blocks" % (M, len(hash_blocks))
     body = hash_blocks[:M]   # (the two copies' main-path blocks are the same instructions)
+    md = blocks[hash_blocks[0]][0]  # loop depth of the tile loop (1 until round 5; 2 since the work items of a group are a loop around it)
     main_ops, rare_ops = collections.Counter(), collections.Counter()
     weights = collections.Counter()
     for i, ((d, b), c) in enumerate(zip(blocks, cnt)):
         in_loop_copy = min(hash_blocks) <= i <= max(hash_blocks)
-        rare = (d == 0 or d >= 2 or (in_loop_copy and i not in body)
+        rare = (d != md or (in_loop_copy and i not in body)
                 or any(c[o] for o in ("ds_add_rtn_u32", "global_atomic_add", "flat_store_dwordx2", "global_store_dwordx2",
                                       "global_load_ubyte", "s_endpgm"))
                 or (c["v_mul_lo_u32"] >= 2 and c["v_mad_u64_u32"] == 0)                 # the per-base validity mask
