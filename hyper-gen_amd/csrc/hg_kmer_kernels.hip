@@ -914,13 +914,23 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
 // (two for k = 64) and a tail of k - 32 bytes.
 constexpr uint32_t LONG_TILE = 1536;                 // k-mer starts per tile (6 per lane)
 constexpr uint32_t LONG_BYTES = 2048;                // staged bytes per tile (>= LONG_TILE + 254), 8 per lane
-constexpr uint32_t LONG_DW = LONG_BYTES / 4 + 4;     // + zero slack behind the last dword
+// dwords between two phase images: the tile + slack, and == 16 (mod 32) -- consecutive lanes take consecutive starts, so a
+// wave reads 16 consecutive dwords of each of the four images at once: with the images 16 banks apart every LDS bank serves
+// exactly two lanes (516 dwords put phase 1 four banks behind phase 0: two- to three-way conflicts on every hash word)
+#ifndef HG_LK_PITCH
+#define HG_LK_PITCH 16
+#endif
+constexpr uint32_t LONG_DW = LONG_BYTES / 4 + HG_LK_PITCH;
 static_assert(GEN_ITEM % LONG_TILE == 0 && LONG_TILE % 8 == 0 && LONG_BYTES == 8 * WG && LONG_TILE + 254 <= LONG_BYTES, "long-k tile geometry");
 
 struct LdsStrand {
   const uint32_t *w32;  // the four phase images
   uint32_t byte0;       // first byte of the k-mer in the strand
+  uint32_t d0, d1;      // its first two dwords when `cached` (the strand choice has read them already)
+  bool cached;
   __device__ __forceinline__ uint32_t dword(uint32_t i) const {  // bytes [byte0 + 4i, byte0 + 4i + 4)
+    if (cached && __builtin_constant_p(i) && i == 0) return d0;
+    if (cached && __builtin_constant_p(i) && i == 1) return d1;
     return w32[(byte0 & 3u) * LONG_DW + (byte0 >> 2) + i];
   }
   __device__ __forceinline__ uint64_t word(uint32_t byte_off, uint32_t nbytes) const {  // little endian, byte_off % 8 == 0
@@ -930,6 +940,15 @@ struct LdsStrand {
     return mk64(lo, hi);
   }
 };
+
+// rot64 whose result is opaque to the optimiser.  `x + rot64(y, s)`: the compiler sees the rotate as {lo} | {hi << 32}, turns
+// the or of disjoint halves into an add, and adds the two halves SEPARATELY -- two 64-bit adds and two v_mov (zero halves) per
+// rotate where one add would do; eight rotates per k-mer in the long-input round.  The empty asm makes the pair one value.
+__device__ __forceinline__ uint64_t rot64p(uint64_t v, unsigned s) {
+  uint64_t r = rot64(v, s);
+  asm("" : "+v"(r));
+  return r;
+}
 
 // t1ha2_atonce of `len` > 32 bytes (published t1ha2: lanes c, d, 32 bytes per round, squash, then the tail switch of
 // src/cuda_kernel.cu:207-245).  LEN > 0: len == LEN is a compile-time constant and everything below unrolls.
@@ -944,12 +963,12 @@ __device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len
     auto round = [&]() __attribute__((always_inline)) {
       const uint64_t w0 = sb.word(off, 8), w1 = sb.word(off + 8, 8), w2 = sb.word(off + 16, 8), w3 = sb.word(off + 24, 8);
       off += 32;
-      const uint64_t d02 = w0 + rot64(w2 + d, 56);
-      const uint64_t c13 = w1 + rot64(w3 + c, 19);
-      d ^= b + rot64(w1, 38);
-      c ^= a + rot64(w0, 57);
-      b ^= P6 * (c13 + w2);
-      a ^= P5 * (d02 + w3);
+      const uint64_t d02 = w0 + rot64p(w2 + d, 56);
+      const uint64_t c13 = w1 + rot64p(w3 + c, 19);
+      d ^= b + rot64p(w1, 38);
+      c ^= a + rot64p(w0, 57);
+      b ^= lo64mul<P6>(c13 + w2);
+      a ^= lo64mul<P5>(d02 + w3);
     };
     if constexpr (LEN != 0) {
       static_assert(LEN > 32 && LEN <= 64, "compile-time lengths: one or two rounds");
@@ -959,8 +978,8 @@ __device__ __forceinline__ uint64_t t1ha2_long(const LdsStrand &sb, uint32_t len
       do round();
       while (off + 31 < len);
     }
-    a ^= P6 * (c + rot64(d, 23));
-    b ^= P5 * (rot64(c, 19) + d);
+    a ^= lo64mul<P6>(c + rot64p(d, 23));
+    b ^= lo64mul<P5>(rot64p(c, 19) + d);
     len &= 31;
   }
   uint32_t rem = len;
@@ -1003,6 +1022,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
   __shared__ HitStage stage;
   __shared__ uint32_t s_f[4 * LONG_DW], s_rc[4 * LONG_DW];  // forward / reverse-complement strand, four byte phases each
   __shared__ uint32_t s_inv[LONG_BYTES / 32 + 12];          // bit i set <=> staged byte i is not a base (zero slack behind)
+  __shared__ uint32_t s_anybad[2];                          // "this tile holds a byte that is not a base", by tile parity
   const uint32_t ksize = KC ? (uint32_t)KC : ksize_rt;
   const uint32_t item = blockIdx.x, tid = threadIdx.x;
   const uint32_t g = item_genome[item];
@@ -1016,10 +1036,13 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
   if (tid == 0) stage.n = 0;
   if (tid < 4) s_f[tid * LONG_DW + LONG_BYTES / 4] = 0u, s_rc[tid * LONG_DW + LONG_BYTES / 4] = 0u;  // (read by a k-mer's last, masked dword)
   if (tid < 12) s_inv[LONG_BYTES / 32 + tid] = 0u;
+  if (tid < 2) s_anybad[tid] = 0u;
   typedef uint32_t __attribute__((aligned(1))) u32u_t;
+  uint32_t tile_par = 0;
 
-  for (uint64_t tile0 = item_start; tile0 < item_start + GEN_ITEM && tile0 < n_starts; tile0 += LONG_TILE) {
+  for (uint64_t tile0 = item_start; tile0 < item_start + GEN_ITEM && tile0 < n_starts; tile0 += LONG_TILE, tile_par ^= 1u) {
     __syncthreads();  // previous tile's readers are done
+    if (tid == 0) s_anybad[tile_par ^ 1u] = 0u;  // (the flag of the tile before: read by everyone in front of the barrier above)
     if (dense_sampling(threshold)) flush_hits_if_filling(stage, stage_cap, gm, g, hits, cnt);
     // ---- stage: the lane's eight bytes [pos0, pos0 + 8) with the four bytes in front of and behind them
     {
@@ -1062,14 +1085,19 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
       // validity bits of the lane's eight bytes: byte tid of the bit image
       const uint32_t b8 = ((((bad[1] & 0x01010101u) * 0x01020408u) >> 24) & 15u) | (((((bad[2] & 0x01010101u) * 0x01020408u) >> 24) & 15u) << 4);
       reinterpret_cast<uint8_t *>(s_inv)[tid] = (uint8_t)b8;
+      if (b8 != 0u) s_anybad[tile_par] = 1u;  // (same value from every writer)
     }
     __syncthreads();
+#ifndef HG_LK_DIRTY
+#define HG_LK_DIRTY 1
+#endif
+    const bool tile_dirty = !HG_LK_DIRTY || s_anybad[tile_par] != 0u;  // workgroup-uniform: a clean tile (nearly all of them) tests no window
     // ---- the lane's six starts
 #pragma unroll 1
     for (uint32_t j = 0; j < LONG_TILE / WG; ++j) {
       const uint32_t p = tid + WG * j;
       if (tile0 + p >= n_starts) break;
-      {  // a non-base inside the window [p, p + k)?
+      if (tile_dirty) {  // a non-base inside the window [p, p + k)?
         const uint32_t dw = p >> 5, sh = p & 31u;
         bool any_bad;
         if constexpr (KC != 0) {
@@ -1088,11 +1116,13 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
         }
         if (any_bad) continue;
       }
-      const LdsStrand f{s_f, p}, r{s_rc, LONG_BYTES - p - ksize};
+      const LdsStrand f{s_f, p, 0u, 0u, false}, r{s_rc, LONG_BYTES - p - ksize, 0u, 0u, false};
       bool use_rc = false;
+      uint32_t fd0 = 0, fd1 = 0, rd0 = 0, rd1 = 0;  // (plain values: a struct that is written after its construction goes to scratch)
       if (canonical) {  // the lexicographically smaller byte string: big-endian compare of its first eight bytes, then the rest
-        const uint64_t fw = mk64(__builtin_bswap32(f.dword(1)), __builtin_bswap32(f.dword(0)));
-        const uint64_t rw = mk64(__builtin_bswap32(r.dword(1)), __builtin_bswap32(r.dword(0)));
+        fd0 = f.dword(0), fd1 = f.dword(1), rd0 = r.dword(0), rd1 = r.dword(1);
+        const uint64_t fw = mk64(__builtin_bswap32(fd1), __builtin_bswap32(fd0));
+        const uint64_t rw = mk64(__builtin_bswap32(rd1), __builtin_bswap32(rd0));
         if (fw != rw) {
           use_rc = rw < fw;
         } else {
@@ -1107,7 +1137,13 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
           }
         }
       }
-      const uint64_t h = t1ha2_long<(uint32_t)KC>(use_rc ? r : f, ksize, seed);
+#ifndef HG_LK_CACHE
+#define HG_LK_CACHE 1
+#endif
+      // the chosen strand, its first two dwords from the compare above when the hash reads them at compile-time offsets
+      const LdsStrand sel{use_rc ? s_rc : s_f, use_rc ? r.byte0 : f.byte0, use_rc ? rd0 : fd0, use_rc ? rd1 : fd1,
+                          KC != 0 && HG_LK_CACHE != 0 && canonical != 0};
+      const uint64_t h = t1ha2_long<(uint32_t)KC>(sel, ksize, seed);
       if (h < threshold) stage_hit(stage, stage_cap, h, gm, g, hits, cnt);
     }
   }
