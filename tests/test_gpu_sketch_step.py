@@ -227,3 +227,45 @@ def test_stream_of_files_with_an_overflowing_genome(hg, orc):
         w = orc.sketch_genome(s)
         hv, n2, nh = seen[i]
         assert nh == w[2] and n2 == w[1] and (hv == w[0]).all(), i
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_sequences_of_steps(hg, ctx, orc, seed):
+    """a soak of the check-word logic: forty steps of random batches -- repeated geometry, new geometry, overflowing genomes one
+    step in five, output buffers drawn from a pool of two (so a re-run may land behind a later step that shares them), other
+    entry points in between -- read only at the end: every buffer must hold the sketches of the LAST step that wrote it"""
+    rng = np.random.default_rng(700 + seed)
+    p = hg.default_params(scaled=int(rng.choice([300, 1500])))
+    pool = [outputs(12), outputs(12)]
+    last = [None, None]  # per buffer: the sequences of the last step that wrote it
+    keep = []            # device inputs stay alive until the final sync (the contract)
+    prev = None
+    kmer = sampled_kmer(orc, rng, int(p.scaled))
+    for step in range(40):
+        if prev is not None and rng.random() < 0.3:
+            seqs = [rng.choice(ACGT, len(s)) for s in prev]  # same geometry, other content
+        else:
+            seqs = [rng.choice(ACGT, int(n)) for n in rng.choice([0, 20, 500, 3048, 9000, 27500, 60_000, 150_000], int(rng.integers(1, 12)))]
+        if rng.random() < 0.2 and len(seqs[0]) >= 60_000:  # a sampled k-mer 3 000 times: overflows a region of ~1 100
+            unit = np.concatenate([kmer, np.frombuffer(b"N", np.uint8)])
+            seqs[0] = np.concatenate([np.tile(unit, 3000), seqs[0][3000 * 22:]])[:len(seqs[0])]
+        prev = seqs
+        d_seq, offs, ln = upload(seqs)
+        keep.append(d_seq)
+        b = int(rng.integers(0, 2))
+        hv, n2, nh = pool[b]
+        ctx.sketch_batch_dev(d_seq.data_ptr(), offs, ln, p, hv.data_ptr(), n2.data_ptr(), nh.data_ptr())
+        last[b] = seqs
+        if rng.random() < 0.15:  # any other entry point completes the queued step first
+            import ctypes
+            tmp = np.zeros(1, np.uint32)
+            ctx._ck(hg.lib().hg_copy_d2h(ctx._h, ctypes.c_void_p(tmp.ctypes.data), ctypes.c_void_p(nh.data_ptr()), 4))
+    ctx.sync()
+    fast, slow, rerun = ctx.sketch_step_counts()
+    assert fast >= 30
+    for b in range(2):
+        if last[b] is None:
+            continue
+        hv, n2, nh = pool[b]
+        k = len(last[b])
+        check(orc, last[b], hv[:k], n2[:k], nh[:k], scaled=int(p.scaled))
