@@ -914,9 +914,11 @@ __device__ __forceinline__ uint32_t base_code(uint8_t c, uint32_t u2t) {
 // (two for k = 64) and a tail of k - 32 bytes.
 constexpr uint32_t LONG_TILE = 1536;                 // k-mer starts per tile (6 per lane)
 constexpr uint32_t LONG_BYTES = 2048;                // staged bytes per tile (>= LONG_TILE + 254), 8 per lane
-// dwords between two phase images: the tile + slack, and == 16 (mod 32) -- consecutive lanes take consecutive starts, so a
-// wave reads 16 consecutive dwords of each of the four images at once: with the images 16 banks apart every LDS bank serves
-// exactly two lanes (516 dwords put phase 1 four banks behind phase 0: two- to three-way conflicts on every hash word)
+// dwords between two phase images: the tile + slack.  Consecutive lanes take consecutive starts, so a wave reads 16
+// consecutive dwords of each of the four images at once; with the images 16 banks apart (pitch == 16 mod 32) every LDS bank
+// serves exactly two lanes, with 516 dwords (pitch 4) up to four.  Measured at k = 33: 18.4 against 18.1 ms -- no gain, the
+// kernel is VALU-bound (SQ_LDS_BANK_CONFLICT is 61 % of its LDS cycles either way, the LDS is busy 59 % of the time); the
+// switches HG_LK_PITCH / HG_LK_DIRTY / HG_LK_CACHE are the A/B builds of tools/build_variant.sh.
 #ifndef HG_LK_PITCH
 #define HG_LK_PITCH 16
 #endif

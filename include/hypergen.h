@@ -174,7 +174,8 @@ hg_status hg_sketch_batch_dev(hg_ctx *ctx, const uint8_t *d_seq, const uint64_t 
  *     HG_NHASH_PENDING (and their HV rows are untouched) until the library has redone the step;
  *   - an error of the re-run is returned by the call that triggered it.
  * Batches whose genomes are EXPECTED to exceed the one-workgroup sort (more than ~7 000 sampled k-mers: 10 Mbp at
- * scaled = 1 500) take the synchronous path at once and are final in stream order. */
+ * scaled = 1 500) take the synchronous path at once and are final in stream order; hg_ctx_set_debug(ctx, "sketch_path",
+ * "sync") sends every batch that way (the behaviour up to round 5: counters read back between sort and encode). */
 #define HG_NHASH_PENDING 0xFFFFFFFFu
 /* How the library would lay a batch out for the k-mer launch (host arithmetic only; no ctx, no device): counts[0] = work items
  * (pieces of 27 432 k-mer starts for k <= 21, 27 324 for k <= 32, 12 288 beyond), [1] = workgroups -- for k <= 32 the work
