@@ -98,6 +98,10 @@ L += ["", "## the other files", "",
       "| `%s_derived.md` | per-kernel derived metrics (instr / cycle, MFMA busy, LDS busy, LDS conflicts, L2 hit, wait split, HBM bytes) | `tools/derive_prof.py %s` |" % (tag, tag),
       "| `%s_kmer_traffic.json`, `%s_kmer_ascii_traffic.json`, `%s_dist_traffic.json` | the `roofline.traffic` figures `bench.py` reports | idem |" % (tag, tag, tag),
       "| `%s_kmer_packed_isa.*`, `%s_kmer_isa.*` | static instruction budget of `kmer_sample_shared<21, true, PACKED>` by class, per k-mer | `tools/kmer_isa.py %s [packed]` |" % (tag, tag, tag),
+      "| `r06_dist_epilogue.md` (+ `r06_dist_epilogue_raw.txt`) | where the dist kernel's time goes between \"no candidates\" and 1.29 M hits: every tile split into main loop / phase 0 / append / phase 2 / reservation / hit write from stamps of all 1 280 workgroups, A/B builds of the phase-2 arithmetic, the sixth round of 47 left-over tiles | `tools/dist_epilogue_split.py` on `-DHG_DIST_STAMPS` builds (`tools/build_variant.sh`) |",
+      "| `r06_small_and_long_k.txt` | the small-genome ladder (400 000 x 2 kbp .. 1 000 x 5 Mbp: Mbase/s and kernel times per step) and the k-mer kernel's time at k = 21 .. 255, with what changed in round 6 | `tools/small_genome_sweep.sh`, `tools/kmer_time.py` |",
+      "| `r06_realistic_kernel_stats.txt` | `rocprofv3 --kernel-trace --stats` of the clean / draft-assembly / many-small-genomes sketch step, both resident forms (round 6: the step's new kernels -- `sort_unique_wave_kernel`, `sort_unique_rest_kernel`, `sketch_finish_kernel`) | `tools/profile_realistic.sh r06` |",
+      "| `design_r05_full.md` | DESIGN.md as it stood at the end of round 5 | -- |",
       "| `r05_gemm_bounds.md` (+ `r05_l2_bound.txt`, `r05_mfma_shape.txt`, `r05_mfma_loop.txt`, `r05_epilogue_bounds.txt`) | what bounds the three GEMM kernels: the all-L2-hits build, MFMA shapes and operand values, the loop's ingredients, the uneven loader split, the epilogue's removable work | `tools/dist_only.py` on `-DHG_DIST_EXPERIMENT` builds, `tools/mfma_shape_microbench.hip`, `tools/mfma_microbench.hip` |",
       "| `r05_realistic_kernel_stats.txt` | `rocprofv3 --kernel-trace --stats` of the clean / draft-assembly / many-small-genomes sketch step, both resident forms | `tools/profile_realistic.sh r05` |",
       "| `r05_cli_kernel_stats.txt` | `rocprofv3 --kernel-trace --stats` of the CLI binary itself (`hyper-gen dist` / `search` on two 10 000-sketch files): every kernel an end-to-end comparison launches | `tools/profile_cli.sh r05` |",
