@@ -926,14 +926,13 @@ constexpr uint32_t LONG_DW = LONG_BYTES / 4 + HG_LK_PITCH;
 static_assert(GEN_ITEM % LONG_TILE == 0 && LONG_TILE % 8 == 0 && LONG_BYTES == 8 * WG && LONG_TILE + 254 <= LONG_BYTES, "long-k tile geometry");
 
 struct LdsStrand {
-  const uint32_t *w32;  // the four phase images
-  uint32_t byte0;       // first byte of the k-mer in the strand
-  uint32_t d0, d1;      // its first two dwords when `cached` (the strand choice has read them already)
+  const uint32_t *base;  // dword 0 of the k-mer in the phase image of its start (image (byte0 & 3), dword byte0 >> 2)
+  uint32_t d0, d1;       // its first two dwords when `cached` (the strand choice has read them already)
   bool cached;
   __device__ __forceinline__ uint32_t dword(uint32_t i) const {  // bytes [byte0 + 4i, byte0 + 4i + 4)
     if (cached && __builtin_constant_p(i) && i == 0) return d0;
     if (cached && __builtin_constant_p(i) && i == 1) return d1;
-    return w32[(byte0 & 3u) * LONG_DW + (byte0 >> 2) + i];
+    return base[i];
   }
   __device__ __forceinline__ uint64_t word(uint32_t byte_off, uint32_t nbytes) const {  // little endian, byte_off % 8 == 0
     uint32_t lo = dword(byte_off / 4), hi = nbytes > 4 ? dword(byte_off / 4 + 1) : 0u;
@@ -1094,13 +1093,22 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
 #define HG_LK_DIRTY 1
 #endif
     const bool tile_dirty = !HG_LK_DIRTY || s_anybad[tile_par] != 0u;  // workgroup-uniform: a clean tile (nearly all of them) tests no window
-    // ---- the lane's six starts
-#pragma unroll 1
-    for (uint32_t j = 0; j < LONG_TILE / WG; ++j) {
-      const uint32_t p = tid + WG * j;
-      if (tile0 + p >= n_starts) break;
+    // ---- the lane's six starts p = tid + 256 j.  256 is a multiple of 4, so the byte phase of a lane's starts is the same for
+    // all j on both strands and the k-mer's first dword moves by 64 dwords per j: two pointers that step, no address arithmetic
+    // per start (forward: byte p; reverse complement: byte LONG_BYTES - p - k)
+    const uint64_t left_starts = n_starts - tile0;  // > 0
+    const uint32_t lim = left_starts < LONG_TILE ? (uint32_t)left_starts : LONG_TILE;
+    const uint32_t jn = lim > tid ? (lim - tid + WG - 1) / WG : 0u;  // this lane's starts inside the genome
+    const uint32_t rb0 = LONG_BYTES - ksize - tid;
+    const uint32_t *fp = s_f + (tid & 3u) * LONG_DW + (tid >> 2);
+    const uint32_t *rp = s_rc + (rb0 & 3u) * LONG_DW + (rb0 >> 2);
+#ifndef HG_LK_UNROLL
+#define HG_LK_UNROLL 1
+#endif
+#pragma unroll HG_LK_UNROLL
+    for (uint32_t j = 0; j < jn; ++j, fp += WG / 4, rp -= WG / 4) {
       if (tile_dirty) {  // a non-base inside the window [p, p + k)?
-        const uint32_t dw = p >> 5, sh = p & 31u;
+        const uint32_t p = tid + WG * j, dw = p >> 5, sh = p & 31u;
         bool any_bad;
         if constexpr (KC != 0) {
           const uint32_t d0 = s_inv[dw], d1 = s_inv[dw + 1], d2 = s_inv[dw + 2];
@@ -1118,18 +1126,21 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
         }
         if (any_bad) continue;
       }
-      const LdsStrand f{s_f, p, 0u, 0u, false}, r{s_rc, LONG_BYTES - p - ksize, 0u, 0u, false};
+      // the lexicographically smaller byte string (canonical): big-endian compare of the first eight bytes, then the rest; the
+      // forward strand's first two dwords are read in any case -- they are the hash's first word (plain values: a struct that
+      // is written after its construction goes to scratch)
+      const uint32_t fd0 = fp[0], fd1 = fp[1];
+      uint32_t rd0 = 0, rd1 = 0;
       bool use_rc = false;
-      uint32_t fd0 = 0, fd1 = 0, rd0 = 0, rd1 = 0;  // (plain values: a struct that is written after its construction goes to scratch)
-      if (canonical) {  // the lexicographically smaller byte string: big-endian compare of its first eight bytes, then the rest
-        fd0 = f.dword(0), fd1 = f.dword(1), rd0 = r.dword(0), rd1 = r.dword(1);
+      if (canonical) {
+        rd0 = rp[0], rd1 = rp[1];
         const uint64_t fw = mk64(__builtin_bswap32(fd1), __builtin_bswap32(fd0));
         const uint64_t rw = mk64(__builtin_bswap32(rd1), __builtin_bswap32(rd0));
         if (fw != rw) {
           use_rc = rw < fw;
         } else {
           for (uint32_t t = 2; 4 * t < ksize; ++t) {
-            uint32_t fd = __builtin_bswap32(f.dword(t)), rd = __builtin_bswap32(r.dword(t));
+            uint32_t fd = __builtin_bswap32(fp[t]), rd = __builtin_bswap32(rp[t]);
             const uint32_t left = ksize - 4 * t;
             if (left < 4) fd &= ~0u << (8 * (4 - left)), rd &= ~0u << (8 * (4 - left));
             if (fd != rd) {
@@ -1142,9 +1153,7 @@ __global__ __launch_bounds__(WG) void kmer_sample_long(
 #ifndef HG_LK_CACHE
 #define HG_LK_CACHE 1
 #endif
-      // the chosen strand, its first two dwords from the compare above when the hash reads them at compile-time offsets
-      const LdsStrand sel{use_rc ? s_rc : s_f, use_rc ? r.byte0 : f.byte0, use_rc ? rd0 : fd0, use_rc ? rd1 : fd1,
-                          KC != 0 && HG_LK_CACHE != 0 && canonical != 0};
+      const LdsStrand sel{use_rc ? rp : fp, use_rc ? rd0 : fd0, use_rc ? rd1 : fd1, HG_LK_CACHE != 0};
       const uint64_t h = t1ha2_long<(uint32_t)KC>(sel, ksize, seed);
       if (h < threshold) stage_hit(stage, stage_cap, h, gm, g, hits, cnt);
     }
